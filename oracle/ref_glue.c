@@ -1,0 +1,77 @@
+/*
+ * ref_glue.c -- thin ctypes-facing shims over the REFERENCE's own sources.
+ *
+ * TEST INFRASTRUCTURE.  This file contains no algorithm: it defines the two
+ * globals qpsk_demod.c expects from main.c (qpsk_demod.c:34-35), and flattens
+ * struct/pointer interfaces into plain arrays so tests can call the reference
+ * through ctypes.  It is compiled together with the reference sources where
+ * they lie under /root/reference (see oracle/Makefile, target _ref); the
+ * result goes to oracle/_ref/ only and is never part of the product.
+ */
+#include <complex.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "qpsk_demod.h"   /* reference header (burst_detect.h neutralised by the recipe's -D flags) */
+#include "rotator.h"      /* reference header */
+#include "simd_kernels.h" /* reference header */
+
+char *save_bursts_dir = NULL;   /* main.c global read by qpsk_demod.c:34 */
+int use_gardner = 1;            /* main.c:143 global read by qpsk_demod.c:35 */
+
+void ref_set_use_gardner(int v) { use_gardner = v; }
+
+/* rotator.h:36-46 (static inline in the reference) */
+void ref_rotator_rotate_n(float *phase, const float *incr, float *out, const float *in, int n)
+{
+    rotator_t r;
+    rotator_init(&r);
+    rotator_set_phase(&r, phase[0] + phase[1] * I);
+    rotator_set_phase_incr(&r, incr[0] + incr[1] * I);
+    rotator_rotate_n(&r, (float complex *)out, (const float complex *)in, n);
+    phase[0] = crealf(r.phase);
+    phase[1] = cimagf(r.phase);
+}
+
+/* qpsk_demod.c:393 through a flat interface.  Returns the reference's return value. */
+int ref_qpsk_demod(const float *samples, int num_samples, float samples_per_symbol,
+                   int direction, double center_frequency, uint64_t id, uint64_t timestamp,
+                   float magnitude, float noise,
+                   int *direction_out, int *confidence, float *level, int *n_symbols,
+                   int *n_payload, int *n_bits, uint8_t *bits, float *llr,
+                   double *center_frequency_out)
+{
+    downmix_frame_t in;
+    memset(&in, 0, sizeof(in));
+    in.id = id;
+    in.timestamp = timestamp;
+    in.center_frequency = center_frequency;
+    in.sample_rate = 250000.0f;
+    in.samples_per_symbol = samples_per_symbol;
+    in.direction = (ir_direction_t)direction;
+    in.magnitude = magnitude;
+    in.noise = noise;
+    in.num_samples = (size_t)num_samples;
+    in.samples = malloc(sizeof(float complex) * (size_t)num_samples);
+    memcpy(in.samples, samples, sizeof(float complex) * (size_t)num_samples);
+    demod_frame_t *out = NULL;
+    int r = qpsk_demod(&in, &out);
+    free(in.samples);
+    if (!r)
+        return 0;
+    *direction_out = (int)out->direction;
+    *confidence = out->confidence;
+    *level = out->level;
+    *n_symbols = out->n_symbols;
+    *n_payload = out->n_payload_symbols;
+    *n_bits = out->n_bits;
+    memcpy(bits, out->bits, (size_t)out->n_bits);
+    if (out->llr)
+        memcpy(llr, out->llr, sizeof(float) * (size_t)out->n_bits);
+    *center_frequency_out = out->center_frequency;
+    free(out->bits);
+    free(out->llr);
+    free(out);
+    return 1;
+}
