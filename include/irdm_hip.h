@@ -1,0 +1,190 @@
+/*
+ * irdm_hip.h -- C-ABI of the MI355X (gfx950) Iridium hot path.
+ *
+ * Plain C, no HIP or torch types: a C99 host (the reference's main.c /
+ * burst_detect.c) links this library and nothing else.  Every entry point
+ * names the reference interface it replaces (file:line into the reference).
+ *
+ * Layers
+ *   1. gpu_burst_fft_*      -- the reference's one accelerator plug point
+ *                              (opencl/burst_fft.h:35-47), same names and
+ *                              conventions, so burst_detect.c's USE_GPU branch
+ *                              (burst_detect.c:304-319, :655-674) links unchanged.
+ *   2. irdm_*               -- batched superset: detect -> downmix -> demod for
+ *                              whole chunks of the IQ stream, device-resident or
+ *                              host buffers.  Same conventions as layer 1: opaque
+ *                              context, NULL / -1 on error, caller-owned buffers,
+ *                              one thread per context.
+ *   3. irdm_format_raw      -- frame_output.c:160-199 RAW line, host C.
+ */
+#ifndef IRDM_HIP_H
+#define IRDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* 1. Reference plug point (opencl/burst_fft.h)                        */
+/* ------------------------------------------------------------------ */
+
+typedef struct gpu_burst_fft gpu_burst_fft_t;
+
+/* opencl/burst_fft.h:35-36.  fft_size: power of two (2048..16384 use the
+ * LDS-resident kernel).  window: fft_size floats, already /0.42
+ * (burst_detect.c:247-250), copied.  NULL on failure => the caller falls back
+ * to its CPU path (burst_detect.c:316-318). */
+gpu_burst_fft_t *gpu_burst_fft_create(int fft_size, int batch_size, const float *window);
+
+/* opencl/burst_fft.h:39.  NULL-safe. */
+void gpu_burst_fft_destroy(gpu_burst_fft_t *g);
+
+/* opencl/burst_fft.h:46-47.  input: batch_count*fft_size interleaved (re,im)
+ * host floats; output: batch_count*fft_size host floats, |X|^2 DC-shifted.
+ * 0 ok, -1 error (batch_count <= 0 or > batch_size, opencl/burst_fft.c:325-326)
+ * => the caller discards the batch (burst_detect.c:659-665). */
+int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, float *output,
+                          int batch_count);
+
+/* Same computation on device-resident buffers (no H2D/D2H); stream is a
+ * hipStream_t passed as void* (NULL = default stream).  Asynchronous. */
+int gpu_burst_fft_process_device(gpu_burst_fft_t *g, const void *d_input, void *d_output,
+                                 int batch_count, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* 2. Batched pipeline                                                  */
+/* ------------------------------------------------------------------ */
+
+#define IRDM_FMT_CI8  0   /* options.c FMT_CI8  */
+#define IRDM_FMT_CI16 1   /* options.c FMT_CI16: ingested as (int8)(v >> 8), main.c:245-246 */
+#define IRDM_FMT_CF32 2   /* options.c FMT_CF32 */
+
+typedef struct {
+    double center_frequency;   /* -c, burst_config_t.center_frequency (burst_detect.h:52) */
+    int sample_rate;           /* -r, burst_config_t.sample_rate */
+    float threshold_db;        /* -d; <= 0 -> 16 dB (iridium.h:37) */
+    int format;                /* IRDM_FMT_* */
+    int feed_block;            /* samples per reference feed call; 0 -> 32768 (main.c:225).
+                                  Results equal the reference fed in blocks of this size. */
+    int use_gardner;           /* main.c:143 default 1; 0 = --no-gardner */
+    uint64_t start_time_ns;    /* replaces the wall clock read at burst_detect.c:849-853; 0 -> now */
+    int device;                /* HIP device ordinal */
+    size_t max_chunk_samples;  /* largest chunk passed to irdm_feed_*; 0 -> 64 Mi */
+    int max_bursts_per_chunk;  /* 0 -> 8192 */
+} irdm_config_t;
+
+/* burst_info_t (burst_detect.h:29-37) + what emit_gone_bursts adds (burst_detect.c:703-742) */
+typedef struct {
+    uint64_t id;
+    uint64_t start;
+    uint64_t stop;
+    uint64_t last_active;
+    int32_t center_bin;
+    float magnitude;           /* dB */
+    float noise;               /* dBFS/Hz */
+    float peak_rel;            /* raw relative magnitude of the creating peak */
+    float base_sum;            /* baseline_sum[center_bin] at creation */
+    uint64_t num_samples;      /* burst_data_t.num_samples */
+    uint64_t avail_end;        /* sample_count at extraction time */
+} irdm_burst_t;
+
+#define IRDM_MAX_FRAME_SAMPLES 4440     /* IR_MAX_FRAME_LENGTH_SIMPLEX * 10 sps */
+#define IRDM_MAX_BITS 896
+
+/* downmix_frame_t (burst_downmix.h:32-51) without the sample pointer, plus stage probes */
+typedef struct {
+    uint64_t id;
+    uint64_t timestamp;
+    double center_frequency;
+    float sample_rate;
+    float samples_per_symbol;
+    int32_t direction;         /* ir_direction_t */
+    float magnitude;
+    float noise;
+    float uw_start;
+    int32_t num_samples;
+    int32_t dec_len;
+    int32_t start;
+    float center_offset;
+    int32_t uw_start_idx;
+    float corr_re, corr_im;
+    int32_t drop_reason;       /* 0 = frame produced; 1..5 = the reference's five early returns
+                                  (burst_downmix.c:645, :677, :702, :744, :773) */
+} irdm_frame_info_t;
+
+/* demod_frame_t (qpsk_demod.h:24-38), bits/llr inline */
+typedef struct {
+    uint64_t id;
+    uint64_t timestamp;
+    double center_frequency;
+    int32_t direction;
+    float magnitude;
+    float noise;
+    int32_t confidence;
+    float level;
+    int32_t n_symbols;
+    int32_t n_payload_symbols;
+    int32_t n_bits;
+    int32_t ok;
+    float total_phase;
+    uint8_t bits[IRDM_MAX_BITS];
+    float llr[IRDM_MAX_BITS];
+} irdm_demod_t;
+
+typedef struct irdm_pipeline irdm_pipeline_t;
+
+/* burst_detector_create + burst_downmix_create (burst_detect.c:174, burst_downmix.c:223):
+ * derives every constant the reference derives, designs the filters on the host with the
+ * host libm, uploads them.  NULL on failure (no device, bad config, allocation). */
+irdm_pipeline_t *irdm_create(const irdm_config_t *cfg);
+void irdm_destroy(irdm_pipeline_t *p);
+
+/* burst_detector_feed / _feed_cf32 (burst_detect.h:74-79) for a whole chunk.
+ * n_samples must be a multiple of feed_block except for the last chunk of the stream.
+ * _device: d_iq is a device pointer in the configured format, stream = hipStream_t or NULL;
+ * the call returns after the chunk is fully processed (results pollable).
+ * Returns the number of bursts emitted by this chunk, or -1 on error. */
+int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
+int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples);
+
+/* Results of all chunks fed so far, in burst-emission order; each call drains up to max
+ * entries.  bursts: one per emitted burst (burst_callback_t payload minus samples).
+ * frames: one per emitted burst (drop_reason says whether a frame was produced).
+ * demods: one per frame that passed the unique-word check (frame_output_print input). */
+int irdm_poll_bursts(irdm_pipeline_t *p, irdm_burst_t *out, int max);
+int irdm_poll_frames(irdm_pipeline_t *p, irdm_frame_info_t *out, float *samples_out /* max*2*4440 or NULL */, int max);
+int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max);
+
+/* "tagged N bursts total" (burst_detect.c:350-351) and stat_sample_count (main.c:199) */
+uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p);
+uint64_t irdm_sample_count(const irdm_pipeline_t *p);
+int irdm_fft_size(const irdm_pipeline_t *p);
+
+/* Stage probes (parity tests): magnitudes of the last chunk (frames x fft_size floats,
+ * device -> host copy), current baseline sum. */
+int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_frames);
+int irdm_baseline_sum(irdm_pipeline_t *p, float *out);
+/* burst_data_t.samples of the i-th burst emitted by the LAST chunk (re-gathered) */
+int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float *out, size_t max_samples);
+
+/* per-stage device time of the last chunk in milliseconds (hipEvent):
+ * [0] fft+mag  [1] detector scan  [2] rotate+FIR decimate  [3] downmix post  [4] demod  [5] total */
+int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n);
+
+/* ------------------------------------------------------------------ */
+/* 3. RAW line (frame_output.c:160-199)                                 */
+/* ------------------------------------------------------------------ */
+/* t0_io: 0 on first call -> set as ensure_initialized does (frame_output.c:144-158).
+ * file_info NULL/"" -> "i-<t0 s>-t1".  Returns the line length incl. '\n', or -1. */
+int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uint64_t *t0_io,
+                    char *buf, size_t cap);
+
+const char *irdm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

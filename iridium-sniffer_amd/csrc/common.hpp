@@ -1,0 +1,108 @@
+// common.hpp -- shared device/host helpers for the gfx950 Iridium hot path.
+//
+// Arithmetic contract (DESIGN.md "Arithmetic contract"): every float operation
+// on the data path is a separately rounded IEEE-754 binary32 add/sub/mul/div,
+// in the order the reference's scalar C code performs it.  This translation
+// unit is compiled with -ffp-contract=off so hipcc never fuses a*b+c.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define IRDM_HIP_CHECK(expr)                                                        \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            fprintf(stderr, "irdm_hip: %s failed: %s (%s:%d)\n", #expr,             \
+                    hipGetErrorString(_e), __FILE__, __LINE__);                     \
+            return -1;                                                              \
+        }                                                                           \
+    } while (0)
+
+#define IRDM_HIP_CHECK_NULL(expr)                                                   \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            fprintf(stderr, "irdm_hip: %s failed: %s (%s:%d)\n", #expr,             \
+                    hipGetErrorString(_e), __FILE__, __LINE__);                     \
+            return nullptr;                                                         \
+        }                                                                           \
+    } while (0)
+
+namespace irdm {
+
+// C99 Annex G complex product for finite operands, as GCC emits it for
+// `float complex * float complex` (rotator.h:38-39, burst_downmix.c:554-555,
+// qpsk_demod.c:153): (a+bi)(c+di) = (ac - bd) + (ad + bc)i, four rounded products.
+__host__ __device__ __forceinline__ float2 cmul(float2 x, float2 y)
+{
+    float ac = x.x * y.x, bd = x.y * y.y, ad = x.x * y.y, bc = x.y * y.x;
+    return make_float2(ac - bd, ad + bc);
+}
+
+__host__ __device__ __forceinline__ float mag2(float2 v)
+{
+    float a = v.x * v.x, b = v.y * v.y;
+    return a + b;
+}
+
+// glibc 2.35 cabsf/hypotf for finite inputs: sqrt in double of the exactly
+// representable double sum of squares, rounded once to float
+// (sysdeps/ieee754/flt-32/e_hypotf.c).  Checked against the host libm in
+// tests/test_host_math.py via irdm_test_cabsf.
+__host__ __device__ __forceinline__ float cabs_f(float2 v)
+{
+    double x = (double)v.x, y = (double)v.y;
+    return (float)sqrt(x * x + y * y);
+}
+
+// ---- pinned FFT: radix-2 decimation in time (DESIGN.md "Pinned FFT") ----
+// The data sits in LDS in bit-reversed order on entry and natural order on exit.
+// tw[k] = (float)cos(2 pi k/N), (float)(-sin(2 pi k/N)), k < N/2, tw[0]=(1,0),
+// tw[N/4]=(0,-1) exact; W.b is the four-product form; the two exact twiddles are
+// applied as copies/swaps.  DIR=-1 forward, +1 backward (conjugated twiddles).
+template <int LOGN, int NT, int DIR>
+__device__ __forceinline__ void fft_lds_radix2(float2 *s, const float2 *__restrict__ tw)
+{
+    constexpr int N = 1 << LOGN;
+    const int tid = threadIdx.x;
+#pragma unroll 1
+    for (int st = 1; st <= LOGN; st++) {
+        const int half = 1 << (st - 1);
+        const int sh = LOGN - st;
+        for (int b = tid; b < N / 2; b += NT) {
+            const int j = b & (half - 1);
+            const int i0 = ((b >> (st - 1)) << st) + j;
+            const int i1 = i0 + half;
+            const int tix = j << sh;
+            float2 a = s[i0], v = s[i1], t;
+            if (tix == 0) {
+                t = v;
+            } else if (tix == N / 4) {
+                t = DIR < 0 ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+            } else {
+                float2 w = tw[tix];
+                if (DIR > 0) w.y = -w.y;
+                t = cmul(w, v);
+            }
+            s[i0] = make_float2(a.x + t.x, a.y + t.y);
+            s[i1] = make_float2(a.x - t.x, a.y - t.y);
+        }
+        __syncthreads();
+    }
+}
+
+__host__ __device__ __forceinline__ unsigned bitrev(unsigned v, int bits)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - bits);
+#else
+    unsigned r = 0;
+    for (int b = 0; b < bits; b++)
+        if (v & (1u << b)) r |= 1u << (bits - 1 - b);
+    return r;
+#endif
+}
+
+}  // namespace irdm

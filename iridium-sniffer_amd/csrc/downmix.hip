@@ -1,0 +1,493 @@
+// downmix.hip -- stage B on gfx950 (burst_downmix.c:643-797), batched over bursts.
+//
+//   rotator checkpoint table   rotator.h:36-46 recurrence, one lane per FFT bin (create time)
+//   fir_decimate_kernel        step 1+2: coarse rotate fused into the 801-tap /M decimator
+//   downmix_post1_kernel       step 2b noise LPF, step 3 find_burst_start, step 4 fine CFO (FFT 4096)
+//   downmix_post2_kernel       step 5 fine rotate, step 6 RRC, step 7 sync correlation
+//                              (FFT 2048 + 2 x IFFT 2048), step 8 phase align, step 9 frame cut
+#include "common.hpp"
+#include "types.hpp"
+#include "kernels.hpp"
+
+namespace irdm {
+
+// ---- burst window sample access (ringbuf_extract, burst_detect.c:401-422) ----
+// Samples at absolute index >= avail_end had not been written when the reference
+// extracted the burst: it read whatever the ring slot held, i.e. the sample one
+// ring length earlier (or the zero page before the ring first wrapped).
+__device__ __forceinline__ float2 load_abs(const SampleSource &src, uint64_t a)
+{
+    if (src.fmt == 2) {
+        if (a >= src.chunk_start)
+            return reinterpret_cast<const float2 *>(src.chunk)[a - src.chunk_start];
+        return reinterpret_cast<const float2 *>(src.ring)[a % src.ring_len];
+    } else {
+        char2 v;
+        if (a >= src.chunk_start)
+            v = reinterpret_cast<const char2 *>(src.chunk)[a - src.chunk_start];
+        else
+            v = reinterpret_cast<const char2 *>(src.ring)[a % src.ring_len];
+        return make_float2((float)v.x / 128.0f, (float)v.y / 128.0f);
+    }
+}
+
+__device__ __forceinline__ float2 burst_sample(const SampleSource &src, uint64_t start,
+                                               uint64_t avail_end, int k)
+{
+    uint64_t a = start + (uint64_t)k;
+    if (a >= avail_end) {
+        if (a < src.ref_ring) return make_float2(0.0f, 0.0f);
+        a -= src.ref_ring;
+    }
+    return load_abs(src, a);
+}
+
+// ---------------------------------------------------------------------------
+// Rotator checkpoint table: phase_k of the float recurrence phase *= incr
+// (rotator.h:38-39) for k = 0, 16, 32, ...; one lane per FFT bin.  The sequence
+// depends only on the burst's centre bin (rotator_init per burst,
+// burst_downmix.c:666-669), so it is computed once and kept in HBM.
+// ---------------------------------------------------------------------------
+__global__ void rotator_table_kernel(const float2 *__restrict__ incr, float2 *__restrict__ table,
+                                     int n_bins, int n_ckpt)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= n_bins) return;
+    const float2 inc = incr[bin];
+    float2 ph = make_float2(1.0f, 0.0f);
+    float2 *row = table + (size_t)bin * n_ckpt;
+    for (int c = 0; c < n_ckpt; c++) {
+        row[c] = ph;
+#pragma unroll
+        for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
+    }
+}
+
+int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rotator_table_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, stream, incr,
+                       table, n_bins, n_ckpt);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------
+// Rotate + decimate.  One workgroup = kFirTileOut outputs of one burst.
+//   staging : samples [o0*M, o0*M + (nout-1)*M + 801) of the burst window are read
+//             once (coalesced by 16-sample segments), rotated exactly as
+//             rotator_rotate_n would (phase restored from the checkpoint table,
+//             continued by the float recurrence), and written to LDS in polyphase
+//             order  lds[(s % M) * ROW + s / M]  so that the tap loop reads
+//             consecutive addresses across lanes (no bank conflicts).
+//   taps    : out[i] = sum_{k<801} t[k] * x[i*M + k], k ascending, real x complex =
+//             two independent mul+add chains (simd_generic.c:86-96).
+// Algorithmic HBM bytes: 8 B (cf32) per burst-window sample in, 8 B per output.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
+    SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
+    int decim, int row, const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *s = reinterpret_cast<float2 *>(smem_raw);
+    const int tid = threadIdx.x;
+    const FirTile tile = tiles[blockIdx.x];
+    const BurstWork w = work[tile.burst];
+    const int o0 = tile.first_out;
+    int n_out = w.dec_len - o0;
+    if (n_out > kFirTileOut) n_out = kFirTileOut;
+    const int span = (n_out - 1) * decim + kFirTaps;
+    const int s0 = o0 * decim;                       // multiple of kRotSeg
+    const float2 inc = rot_incr[w.center_bin];
+    const float2 *ck = rot_table + (size_t)w.center_bin * n_ckpt + s0 / kRotSeg;
+    const int n_seg = (span + kRotSeg - 1) / kRotSeg;
+
+    for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
+        float2 ph = ck[seg];
+        const int k0 = seg * kRotSeg;
+        int p = k0 % decim, q = k0 / decim;
+#pragma unroll 4
+        for (int u = 0; u < kRotSeg; u++) {
+            const int k = k0 + u;
+            if (k < span) {
+                const float2 x = burst_sample(src, w.start, w.avail_end, s0 + k);
+                s[p * row + q] = cmul(x, ph);        // out[i] = in[i] * phase (rotator.h:38)
+                ph = cmul(ph, inc);                  // phase *= incr          (rotator.h:39)
+            }
+            if (++p == decim) { p = 0; q++; }
+        }
+    }
+    __syncthreads();
+
+    if (tid < n_out) {
+        float ar = 0.0f, ai = 0.0f;
+        int k = 0;
+        for (int q = 0; k < kFirTaps; q++) {
+            const float2 *col = s + tid + q;
+            const int pmax = (kFirTaps - k) < decim ? (kFirTaps - k) : decim;
+            for (int p = 0; p < pmax; p++, k++) {
+                const float t = taps[k];
+                const float2 v = col[p * row];
+                ar += t * v.x;
+                ai += t * v.y;
+            }
+        }
+        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(ar, ai);
+    }
+}
+
+static int fir_row(int decim)
+{
+    int r = kFirTileOut + kFirTaps / decim + 2;
+    while ((r & 15) != 1) r++;
+    return r;
+}
+
+int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
+                        int n_tiles, int decim, const float *taps, const float2 *rot_incr,
+                        const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
+                        hipStream_t stream)
+{
+    if (n_tiles <= 0) return 0;
+    const int row = fir_row(decim);
+    const size_t lds = sizeof(float2) * (size_t)row * decim;
+    if (lds > 160 * 1024) return -1;
+    (void)hipFuncSetAttribute((const void *)fir_decimate_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
+                       tiles, decim, row, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// burst_data_t.samples re-gathered (stage probe for parity tests)
+__global__ void gather_burst_kernel(SampleSource src, uint64_t start, uint64_t avail_end, int n,
+                                    float2 *__restrict__ out)
+{
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x)
+        out[k] = burst_sample(src, start, avail_end, k);
+}
+
+int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
+                        float2 *out, hipStream_t stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gather_burst_kernel, dim3(256), dim3(256), 0, stream, src, start, avail_end, n, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- block reductions (256 threads) ----
+__device__ __forceinline__ float block_max(float v, float *red)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_down(v, off);
+        v = o > v ? o : v;
+    }
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = red[i] > r ? red[i] : r;
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ int block_min_int(int v, int *red)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_down(v, off);
+        v = o < v ? o : v;
+    }
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    int r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = red[i] < r ? red[i] : r;
+    __syncthreads();
+    return r;
+}
+
+// first-strict-max semantics of `if (m > max) { max = m; idx = i; }` (burst_downmix.c:497-505,
+// :565-586): larger value wins, ties keep the lower index, start value (0, 0)
+__device__ __forceinline__ void argmax_combine(float &m, int &i, float om, int oi)
+{
+    if (om > m || (om == m && oi < i)) { m = om; i = oi; }
+}
+
+__device__ __forceinline__ void block_argmax(float &m, int &i, float *redf, int *redi)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_down(m, off);
+        const int oi = __shfl_down(i, off);
+        argmax_combine(m, i, om, oi);
+    }
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { redf[tid >> 6] = m; redi[tid >> 6] = i; }
+    __syncthreads();
+    m = redf[0]; i = redi[0];
+    for (int k = 1; k < (int)(blockDim.x >> 6); k++) argmax_combine(m, i, redf[k], redi[k]);
+    __syncthreads();
+}
+
+__device__ __forceinline__ float parabolic(float alpha, float beta, float gamma)
+{
+    const float denom = alpha - 2.0f * beta + gamma;
+    if (fabsf(denom) > 1e-10f) return 0.5f * (alpha - gamma) / denom;
+    return 0.0f;
+}
+
+constexpr int kPostThreads = 256;
+
+// ---------------------------------------------------------------------------
+// post1: one workgroup per burst.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
+    BurstWork *__restrict__ work, const float2 *__restrict__ dec, int dec_stride,
+    float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps,
+    const float *__restrict__ start_taps, int start_ntaps, int search_depth, int pre_start,
+    const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096)
+{
+    __shared__ __attribute__((aligned(16))) float2 s[kCfoTotal];
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    const int tid = threadIdx.x;
+    BurstWork &w = work[blockIdx.x];
+    if (w.drop_reason != 0) return;
+    const int dec_len = w.dec_len;
+    const float2 *x = dec + (size_t)blockIdx.x * dec_stride;
+    float2 *y = lpf + (size_t)blockIdx.x * dec_stride;
+
+    // step 2b (burst_downmix.c:683-698): centred 25-tap LPF over the zero-padded burst
+    if (dec_len - noise_ntaps + 1 > 0) {
+        const int half = (noise_ntaps - 1) / 2;
+        for (int i = tid; i < dec_len; i += kPostThreads) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int k = 0; k < noise_ntaps; k++) {
+                const int j = i + k - half;
+                const float2 v = (j >= 0 && j < dec_len) ? x[j] : make_float2(0.0f, 0.0f);
+                const float t = noise_taps[k];
+                ar += t * v.x;
+                ai += t * v.y;
+            }
+            y[i] = make_float2(ar, ai);
+        }
+    } else {
+        for (int i = tid; i < dec_len; i += kPostThreads) y[i] = x[i];
+    }
+    __syncthreads();
+
+    // step 3 (burst_downmix.c:441-478)
+    int search = search_depth < dec_len ? search_depth : dec_len;
+    int mag_len = search + start_ntaps - 1;
+    if (mag_len > dec_len) mag_len = dec_len;
+    int flen = mag_len - start_ntaps + 1;
+    int start = 0;
+    if (flen > 0) {
+        if (flen > search) flen = search;
+        auto filt = [&](int i) {
+            float acc = 0.0f;
+            for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * mag2(y[i + k]);
+            return acc;
+        };
+        float mx = -1e30f;
+        for (int i = tid; i < flen; i += kPostThreads) {
+            const float v = filt(i);
+            mx = v > mx ? v : mx;
+        }
+        mx = block_max(mx, redf);
+        const float thr = 0.45f * mx;                       // START_THRESHOLD
+        int first = flen;
+        for (int i = tid; i < flen; i += kPostThreads) {
+            if (filt(i) >= thr) { first = i; break; }
+        }
+        start = block_min_int(first, redi);
+        if (start > 0) {
+            start = start + (start_ntaps - 1) / 2 - pre_start;
+            if (start < 0) start = 0;
+        }
+    }
+    if (start >= dec_len - 100) {                           // burst_downmix.c:702-705
+        if (tid == 0) { w.start_idx = start; w.drop_reason = 3; }
+        return;
+    }
+    const int frame_len = dec_len - start;
+
+    // step 4 (burst_downmix.c:482-535): x^2 * blackman(256), zero-padded 4096-pt FFT
+    int n = kCfoN < frame_len ? kCfoN : frame_len;
+    for (int i = tid; i < kCfoTotal; i += kPostThreads) {
+        float2 v = make_float2(0.0f, 0.0f);
+        if (i < n) {
+            const float2 sv = y[start + i];
+            const float2 sq = cmul(sv, sv);                 // simd_csquare_window: (s*s)*w
+            const float wv = cfo_window[i];
+            v = make_float2(sq.x * wv, sq.y * wv);
+        }
+        s[bitrev((unsigned)i, 12)] = v;
+    }
+    __syncthreads();
+    fft_lds_radix2<12, kPostThreads, -1>(s, tw4096);
+    float bm = 0.0f;
+    int bi = 0;
+    for (int i = tid; i < kCfoTotal; i += kPostThreads) {
+        const float m = mag2(s[i]);
+        if (m > bm) { bm = m; bi = i; }
+    }
+    block_argmax(bm, bi, redf, redi);
+    if (tid == 0) {
+        const int idx = bi >= kCfoTotal / 2 ? bi - kCfoTotal : bi;
+        float corr = 0.0f;
+        if (bi > 0 && bi < kCfoTotal - 1) {
+            const int im1 = idx - 1 < 0 ? idx - 1 + kCfoTotal : idx - 1;
+            const int ip1 = idx + 1 < 0 ? idx + 1 + kCfoTotal : idx + 1;
+            corr = parabolic(mag2(s[im1]), bm, mag2(s[ip1]));
+        }
+        w.start_idx = start;
+        w.center_offset = ((float)idx + corr) / (float)kCfoTotal / 2.0f;
+    }
+}
+
+int launch_downmix_post1(BurstWork *work, int n_bursts, const float2 *dec, int dec_stride,
+                         float2 *lpf, const float *noise_taps, int noise_ntaps,
+                         const float *start_taps, int start_ntaps, int search_depth, int pre_start,
+                         const float *cfo_window, const float2 *tw4096, hipStream_t stream)
+{
+    if (n_bursts <= 0) return 0;
+    hipLaunchKernelGGL(downmix_post1_kernel, dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
+                       dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
+                       pre_start, cfo_window, tw4096);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------
+// post2: one workgroup per burst.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
+    BurstWork *__restrict__ work, const float2 *__restrict__ lpf, int dec_stride,
+    const float *__restrict__ rrc_taps, int rrc_ntaps, const float2 *__restrict__ tw2048,
+    const float2 *__restrict__ dl_fft, const float2 *__restrict__ ul_fft, int dl_len, int ul_len,
+    float sps, float2 *__restrict__ rrc_ws, float2 *__restrict__ frames)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *rot = reinterpret_cast<float2 *>(smem_raw);          // kFrameNeed
+    float2 *fa = rot + kFrameNeed;                               // kCorrN
+    float2 *fd = fa + kCorrN;                                    // kCorrN
+    float2 *fu = fd + kCorrN;                                    // kCorrN
+    float *redf = reinterpret_cast<float *>(fu + kCorrN);
+    int *redi = reinterpret_cast<int *>(redf + 4);
+    const int tid = threadIdx.x;
+    BurstWork &w = work[blockIdx.x];
+    if (w.drop_reason != 0) return;
+    const int start = w.start_idx;
+    const int frame_len = w.dec_len - start;
+    const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+    const float2 *x = lpf + (size_t)blockIdx.x * dec_stride + start;
+    float2 *r = rrc_ws + (size_t)blockIdx.x * kFrameNeed;
+
+    // step 5 (burst_downmix.c:713-720): sequential float recurrence, phase_0 = 1
+    if (tid == 0) {
+        const float2 inc = make_float2(w.incr_re, w.incr_im);
+        float2 ph = make_float2(1.0f, 0.0f);
+        for (int k = 0; k < L; k++) {
+            rot[k] = ph;
+            ph = cmul(ph, inc);
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < L; k += kPostThreads) rot[k] = cmul(x[k], rot[k]);
+    __syncthreads();
+
+    // step 6 (burst_downmix.c:723-734): centred 51-tap RRC over the zero-padded frame
+    const int half = (rrc_ntaps - 1) / 2;
+    for (int i = tid; i < L; i += kPostThreads) {
+        float ar = 0.0f, ai = 0.0f;
+        for (int k = 0; k < rrc_ntaps; k++) {
+            const int j = i + k - half;
+            // j >= L only for outputs that can never reach the frame (kFrameNeed margin)
+            const float2 v = (j >= 0 && j < L) ? rot[j] : make_float2(0.0f, 0.0f);
+            const float t = rrc_taps[k];
+            ar += t * v.x;
+            ai += t * v.y;
+        }
+        r[i] = make_float2(ar, ai);
+    }
+    __syncthreads();
+
+    // step 7 (burst_downmix.c:539-639)
+    const int sl = kSyncSearch < frame_len ? kSyncSearch : frame_len;
+    for (int i = tid; i < kCorrN; i += kPostThreads)
+        fa[bitrev((unsigned)i, 11)] = i < sl ? r[i] : make_float2(0.0f, 0.0f);
+    __syncthreads();
+    fft_lds_radix2<11, kPostThreads, -1>(fa, tw2048);
+    for (int i = tid; i < kCorrN; i += kPostThreads) {
+        const float2 v = fa[i];
+        const unsigned br = bitrev((unsigned)i, 11);
+        fd[br] = cmul(v, dl_fft[i]);
+        fu[br] = cmul(v, ul_fft[i]);
+    }
+    __syncthreads();
+    fft_lds_radix2<11, kPostThreads, +1>(fd, tw2048);
+    fft_lds_radix2<11, kPostThreads, +1>(fu, tw2048);
+    float mdl = 0.0f, mul = 0.0f;
+    int odl = 0, oul = 0;
+    for (int i = tid; i < sl; i += kPostThreads) {
+        const float a = mag2(fd[i]);
+        if (a > mdl) { mdl = a; odl = i; }
+        const float b = mag2(fu[i]);
+        if (b > mul) { mul = b; oul = i; }
+    }
+    block_argmax(mdl, odl, redf, redi);
+    block_argmax(mul, oul, redf, redi);
+
+    int direction, off, slen;
+    const float2 *res;
+    if (mdl >= mul) { direction = 1; off = odl; res = fd; slen = dl_len; }
+    else            { direction = 2; off = oul; res = fu; slen = ul_len; }
+    const float2 peak = res[off];
+    float corr = 0.0f;
+    if (off > 0 && off < sl - 1)
+        corr = parabolic(mag2(res[off - 1]), mag2(res[off]), mag2(res[off + 1]));
+    const int pre_syms = direction == 1 ? 16 : 32;                 // burst_downmix.c:633-634
+    const int uw_start = off - slen + 1 + (int)(pre_syms * sps);
+
+    int drop = 0, ext = 0;
+    if (uw_start < 0 || uw_start >= frame_len) {
+        drop = 4;                                                  // burst_downmix.c:744-747
+    } else {
+        const int max_len = (int)((w.simplex ? 444 : 191) * sps);  // iridium.h:23-27
+        const int min_len = (int)((w.simplex ? 80 : 131) * sps);
+        const int avail = frame_len - uw_start;
+        if (avail < min_len) drop = 5;                             // burst_downmix.c:773-776
+        else ext = avail < max_len ? avail : max_len;
+    }
+    if (!drop) {
+        // step 8 (burst_downmix.c:750-760): constant phase conj(peak/|peak|), incr = 1
+        const float mag = cabs_f(peak);
+        const float2 pc = mag > 0 ? make_float2(peak.x / mag, -(peak.y / mag)) : make_float2(1.0f, 0.0f);
+        float2 *out = frames + (size_t)blockIdx.x * kMaxFrameSamples;
+        for (int k = tid; k < ext; k += kPostThreads) out[k] = cmul(r[uw_start + k], pc);
+    }
+    if (tid == 0) {
+        w.direction = direction;
+        w.uw_start = uw_start;
+        w.uw_corr = corr;
+        w.corr_re = peak.x;
+        w.corr_im = peak.y;
+        w.num_samples = ext;
+        w.drop_reason = drop;
+    }
+}
+
+int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
+                         const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
+                         const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
+                         float sps, float2 *rrc_ws, float2 *frames, hipStream_t stream)
+{
+    if (n_bursts <= 0) return 0;
+    const size_t lds = sizeof(float2) * (kFrameNeed + 3 * kCorrN) + 64;
+    (void)hipFuncSetAttribute((const void *)downmix_post2_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(downmix_post2_kernel, dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
+                       dec_stride, rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
+                       rrc_ws, frames);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace irdm

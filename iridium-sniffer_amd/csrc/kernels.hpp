@@ -1,0 +1,47 @@
+// kernels.hpp -- host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "types.hpp"
+
+namespace irdm {
+
+// detect.hip
+int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
+                   float *mag, int n_frames, hipStream_t stream);
+int launch_detect_scan(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
+                       int n_frames, GoneBurst *gone, int gone_cap, PeakCand *cand_a,
+                       PeakCand *cand_b, hipStream_t stream);
+
+// where a burst window's samples live: the chunk being fed, or the history ring
+struct SampleSource {
+    const void *chunk;        // device pointer, configured format
+    uint64_t chunk_start;     // absolute index of chunk[0]
+    uint64_t chunk_end;
+    const void *ring;         // history ring, same format, indexed by absolute index % ring_len
+    uint64_t ring_len;
+    uint64_t ref_ring;        // the REFERENCE's ring size (burst_detect.c:292-296): stale slot = a - ref_ring
+    int fmt;                  // 0 ci8, 2 cf32
+};
+
+// downmix.hip
+int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream);
+int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
+                        int n_tiles, int decim, const float *taps, const float2 *rot_incr,
+                        const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
+                        hipStream_t stream);
+int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
+                        float2 *out, hipStream_t stream);
+int launch_downmix_post1(BurstWork *work, int n_bursts, const float2 *dec, int dec_stride,
+                         float2 *lpf, const float *noise_taps, int noise_ntaps,
+                         const float *start_taps, int start_ntaps, int search_depth, int pre_start,
+                         const float *cfo_window, const float2 *tw4096, hipStream_t stream);
+int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
+                         const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
+                         const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
+                         float sps, float2 *rrc_ws, float2 *frames, hipStream_t stream);
+
+// demod.hip
+int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,
+                 float sps, float2 *ws, DemodOut *out, hipStream_t stream);
+
+}  // namespace irdm

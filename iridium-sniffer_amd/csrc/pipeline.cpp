@@ -1,0 +1,772 @@
+// pipeline.cpp -- host orchestration + C-ABI (include/irdm_hip.h).
+//
+// One context = one stream of IQ on one GPU, driven by one host thread (the
+// reference's convention for gpu_burst_fft_t / burst_downmix_t contexts,
+// burst_downmix.c:107-112).  Per chunk:
+//
+//   K1 fft_mag            all frames of the chunk, parallel           (detect.hip)
+//   K2 detect_scan        sequential detector state machine            (detect.hip)
+//   -- host: burst records (dB fields with the host libm), work list --
+//   K4 fir_decimate       rotate + 801-tap /M, tiles over all bursts   (downmix.hip)
+//   K5 downmix_post1      noise LPF, start, fine CFO                   (downmix.hip)
+//   -- host: cexpf of the fine CFO with the host libm --
+//   K6 downmix_post2      rotate, RRC, sync correlation, align, cut    (downmix.hip)
+//   K7 demod              Gardner / PLL / slicer / UW / DQPSK          (demod.hip)
+//   -- host: records appended to the result queues; history ring updated --
+#include <math.h>
+#include <string.h>
+#include <time.h>
+
+#include <algorithm>
+#include <deque>
+#include <new>
+#include <vector>
+
+#include "../../include/irdm_hip.h"
+#include "common.hpp"
+#include "host_design.hpp"
+#include "kernels.hpp"
+#include "types.hpp"
+
+using namespace irdm;
+
+namespace {
+
+template <typename T>
+T *dev_alloc(size_t count)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, count * sizeof(T)) != hipSuccess) return nullptr;
+    return static_cast<T *>(p);
+}
+
+template <typename T>
+T *dev_upload(const T *src, size_t count)
+{
+    T *p = dev_alloc<T>(count);
+    if (!p) return nullptr;
+    if (hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
+    return p;
+}
+
+int ilog2(int n)
+{
+    int l = 0;
+    while ((1 << l) < n) l++;
+    return (1 << l) == n ? l : -1;
+}
+
+}  // namespace
+
+// ===========================================================================
+// 1. gpu_burst_fft_* : the reference's plug point (opencl/burst_fft.h:35-47)
+// ===========================================================================
+struct gpu_burst_fft {
+    int n, log_n, batch;
+    float *d_window;
+    float2 *d_tw;
+    float2 *d_in;
+    float *d_out;
+    hipStream_t stream;
+};
+
+extern "C" gpu_burst_fft_t *gpu_burst_fft_create(int fft_size, int batch_size, const float *window)
+{
+    const int lg = ilog2(fft_size);
+    if (lg < 8 || lg > 14 || batch_size <= 0 || !window) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "irdm_hip: no HIP device\n");
+        return nullptr;
+    }
+    gpu_burst_fft *g = new (std::nothrow) gpu_burst_fft();
+    if (!g) return nullptr;
+    g->n = fft_size;
+    g->log_n = lg;
+    g->batch = batch_size;
+    std::vector<cfloat> tw = design_twiddles(fft_size);
+    g->d_window = dev_upload(window, (size_t)fft_size);
+    g->d_tw = reinterpret_cast<float2 *>(dev_upload(tw.data(), tw.size()));
+    g->d_in = dev_alloc<float2>((size_t)fft_size * batch_size);
+    g->d_out = dev_alloc<float>((size_t)fft_size * batch_size);
+    g->stream = nullptr;
+    if (!g->d_window || !g->d_tw || !g->d_in || !g->d_out ||
+        hipStreamCreate(&g->stream) != hipSuccess) {
+        gpu_burst_fft_destroy(g);
+        return nullptr;
+    }
+    return g;
+}
+
+extern "C" void gpu_burst_fft_destroy(gpu_burst_fft_t *g)
+{
+    if (!g) return;
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    (void)hipFree(g->d_window);
+    (void)hipFree(g->d_tw);
+    (void)hipFree(g->d_in);
+    (void)hipFree(g->d_out);
+    delete g;
+}
+
+extern "C" int gpu_burst_fft_process_device(gpu_burst_fft_t *g, const void *d_input, void *d_output,
+                                            int batch_count, void *stream)
+{
+    if (!g || !d_input || !d_output || batch_count <= 0) return -1;
+    return launch_fft_mag(g->log_n, 2, d_input, g->d_window, g->d_tw, static_cast<float *>(d_output),
+                          batch_count, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, float *output,
+                                     int batch_count)
+{
+    if (!g || !input || !output) return -1;
+    if (batch_count <= 0 || batch_count > g->batch) return -1;       // opencl/burst_fft.c:325-326
+    const size_t ns = (size_t)g->n * batch_count;
+    IRDM_HIP_CHECK(hipMemcpyAsync(g->d_in, input, ns * sizeof(float2), hipMemcpyHostToDevice, g->stream));
+    if (launch_fft_mag(g->log_n, 2, g->d_in, g->d_window, g->d_tw, g->d_out, batch_count, g->stream) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipMemcpyAsync(output, g->d_out, ns * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+// ===========================================================================
+// 2. batched pipeline
+// ===========================================================================
+struct irdm_pipeline {
+    irdm_config_t cfg;
+    DetParams P;
+    int dev_fmt;                // 0 ci8, 2 cf32 (ci16 is narrowed to ci8 on ingest, main.c:245-246)
+    size_t bps;                 // bytes per device sample
+    int feed_block, decim, out_rate;
+    float sps;
+    uint64_t ref_ring, ring_len;
+    size_t l_cap;
+    int n_ckpt, dec_stride, burst_cap, gone_cap;
+    size_t max_chunk;
+    int search_depth, pre_start;
+    int in_ntaps, noise_ntaps, start_ntaps, rrc_ntaps, dl_len, ul_len;
+
+    hipStream_t stream;
+    hipEvent_t ev[10];   // 0 start,1 fft,2 scan,3 pre-fir,4 fir,5 post,6 demod,7 end,8 caller sync
+
+    float *d_window, *d_hist, *d_sum, *d_mag;
+    float2 *d_tw, *d_tw4096, *d_tw2048, *d_dl_fft, *d_ul_fft, *d_rot_incr, *d_rot_table;
+    DetState *d_state;
+    GoneBurst *d_gone;
+    PeakCand *d_cand_a, *d_cand_b;
+    void *d_ring, *d_stage;
+    float *d_in_taps, *d_noise_taps, *d_start_taps, *d_rrc_taps, *d_cfo_window;
+    BurstWork *d_work;
+    FirTile *d_tiles;
+    size_t tiles_cap;
+    float2 *d_dec, *d_lpf, *d_rrc_ws, *d_frames, *d_demod_ws, *d_probe;
+    DemodOut *d_demod;
+
+    std::vector<GoneBurst> h_gone;
+    std::vector<BurstWork> h_work;
+    std::vector<FirTile> h_tiles;
+    std::vector<DemodOut> h_demod;
+    std::vector<float> h_frames;
+
+    // result queues
+    std::deque<irdm_burst_t> q_bursts;
+    std::deque<irdm_frame_info_t> q_frames;
+    std::deque<std::vector<float>> q_frame_samples;
+    std::deque<irdm_demod_t> q_demods;
+
+    uint64_t total_samples, tagged, start_time_ns;
+    bool stream_closed;
+    // last chunk (probes)
+    int last_frames;
+    const void *last_chunk;
+    uint64_t last_chunk_start, last_chunk_end;
+    std::vector<irdm_burst_t> last_bursts;
+    float last_ms[6];
+    int keep_frame_samples;
+};
+
+static void pipeline_free(irdm_pipeline *p)
+{
+    if (!p) return;
+    void *ptrs[] = { p->d_window, p->d_hist, p->d_sum, p->d_mag, p->d_tw, p->d_tw4096, p->d_tw2048,
+                     p->d_dl_fft, p->d_ul_fft, p->d_rot_incr, p->d_rot_table, p->d_state, p->d_gone,
+                     p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
+                     p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
+                     p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod };
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    for (auto &e : p->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+extern "C" void irdm_destroy(irdm_pipeline_t *p) { pipeline_free(p); }
+
+extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
+{
+    if (!cfg || cfg->sample_rate <= 0) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "irdm_hip: no HIP device -- there is no CPU fallback in this library\n");
+        return nullptr;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+
+    irdm_pipeline *p = new (std::nothrow) irdm_pipeline();
+    if (!p) return nullptr;
+    p->cfg = *cfg;
+    const int fs = cfg->sample_rate;
+
+    // ---- detector constants (burst_detect.c:180-226) ----
+    DetParams &P = p->P;
+    P.log_n = (int)round(log2(fs / 1000.0));
+    P.n = 1 << P.log_n;
+    P.pre_len = 2 * P.n;
+    P.post_len = (int)(fs * 16e-3);
+    const int burst_width_hz = 40000;                               // iridium.h:40
+    P.width = burst_width_hz / (fs / P.n);
+    P.max_bursts = (int)((fs / (float)burst_width_hz) * 0.8f);
+    P.max_len = (int)(fs * 0.09);
+    const float tdb = cfg->threshold_db > 0 ? cfg->threshold_db : 16.0f;
+    P.threshold = powf(10.0f, tdb / 10.0f) / kHistory / 1.72f;
+    if (P.n < kScanThreads || P.n > 16384 || P.max_bursts + P.n / (P.width > 0 ? P.width : 1) + 8 > kMaxActive) {
+        fprintf(stderr, "irdm_hip: unsupported sample rate %d (fft_size %d)\n", fs, P.n);
+        delete p;
+        return nullptr;
+    }
+    p->feed_block = cfg->feed_block > 0 ? cfg->feed_block : 32768;
+    if (p->feed_block % P.n != 0) {
+        fprintf(stderr, "irdm_hip: feed_block %d must be a multiple of fft_size %d\n", p->feed_block, P.n);
+        delete p;
+        return nullptr;
+    }
+    p->dev_fmt = cfg->format == IRDM_FMT_CF32 ? 2 : 0;
+    p->bps = p->dev_fmt == 2 ? 8 : 2;
+    p->max_chunk = cfg->max_chunk_samples ? cfg->max_chunk_samples : ((size_t)64 << 20);
+    p->max_chunk = (p->max_chunk + p->feed_block - 1) / p->feed_block * p->feed_block;
+    p->burst_cap = cfg->max_bursts_per_chunk > 0 ? cfg->max_bursts_per_chunk : 4096;
+    p->gone_cap = p->burst_cap;
+    p->start_time_ns = cfg->start_time_ns;
+    if (p->start_time_ns == 0) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        p->start_time_ns = ts.tv_sec * 1000000000ULL + ts.tv_nsec;
+    }
+
+    // reference ring size (burst_detect.c:292-296)
+    p->ref_ring = (uint64_t)P.max_len + P.pre_len + P.post_len + (uint64_t)P.n * 4;
+    if (p->ref_ring < (uint64_t)2 * fs) p->ref_ring = (uint64_t)2 * fs;
+    // longest possible burst window: stop - start < max_len + post_len + N, plus pre_len
+    p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
+    p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
+    p->n_ckpt = (int)(p->l_cap / kRotSeg) + 2;
+
+    // ---- downmix constants (burst_downmix.c:223-373) ----
+    p->out_rate = 10 * 25000;
+    p->sps = (float)p->out_rate / 25000;
+    p->search_depth = p->out_rate;
+    p->pre_start = (int)(100 * 1e-6f * p->out_rate);
+    p->decim = (int)roundf((float)fs / p->out_rate);
+    if (p->decim < 1) p->decim = 1;
+    p->dec_stride = (int)(p->l_cap / p->decim) + 8;
+
+    std::vector<float> in_taps = design_lpf(1.0f, 10000000.0f, p->out_rate * 0.4f, p->out_rate * 0.2f);
+    std::vector<float> noise_taps = design_lpf(1.0f, (float)p->out_rate, 40000.0f / 2.0f, 40000.0f);
+    int box = (int)(p->sps * 2);
+    if (box < 3) box = 3;
+    std::vector<float> start_taps = design_box(box);
+    std::vector<float> rrc = design_rrc(1.0f, (float)p->out_rate, 25000.0f, 0.4f, 51);
+    std::vector<float> rc = design_rc((float)p->out_rate, 25000.0f, 0.4f, 51);
+    std::vector<float> cfo_window = design_blackman(kCfoN);
+    if ((int)in_taps.size() != kFirTaps) {
+        delete p;
+        return nullptr;
+    }
+    p->in_ntaps = (int)in_taps.size();
+    p->noise_ntaps = (int)noise_taps.size();
+    p->start_ntaps = (int)start_taps.size();
+    p->rrc_ntaps = (int)rrc.size();
+    std::vector<cfloat> dl = design_sync_template(rc, kCorrN, p->sps, false, &p->dl_len);
+    std::vector<cfloat> ul = design_sync_template(rc, kCorrN, p->sps, true, &p->ul_len);
+
+    std::vector<float> window = design_blackman(P.n);
+    for (int i = 0; i < P.n; i++) window[i] /= 0.42f;               // burst_detect.c:249-250
+    std::vector<cfloat> tw = design_twiddles(P.n), tw4096 = design_twiddles(kCfoTotal),
+                        tw2048 = design_twiddles(kCorrN);
+    std::vector<cfloat> rot_incr = design_rotator_incr(P.n);
+
+    bool ok = hipStreamCreate(&p->stream) == hipSuccess;
+    for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+#define UP(dst, vec) ok = ok && ((dst = reinterpret_cast<decltype(dst)>(dev_upload((vec).data(), (vec).size()))) != nullptr)
+#define AL(dst, T, count) ok = ok && ((dst = dev_alloc<T>(count)) != nullptr)
+    UP(p->d_window, window);
+    UP(p->d_tw, tw);
+    UP(p->d_tw4096, tw4096);
+    UP(p->d_tw2048, tw2048);
+    UP(p->d_dl_fft, dl);
+    UP(p->d_ul_fft, ul);
+    UP(p->d_rot_incr, rot_incr);
+    UP(p->d_in_taps, in_taps);
+    UP(p->d_noise_taps, noise_taps);
+    UP(p->d_start_taps, start_taps);
+    UP(p->d_rrc_taps, rrc);
+    UP(p->d_cfo_window, cfo_window);
+    AL(p->d_hist, float, (size_t)kHistory * P.n);
+    AL(p->d_sum, float, (size_t)P.n);
+    AL(p->d_mag, float, p->max_chunk);
+    AL(p->d_state, DetState, 1);
+    AL(p->d_gone, GoneBurst, (size_t)p->gone_cap);
+    AL(p->d_cand_a, PeakCand, (size_t)P.n);
+    AL(p->d_cand_b, PeakCand, (size_t)P.n);
+    AL(p->d_rot_table, float2, (size_t)P.n * p->n_ckpt);
+    AL(p->d_work, BurstWork, (size_t)p->burst_cap);
+    p->tiles_cap = (size_t)p->burst_cap * 64;
+    AL(p->d_tiles, FirTile, p->tiles_cap);
+    AL(p->d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
+    AL(p->d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
+    AL(p->d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
+    AL(p->d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
+    AL(p->d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
+    AL(p->d_demod, DemodOut, (size_t)p->burst_cap);
+    AL(p->d_probe, float2, p->l_cap);
+    if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
+#undef UP
+#undef AL
+    if (!ok) {
+        fprintf(stderr, "irdm_hip: device allocation failed\n");
+        pipeline_free(p);
+        return nullptr;
+    }
+    ok = hipMemset(p->d_hist, 0, sizeof(float) * (size_t)kHistory * P.n) == hipSuccess &&
+         hipMemset(p->d_sum, 0, sizeof(float) * P.n) == hipSuccess &&
+         hipMemset(p->d_state, 0, sizeof(DetState)) == hipSuccess &&
+         hipMemset(p->d_ring, 0, p->ring_len * p->bps) == hipSuccess;
+    ok = ok && launch_rotator_table(p->d_rot_incr, p->d_rot_table, P.n, p->n_ckpt, p->stream) == 0;
+    ok = ok && hipStreamSynchronize(p->stream) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "irdm_hip: device initialisation failed\n");
+        pipeline_free(p);
+        return nullptr;
+    }
+    p->h_gone.resize(p->gone_cap);
+    p->total_samples = 0;
+    p->tagged = 0;
+    p->stream_closed = false;
+    p->last_frames = 0;
+    p->last_chunk = nullptr;
+    p->keep_frame_samples = 1;
+    return p;
+}
+
+extern "C" uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p) { return p ? p->tagged : 0; }
+extern "C" uint64_t irdm_sample_count(const irdm_pipeline_t *p) { return p ? p->total_samples : 0; }
+extern "C" int irdm_fft_size(const irdm_pipeline_t *p) { return p ? p->P.n : -1; }
+
+static SampleSource make_source(const irdm_pipeline *p, const void *chunk, uint64_t c0, uint64_t c1)
+{
+    SampleSource s;
+    s.chunk = chunk;
+    s.chunk_start = c0;
+    s.chunk_end = c1;
+    s.ring = p->d_ring;
+    s.ring_len = p->ring_len;
+    s.ref_ring = p->ref_ring;
+    s.fmt = p->dev_fmt;
+    return s;
+}
+
+// copy the chunk's tail into the history ring (absolute index % ring_len)
+static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1)
+{
+    uint64_t a0 = c1 > p->ring_len ? std::max(c0, c1 - p->ring_len) : c0;
+    while (a0 < c1) {
+        const uint64_t pos = a0 % p->ring_len;
+        const uint64_t run = std::min<uint64_t>(c1 - a0, p->ring_len - pos);
+        IRDM_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(p->d_ring) + pos * p->bps,
+                                      static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
+                                      run * p->bps, hipMemcpyDeviceToDevice, p->stream));
+        a0 += run;
+    }
+    return 0;
+}
+
+static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
+{
+    const DetParams &P = p->P;
+    const int fs = p->cfg.sample_rate;
+    for (int base = 0; base < n_gone; base += p->burst_cap) {
+        const int nb = std::min(p->burst_cap, n_gone - base);
+        p->h_work.assign(nb, BurstWork());
+        p->h_tiles.clear();
+        std::vector<irdm_burst_t> recs(nb);
+        for (int i = 0; i < nb; i++) {
+            const GoneBurst &g = p->h_gone[base + i];
+            irdm_burst_t &r = recs[i];
+            r.id = g.id; r.start = g.start; r.stop = g.stop; r.last_active = g.last_active;
+            r.center_bin = g.center_bin;
+            r.peak_rel = g.peak_rel; r.base_sum = g.base_sum;
+            // burst_detect.c:572, :583-586 with the host libm
+            r.magnitude = 10.0f * log10f(g.peak_rel * kHistory * 1.72f);
+            r.noise = 10.0f * log10f(g.base_sum / kHistory / ((float)P.n * P.n) / 1.72f /
+                                     ((float)fs / P.n));
+            r.num_samples = g.stop + (uint64_t)P.pre_len - g.start;          // burst_detect.c:708-712
+            // the frame [stop, stop+N) was processed by the feed call that delivered its last sample
+            uint64_t e = (g.stop + (uint64_t)P.n + p->feed_block - 1) / p->feed_block * p->feed_block;
+            r.avail_end = std::min<uint64_t>(e, src.chunk_end);
+
+            BurstWork &w = p->h_work[i];
+            w.start = g.start;
+            w.avail_end = r.avail_end;
+            w.center_bin = g.center_bin;
+            int n = r.num_samples > (uint64_t)(2 * 1024 * 1024) ? 2 * 1024 * 1024 : (int)r.num_samples;
+            if ((size_t)n > p->l_cap) {
+                fprintf(stderr, "irdm_hip: burst window %d exceeds l_cap %zu\n", n, p->l_cap);
+                return -1;
+            }
+            w.n = n;
+            w.dec_len = 0;
+            w.drop_reason = 0;
+            if (r.num_samples < 100) {
+                w.drop_reason = 1;                                           // burst_downmix.c:645
+            } else {
+                int n_out = (n - p->in_ntaps + 1) / p->decim;                // burst_downmix.c:423
+                if (n_out < 0) n_out = 0;
+                w.dec_len = n_out;
+                if (n_out < 100) w.drop_reason = 2;                          // burst_downmix.c:677
+            }
+            if (!w.drop_reason)
+                for (int o = 0; o < w.dec_len; o += kFirTileOut) p->h_tiles.push_back(FirTile{ i, o });
+        }
+        if (p->h_tiles.size() > p->tiles_cap) {
+            (void)hipFree(p->d_tiles);
+            p->tiles_cap = p->h_tiles.size() * 2;
+            p->d_tiles = dev_alloc<FirTile>(p->tiles_cap);
+            if (!p->d_tiles) return -1;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb,
+                                      hipMemcpyHostToDevice, p->stream));
+        if (!p->h_tiles.empty())
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_tiles, p->h_tiles.data(), sizeof(FirTile) * p->h_tiles.size(),
+                                          hipMemcpyHostToDevice, p->stream));
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[3], p->stream));
+        if (launch_fir_decimate(src, p->d_work, p->d_tiles, (int)p->h_tiles.size(), p->decim, p->d_in_taps,
+                                p->d_rot_incr, p->d_rot_table, p->n_ckpt, p->d_dec, p->dec_stride,
+                                p->stream) != 0)
+            return -1;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[4], p->stream));
+        if (launch_downmix_post1(p->d_work, nb, p->d_dec, p->dec_stride, p->d_lpf, p->d_noise_taps,
+                                 p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
+                                 p->pre_start, p->d_cfo_window, p->d_tw4096, p->stream) != 0)
+            return -1;
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
+                                      hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+
+        // host: fine-CFO increment with the host libm; centre frequency (burst_downmix.c:663-671, :716-719)
+        std::vector<double> cfreq(nb);
+        for (int i = 0; i < nb; i++) {
+            BurstWork &w = p->h_work[i];
+            const float rel = (w.center_bin - P.n / 2) / (float)P.n;
+            double cf = p->cfg.center_frequency;
+            cf += rel * fs;
+            if (!w.drop_reason) {
+                const cfloat inc = fine_rotator_incr(w.center_offset);
+                w.incr_re = inc.real();
+                w.incr_im = inc.imag();
+                cf += w.center_offset * p->out_rate;
+            }
+            cfreq[i] = cf;
+            w.simplex = cf > 1626000000 ? 1 : 0;                             // iridium.h:18
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb,
+                                      hipMemcpyHostToDevice, p->stream));
+        if (launch_downmix_post2(p->d_work, nb, p->d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
+                                 p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
+                                 p->d_rrc_ws, p->d_frames, p->stream) != 0)
+            return -1;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[5], p->stream));
+        if (launch_demod(p->d_work, nb, p->d_frames, p->cfg.use_gardner, p->sps, p->d_demod_ws,
+                         p->d_demod, p->stream) != 0)
+            return -1;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[6], p->stream));
+        p->h_demod.resize(nb);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
+                                      hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_demod.data(), p->d_demod, sizeof(DemodOut) * nb,
+                                      hipMemcpyDeviceToHost, p->stream));
+        if (p->keep_frame_samples) {
+            p->h_frames.resize((size_t)nb * kMaxFrameSamples * 2);
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->h_frames.data(), p->d_frames,
+                                          sizeof(float2) * (size_t)nb * kMaxFrameSamples,
+                                          hipMemcpyDeviceToHost, p->stream));
+        }
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+
+        for (int i = 0; i < nb; i++) {
+            const BurstWork &w = p->h_work[i];
+            const irdm_burst_t &r = recs[i];
+            p->q_bursts.push_back(r);
+            p->last_bursts.push_back(r);
+            p->tagged++;
+
+            irdm_frame_info_t f;
+            memset(&f, 0, sizeof(f));
+            f.id = r.id;
+            f.drop_reason = w.drop_reason;
+            f.dec_len = w.dec_len;
+            uint64_t timestamp = p->start_time_ns + (uint64_t)((double)r.start / fs * 1e9);   // :659-660
+            if (w.dec_len > 0) timestamp += (uint64_t)((p->in_ntaps / 2) * 1000000000ULL / fs); // :431-433
+            if (w.drop_reason == 0 || w.drop_reason >= 3) f.start = w.start_idx;
+            if (w.drop_reason == 0 || w.drop_reason >= 4) {
+                f.center_offset = w.center_offset;
+                f.uw_start_idx = w.uw_start;
+                f.corr_re = w.corr_re;
+                f.corr_im = w.corr_im;
+                f.direction = w.direction;
+            }
+            if (w.drop_reason == 0) {
+                f.timestamp = timestamp + (uint64_t)((double)w.start_idx / p->out_rate * 1e9);  // :783
+                f.center_frequency = cfreq[i];
+                f.sample_rate = (float)p->out_rate;
+                f.samples_per_symbol = p->sps;
+                f.magnitude = r.magnitude;
+                f.noise = r.noise;
+                f.uw_start = w.uw_corr;
+                f.num_samples = w.num_samples;
+            }
+            p->q_frames.push_back(f);
+            if (p->keep_frame_samples) {
+                std::vector<float> s;
+                if (w.drop_reason == 0)
+                    s.assign(p->h_frames.begin() + (size_t)i * kMaxFrameSamples * 2,
+                             p->h_frames.begin() + (size_t)i * kMaxFrameSamples * 2 + 2 * (size_t)w.num_samples);
+                p->q_frame_samples.push_back(std::move(s));
+            }
+            if (w.drop_reason == 0 && p->h_demod[i].ok) {
+                const DemodOut &d = p->h_demod[i];
+                irdm_demod_t o;
+                memset(&o, 0, sizeof(o));
+                o.id = r.id;
+                o.timestamp = f.timestamp;
+                o.direction = d.direction;
+                o.magnitude = r.magnitude;
+                o.noise = r.noise;
+                o.confidence = d.confidence;
+                o.level = d.level;
+                o.n_symbols = d.n_symbols;
+                o.n_payload_symbols = d.n_symbols - 12;
+                o.n_bits = 2 * d.n_symbols;
+                o.ok = 1;
+                o.total_phase = d.total_phase;
+                memcpy(o.bits, d.bits, sizeof(o.bits));
+                memcpy(o.llr, d.llr, sizeof(o.llr));
+                if (d.n_symbols > 0) {                                       // qpsk_demod.c:521-527
+                    const double duration = (double)d.n_symbols / 25000;
+                    o.center_frequency = f.center_frequency + d.total_phase / duration / M_PI / 2.0;
+                } else {
+                    o.center_frequency = f.center_frequency;
+                }
+                p->q_demods.push_back(o);
+            }
+        }
+    }
+    return 0;
+}
+
+extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
+{
+    if (!p || (!d_iq && n_samples)) return -1;
+    if (p->stream_closed) {
+        fprintf(stderr, "irdm_hip: stream already ended by a chunk that was not a multiple of feed_block\n");
+        return -1;
+    }
+    if (n_samples > p->max_chunk) {
+        fprintf(stderr, "irdm_hip: chunk of %zu samples exceeds max_chunk_samples %zu\n", n_samples, p->max_chunk);
+        return -1;
+    }
+    if (n_samples % p->feed_block != 0) p->stream_closed = true;     // last, ragged chunk of the stream
+    (void)hipSetDevice(p->cfg.device);
+    // order after the caller's stream (the producer of d_iq)
+    hipStream_t caller = static_cast<hipStream_t>(stream_v);
+    if (caller != p->stream) {
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[8], caller));
+        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[8], 0));
+    }
+    const DetParams &P = p->P;
+    const uint64_t c0 = p->total_samples, c1 = c0 + n_samples;
+    const int n_frames = (int)(n_samples / (size_t)P.n);
+
+    IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[0], p->stream));
+    if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, p->d_mag, n_frames, p->stream) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->stream));
+    if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, n_frames, p->d_gone, p->gone_cap,
+                           p->d_cand_a, p->d_cand_b, p->stream) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
+    uint32_t counters[2] = { 0, 0 };
+    IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(counters), hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    const int n_gone = (int)counters[0];
+    if (counters[1] || n_gone > p->gone_cap) {
+        fprintf(stderr, "irdm_hip: detector capacity exceeded (%d bursts in one chunk, cap %d)\n", n_gone, p->gone_cap);
+        return -1;
+    }
+    if (n_gone > 0)
+        IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));
+
+    p->last_bursts.clear();
+    p->last_frames = n_frames;
+    p->last_chunk = d_iq;
+    p->last_chunk_start = c0;
+    p->last_chunk_end = c1;
+    const SampleSource src = make_source(p, d_iq, c0, c1);
+    // events 3..6 are re-recorded per sub-batch; record them once so an empty chunk has valid timings
+    for (int i = 3; i <= 6; i++) IRDM_HIP_CHECK(hipEventRecord(p->ev[i], p->stream));
+    if (process_bursts(p, src, n_gone) != 0) return -1;
+    if (ring_update(p, d_iq, c0, c1) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->total_samples = c1;
+
+    float ms = 0;
+    const int pairs[6][2] = { { 0, 1 }, { 1, 2 }, { 3, 4 }, { 4, 5 }, { 5, 6 }, { 0, 7 } };
+    for (int i = 0; i < 6; i++)
+        p->last_ms[i] = hipEventElapsedTime(&ms, p->ev[pairs[i][0]], p->ev[pairs[i][1]]) == hipSuccess ? ms : -1.0f;
+    return n_gone;
+}
+
+extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples)
+{
+    if (!p || (!h_iq && n_samples)) return -1;
+    if (n_samples > p->max_chunk) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (!p->d_stage) {
+        if (hipMalloc(&p->d_stage, p->max_chunk * p->bps) != hipSuccess) return -1;
+    }
+    if (p->cfg.format == IRDM_FMT_CI16) {
+        // spewer_thread's ci16 narrowing (main.c:245-246): (int8_t)(v >> 8)
+        std::vector<int8_t> tmp(2 * n_samples);
+        const int16_t *s = static_cast<const int16_t *>(h_iq);
+        for (size_t i = 0; i < 2 * n_samples; i++) tmp[i] = (int8_t)(s[i] >> 8);
+        IRDM_HIP_CHECK(hipMemcpy(p->d_stage, tmp.data(), n_samples * p->bps, hipMemcpyHostToDevice));
+    } else {
+        IRDM_HIP_CHECK(hipMemcpy(p->d_stage, h_iq, n_samples * p->bps, hipMemcpyHostToDevice));
+    }
+    return irdm_feed_device(p, p->d_stage, n_samples, p->stream);
+}
+
+template <typename T>
+static int drain(std::deque<T> &q, T *out, int max)
+{
+    int n = 0;
+    while (n < max && !q.empty()) {
+        out[n++] = q.front();
+        q.pop_front();
+    }
+    return n;
+}
+
+extern "C" int irdm_poll_bursts(irdm_pipeline_t *p, irdm_burst_t *out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    return drain(p->q_bursts, out, max);
+}
+
+extern "C" int irdm_poll_frames(irdm_pipeline_t *p, irdm_frame_info_t *out, float *samples_out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    int n = 0;
+    while (n < max && !p->q_frames.empty()) {
+        out[n] = p->q_frames.front();
+        p->q_frames.pop_front();
+        if (!p->q_frame_samples.empty()) {
+            if (samples_out) {
+                const std::vector<float> &s = p->q_frame_samples.front();
+                memcpy(samples_out + (size_t)n * 2 * IRDM_MAX_FRAME_SAMPLES, s.data(), s.size() * sizeof(float));
+            }
+            p->q_frame_samples.pop_front();
+        }
+        n++;
+    }
+    return n;
+}
+
+extern "C" int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    return drain(p->q_demods, out, max);
+}
+
+extern "C" int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_frames)
+{
+    if (!p || !out) return -1;
+    const size_t nf = std::min<size_t>(max_frames, (size_t)p->last_frames);
+    IRDM_HIP_CHECK(hipMemcpy(out, p->d_mag, nf * p->P.n * sizeof(float), hipMemcpyDeviceToHost));
+    return (int)nf;
+}
+
+extern "C" int irdm_baseline_sum(irdm_pipeline_t *p, float *out)
+{
+    if (!p || !out) return -1;
+    IRDM_HIP_CHECK(hipMemcpy(out, p->d_sum, p->P.n * sizeof(float), hipMemcpyDeviceToHost));
+    return p->P.n;
+}
+
+extern "C" int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float *out, size_t max_samples)
+{
+    if (!p || !out || burst_in_chunk < 0 || burst_in_chunk >= (int)p->last_bursts.size() || !p->last_chunk)
+        return -1;
+    const irdm_burst_t &r = p->last_bursts[burst_in_chunk];
+    const size_t n = std::min<size_t>(std::min<size_t>(max_samples, r.num_samples), p->l_cap);
+    // NOTE: valid only until the next feed (the chunk pointer and ring are read again)
+    SampleSource src = make_source(p, p->last_chunk, p->last_chunk_start, p->last_chunk_end);
+    // the ring already holds the chunk tail; reading through the chunk pointer is equivalent
+    if (launch_gather_burst(src, r.start, r.avail_end, (int)n, p->d_probe, p->stream) != 0) return -1;
+    IRDM_HIP_CHECK(hipMemcpyAsync(out, p->d_probe, n * sizeof(float2), hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    return (int)n;
+}
+
+extern "C" int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n)
+{
+    if (!p || !ms_out) return -1;
+    for (int i = 0; i < n && i < 6; i++) ms_out[i] = p->last_ms[i];
+    return n < 6 ? n : 6;
+}
+
+// ===========================================================================
+// 3. RAW line (frame_output.c:144-199)
+// ===========================================================================
+extern "C" int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uint64_t *t0_io, char *buf,
+                               size_t cap)
+{
+    if (!f || !t0_io || !buf) return -1;
+    char auto_info[64];
+    if (*t0_io == 0) *t0_io = (f->timestamp / 1000000000ULL) * 1000000000ULL;
+    const uint64_t t0 = *t0_io;
+    if (!file_info || !file_info[0]) {
+        snprintf(auto_info, sizeof(auto_info), "i-%llu-t1", (unsigned long long)(t0 / 1000000000ULL));
+        file_info = auto_info;
+    }
+    const double ts_ms = (double)(f->timestamp - t0) / 1000000.0;
+    const int freq_hz = (int)(f->center_frequency + 0.5);
+    const int payload = f->n_payload_symbols < 0 ? 0 : f->n_payload_symbols;
+    int pos = snprintf(buf, cap, "RAW: %s %012.4f %010d N:%05.2f%+06.2f I:%011llu %3d%% %.5f %3d ", file_info,
+                       ts_ms, freq_hz, f->magnitude, f->noise, (unsigned long long)f->id, f->confidence,
+                       f->level, payload);
+    if (pos < 0 || (size_t)pos + (size_t)f->n_bits + 2 > cap) return -1;
+    for (int i = 0; i < f->n_bits; i++) buf[pos++] = (char)('0' + f->bits[i]);
+    buf[pos++] = '\n';
+    buf[pos] = 0;
+    return pos;
+}
+
+extern "C" const char *irdm_version(void) { return "irdm_hip 0.1 (gfx950)"; }

@@ -1,0 +1,85 @@
+// types.hpp -- device-resident state and work descriptors of the pipeline.
+#pragma once
+#include <stdint.h>
+
+namespace irdm {
+
+constexpr int kHistory = 512;            // iridium.h:46
+constexpr int kMaxActive = 1024;         // max_bursts (<= 240) + bursts one frame can add before the squelch check
+constexpr int kScanThreads = 1024;
+constexpr int kFirTaps = 801;            // lpf_taps(.., 1e7, 1e5, 5e4), burst_downmix.c:251-261
+constexpr int kRotSeg = 16;              // rotator checkpoint spacing (samples)
+constexpr int kFirTileOut = 128;         // decimator outputs per workgroup
+constexpr int kMaxFrameSamples = 4440;   // IR_MAX_FRAME_LENGTH_SIMPLEX * 10
+constexpr int kMaxBits = 896;
+constexpr int kMaxSymbols = 448;         // 4440 samples / 10 sps + slack; matches kMaxBits / 2
+constexpr int kFrameNeed = 5696;         // decimated samples after `start` that can reach the output frame
+constexpr int kCfoN = 256, kCfoTotal = 4096, kCorrN = 2048, kSyncSearch = 840;
+
+// active_burst_t (burst_detect.c:39-47) minus the dB fields, which the host
+// derives with its own libm from peak_rel / base_sum (burst_detect.c:572, :583-586)
+struct ActiveBurst {
+    uint64_t id, start, last_active;
+    int32_t center_bin;
+    float peak_rel, base_sum;
+    int32_t pad;
+};
+
+struct GoneBurst {
+    uint64_t id, start, stop, last_active;
+    int32_t center_bin;
+    float peak_rel, base_sum;
+    int32_t pad;
+};
+
+// detector parameters derived at create (burst_detect.c:180-226)
+struct DetParams {
+    int n, log_n, pre_len, post_len, width, max_bursts, max_len;
+    float threshold;
+};
+
+// detector state carried between chunks (and, for multi-GPU time-chunk sharding,
+// handed to the next rank together with baseline sum + history)
+struct DetState {
+    uint64_t index;          // absolute sample index of the next frame
+    uint64_t burst_id;
+    int32_t hist_idx, primed, squelch, n_act;
+    uint32_t n_gone;         // bursts emitted by the current chunk
+    uint32_t overflow;       // 1 if a fixed capacity was exceeded (results invalid)
+    ActiveBurst act[kMaxActive];
+};
+
+struct PeakCand {
+    float rel;
+    int32_t bin;
+};
+
+// one decimator tile = kFirTileOut outputs of one burst
+struct FirTile {
+    int32_t burst;           // index into BurstWork[]
+    int32_t first_out;       // first output index of the tile
+};
+
+struct BurstWork {
+    uint64_t start;          // absolute index of sample 0 of the burst window
+    uint64_t avail_end;      // samples at/after this index read the stale ring slot (burst_detect.c:401-422)
+    int32_t n;               // samples used (min(num_samples, 2 Mi)), burst_downmix.c:650-651
+    int32_t dec_len;         // (n - 801 + 1) / M
+    int32_t center_bin;
+    int32_t simplex;         // center frequency after CFO > 1626 MHz (burst_downmix.c:764)
+    // filled by the device
+    int32_t start_idx;       // find_burst_start
+    float center_offset;     // estimate_fine_cfo
+    float incr_re, incr_im;  // cexpf(-2 pi center_offset i), host libm
+    int32_t direction, uw_start, num_samples, drop_reason;
+    float uw_corr, corr_re, corr_im;
+};
+
+struct DemodOut {
+    int32_t ok, direction, confidence, n_symbols;
+    float level, total_phase;
+    uint8_t bits[kMaxBits];
+    float llr[kMaxBits];
+};
+
+}  // namespace irdm

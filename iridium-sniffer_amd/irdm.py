@@ -1,0 +1,252 @@
+"""ctypes view of the C-ABI in include/irdm_hip.h (libirdm_hip.so, gfx950).
+
+Host-side mirror used by tests, bench.py and __graft_entry__: the same entry
+points a C host binds.  There is no CPU fallback here: if the
+HIP library is missing or no GPU is present, creation fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libirdm_hip.so")
+
+FMT_CI8, FMT_CI16, FMT_CF32 = 0, 1, 2
+MAX_FRAME_SAMPLES = 4440
+MAX_BITS = 896
+
+
+class Config(C.Structure):
+    _fields_ = [("center_frequency", C.c_double), ("sample_rate", C.c_int),
+                ("threshold_db", C.c_float), ("format", C.c_int), ("feed_block", C.c_int),
+                ("use_gardner", C.c_int), ("start_time_ns", C.c_uint64), ("device", C.c_int),
+                ("max_chunk_samples", C.c_size_t), ("max_bursts_per_chunk", C.c_int)]
+
+
+class Burst(C.Structure):
+    _fields_ = [("id", C.c_uint64), ("start", C.c_uint64), ("stop", C.c_uint64),
+                ("last_active", C.c_uint64), ("center_bin", C.c_int32),
+                ("magnitude", C.c_float), ("noise", C.c_float), ("peak_rel", C.c_float),
+                ("base_sum", C.c_float), ("num_samples", C.c_uint64),
+                ("avail_end", C.c_uint64)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("id", C.c_uint64), ("timestamp", C.c_uint64),
+                ("center_frequency", C.c_double), ("sample_rate", C.c_float),
+                ("samples_per_symbol", C.c_float), ("direction", C.c_int32),
+                ("magnitude", C.c_float), ("noise", C.c_float), ("uw_start", C.c_float),
+                ("num_samples", C.c_int32), ("dec_len", C.c_int32), ("start", C.c_int32),
+                ("center_offset", C.c_float), ("uw_start_idx", C.c_int32),
+                ("corr_re", C.c_float), ("corr_im", C.c_float), ("drop_reason", C.c_int32)]
+
+
+class Demod(C.Structure):
+    _fields_ = [("id", C.c_uint64), ("timestamp", C.c_uint64),
+                ("center_frequency", C.c_double), ("direction", C.c_int32),
+                ("magnitude", C.c_float), ("noise", C.c_float), ("confidence", C.c_int32),
+                ("level", C.c_float), ("n_symbols", C.c_int32),
+                ("n_payload_symbols", C.c_int32), ("n_bits", C.c_int32), ("ok", C.c_int32),
+                ("total_phase", C.c_float), ("bits", C.c_uint8 * MAX_BITS),
+                ("llr", C.c_float * MAX_BITS)]
+
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 ... -> iridium-sniffer_amd/libirdm_hip.so (in-tree)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-s", "-C", PKG_DIR, "-j8"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libirdm_hip.so is not built (run __graft_entry__.build()); "
+                               "there is no CPU fallback for the product path")
+        L = C.CDLL(LIB_PATH)
+        L.gpu_burst_fft_create.restype = C.c_void_p
+        L.gpu_burst_fft_create.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.gpu_burst_fft_destroy.argtypes = [C.c_void_p]
+        L.gpu_burst_fft_process.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+        L.gpu_burst_fft_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.irdm_create.restype = C.c_void_p
+        L.irdm_create.argtypes = [C.POINTER(Config)]
+        L.irdm_destroy.argtypes = [C.c_void_p]
+        L.irdm_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.irdm_feed_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
+        L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
+        L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
+        L.irdm_tagged_bursts.argtypes = [C.c_void_p]
+        L.irdm_tagged_bursts.restype = C.c_uint64
+        L.irdm_sample_count.argtypes = [C.c_void_p]
+        L.irdm_sample_count.restype = C.c_uint64
+        L.irdm_fft_size.argtypes = [C.c_void_p]
+        L.irdm_last_magnitudes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]
+        L.irdm_baseline_sum.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.irdm_burst_samples.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]
+        L.irdm_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.irdm_format_raw.argtypes = [C.POINTER(Demod), C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+        L.irdm_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class GpuBurstFFT:
+    """gpu_burst_fft_* (opencl/burst_fft.h:35-47)."""
+
+    def __init__(self, fft_size, batch_size, window):
+        self.L = lib()
+        self.n, self.batch = fft_size, batch_size
+        w = np.ascontiguousarray(window, np.float32)
+        self.h = self.L.gpu_burst_fft_create(fft_size, batch_size, _fp(w))
+        if not self.h:
+            raise RuntimeError("gpu_burst_fft_create failed (no GPU?)")
+
+    def process(self, frames):
+        """frames: complex64 [count, n] -> float32 [count, n] (mag^2, DC-shifted); raises on -1."""
+        x = np.ascontiguousarray(frames, np.complex64)
+        count = x.shape[0]
+        out = np.empty((count, self.n), np.float32)
+        rc = self.L.gpu_burst_fft_process(self.h, _fp(x.view(np.float32)), _fp(out), count)
+        if rc != 0:
+            raise RuntimeError("gpu_burst_fft_process returned %d" % rc)
+        return out
+
+    def process_rc(self, frames, count):
+        x = np.ascontiguousarray(frames, np.complex64)
+        out = np.empty((max(count, 1), self.n), np.float32)
+        return self.L.gpu_burst_fft_process(self.h, _fp(x.view(np.float32)), _fp(out), count)
+
+    def close(self):
+        if self.h:
+            self.L.gpu_burst_fft_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Pipeline:
+    """irdm_* batched detect -> downmix -> demod context."""
+
+    def __init__(self, sample_rate, fmt=FMT_CF32, center_frequency=1622000000.0, threshold_db=0.0,
+                 feed_block=0, use_gardner=1, start_time_ns=1700000000 * 10**9, device=0,
+                 max_chunk_samples=0, max_bursts_per_chunk=0):
+        self.L = lib()
+        self.cfg = Config(center_frequency, int(sample_rate), threshold_db, fmt, feed_block,
+                          use_gardner, start_time_ns, device, max_chunk_samples, max_bursts_per_chunk)
+        self.h = self.L.irdm_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("irdm_create failed (no GPU, or bad config)")
+        self.fmt = fmt
+        self.fft_size = self.L.irdm_fft_size(self.h)
+
+    def feed_host(self, iq):
+        iq = np.ascontiguousarray(iq)
+        n = len(iq) if self.fmt == FMT_CF32 else len(iq) // 2
+        rc = self.L.irdm_feed_host(self.h, iq.ctypes.data_as(C.c_void_p), n)
+        if rc < 0:
+            raise RuntimeError("irdm_feed_host failed")
+        return rc
+
+    def feed_device(self, ptr, n_samples, stream=None):
+        rc = self.L.irdm_feed_device(self.h, C.c_void_p(ptr), n_samples, C.c_void_p(stream or 0))
+        if rc < 0:
+            raise RuntimeError("irdm_feed_device failed")
+        return rc
+
+    def _poll(self, fn, typ, chunk=256):
+        out = []
+        buf = (typ * chunk)()
+        while True:
+            n = fn(self.h, buf, chunk)
+            if n <= 0:
+                break
+            out += [typ.from_buffer_copy(buf[i]) for i in range(n)]
+        return out
+
+    def poll_bursts(self):
+        return self._poll(self.L.irdm_poll_bursts, Burst)
+
+    def poll_demods(self):
+        return self._poll(self.L.irdm_poll_demods, Demod)
+
+    def poll_frames(self, chunk=64):
+        infos, samples = [], []
+        buf = (FrameInfo * chunk)()
+        sb = np.zeros((chunk, 2 * MAX_FRAME_SAMPLES), np.float32)
+        while True:
+            n = self.L.irdm_poll_frames(self.h, buf, _fp(sb), chunk)
+            if n <= 0:
+                break
+            for i in range(n):
+                fi = FrameInfo.from_buffer_copy(buf[i])
+                infos.append(fi)
+                samples.append(sb[i, :2 * fi.num_samples].copy().view(np.complex64))
+        return infos, samples
+
+    def last_magnitudes(self, max_frames):
+        out = np.zeros((max_frames, self.fft_size), np.float32)
+        n = self.L.irdm_last_magnitudes(self.h, _fp(out), max_frames)
+        return out[:n]
+
+    def baseline_sum(self):
+        out = np.zeros(self.fft_size, np.float32)
+        self.L.irdm_baseline_sum(self.h, _fp(out))
+        return out
+
+    def burst_samples(self, i, n):
+        out = np.zeros(2 * n, np.float32)
+        got = self.L.irdm_burst_samples(self.h, i, _fp(out), n)
+        if got < 0:
+            raise RuntimeError("irdm_burst_samples failed")
+        return out[:2 * got].view(np.complex64)
+
+    def timings(self):
+        t = (C.c_float * 6)()
+        self.L.irdm_last_timings(self.h, t, 6)
+        return dict(zip(["fft_mag", "scan", "fir", "post", "demod", "total"], [float(v) for v in t]))
+
+    @property
+    def tagged(self):
+        return self.L.irdm_tagged_bursts(self.h)
+
+    @property
+    def sample_count(self):
+        return self.L.irdm_sample_count(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.irdm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_raw(demods, file_info="golden"):
+    """frame_output_print for a list of Demod records (t0 from the first, frame_output.c:144-158)."""
+    L = lib()
+    t0 = C.c_uint64(0)
+    buf = C.create_string_buffer(4096)
+    out = []
+    for d in demods:
+        n = L.irdm_format_raw(C.byref(d), file_info.encode() if file_info else None, C.byref(t0), buf, 4096)
+        if n < 0:
+            raise RuntimeError("irdm_format_raw failed")
+        out.append(buf.value.decode())
+    return out

@@ -1,0 +1,86 @@
+"""Shared comparison helpers: HIP pipeline (through the C-ABI) vs the CPU oracle."""
+import numpy as np
+
+import irdm
+import orc
+
+SOFT_TOL = 1e-4          # north_star tolerance on soft outputs
+
+
+def bits_of(x):
+    return np.float32(x).view(np.uint32)
+
+
+def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, **kw):
+    """Feed `iq` through the HIP pipeline in the given chunk sizes (samples)."""
+    n = len(iq) if fmt == irdm.FMT_CF32 else len(iq) // 2
+    max_chunk = max(chunks) if chunks else n
+    p = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=max_chunk, max_bursts_per_chunk=1024, **kw)
+    per = 1 if fmt == irdm.FMT_CF32 else 2
+    off = 0
+    for c in (chunks or [n]):
+        p.feed_host(iq[off * per:(off + c) * per])
+        off += c
+    assert off == n
+    bursts = p.poll_bursts()
+    infos, samples = p.poll_frames()
+    demods = p.poll_demods()
+    res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, tagged=p.tagged,
+               n_samples=p.sample_count, timings=p.timings())
+    p.close()
+    return res
+
+
+def compare(gpu, ref, exact_frames=True):
+    """ref: orc.StreamResult.  Returns a small summary dict; asserts on any mismatch."""
+    assert gpu["tagged"] == ref.n_tagged, (gpu["tagged"], ref.n_tagged)
+    assert len(gpu["bursts"]) == len(ref.bursts)
+    for g, r in zip(gpu["bursts"], ref.bursts):
+        for f in ("id", "start", "stop", "last_active", "center_bin", "num_samples", "avail_end"):
+            assert getattr(g, f) == getattr(r, f), (f, g.id, getattr(g, f), getattr(r, f))
+        for f in ("magnitude", "noise", "peak_rel", "base_sum"):        # bit-identical floats
+            assert bits_of(getattr(g, f)) == bits_of(getattr(r, f)), (f, g.id)
+    assert len(gpu["infos"]) == len(ref.frames)
+    n_frames = 0
+    for g, s, r in zip(gpu["infos"], gpu["samples"], ref.frames):
+        assert g.id == r.id and g.drop_reason == r.drop_reason, (g.id, g.drop_reason, r.drop_reason)
+        assert g.dec_len == r.dec_len
+        if r.drop_reason in (0, 3, 4, 5):
+            assert g.start == r.start, (g.id, g.start, r.start)
+        if r.drop_reason in (0, 4, 5):
+            assert bits_of(g.center_offset) == bits_of(r.center_offset), (g.id, g.center_offset, r.center_offset)
+            assert g.uw_start_idx == r.uw_start_idx and g.direction == r.direction
+            assert bits_of(g.corr_re) == bits_of(r.corr_re) and bits_of(g.corr_im) == bits_of(r.corr_im)
+        if r.drop_reason == 0:
+            n_frames += 1
+            assert g.timestamp == r.timestamp and g.center_frequency == r.center_frequency
+            assert g.num_samples == r.num_samples
+            assert bits_of(g.uw_start) == bits_of(r.uw_start)
+            rs = np.ctypeslib.as_array(r.samples)[:2 * r.num_samples].view(np.complex64)
+            if exact_frames:
+                assert np.array_equal(s.view(np.uint32), rs.view(np.uint32)), \
+                    (g.id, float(np.abs(s - rs).max()))
+            else:
+                assert np.allclose(s, rs, atol=1e-6)
+    assert len(gpu["demods"]) == len(ref.demods), (len(gpu["demods"]), len(ref.demods))
+    max_soft = 0.0
+    for g, r in zip(gpu["demods"], ref.demods):
+        assert g.id == r.id and g.timestamp == r.timestamp
+        assert (g.direction, g.n_symbols, g.n_payload_symbols, g.n_bits) == \
+               (r.direction, r.n_symbols, r.n_payload_symbols, r.n_bits), g.id
+        assert bytes(g.bits[:g.n_bits]) == bytes(r.bits[:r.n_bits]), g.id     # hard bits identical
+        assert g.confidence == r.confidence, (g.id, g.confidence, r.confidence)
+        assert abs(g.level - r.level) <= SOFT_TOL
+        gl = np.array(g.llr[:g.n_bits], np.float32)
+        rl = np.array(r.llr[:r.n_bits], np.float32)
+        assert np.max(np.abs(gl - rl)) <= SOFT_TOL
+        max_soft = max(max_soft, float(np.max(np.abs(gl - rl))), abs(g.level - r.level))
+        assert abs(g.center_frequency - r.center_frequency) <= 0.05      # Hz; printed rounded to 1 Hz
+        assert bits_of(g.magnitude) == bits_of(r.magnitude) and bits_of(g.noise) == bits_of(r.noise)
+    return dict(bursts=len(ref.bursts), frames=n_frames, demods=len(ref.demods), max_soft=max_soft)
+
+
+def raw_fields(line):
+    """RAW line -> (file_info, ts, freq, N-field, id, conf, level, payload, bits)"""
+    p = line.split()
+    return p[1], float(p[2]), int(p[3]), p[4], p[5], p[6], float(p[7]), int(p[8]), p[9]

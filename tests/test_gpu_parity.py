@@ -1,0 +1,193 @@
+"""-m gpu: the HIP hot path, called through the C-ABI, against the CPU oracle
+on the same seeded inputs.  Integer fields, burst indices, downmixed frame
+samples and hard bits: bit-exact.  Soft demod outputs: 1e-4 (north_star)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import irdm
+import orc
+import parity
+import siggen
+
+pytestmark = pytest.mark.gpu
+
+
+def _window(n):
+    w = np.zeros(n, np.float32)
+    orc.lib().orc_blackman_window(orc.fptr(w), n)
+    return (w / np.float32(0.42)).astype(np.float32)
+
+
+def _oracle_mags(fs, frames):
+    L = orc.lib()
+    det = L.orc_detector_create(1.622e9, fs, 0.0, 0)
+    n = L.orc_detector_fft_size(det)
+    out = np.zeros((len(frames), n), np.float32)
+    for i, f in enumerate(frames):
+        L.orc_detector_magnitude_frame(det, orc.fptr(np.ascontiguousarray(f).view(np.float32)), orc.fptr(out[i]))
+    L.orc_detector_destroy(det)
+    return out
+
+
+@pytest.mark.parametrize("fs,n", [(2_000_000, 2048), (10_000_000, 8192), (12_000_000, 16384)])
+def test_gpu_burst_fft_bit_exact(fs, n):
+    """a3/a12: gpu_burst_fft_process == window + pinned FFT + fftshift |.|^2, bit for bit."""
+    rng = np.random.default_rng(n)
+    frames = ((rng.standard_normal((16, n)) + 1j * rng.standard_normal((16, n))) * 0.01).astype(np.complex64)
+    frames[3, :] = 0
+    frames[4, :] = 0.25                      # DC: the reference's Vulkan self-test input
+    frames[5] += (0.05 * np.exp(2j * np.pi * 0.123 * np.arange(n))).astype(np.complex64)
+    g = irdm.GpuBurstFFT(n, 16, _window(n))
+    got = g.process(frames)
+    want = _oracle_mags(fs, frames)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.all(got[3] == 0)
+    # partial batch and error conventions (opencl/burst_fft.c:325-326, burst_detect.c:659-665)
+    assert np.array_equal(g.process(frames[:5]).view(np.uint32), want[:5].view(np.uint32))
+    assert g.process_rc(frames, 0) == -1
+    assert g.process_rc(frames, 17) == -1
+    g.close()
+
+
+def test_gpu_burst_fft_create_rejects_bad_arguments():
+    L = irdm.lib()
+    w = _window(2048)
+    assert not L.gpu_burst_fft_create(2000, 16, irdm._fp(w))     # not a power of two -> NULL => CPU fallback in caller
+    assert not L.gpu_burst_fft_create(2048, 0, irdm._fp(w))
+    L.gpu_burst_fft_destroy(None)                                # NULL-safe
+
+
+def _scene_2m(seed=11, n_bursts=8, secs=2.4, **kw):
+    fs = 2_000_000
+    return fs, siggen.standard_scene(fs, int(secs * fs), n_bursts, seed=seed, uplink_every=4, **kw)[0]
+
+
+def test_pipeline_2mhz_cf32_full_parity():
+    fs, iq = _scene_2m()
+    ref = orc.run_stream(iq, fs)
+    got = parity.run_gpu(iq, fs)
+    s = parity.compare(got, ref)
+    assert s["bursts"] >= 8 and s["demods"] >= 5, s
+    # RAW lines: identical text except (possibly) the last printed digit of soft fields
+    for a, b in zip(irdm.format_raw(got["demods"]), ref.raw_lines()):
+        fa, fb = parity.raw_fields(a), parity.raw_fields(b)
+        assert fa[0] == fb[0] and fa[1] == fb[1] and fa[3:6] == fb[3:6] and fa[7:] == fb[7:]
+        assert abs(fa[2] - fb[2]) <= 1 and abs(fa[6] - fb[6]) <= 1e-4
+
+
+def test_pipeline_chunked_equals_single_chunk():
+    """Detector state, active bursts and the IQ history ring carry across feed calls."""
+    fs, iq = _scene_2m(seed=12)
+    ref = orc.run_stream(iq, fs)
+    n = len(iq)
+    blk = 32768
+    chunks = [blk * 7, blk * 3, blk * 40, blk * 1, blk * 20]
+    rest = n - sum(chunks)
+    chunks += [rest // blk * blk, rest % blk] if rest % blk else [rest]
+    chunks = [c for c in chunks if c > 0]
+    got = parity.run_gpu(iq, fs, chunks=chunks)
+    parity.compare(got, ref)
+
+
+def test_pipeline_ci16_and_ci8():
+    fs, iq = _scene_2m(seed=13, n_bursts=5, secs=2.0)
+    i16 = siggen.to_ci16(iq)
+    ref = orc.run_stream(i16, fs, fmt=1)
+    got = parity.run_gpu(i16, fs, fmt=irdm.FMT_CI16)
+    s = parity.compare(got, ref)
+    assert s["demods"] >= 3, s
+    i8 = siggen.to_ci8(iq * 8)
+    ref = orc.run_stream(i8, fs, fmt=0)
+    got = parity.run_gpu(i8, fs, fmt=irdm.FMT_CI8)
+    parity.compare(got, ref)
+
+
+def test_known_answer_bits_from_reference_docs():
+    """ARCHITECTURE.md:264/:270 -- the documented PRBS15 RAW line: 179 payload symbols, same bits."""
+    fs = 2_000_000
+    q = siggen.bits_to_quadrants(siggen.KNOWN_ANSWER_BITS)
+    iq, _ = siggen.make_stream(fs, int(1.0 * fs) // 32768 * 32768,
+                               [dict(start=520 * 2048 + 777, freq_hz=siggen.channel_freq(3), quads=[0] * 16 + q)],
+                               seed=5)
+    got = parity.run_gpu(iq, fs)
+    assert len(got["demods"]) == 1
+    d = got["demods"][0]
+    assert d.n_payload_symbols == 179
+    assert "".join(str(b) for b in d.bits[:d.n_bits]) == siggen.KNOWN_ANSWER_BITS
+    parity.compare(got, orc.run_stream(iq, fs))
+
+
+def test_burst_window_samples_and_stale_tail():
+    """a11: ringbuf_extract semantics incl. the not-yet-written tail of the ring."""
+    fs, iq = _scene_2m(seed=14, n_bursts=4, secs=1.6)
+    L = orc.lib()
+    recs, sams = [], []
+
+    @orc.BURST_CB
+    def cb(rec, samples, user):
+        r = rec.contents
+        recs.append(orc.BurstRec.from_buffer_copy(r))
+        sams.append(np.ctypeslib.as_array(samples, (2 * r.num_samples,)).copy().view(np.complex64))
+
+    det = L.orc_detector_create(1.622e9, fs, 0.0, 0)
+    for off in range(0, len(iq), 32768):
+        blk = np.ascontiguousarray(iq[off:off + 32768])
+        L.orc_detector_feed_cf32(det, orc.fptr(blk.view(np.float32)), len(blk), cb, None)
+    L.orc_detector_destroy(det)
+    assert len(recs) >= 4
+    p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=256)
+    p.feed_host(iq)
+    bursts = p.poll_bursts()
+    assert [b.id for b in bursts] == [r.id for r in recs]
+    stale = 0
+    for i, (b, r, s) in enumerate(zip(bursts, recs, sams)):
+        g = p.burst_samples(i, int(b.num_samples))
+        assert np.array_equal(g.view(np.uint32), s.view(np.uint32)), b.id
+        stale += int(b.start + b.num_samples > b.avail_end)
+    p.close()
+
+
+def test_detector_magnitudes_and_baseline_10mhz():
+    """cfg2 shape (10 MHz, N=8192): magnitudes of a chunk and the baseline sum after priming."""
+    fs = 10_000_000
+    n = 8192 * 600
+    iq, _ = siggen.make_stream(fs, n, [dict(start=8192 * 560, freq_hz=siggen.channel_freq(20), payload=[0, 1, 2, 3] * 40)], seed=21)
+    L = orc.lib()
+    det = L.orc_detector_create(1.622e9, fs, 0.0, 0)
+    sink = np.zeros((600, 8192), np.float32)
+    L.orc_detector_set_mag_sink(det, orc.fptr(sink), 600)
+    for off in range(0, n, 32768):
+        blk = np.ascontiguousarray(iq[off:off + 32768])
+        L.orc_detector_feed_cf32(det, orc.fptr(blk.view(np.float32)), len(blk), orc.BURST_CB(0), None)
+    base = np.ctypeslib.as_array(L.orc_detector_baseline_sum(det), (8192,)).copy()
+    L.orc_detector_destroy(det)
+    p = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=256)
+    p.feed_host(iq)
+    mags = p.last_magnitudes(600)
+    assert np.array_equal(mags.view(np.uint32), sink.view(np.uint32))
+    assert np.array_equal(p.baseline_sum().view(np.uint32), base.view(np.uint32))
+    p.close()
+
+
+@pytest.mark.parametrize("fs,secs,nb", [(10_000_000, 0.9, 6), (12_000_000, 1.1, 5)])
+def test_pipeline_10_and_12_mhz(fs, secs, nb):
+    """cfg3 / cfg4 shapes at oracle-sized lengths."""
+    n = int(secs * fs) // 32768 * 32768
+    iq, _ = siggen.standard_scene(fs, n, nb, seed=fs // 1_000_000)
+    ref = orc.run_stream(iq, fs)
+    got = parity.run_gpu(iq, fs)
+    s = parity.compare(got, ref)
+    assert s["demods"] >= 3, s
+
+
+def test_eof_burst_not_emitted_and_ragged_last_chunk():
+    """bursts still active at EOF are never emitted; trailing < N samples unprocessed."""
+    fs = 2_000_000
+    n = 520 * 2048 + 60000 + 1234
+    iq, _ = siggen.make_stream(fs, n, [dict(start=520 * 2048 + 20000, freq_hz=siggen.channel_freq(4), payload=[1] * 150)], seed=3)
+    ref = orc.run_stream(iq, fs)
+    got = parity.run_gpu(iq, fs, chunks=[32768 * 20, n - 32768 * 20])
+    assert ref.n_tagged == 0 and got["tagged"] == 0
+    assert got["n_samples"] == n
