@@ -170,6 +170,12 @@ int irdm_baseline_sum(irdm_pipeline_t *p, float *out);
 /* burst_data_t.samples of the i-th burst emitted by the LAST chunk (re-gathered) */
 int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float *out, size_t max_samples);
 
+/* Options: "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
+ * "scan_mode" (0 = sparse detector scan with exact dense fallback, 1 = dense scan only).
+ * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */
+int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);
+int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);
+
 /* per-stage device time of the last chunk in milliseconds (hipEvent):
  * [0] fft+mag  [1] detector scan  [2] rotate+FIR decimate  [3] downmix post  [4] demod  [5] total */
 int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n);

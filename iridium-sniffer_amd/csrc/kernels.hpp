@@ -12,6 +12,14 @@ int launch_detect_scan(const DetParams &P, DetState *st, float *sum, float *hist
                        int n_frames, GoneBurst *gone, int gone_cap, PeakCand *cand_a,
                        PeakCand *cand_b, hipStream_t stream);
 
+// scan_fast.hip
+int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, int n,
+                     unsigned *counts, ListEntry *entries, int n_frames, hipStream_t stream);
+int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
+                            int n_frames, const unsigned *counts, const ListEntry *entries,
+                            const float *pre, GoneBurst *gone, int gone_cap, int *status,
+                            hipStream_t stream);
+
 // where a burst window's samples live: the chunk being fed, or the history ring
 struct SampleSource {
     const void *chunk;        // device pointer, configured format

@@ -166,6 +166,15 @@ struct irdm_pipeline {
     size_t tiles_cap;
     float2 *d_dec, *d_lpf, *d_rrc_ws, *d_frames, *d_demod_ws, *d_probe;
     DemodOut *d_demod;
+    // sparse scan (scan_fast.hip): prefilter lists, status word, pre-chunk snapshot for the dense fallback
+    unsigned *d_counts;
+    ListEntry *d_entries;
+    float *d_pre, *d_sum_bak, *d_hist_bak;
+    DetState *d_state_bak;
+    int *d_status;
+    int scan_mode;              // 0 auto (sparse, dense fallback), 1 dense only
+    uint64_t stat_fast_chunks, stat_fallbacks, stat_dense_frames;
+    int host_primed, host_hist_idx;
 
     std::vector<GoneBurst> h_gone;
     std::vector<BurstWork> h_work;
@@ -197,7 +206,9 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_dl_fft, p->d_ul_fft, p->d_rot_incr, p->d_rot_table, p->d_state, p->d_gone,
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
-                     p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod };
+                     p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod,
+                     p->d_counts, p->d_entries, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
+                     p->d_status };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (auto &e : p->ev)
@@ -335,6 +346,16 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
     AL(p->d_demod, DemodOut, (size_t)p->burst_cap);
     AL(p->d_probe, float2, p->l_cap);
+    {
+        const size_t max_frames = p->max_chunk / P.n;
+        AL(p->d_counts, unsigned, max_frames);
+        AL(p->d_entries, ListEntry, max_frames * kListCap);
+        AL(p->d_pre, float, (size_t)P.n);
+        AL(p->d_sum_bak, float, (size_t)P.n);
+        AL(p->d_hist_bak, float, (size_t)kHistory * P.n);
+        AL(p->d_state_bak, DetState, 1);
+        AL(p->d_status, int, 4);
+    }
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
 #undef UP
 #undef AL
@@ -360,7 +381,11 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->stream_closed = false;
     p->last_frames = 0;
     p->last_chunk = nullptr;
-    p->keep_frame_samples = 1;
+    p->keep_frame_samples = 0;
+    p->scan_mode = 0;
+    p->stat_fast_chunks = p->stat_fallbacks = p->stat_dense_frames = 0;
+    p->host_primed = 0;
+    p->host_hist_idx = 0;
     return p;
 }
 
@@ -607,13 +632,63 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, p->d_mag, n_frames, p->stream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->stream));
-    if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, n_frames, p->d_gone, p->gone_cap,
-                           p->d_cand_a, p->d_cand_b, p->stream) != 0)
-        return -1;
+    // ---- detector scan: sparse kernel with the dense kernel as exact fallback ----
+    bool need_dense_all = p->scan_mode == 1;
+    if (!need_dense_all) {
+        // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
+                                      hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 4, p->stream));
+        int done = 0;
+        if (!p->host_primed) {
+            // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428)
+            done = std::min(n_frames, kHistory - p->host_hist_idx);
+            if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, done, p->d_gone, p->gone_cap,
+                                   p->d_cand_a, p->d_cand_b, p->stream) != 0)
+                return -1;
+            p->stat_dense_frames += done;
+        }
+        if (done < n_frames) {
+            const float *mag_rest = p->d_mag + (size_t)done * P.n;
+            if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
+                                 n_frames - done, p->stream) != 0)
+                return -1;
+            if (launch_detect_scan_fast(P, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done,
+                                        p->d_counts, p->d_entries, p->d_pre, p->d_gone, p->gone_cap,
+                                        p->d_status, p->stream) != 0)
+                return -1;
+        }
+        int status = 0;
+        IRDM_HIP_CHECK(hipMemcpyAsync(&status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        if (status != 0) {
+            // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
+            p->stat_fallbacks++;
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
+                                          hipMemcpyDeviceToDevice, p->stream));
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+            need_dense_all = true;
+        } else {
+            p->stat_fast_chunks++;
+        }
+    }
+    if (need_dense_all) {
+        if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, n_frames, p->d_gone, p->gone_cap,
+                               p->d_cand_a, p->d_cand_b, p->stream) != 0)
+            return -1;
+        p->stat_dense_frames += n_frames;
+    }
     IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
     uint32_t counters[2] = { 0, 0 };
+    int32_t hdr[2] = { 0, 0 };
     IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(counters), hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(hdr), hipMemcpyDeviceToHost, p->stream));
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->host_hist_idx = hdr[0];
+    p->host_primed = hdr[1];
     const int n_gone = (int)counters[0];
     if (counters[1] || n_gone > p->gone_cap) {
         fprintf(stderr, "irdm_hip: detector capacity exceeded (%d bursts in one chunk, cap %d)\n", n_gone, p->gone_cap);
@@ -733,6 +808,23 @@ extern "C" int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float 
     IRDM_HIP_CHECK(hipMemcpyAsync(out, p->d_probe, n * sizeof(float2), hipMemcpyDeviceToHost, p->stream));
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
     return (int)n;
+}
+
+extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
+{
+    if (!p || !key) return -1;
+    if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
+    if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
+    return -1;
+}
+
+extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
+{
+    if (!p || !key) return -1;
+    if (!strcmp(key, "scan_fast_chunks")) return (int64_t)p->stat_fast_chunks;
+    if (!strcmp(key, "scan_fallbacks")) return (int64_t)p->stat_fallbacks;
+    if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
+    return -1;
 }
 
 extern "C" int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n)

@@ -54,6 +54,13 @@ struct PeakCand {
     int32_t bin;
 };
 
+// prefilter list entry (scan_fast.hip): a bin whose |X|^2 may exceed the threshold
+struct ListEntry {
+    int32_t bin;
+    float mag;
+};
+constexpr int kListCap = 1024;           // entries per frame; more -> dense scan fallback
+
 // one decimator tile = kFirTileOut outputs of one burst
 struct FirTile {
     int32_t burst;           // index into BurstWork[]

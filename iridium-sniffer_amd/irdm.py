@@ -91,6 +91,9 @@ def lib():
         L.irdm_last_magnitudes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]
         L.irdm_baseline_sum.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.irdm_burst_samples.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]
+        L.irdm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.irdm_get_stat.argtypes = [C.c_void_p, C.c_char_p]
+        L.irdm_get_stat.restype = C.c_int64
         L.irdm_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
         L.irdm_format_raw.argtypes = [C.POINTER(Demod), C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         L.irdm_version.restype = C.c_char_p
@@ -151,6 +154,13 @@ class Pipeline:
             raise RuntimeError("irdm_create failed (no GPU, or bad config)")
         self.fmt = fmt
         self.fft_size = self.L.irdm_fft_size(self.h)
+
+    def set_option(self, key, value):
+        if self.L.irdm_set_option(self.h, key.encode(), int(value)) != 0:
+            raise ValueError("unknown option %r" % key)
+
+    def stat(self, key):
+        return int(self.L.irdm_get_stat(self.h, key.encode()))
 
     def feed_host(self, iq):
         iq = np.ascontiguousarray(iq)

@@ -75,13 +75,21 @@ def frame_quadrants(payload_quads, uplink=False):
 
 
 def make_burst(fs, quads, freq_hz, phase, amp=0.05, alpha=0.4, span=5):
-    """Complex baseband burst at sample rate fs (must be a multiple of 25 kHz)."""
+    """Complex baseband burst at sample rate fs (must be a multiple of 25 kHz).
+
+    Pulse shaping is evaluated in polyphase form (each output sample is the sum of the
+    2*span+1 symbol pulses that overlap it), float64, deterministic."""
     sps = int(round(fs / SYMBOL_RATE))
     sym = np.exp(1j * (np.pi / 4 + np.asarray(quads, dtype=np.float64) * np.pi / 2))
-    up = np.zeros((len(sym) - 1) * sps + 1, dtype=np.complex128)
-    up[::sps] = sym
-    h = rrc_pulse(sps, alpha, span)
-    sig = np.convolve(up, h) / np.sqrt(sps)   # peak ~ 1 per symbol before amp
+    nsym = len(sym)
+    h = rrc_pulse(sps, alpha, span) / np.sqrt(sps)   # peak ~ 1 per symbol before amp
+    nj = 2 * span + 1
+    hp = np.zeros((nj, sps))
+    hp.reshape(-1)[:len(h)] = h                       # hp[j, r] = h[j*sps + r]
+    out = np.zeros((nsym + nj - 1, sps), dtype=np.complex128)
+    for j in range(nj):
+        out[j:j + nsym, :] += sym[:, None] * hp[j][None, :]
+    sig = out.reshape(-1)[:(nsym + 2 * span - 1) * sps + 1]
     n = np.arange(len(sig), dtype=np.float64)
     sig = amp * sig * np.exp(1j * (2 * np.pi * freq_hz / fs * n + phase))
     return sig.astype(np.complex64)

@@ -11,11 +11,13 @@ def bits_of(x):
     return np.float32(x).view(np.uint32)
 
 
-def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, **kw):
+def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, **kw):
     """Feed `iq` through the HIP pipeline in the given chunk sizes (samples)."""
     n = len(iq) if fmt == irdm.FMT_CF32 else len(iq) // 2
     max_chunk = max(chunks) if chunks else n
     p = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=max_chunk, max_bursts_per_chunk=1024, **kw)
+    p.set_option("keep_frame_samples", 1)
+    p.set_option("scan_mode", scan_mode)
     per = 1 if fmt == irdm.FMT_CF32 else 2
     off = 0
     for c in (chunks or [n]):
@@ -26,7 +28,8 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, **kw):
     infos, samples = p.poll_frames()
     demods = p.poll_demods()
     res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, tagged=p.tagged,
-               n_samples=p.sample_count, timings=p.timings())
+               n_samples=p.sample_count, timings=p.timings(),
+               stats={k: p.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames")})
     p.close()
     return res
 

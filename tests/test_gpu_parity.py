@@ -191,3 +191,37 @@ def test_eof_burst_not_emitted_and_ragged_last_chunk():
     got = parity.run_gpu(iq, fs, chunks=[32768 * 20, n - 32768 * 20])
     assert ref.n_tagged == 0 and got["tagged"] == 0
     assert got["n_samples"] == n
+
+
+def test_sparse_scan_is_used_and_equals_dense_scan():
+    """The sparse detector scan (scan_fast.hip) is what normally runs, and it yields exactly
+    the state and bursts of the dense scan (and of the oracle)."""
+    fs, iq = _scene_2m(seed=15, n_bursts=12, secs=3.0)
+    ref = orc.run_stream(iq, fs)
+    blk = 32768
+    n = len(iq)
+    chunks = [blk * 40, blk * 50, n - blk * 90]
+    fast = parity.run_gpu(iq, fs, chunks=chunks, scan_mode=0)
+    dense = parity.run_gpu(iq, fs, chunks=chunks, scan_mode=1)
+    parity.compare(fast, ref)
+    parity.compare(dense, ref)
+    assert fast["stats"]["scan_fast_chunks"] == 3 and fast["stats"]["scan_fallbacks"] == 0, fast["stats"]
+    assert fast["stats"]["scan_dense_frames"] == 512          # only the priming frames of the stream
+    assert dense["stats"]["scan_fast_chunks"] == 0
+
+
+def test_sparse_scan_falls_back_when_noise_floor_drops():
+    """A 12 dB drop of the noise floor inside a chunk makes the prefilter lists stale; the scan
+    must notice (safety net / validation), fall back to the dense scan, and stay exact."""
+    fs = 2_000_000
+    n = 32768 * 110
+    iq, _ = siggen.standard_scene(fs, n, 6, seed=16, first_start=600 * 2048)
+    iq = iq.copy()
+    cut = 32768 * 45
+    # weaken everything (noise and bursts) after `cut`; bursts stay well above the new floor
+    iq[cut:] *= np.float32(0.25)
+    iq[cut:] += siggen.standard_scene(fs, n - cut, 4, seed=17, first_start=700 * 2048, amp=0.03)[0] * np.float32(0.0)
+    ref = orc.run_stream(iq, fs)
+    got = parity.run_gpu(iq, fs, chunks=[32768 * 40, n - 32768 * 40])
+    parity.compare(got, ref)
+    assert got["stats"]["scan_fast_chunks"] + got["stats"]["scan_fallbacks"] == 2
