@@ -160,8 +160,10 @@ __global__ __launch_bounds__(kScanThreads) void detect_scan_kernel(
     // dense baseline update for this thread's bins (simd_baseline_update + memcpy, :441-452)
     auto baseline_update = [&](const float(&mm)[J]) {
         float *hrow = hist + (size_t)hist_idx * N + b0;
+        float oldv[J];
+        for (int j = 0; j < J; j++) oldv[j] = hrow[j];   // unconditional loads (no per-element branch)
         for (int j = 0; j < J; j++) {
-            const float old = primed ? hrow[j] : 0.0f;   // rows not yet rewritten since a reset read 0 (:623-624)
+            const float old = primed ? oldv[j] : 0.0f;   // rows not yet rewritten since a reset read 0 (:623-624)
             const float d = s_sum[b0 + j] - old;
             s_sum[b0 + j] = d + mm[j];
             hrow[j] = mm[j];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(kScanThreads) void detect_scan_kernel(
         __syncthreads();                                                    // S5
         // P4: create_new_bursts + squelch (thread 0)
         if (tid == 0) {
-            volatile unsigned char *vmask = s_mask;
+            unsigned char *vmask = s_mask;   // single thread: program order suffices (never volatile: FLAT sc0 sc1 loads)
             int na = sh.n_act;
             for (int i = 0; i < n_cand; i++) {
                 const PeakCand c = cand_b[i];

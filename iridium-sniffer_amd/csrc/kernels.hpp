@@ -14,11 +14,12 @@ int launch_detect_scan(const DetParams &P, DetState *st, float *sum, float *hist
 
 // scan_fast.hip
 int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, int n,
-                     unsigned *counts, ListEntry *entries, int n_frames, hipStream_t stream);
+                     unsigned *counts, ListEntry *entries, unsigned *goff, ListEntry *compact,
+                     int n_frames, hipStream_t stream);
 int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
-                            int n_frames, const unsigned *counts, const ListEntry *entries,
-                            const float *pre, GoneBurst *gone, int gone_cap, int *status,
-                            hipStream_t stream);
+                            int n_frames, const unsigned *counts, const unsigned *goff,
+                            const ListEntry *compact, const float *pre, GoneBurst *gone, int gone_cap,
+                            int *status, hipStream_t stream);
 
 // where a burst window's samples live: the chunk being fed, or the history ring
 struct SampleSource {

@@ -14,6 +14,7 @@
 //   K7 demod              Gardner / PLL / slicer / UW / DQPSK          (demod.hip)
 //   -- host: records appended to the result queues; history ring updated --
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -167,8 +168,8 @@ struct irdm_pipeline {
     float2 *d_dec, *d_lpf, *d_rrc_ws, *d_frames, *d_demod_ws, *d_probe;
     DemodOut *d_demod;
     // sparse scan (scan_fast.hip): prefilter lists, status word, pre-chunk snapshot for the dense fallback
-    unsigned *d_counts;
-    ListEntry *d_entries;
+    unsigned *d_counts, *d_goff;
+    ListEntry *d_entries, *d_compact;
     float *d_pre, *d_sum_bak, *d_hist_bak;
     DetState *d_state_bak;
     int *d_status;
@@ -207,7 +208,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod,
-                     p->d_counts, p->d_entries, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
+                     p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -350,11 +351,13 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         const size_t max_frames = p->max_chunk / P.n;
         AL(p->d_counts, unsigned, max_frames);
         AL(p->d_entries, ListEntry, max_frames * kListCap);
+        AL(p->d_goff, unsigned, max_frames + 1);
+        AL(p->d_compact, ListEntry, max_frames * kListCap);
         AL(p->d_pre, float, (size_t)P.n);
         AL(p->d_sum_bak, float, (size_t)P.n);
         AL(p->d_hist_bak, float, (size_t)kHistory * P.n);
         AL(p->d_state_bak, DetState, 1);
-        AL(p->d_status, int, 4);
+        AL(p->d_status, int, 64);
     }
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
 #undef UP
@@ -640,7 +643,7 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
                                       hipMemcpyDeviceToDevice, p->stream));
         IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 4, p->stream));
+        IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 64, p->stream));
         int done = 0;
         if (!p->host_primed) {
             // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428)
@@ -653,16 +656,24 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         if (done < n_frames) {
             const float *mag_rest = p->d_mag + (size_t)done * P.n;
             if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
-                                 n_frames - done, p->stream) != 0)
+                                 p->d_goff, p->d_compact, n_frames - done, p->stream) != 0)
                 return -1;
             if (launch_detect_scan_fast(P, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done,
-                                        p->d_counts, p->d_entries, p->d_pre, p->d_gone, p->gone_cap,
-                                        p->d_status, p->stream) != 0)
+                                        p->d_counts, p->d_goff, p->d_compact, p->d_pre, p->d_gone,
+                                        p->gone_cap, p->d_status, p->stream) != 0)
                 return -1;
         }
         int status = 0;
-        IRDM_HIP_CHECK(hipMemcpyAsync(&status, p->d_status, sizeof(int), hipMemcpyDeviceToHost, p->stream));
+        int status_buf[64];
+        IRDM_HIP_CHECK(hipMemcpyAsync(status_buf, p->d_status, sizeof(status_buf), hipMemcpyDeviceToHost, p->stream));
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        status = status_buf[0];
+        if (getenv("IRDM_SCAN_DEBUG")) {
+            const long long *d = reinterpret_cast<const long long *>(status_buf + 4);
+            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld bulk=%lld validate=%lld zero=%lld | n_bulk=%lld n_validate=%lld n_zero=%lld n_complex=%lld n_sparse=%lld | s1(top)=%lld s2(flags)=%lld s3(frame)=%lld cal=%lld cA=%lld cB=%lld\n",
+                    d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+
+        }
         if (status != 0) {
             // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
             p->stat_fallbacks++;

@@ -186,6 +186,39 @@ class Pipeline:
             out += [typ.from_buffer_copy(buf[i]) for i in range(n)]
         return out
 
+    def _poll_raw(self, fn, typ, chunk):
+        """Drain a result queue into one numpy byte matrix [n, sizeof(typ)] (no per-record objects)."""
+        size = C.sizeof(typ)
+        parts = []
+        while True:
+            buf = np.empty((chunk, size), np.uint8)
+            n = fn(self.h, buf.ctypes.data_as(C.POINTER(typ)), chunk)
+            if n <= 0:
+                break
+            parts.append(buf[:n])
+            if n < chunk:
+                break
+        return np.concatenate(parts) if parts else np.empty((0, size), np.uint8)
+
+    def poll_bursts_raw(self, chunk=4096):
+        return self._poll_raw(self.L.irdm_poll_bursts, Burst, chunk)
+
+    def poll_demods_raw(self, chunk=2048):
+        return self._poll_raw(self.L.irdm_poll_demods, Demod, chunk)
+
+    def drop_frames(self, chunk=4096):
+        """Discard queued frame records (metadata only path)."""
+        buf = (FrameInfo * chunk)()
+        total = 0
+        while True:
+            n = self.L.irdm_poll_frames(self.h, buf, None, chunk)
+            if n <= 0:
+                break
+            total += n
+            if n < chunk:
+                break
+        return total
+
     def poll_bursts(self):
         return self._poll(self.L.irdm_poll_bursts, Burst)
 
