@@ -170,6 +170,28 @@ int irdm_baseline_sum(irdm_pipeline_t *p, float *out);
 /* burst_data_t.samples of the i-th burst emitted by the LAST chunk (re-gathered) */
 int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float *out, size_t max_samples);
 
+/* Stage C alone, batched: qpsk_demod() (qpsk_demod.h:42) for n downmixed frames.
+ * samples: n rows of 2*IRDM_MAX_FRAME_SAMPLES floats (re,im interleaved, row-padded);
+ * num_samples[i] <= IRDM_MAX_FRAME_SAMPLES; direction[i] = the downmixer's ir_direction_t.
+ * out[i].ok = the reference's return value (1 = unique word accepted); metadata fields other
+ * than direction, confidence, level, the symbol counts, bits, llr and total_phase are left zero.  Returns 0 or -1. */
+int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, const int *num_samples,
+                          const int *direction, int n, irdm_demod_t *out);
+
+/* ---- time-chunk sharding of ONE stream across GPUs ----
+ * The detector is sequential across frames (noise-floor ring, active bursts, ids); exact
+ * sharding hands its state from the rank that scanned chunk k to the rank that scans chunk k+1.
+ * irdm_state_bytes: size of the blob (DetState + baseline sum + 512-frame history).
+ * irdm_export_state / irdm_import_state: blob to / from a HOST buffer (the caller moves it
+ * between ranks, e.g. RCCL send/recv of the same bytes).  Returns bytes written / 0, or -1.
+ * irdm_seed_history: tells a fresh context that its stream position is abs_start and gives it
+ * the n_samples of IQ (host buffer, configured format) that precede that position, so burst
+ * windows reaching back across the chunk boundary read real samples (the chunk overlap). */
+size_t irdm_state_bytes(const irdm_pipeline_t *p);
+long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap);
+int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n);
+int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start);
+
 /* Options: "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
  * "scan_mode" (0 = sparse detector scan with exact dense fallback, 1 = dense scan only).
  * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */

@@ -821,6 +821,129 @@ extern "C" int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float 
     return (int)n;
 }
 
+// ---- detector-state hand-off for time-chunk sharding ----
+struct StateHeader {
+    uint64_t magic, n, hist, total_samples, tagged, start_time_ns;
+    int32_t host_primed, host_hist_idx;
+};
+
+extern "C" size_t irdm_state_bytes(const irdm_pipeline_t *p)
+{
+    if (!p) return 0;
+    return sizeof(StateHeader) + sizeof(DetState) + sizeof(float) * (size_t)p->P.n * (1 + kHistory);
+}
+
+extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap)
+{
+    if (!p || !buf || cap < irdm_state_bytes(p)) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    char *o = static_cast<char *>(buf);
+    StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
+                      p->start_time_ns, p->host_primed, p->host_hist_idx };
+    memcpy(o, &h, sizeof(h));
+    o += sizeof(h);
+    IRDM_HIP_CHECK(hipMemcpy(o, p->d_state, sizeof(DetState), hipMemcpyDeviceToHost));
+    o += sizeof(DetState);
+    IRDM_HIP_CHECK(hipMemcpy(o, p->d_sum, sizeof(float) * p->P.n, hipMemcpyDeviceToHost));
+    o += sizeof(float) * p->P.n;
+    IRDM_HIP_CHECK(hipMemcpy(o, p->d_hist, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyDeviceToHost));
+    return (long long)irdm_state_bytes(p);
+}
+
+extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
+{
+    if (!p || !buf || n < irdm_state_bytes(p)) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    const char *i = static_cast<const char *>(buf);
+    StateHeader h;
+    memcpy(&h, i, sizeof(h));
+    if (h.magic != 0x4952444d53544154ull || h.n != (uint64_t)p->P.n || h.hist != (uint64_t)kHistory) return -1;
+    i += sizeof(h);
+    IRDM_HIP_CHECK(hipMemcpy(p->d_state, i, sizeof(DetState), hipMemcpyHostToDevice));
+    i += sizeof(DetState);
+    IRDM_HIP_CHECK(hipMemcpy(p->d_sum, i, sizeof(float) * p->P.n, hipMemcpyHostToDevice));
+    i += sizeof(float) * p->P.n;
+    IRDM_HIP_CHECK(hipMemcpy(p->d_hist, i, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyHostToDevice));
+    p->total_samples = h.total_samples;
+    p->tagged = h.tagged;
+    p->start_time_ns = h.start_time_ns;
+    p->host_primed = h.host_primed;
+    p->host_hist_idx = h.host_hist_idx;
+    return 0;
+}
+
+extern "C" int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start)
+{
+    if (!p || (!h_iq && n_samples) || n_samples > abs_start) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (n_samples > p->ring_len) {       // only the most recent ring_len samples can matter
+        h_iq = static_cast<const char *>(h_iq) + (n_samples - p->ring_len) * (p->cfg.format == IRDM_FMT_CI16 ? 4 : p->bps);
+        n_samples = p->ring_len;
+    }
+    std::vector<int8_t> narrowed;
+    const char *src = static_cast<const char *>(h_iq);
+    if (p->cfg.format == IRDM_FMT_CI16) {
+        narrowed.resize(2 * n_samples);
+        const int16_t *s16 = static_cast<const int16_t *>(h_iq);
+        for (size_t k = 0; k < 2 * n_samples; k++) narrowed[k] = (int8_t)(s16[k] >> 8);
+        src = reinterpret_cast<const char *>(narrowed.data());
+    }
+    uint64_t a0 = abs_start - n_samples;
+    size_t done = 0;
+    while (done < n_samples) {
+        const uint64_t pos = (a0 + done) % p->ring_len;
+        const size_t run = std::min<size_t>(n_samples - done, p->ring_len - pos);
+        IRDM_HIP_CHECK(hipMemcpy(static_cast<char *>(p->d_ring) + pos * p->bps, src + done * p->bps, run * p->bps,
+                                 hipMemcpyHostToDevice));
+        done += run;
+    }
+    p->total_samples = abs_start;
+    return 0;
+}
+
+extern "C" int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, const int *num_samples,
+                                     const int *direction, int n, irdm_demod_t *out)
+{
+    if (!p || !samples || !num_samples || !direction || !out || n < 0) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    for (int base = 0; base < n; base += p->burst_cap) {
+        const int nb = std::min(p->burst_cap, n - base);
+        p->h_work.assign(nb, BurstWork());
+        for (int i = 0; i < nb; i++) {
+            if (num_samples[base + i] < 0 || num_samples[base + i] > kMaxFrameSamples) return -1;
+            p->h_work[i].num_samples = num_samples[base + i];
+            p->h_work[i].direction = direction[base + i];
+            p->h_work[i].drop_reason = 0;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb, hipMemcpyHostToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_frames, samples + (size_t)base * 2 * kMaxFrameSamples,
+                                      sizeof(float2) * (size_t)nb * kMaxFrameSamples, hipMemcpyHostToDevice, p->stream));
+        if (launch_demod(p->d_work, nb, p->d_frames, p->cfg.use_gardner, p->sps, p->d_demod_ws, p->d_demod,
+                         p->stream) != 0)
+            return -1;
+        p->h_demod.resize(nb);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_demod.data(), p->d_demod, sizeof(DemodOut) * nb, hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        for (int i = 0; i < nb; i++) {
+            const DemodOut &d = p->h_demod[i];
+            irdm_demod_t &o = out[base + i];
+            memset(&o, 0, sizeof(o));
+            o.ok = d.ok;
+            if (!d.ok) continue;
+            o.direction = d.direction;
+            o.confidence = d.confidence;
+            o.level = d.level;
+            o.n_symbols = d.n_symbols;
+            o.n_payload_symbols = d.n_symbols - 12;
+            o.n_bits = 2 * d.n_symbols;
+            o.total_phase = d.total_phase;
+            memcpy(o.bits, d.bits, sizeof(o.bits));
+            memcpy(o.llr, d.llr, sizeof(o.llr));
+        }
+    }
+    return 0;
+}
+
 extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
 {
     if (!p || !key) return -1;

@@ -91,6 +91,14 @@ def lib():
         L.irdm_last_magnitudes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]
         L.irdm_baseline_sum.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.irdm_burst_samples.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]
+        L.irdm_qpsk_demod_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int), C.c_int, C.POINTER(Demod)]
+        L.irdm_state_bytes.argtypes = [C.c_void_p]
+        L.irdm_state_bytes.restype = C.c_size_t
+        L.irdm_export_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_export_state.restype = C.c_longlong
+        L.irdm_import_state.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_seed_history.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
         L.irdm_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.irdm_get_stat.argtypes = [C.c_void_p, C.c_char_p]
         L.irdm_get_stat.restype = C.c_int64
@@ -238,6 +246,41 @@ class Pipeline:
                 infos.append(fi)
                 samples.append(sb[i, :2 * fi.num_samples].copy().view(np.complex64))
         return infos, samples
+
+    def qpsk_demod_batch(self, frames, directions):
+        """frames: list of complex64 arrays (<= 4440 samples); returns list of Demod."""
+        n = len(frames)
+        buf = np.zeros((n, 2 * MAX_FRAME_SAMPLES), np.float32)
+        ns = np.zeros(n, np.int32)
+        for i, f in enumerate(frames):
+            f = np.ascontiguousarray(f, np.complex64)
+            ns[i] = len(f)
+            buf[i, :2 * len(f)] = f.view(np.float32)
+        dirs = np.ascontiguousarray(directions, np.int32)
+        out = (Demod * n)()
+        rc = self.L.irdm_qpsk_demod_batch(self.h, _fp(buf), ns.ctypes.data_as(C.POINTER(C.c_int)),
+                                          dirs.ctypes.data_as(C.POINTER(C.c_int)), n, out)
+        if rc != 0:
+            raise RuntimeError("irdm_qpsk_demod_batch failed")
+        return [Demod.from_buffer_copy(out[i]) for i in range(n)]
+
+    def export_state(self):
+        n = self.L.irdm_state_bytes(self.h)
+        buf = np.empty(n, np.uint8)
+        if self.L.irdm_export_state(self.h, buf.ctypes.data_as(C.c_void_p), n) != n:
+            raise RuntimeError("irdm_export_state failed")
+        return buf
+
+    def import_state(self, buf):
+        buf = np.ascontiguousarray(buf, np.uint8)
+        if self.L.irdm_import_state(self.h, buf.ctypes.data_as(C.c_void_p), len(buf)) != 0:
+            raise RuntimeError("irdm_import_state failed")
+
+    def seed_history(self, iq_tail, abs_start):
+        iq_tail = np.ascontiguousarray(iq_tail)
+        n = len(iq_tail) if self.fmt == FMT_CF32 else len(iq_tail) // 2
+        if self.L.irdm_seed_history(self.h, iq_tail.ctypes.data_as(C.c_void_p), n, abs_start) != 0:
+            raise RuntimeError("irdm_seed_history failed")
 
     def last_magnitudes(self, max_frames):
         out = np.zeros((max_frames, self.fft_size), np.float32)

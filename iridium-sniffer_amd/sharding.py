@@ -1,0 +1,119 @@
+"""Multi-GPU plumbing for the hot path, one process per GPU over
+torch.distributed ("nccl" == RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+Two ways the path shards:
+  streams      independent IQ streams, one per rank: no data-path collective, only the
+               gather of demodulated-frame records to rank 0 (what bench.py --gpus N runs).
+  time chunks  ONE stream cut into contiguous chunks of whole feed blocks.  The per-frame
+               FFT/|.|^2 and all per-burst work are independent; the detector state machine is
+               not (512-frame noise ring, active bursts, burst ids), so rank k receives the
+               detector state from rank k-1 (point-to-point send/recv: 16-32 MiB, ~0.2 ms on one
+               xGMI link) and each rank also loads the `overlap` samples that precede its
+               chunk so burst windows can reach back across the boundary.
+"""
+import numpy as np
+
+
+def chunk_plan(total_samples, world, block=32768, overlap=0):
+    """Contiguous time-chunks of whole feed blocks (the last chunk takes the ragged tail).
+
+    Returns [(start, stop, history_start)] per rank; history_start..start is the overlap
+    (clamped at 0) a rank must load in front of its chunk."""
+    n_blocks = total_samples // block
+    per = [n_blocks // world + (1 if r < n_blocks % world else 0) for r in range(world)]
+    plan, pos = [], 0
+    for r in range(world):
+        start = pos
+        stop = start + per[r] * block
+        if r == world - 1:
+            stop = total_samples
+        plan.append((start, stop, max(0, start - overlap)))
+        pos = stop
+    return plan
+
+
+def required_overlap(sample_rate, fft_size):
+    """Samples a rank must see before its chunk: the reference's ring (stale-slot reads reach one
+    ring length back, burst_detect.c:292-296, :401-422) plus the longest burst window."""
+    max_len = int(sample_rate * 0.09)
+    post = int(sample_rate * 16e-3)
+    pre = 2 * fft_size
+    ring = max(2 * sample_rate, max_len + pre + post + 4 * fft_size)
+    return ring + max_len + post + pre + 2 * fft_size
+
+
+def gather_records(dist, records, rec_size, cap, device=None):
+    """Gather fixed-size records (uint8 [n, rec_size]) from every rank to rank 0.
+
+    One padded dist.gather of cap*rec_size bytes plus the counts: burst records are ~0.5-4.5 KB
+    each, so this is latency-, not bandwidth-bound.  Returns list-per-rank on rank 0, else None."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    recs = np.ascontiguousarray(records, np.uint8).reshape(-1, rec_size)
+    k = min(len(recs), cap)
+    buf = torch.zeros(cap * rec_size + 8, dtype=torch.uint8, device=device)
+    hdr = np.array([k], np.int64).view(np.uint8)
+    buf[:8] = torch.from_numpy(hdr.copy()).to(buf.device)
+    if k:
+        buf[8:8 + k * rec_size] = torch.from_numpy(recs[:k].reshape(-1).copy()).to(buf.device)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    res = []
+    for t in out:
+        a = t.cpu().numpy()
+        n = int(a[:8].view(np.int64)[0])
+        res.append(a[8:8 + n * rec_size].reshape(n, rec_size).copy())
+    return res
+
+
+def max_over_ranks(dist, value, device=None):
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def handoff_recv(dist, nbytes, device=None):
+    """Rank k>0: receive the detector state blob from rank k-1."""
+    import torch
+    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dist.recv(t, src=dist.get_rank() - 1)
+    return t.cpu().numpy()
+
+
+def handoff_send(dist, blob, device=None):
+    """Rank k<world-1: send the detector state blob to rank k+1."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(blob, np.uint8))
+    if device is not None:
+        t = t.to(device)
+    dist.send(t, dst=dist.get_rank() + 1)
+
+
+def run_time_sharded(dist, make_pipeline, iq, fmt_is_cf32, sample_rate, fft_size, block=32768, device=None):
+    """Process ONE stream `iq` (host array, every rank holds or can read it) across all ranks.
+
+    make_pipeline() -> object with feed_host/seed_history/import_state/export_state/
+    poll_demods_raw (irdm.Pipeline).  Ranks scan in order (state hand-off); everything after the
+    scan of a chunk (downmix, demod) overlaps with the next rank's scan.  Returns the gathered
+    record arrays on rank 0."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    per = 1 if fmt_is_cf32 else 2
+    n = len(iq) // per
+    plan = chunk_plan(n, world, block, required_overlap(sample_rate, fft_size))
+    start, stop, hist0 = plan[rank]
+    pipe = make_pipeline(stop - start)
+    if rank > 0:
+        pipe.seed_history(iq[hist0 * per:start * per], start)
+        blob = handoff_recv(dist, pipe.L.irdm_state_bytes(pipe.h), device)
+        pipe.import_state(blob)
+    if rank < world - 1:
+        # detector pass of this chunk must finish before the state can move on
+        pipe.feed_host(iq[start * per:stop * per])
+        handoff_send(dist, pipe.export_state(), device)
+    else:
+        pipe.feed_host(iq[start * per:stop * per])
+    recs = pipe.poll_demods_raw()
+    return gather_records(dist, recs, recs.shape[1] if recs.size else 4544, 4096, device)

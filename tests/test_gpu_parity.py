@@ -225,3 +225,43 @@ def test_sparse_scan_falls_back_when_noise_floor_drops():
     got = parity.run_gpu(iq, fs, chunks=[32768 * 40, n - 32768 * 40])
     parity.compare(got, ref)
     assert got["stats"]["scan_fast_chunks"] + got["stats"]["scan_fallbacks"] == 2
+
+
+def test_time_chunk_handoff_equals_single_context():
+    """chunk k+1 processed by a DIFFERENT context that received the detector state
+    (irdm_export_state/irdm_import_state) and the preceding samples (irdm_seed_history)
+    gives exactly the single-context result (what rank k+1 does in a time-sharded run)."""
+    import sharding
+    fs, iq = _scene_2m(seed=18, n_bursts=10, secs=2.6)
+    ref = orc.run_stream(iq, fs)
+    n = len(iq)
+    # cut the stream inside a burst window so that it straddles the two contexts
+    cut = None
+    for rb in ref.bursts:
+        c = (rb.start + rb.num_samples // 2) // 32768 * 32768
+        if rb.start < c < rb.start + rb.num_samples and c > 600 * 2048:
+            cut = int(c)
+            break
+    assert cut is not None
+    a = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=512)
+    b = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=512)
+    for p in (a, b):
+        p.set_option("keep_frame_samples", 1)
+    a.feed_host(iq[:cut])
+    blob = a.export_state()
+    assert len(blob) == a.L.irdm_state_bytes(a.h)
+    ov = min(cut, sharding.required_overlap(fs, 2048))
+    b.seed_history(iq[cut - ov:cut], cut)
+    b.import_state(blob)
+    b.feed_host(iq[cut:])
+    got = dict(bursts=a.poll_bursts() + b.poll_bursts(), demods=a.poll_demods() + b.poll_demods(),
+               tagged=b.tagged, n_samples=b.sample_count)
+    ia, sa = a.poll_frames()
+    ib, sb_ = b.poll_frames()
+    got["infos"], got["samples"] = ia + ib, sa + sb_
+    s = parity.compare(got, ref)
+    assert s["bursts"] >= 10
+    # at least one burst window straddles the cut (reads the seeded history)
+    assert any(bb.start < cut < bb.start + bb.num_samples for bb in got["bursts"])
+    a.close()
+    b.close()
