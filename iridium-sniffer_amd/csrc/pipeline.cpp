@@ -670,8 +670,10 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         status = status_buf[0];
         if (getenv("IRDM_SCAN_DEBUG")) {
             const long long *d = reinterpret_cast<const long long *>(status_buf + 4);
-            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld bulk=%lld validate=%lld zero=%lld | n_bulk=%lld n_validate=%lld n_zero=%lld n_complex=%lld n_sparse=%lld | s1(top)=%lld s2(flags)=%lld s3(frame)=%lld cal=%lld cA=%lld cB=%lld\n",
-                    d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld bulk=%lld validate=%lld | n_bulk=%lld n_complex=%lld n_simple=%lld | "
+                            "stage=%lld(%lld) flags=%lld(%lld) build=%lld(%lld) loop=%lld partA=%lld partB=%lld quiet=%lld\n",
+                    d[0], d[1], d[2], d[3], d[5], d[8], d[9], d[10], d[17], d[11], d[18], d[12], d[19], d[13], d[14], d[15], d[16]);
+
 
         }
         if (status != 0) {

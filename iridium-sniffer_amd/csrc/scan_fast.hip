@@ -103,7 +103,12 @@ __global__ __launch_bounds__(256) void list_compact_kernel(const unsigned *__res
         const unsigned c = counts[frame] < (unsigned)kListCap ? counts[frame] : (unsigned)kListCap;
         const ListEntry *src = entries + (size_t)frame * kListCap;
         ListEntry *dst = compact + goff[frame];
-        for (unsigned i = threadIdx.x; i < c; i += 256) dst[i] = src[i];
+        // bin (14 bits) | frame index within the scanned range << 14: the scan regroups entries by frame
+        for (unsigned i = threadIdx.x; i < c; i += 256) {
+            ListEntry e = src[i];
+            e.bin |= frame << 14;
+            dst[i] = e;
+        }
     }
 }
 
@@ -123,7 +128,7 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
 enum { CMD_EXIT = 0, CMD_BULK = 1, CMD_VALIDATE = 2, CMD_ZERO = 3 };
 constexpr int kFastMaxActive = 64;      // active bursts live in the leader's lanes; more -> dense fallback
 constexpr int kStageCap = 4096;         // list entries staged in LDS per batch
-constexpr int kStageFrames = 63;
+constexpr int kStageFrames = 16;
 constexpr int kGoneLds = 256;           // gone records buffered in LDS between flushes        // frames per batch (lane k <-> frame k, lane k+1 holds its end offset)
 
 struct FastShared {
@@ -159,7 +164,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     ListEntry *s_ent = reinterpret_cast<ListEntry *>(s_cand + kListCap);                  // kStageCap
     unsigned char *s_flag = reinterpret_cast<unsigned char *>(s_ent + kStageCap);         // kStageCap
     GoneBurst *s_gone = reinterpret_cast<GoneBurst *>(s_flag + kStageCap);                // kGoneLds
-    FastShared &sh = *reinterpret_cast<FastShared *>(s_gone + kGoneLds);
+    unsigned long long *s_hit = reinterpret_cast<unsigned long long *>(s_gone + kGoneLds); // 64
+    unsigned *s_cnd = reinterpret_cast<unsigned *>(s_hit + 64);                           // 64
+    FastShared &sh = *reinterpret_cast<FastShared *>(s_cnd + 64);
     // NOTE: never `volatile` here -- a volatile access through a generic pointer compiles to a
     // system-coherent FLAT load (microseconds); LDS ops of one wavefront execute in order, so a
     // compiler barrier between the write and read phases is all the ordering that is needed.
@@ -232,28 +239,43 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     __syncthreads();
 
     // ---- leader state (registers of wavefront 0) ----
+    // Active bursts live in fixed lane slots: lane s mirrors slot s while bit s of `occ` is set.
+    // The reference's list order (burst_detect.c:148-160) is creation order == ascending id.
     int hist_idx = st->hist_idx, primed = st->primed, squelch = st->squelch;
-    int n_act = n_act_in < kFastMaxActive ? n_act_in : kFastMaxActive;
+    unsigned long long occ = 0;
+    {
+        const int na = n_act_in < kFastMaxActive ? n_act_in : kFastMaxActive;
+        occ = na >= 64 ? ~0ull : ((1ull << na) - 1ull);
+    }
     unsigned n_gone = st->n_gone;
     unsigned gone_base = n_gone;
     unsigned long long burst_id = st->burst_id;
     int abort_code = sh.abort;
-    int r_cb = 0;                          // lane i mirrors active burst i
-    uint64_t r_la = 0, r_start = 0;
-    if (lane < n_act) {
+    int r_cb = 0;
+    uint64_t r_la = 0, r_start = 0, r_id = 0;
+    if ((occ >> lane) & 1) {
         r_cb = s_act[lane].center_bin;
         r_la = s_act[lane].last_active;
         r_start = s_act[lane].start;
+        r_id = s_act[lane].id;
     }
     int sb = 0, snf = 0;                   // staged batch: frames [sb, sb+snf)
     unsigned r_off = 0;                    // lane k: offset of frame sb+k in s_ent (lane snf: total)
-    bool flags_valid = false;
+    bool flags_valid = false;              // s_flag[] (exact crossing test) valid from flags_from on
+    bool summ_valid = false;               // per-frame summaries valid for frames >= current
+    unsigned h_lo = 0, h_hi = 0, cndv = 0; // lane k: summary of staged frame k (hit bits per slot, candidate flag)
     int f = 0, state = S_TOP;
-    long long t_cmd[4] = {0, 0, 0, 0}, t_lead = 0, t_s1 = 0, t_s2 = 0, t_s3 = 0, t_s4 = 0, t_cal = 0, t_cA = 0, t_cB = 0, t_fe = 0;
+    long long t_cmd[4] = {0, 0, 0, 0}, t_lead = 0, tS = 0, tF = 0, tB = 0, tL = 0, tA = 0, tC = 0, tQ = 0;
+    int nS = 0, nF = 0, nBd = 0;
     int n_cmd[4] = {0, 0, 0, 0}, n_cplx = 0, n_sparse = 0;
     const long long t_begin = IRDM_TICK();
     int e0 = 0, e1 = 0, n_cand = 0, hist_before = 0;
     bool any_cand = false, was_quiet = false;
+    unsigned long long ev_del = 0, new_slots = 0;
+    bool need_light = false;
+
+#define RL64(v, l) (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((v) >> 32), (l)) << 32) | \
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
 
     for (;;) {
         const long long t_l0 = IRDM_TICK();
@@ -263,7 +285,6 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             while (cmd < 0) {
                 if (abort_code || (state == S_TOP && f >= n_frames)) { cmd = CMD_EXIT; break; }
                 if (state == S_TOP) {
-                    const long long ta = IRDM_TICK();
                     if (!primed) {
                         // update_filters_pre returns 0 (:427-428): updates only, up to the priming frame
                         int run = kHistory - hist_idx;
@@ -272,7 +293,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         f += run;
                         break;
                     }
+                    const long long tt0 = IRDM_TICK();
                     if (f < sb || f >= sb + snf) {
+                        nS++;
                         // ---- stage the compact lists of up to kStageFrames frames starting at f ----
                         const int nf = n_frames - f < kStageFrames ? n_frames - f : kStageFrames;
                         unsigned g = 0, c = 0;
@@ -298,11 +321,21 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         }
                         WAVE_SYNC();
                         flags_valid = false;
+                        summ_valid = false;
                     }
+                    const long long tt1 = IRDM_TICK();
+                    tS += tt1 - tt0;
                     const int k0 = f - sb;
-                    if (n_act == 0) {
-                        // quiet: frames with an empty list are updated in bulk, every thread re-checking
-                        // its own bins exactly (safety net)
+                    e0 = __builtin_amdgcn_readlane((int)r_off, k0);
+                    e1 = __builtin_amdgcn_readlane((int)r_off, k0 + 1);
+                    const uint64_t index = index0 + (uint64_t)f * N;
+                    was_quiet = occ == 0;
+                    hist_before = hist_idx;
+
+                    if (occ == 0) {
+                        // ---------------- quiet ----------------
+                        // frames with an empty list are updated in bulk, every thread re-checking its own
+                        // bins exactly (safety net)
                         const unsigned nxt = __shfl_down(r_off, 1);
                         const bool nonempty = lane >= k0 && lane < snf && nxt != r_off;
                         const unsigned long long nz = __ballot(nonempty) >> k0;
@@ -313,136 +346,212 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             f += run;
                             break;
                         }
-                    }
-                    const long long tb = IRDM_TICK();
-                    t_s1 += tb - ta;
-                    e0 = __builtin_amdgcn_readlane((int)r_off, k0);
-                    e1 = __builtin_amdgcn_readlane((int)r_off, k0 + 1);
-                    if (!flags_valid) {
-                        // exact threshold test of the staged entries from this frame on
-                        // (simd_relative_mag + `> threshold`)
-                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
-                        for (int i = e0 + lane; i < total; i += 64) {
-                            const ListEntry e = s_ent[i];
-                            const float sv = s_sum[e.bin];
-                            const float rel = sv > 0 ? e.mag / sv : 0.0f;
-                            s_flag[i] = rel > thr ? 1 : 0;
-                        }
-                        WAVE_SYNC();
-                        flags_valid = true;
-                    }
-                    // ---- one frame, sparse ----
-                    const long long tc = IRDM_TICK();
-                    t_s2 += tc - tb;
-                    n_sparse++;
-                    const uint64_t index = index0 + (uint64_t)f * N;
-                    was_quiet = n_act == 0;
-                    hist_before = hist_idx;
-                    any_cand = false;
-                    for (int base = e0; base < e1; base += 64) {
-                        const int i = base + lane;
-                        bool cross = false;
-                        int bin = -100;
-                        if (i < e1) {
-                            cross = s_flag[i] != 0;
-                            bin = s_ent[i].bin;
-                        }
-                        // update_bursts (:458-469): a crossing bin within +-1 of an active burst's centre
-                        for (int j = 0; j < n_act; j++) {
-                            const int cb = __builtin_amdgcn_readlane(r_cb, j);
-                            const bool near = cross && bin >= cb - 1 && bin <= cb + 1;
-                            if (__any(near) && lane == j) r_la = index;
-                        }
-                        // peak candidates (:522-548): crossing, not under the previous frame's mask, in range
-                        const bool cand = cross && vmask[bin < 0 ? 0 : bin] && VALID_BIN(bin);
-                        any_cand |= __any(cand) != 0;
-                    }
-                    bool del = false;
-                    if (lane < n_act) {
-                        const bool too_long = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
-                        del = (r_la + (uint64_t)P.post_len <= index) || too_long;
-                    }
-                    const long long td = IRDM_TICK();
-                    t_s3 += td - tc;
-                    { const long long te = IRDM_TICK(); t_cal += te - td; }
-                    if (!any_cand && !__any(del)) {
-                        if (squelch > 0) squelch--;                               // :629-630
-                        state = S_FRAME_END;
-                        continue;
-                    }
-                    n_cplx++;
-                    const long long tA0 = IRDM_TICK();
-                    // ---- a burst ends or may start in this frame (burst_detect.c:490-632), part A ----
-                    if (lane < n_act) s_act[lane].last_active = r_la;
-                    WAVE_SYNC();
-                    n_cand = 0;
-                    if (any_cand) {
+                        // a listed frame: exact test of ITS entries against the live sums; with no burst
+                        // active the mask is all ones, so a valid crossing is a peak (burst_detect.c:529-548)
+                        n_cand = 0;
                         for (int base = e0; base < e1; base += 64) {
                             const int i = base + lane;
                             bool cand = false;
                             PeakCand c;
                             c.rel = 0.0f; c.bin = 0;
-                            if (i < e1 && s_flag[i]) {
+                            if (i < e1) {
                                 const ListEntry e = s_ent[i];
-                                cand = vmask[e.bin] && VALID_BIN(e.bin);
-                                c.bin = e.bin;
-                                c.rel = e.mag / s_sum[e.bin];
+                                const int bin = e.bin & 0x3FFF;
+                                const float sv = s_sum[bin];
+                                c.rel = sv > 0 ? e.mag / sv : 0.0f;
+                                c.bin = bin;
+                                cand = c.rel > thr && VALID_BIN(bin);
                             }
                             const unsigned long long cm = __ballot(cand);
                             if (cand) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
                             n_cand += __popcll(cm);
                         }
                         WAVE_SYNC();
-                    }
-                    // delete_gone_bursts (:490-518), order preserving (n_act <= 64: one pass)
-                    bool force = false;
-                    {
-                        ActiveBurst b;
-                        const bool valid = lane < n_act;
-                        bool dl = false;
-                        if (valid) {
-                            b = s_act[lane];
-                            const bool too_long = P.max_len > 0 && (b.last_active - b.start > (uint64_t)P.max_len);
-                            if (too_long) force = true;
-                            dl = (b.last_active + (uint64_t)P.post_len <= index) || too_long;
+                        tQ += IRDM_TICK() - tt1;
+                        if (n_cand == 0) {
+                            if (squelch > 0) squelch--;                           // :629-630
+                            state = S_FRAME_END;
+                            continue;
                         }
-                        const unsigned long long dm = __ballot(dl), km = __ballot(valid && !dl);
-                        if (dl) PUSH_GONE(b, index, n_gone + __popcll(dm & lt_mask));
-                        n_gone += __popcll(dm);
+                        n_cplx++;
+                        ev_del = 0;
+                        state = S_CPLX_B;                                         // nothing to delete
+                        continue;
+                    }
+
+                    // ---------------- busy ----------------
+                    if (!flags_valid) {
+                        nF++;
+                        // exact threshold test of the staged entries from this frame on
+                        // (simd_relative_mag + `> threshold`); the baseline is frozen while busy
+                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
+                        for (int i = e0 + lane; i < total; i += 64) {
+                            const ListEntry e = s_ent[i];
+                            const float sv = s_sum[e.bin & 0x3FFF];
+                            const float rel = sv > 0 ? e.mag / sv : 0.0f;
+                            s_flag[i] = rel > thr ? 1 : 0;
+                        }
                         WAVE_SYNC();
-                        if (valid && !dl) s_act[__popcll(km & lt_mask)] = b;
+                        flags_valid = true;
+                        summ_valid = false;
+                    }
+                    const long long tt2 = IRDM_TICK();
+                    tF += tt2 - tt1;
+                    if (!summ_valid) {
+                        nBd++;
+                        // per-frame summaries for frames k0.. of the batch: which slots see a crossing within
+                        // +-1 bin of their centre (update_bursts, :458-469) and whether the frame holds a
+                        // peak candidate under the current mask (:522-548)
+                        if (lane >= k0 && lane < 64) {
+                            s_hit[lane] = 0ull;
+                            s_cnd[lane] = 0u;
+                        }
                         WAVE_SYNC();
-                        force = __any(force) != 0;
-                        const int w = __popcll(km);
-                        if (w != n_act) {
-                            // update_burst_mask (:482-486): only the deleted bursts' ranges can change:
-                            // set them to 1, then re-apply every surviving burst's range
-                            unsigned long long d2 = dm;
+                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
+                        for (int base = e0; base < total; base += 64) {
+                            const int i = base + lane;
+                            bool cross = false;
+                            int bin = -100, k = 0;
+                            if (i < total && s_flag[i]) {
+                                const int pk = s_ent[i].bin;
+                                cross = true;
+                                bin = pk & 0x3FFF;
+                                k = (pk >> 14) - sb;
+                            }
+                            if (__any(cross)) {
+                                unsigned long long o = occ;
+                                while (o) {
+                                    const int sl = __builtin_ctzll(o);
+                                    o &= o - 1;
+                                    const int cb = __builtin_amdgcn_readlane(r_cb, sl);
+                                    if (cross && bin >= cb - 1 && bin <= cb + 1)
+                                        atomicOr(reinterpret_cast<unsigned long long *>(&s_hit[k]), 1ull << sl);
+                                }
+                                if (cross && vmask[bin < 0 ? 0 : bin] && VALID_BIN(bin)) atomicOr(&s_cnd[k], 1u);
+                            }
+                        }
+                        WAVE_SYNC();
+                        const unsigned long long hv = s_hit[lane];
+                        h_lo = (unsigned)hv;
+                        h_hi = (unsigned)(hv >> 32);
+                        cndv = s_cnd[lane];
+                        summ_valid = true;
+                    }
+                    const long long tt3 = IRDM_TICK();
+                    tB += tt3 - tt2;
+                    // ---- simple frames: nothing but last_active refreshes ----
+                    {
+                        int k = k0;
+                        bool ev = false;
+                        const unsigned long long mybit = 1ull << lane;
+                        while (k < snf) {
+                            const uint64_t idx = index0 + (uint64_t)f * N;
+                            const unsigned hl = (unsigned)__builtin_amdgcn_readlane((int)h_lo, k);
+                            const unsigned hh = (unsigned)__builtin_amdgcn_readlane((int)h_hi, k);
+                            const unsigned cn = (unsigned)__builtin_amdgcn_readlane((int)cndv, k);
+                            const unsigned long long hk = ((unsigned long long)hh << 32) | hl;
+                            if (hk & mybit) r_la = idx;
+                            const bool too_long = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
+                            const bool del = (occ & mybit) && ((r_la + (uint64_t)P.post_len <= idx) || too_long);
+                            const unsigned long long dm = __ballot(del);
+                            n_sparse++;
+                            if (cn | (dm != 0)) {
+                                ev = true;
+                                ev_del = dm;
+                                any_cand = cn != 0;
+                                break;
+                            }
+                            if (squelch > 0) squelch--;                           // :629-630
+                            f++;
+                            k++;
+                        }
+                        tL += IRDM_TICK() - tt3;
+                        if (!ev) continue;                                        // batch exhausted: restage
+                    }
+                    const long long tt4 = IRDM_TICK();
+                    // ---- a burst ends or may start in frame f (burst_detect.c:490-632), part A ----
+                    n_cplx++;
+                    {
+                        const int k = f - sb;
+                        e0 = __builtin_amdgcn_readlane((int)r_off, k);
+                        e1 = __builtin_amdgcn_readlane((int)r_off, k + 1);
+                        const uint64_t idx = index0 + (uint64_t)f * N;
+                        n_cand = 0;
+                        if (any_cand) {
+                            for (int base = e0; base < e1; base += 64) {
+                                const int i = base + lane;
+                                bool cand = false;
+                                PeakCand c;
+                                c.rel = 0.0f; c.bin = 0;
+                                if (i < e1 && s_flag[i]) {
+                                    const ListEntry e = s_ent[i];
+                                    const int bin = e.bin & 0x3FFF;
+                                    cand = vmask[bin] && VALID_BIN(bin);
+                                    c.bin = bin;
+                                    c.rel = e.mag / s_sum[bin];
+                                }
+                                const unsigned long long cm = __ballot(cand);
+                                if (cand) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
+                                n_cand += __popcll(cm);
+                            }
+                            WAVE_SYNC();
+                        }
+                        // delete_gone_bursts (:490-518): emitted in list order == ascending id
+                        bool force = false;
+                        if (ev_del) {
+                            const bool mine = (ev_del >> lane) & 1;
+                            int rank = 0;
+                            unsigned long long d2 = ev_del;
                             while (d2) {
-                                const int src = __builtin_ctzll(d2);
+                                const int sl = __builtin_ctzll(d2);
                                 d2 &= d2 - 1;
-                                const int cbd = __builtin_amdgcn_readlane(b.center_bin, src);
+                                const unsigned long long oid = RL64(r_id, sl);
+                                rank += (oid < r_id) ? 1 : 0;
+                            }
+                            if (mine) {
+                                ActiveBurst b = s_act[lane];
+                                b.last_active = r_la;
+                                force = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
+                                PUSH_GONE(b, idx, n_gone + rank);
+                            }
+                            n_gone += __popcll(ev_del);
+                            force = __any(force) != 0;
+                            // update_burst_mask (:482-486): only the deleted bursts' ranges can change
+                            d2 = ev_del;
+                            while (d2) {
+                                const int sl = __builtin_ctzll(d2);
+                                d2 &= d2 - 1;
+                                const int cbd = __builtin_amdgcn_readlane(r_cb, sl);
                                 int lo_ = cbd - half_bw, hi_ = cbd + half_bw;
                                 if (lo_ < 0) lo_ = 0;
                                 if (hi_ >= N) hi_ = N - 1;
                                 for (int b_ = lo_ + lane; b_ <= hi_; b_ += 64) vmask[b_] = 1;
                             }
-                            n_act = w;
+                            occ &= ~ev_del;
                             WAVE_SYNC();
-                            for (int i = 0; i < n_act; i++) MASK_RANGE(s_act[i].center_bin);
+                            d2 = occ;
+                            while (d2) {
+                                const int sl = __builtin_ctzll(d2);
+                                d2 &= d2 - 1;
+                                MASK_RANGE(__builtin_amdgcn_readlane(r_cb, sl));
+                            }
                             WAVE_SYNC();
+                            // freed slots: drop their hit bits in the frames still ahead; candidate flags are
+                            // recomputed by the light pass below (bins they masked are peaks again)
+                            if (lane > f - sb && lane < 64) s_hit[lane] &= ~ev_del;
+                            need_light = true;
                         }
-                    }
-                    t_cA += IRDM_TICK() - tA0;
-                    state = S_CPLX_B;
-                    if (force) {                                                  // update_filters_post(d, 1)
-                        cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0;
-                        break;
+                        tA += IRDM_TICK() - tt4;
+                        state = S_CPLX_B;
+                        if (force) {                                              // update_filters_post(d, 1)
+                            cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0;
+                            break;
+                        }
                     }
                     continue;
                 }
                 if (state == S_CPLX_B) {
-                    const long long tB0 = IRDM_TICK();
+                    const long long tt5 = IRDM_TICK();
                     const uint64_t index = index0 + (uint64_t)f * N;
                     // create_new_bursts (:556-591): descending magnitude, ties by ascending bin, skipping
                     // bins masked by bursts created earlier in the same frame == repeated arg-max
@@ -459,8 +568,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (orr > br || (orr == br && ob < bb)) { br = orr; bb = ob; }
                         }
                         if (bb == 0x7fffffff) break;
-                        if (n_act >= kFastMaxActive) { abort_code |= 4; break; }
-                        if (lane == 0) {
+                        if (occ == ~0ull) { abort_code |= 4; break; }
+                        const int sl = __builtin_ctzll(~occ);
+                        if (lane == sl) {
                             ActiveBurst b;
                             b.id = burst_id;
                             b.center_bin = bb;
@@ -469,26 +579,38 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             b.last_active = b.start;
                             b.base_sum = s_sum[bb];
                             b.pad = 0;
-                            s_act[n_act] = b;
+                            s_act[sl] = b;
+                            r_cb = bb;
+                            r_start = b.start;
+                            r_la = b.start;
+                            r_id = burst_id;
                         }
-                        n_act++;
+                        occ |= 1ull << sl;
+                        new_slots |= 1ull << sl;
                         burst_id += 10;
                         MASK_RANGE(bb);
                         WAVE_SYNC();
+                        need_light = true;
                     }
                     if (abort_code) continue;
                     bool reset = false;
-                    if (P.max_bursts > 0 && n_act > P.max_bursts) {               // squelch (:594-631)
-                        ActiveBurst b;
-                        bool out = false;
-                        if (lane < n_act) {
-                            b = s_act[lane];
-                            out = b.start != index - (uint64_t)P.pre_len;
+                    if (P.max_bursts > 0 && __popcll(occ) > P.max_bursts) {       // squelch (:594-631)
+                        const bool mine = ((occ >> lane) & 1) && r_start != index - (uint64_t)P.pre_len;
+                        const unsigned long long om = __ballot(mine);
+                        int rank = 0;
+                        unsigned long long d2 = om;
+                        while (d2) {
+                            const int sl = __builtin_ctzll(d2);
+                            d2 &= d2 - 1;
+                            rank += (RL64(r_id, sl) < r_id) ? 1 : 0;
                         }
-                        const unsigned long long om = __ballot(out);
-                        if (out) PUSH_GONE(b, index, n_gone + __popcll(om & lt_mask));
+                        if (mine) {
+                            ActiveBurst b = s_act[lane];
+                            b.last_active = r_la;
+                            PUSH_GONE(b, index, n_gone + rank);
+                        }
                         n_gone += __popcll(om);
-                        n_act = 0;
+                        occ = 0;
                         MASK_ALL_ONES();
                         squelch += 3;
                         if (squelch >= 10) {
@@ -497,25 +619,62 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             squelch = 0;
                             reset = true;
                         }
+                        summ_valid = false;
+                        need_light = false;
                     } else if (squelch > 0) {
                         squelch--;
                     }
                     WAVE_SYNC();
-                    if (lane < n_act) {
-                        r_cb = s_act[lane].center_bin;
-                        r_la = s_act[lane].last_active;
-                        r_start = s_act[lane].start;
+                    if (need_light && summ_valid && flags_valid && occ != 0) {
+                        // incremental summary update for the frames after f: hit bits of the slots created in
+                        // this frame, and every candidate flag (the mask changed)
+                        const int kf = f - sb;
+                        if (lane > kf && lane < 64) s_cnd[lane] = 0u;
+                        WAVE_SYNC();
+                        const int ee = __builtin_amdgcn_readlane((int)r_off, kf + 1);
+                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
+                        for (int base = ee; base < total; base += 64) {
+                            const int i = base + lane;
+                            bool cross = false;
+                            int bin = -100, k = 0;
+                            if (i < total && s_flag[i]) {
+                                const int pk = s_ent[i].bin;
+                                cross = true;
+                                bin = pk & 0x3FFF;
+                                k = (pk >> 14) - sb;
+                            }
+                            if (__any(cross)) {
+                                unsigned long long o = new_slots;
+                                while (o) {
+                                    const int sl = __builtin_ctzll(o);
+                                    o &= o - 1;
+                                    const int cb = __builtin_amdgcn_readlane(r_cb, sl);
+                                    if (cross && bin >= cb - 1 && bin <= cb + 1)
+                                        atomicOr(reinterpret_cast<unsigned long long *>(&s_hit[k]), 1ull << sl);
+                                }
+                                if (cross && vmask[bin < 0 ? 0 : bin] && VALID_BIN(bin)) atomicOr(&s_cnd[k], 1u);
+                            }
+                        }
+                        WAVE_SYNC();
+                        const unsigned long long hv = s_hit[lane];
+                        h_lo = (unsigned)hv;
+                        h_hi = (unsigned)(hv >> 32);
+                        cndv = s_cnd[lane];
+                    } else if (need_light) {
+                        summ_valid = false;
                     }
+                    need_light = false;
+                    new_slots = 0;
                     state = S_FRAME_END;
-                    t_cB += IRDM_TICK() - tB0;
+                    tC += IRDM_TICK() - tt5;
                     if (reset) { cmd = CMD_ZERO; break; }
                     continue;
                 }
                 // S_FRAME_END: update_filters_post(d, 0) (:698)
                 state = S_TOP;
-                if (n_gone - gone_base > (unsigned)(kGoneLds - 80)) { WAVE_SYNC(); FLUSH_GONE(); }
-                if (n_act == 0 || !primed) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
+                if (occ == 0 || !primed) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
                 else if (was_quiet || hist_idx != hist_before) { cmd = CMD_VALIDATE; }
+                if (n_gone - gone_base > (unsigned)(kGoneLds - 80)) { WAVE_SYNC(); FLUSH_GONE(); }
                 f++;
             }
             if (lane == 0) {
@@ -527,8 +686,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 if (tot >= kHistory) primed = 1;
                 hist_idx = tot % kHistory;
                 flags_valid = false;                 // the baseline moves
+                summ_valid = false;
             } else if (cmd == CMD_ZERO) {
                 flags_valid = false;
+                summ_valid = false;
             }
         }
         const long long t_l1 = IRDM_TICK();
@@ -631,15 +792,28 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     }
 
     if (tid < 64) {
-        if (lane < n_act) s_act[lane].last_active = r_la;
         WAVE_SYNC();
         FLUSH_GONE();
+        // carried bursts go back in list order (ascending id)
+        const bool mine = (occ >> lane) & 1;
+        int rank = 0;
+        unsigned long long d2 = occ;
+        while (d2) {
+            const int sl = __builtin_ctzll(d2);
+            d2 &= d2 - 1;
+            rank += (RL64(r_id, sl) < r_id) ? 1 : 0;
+        }
+        if (mine) {
+            ActiveBurst b = s_act[lane];
+            b.last_active = r_la;
+            st->act[rank] = b;
+        }
         if (lane == 0) {
 #ifdef IRDM_SCAN_PROFILE
             long long *dbg = reinterpret_cast<long long *>(status + 4);
             dbg[0] = IRDM_TICK() - t_begin; dbg[1] = t_lead; dbg[2] = t_cmd[1]; dbg[3] = t_cmd[2]; dbg[4] = t_cmd[3];
             dbg[5] = n_cmd[1]; dbg[6] = n_cmd[2]; dbg[7] = n_cmd[3]; dbg[8] = n_cplx; dbg[9] = n_sparse;
-            dbg[10] = t_s1; dbg[11] = t_s2; dbg[12] = t_s3; dbg[13] = t_cal; dbg[14] = t_cA; dbg[15] = t_cB; (void)t_s4; (void)t_fe;
+            dbg[10] = tS; dbg[11] = tF; dbg[12] = tB; dbg[13] = tL; dbg[14] = tA; dbg[15] = tC; dbg[16] = tQ; dbg[17] = nS; dbg[18] = nF; dbg[19] = nBd;
 #endif
             status[0] = abort_code | sh.abort;
             if (n_gone > (unsigned)gone_cap) st->overflow = 1;
@@ -648,10 +822,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             st->hist_idx = hist_idx;
             st->primed = primed;
             st->squelch = squelch;
-            st->n_act = n_act;
+            st->n_act = __popcll(occ);
             st->n_gone = n_gone;
         }
-        for (int i = lane; i < n_act; i += 64) st->act[i] = s_act[i];
     }
     __syncthreads();
 #pragma unroll
@@ -661,6 +834,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 #undef VALID_BIN
 #undef MASK_RANGE
 #undef MASK_ALL_ONES
+#undef RL64
 #undef PUSH_GONE
 #undef FLUSH_GONE
 }
@@ -668,7 +842,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 size_t scan_fast_lds_bytes(int n)
 {
     return (size_t)n * 4 + (size_t)n + sizeof(ActiveBurst) * kFastMaxActive + sizeof(PeakCand) * kListCap +
-           sizeof(ListEntry) * kStageCap + kStageCap + sizeof(GoneBurst) * kGoneLds + sizeof(FastShared) + 16;
+           sizeof(ListEntry) * kStageCap + kStageCap + sizeof(GoneBurst) * kGoneLds + 64 * 12 + sizeof(FastShared) + 16;
 }
 
 int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
