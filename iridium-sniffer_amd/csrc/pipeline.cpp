@@ -670,9 +670,12 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         status = status_buf[0];
         if (getenv("IRDM_SCAN_DEBUG")) {
             const long long *d = reinterpret_cast<const long long *>(status_buf + 4);
-            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld bulk=%lld validate=%lld | n_bulk=%lld n_complex=%lld n_simple=%lld | "
-                            "stage=%lld(%lld) flags=%lld(%lld) build=%lld(%lld) loop=%lld partA=%lld partB=%lld quiet=%lld\n",
-                    d[0], d[1], d[2], d[3], d[5], d[8], d[9], d[10], d[17], d[11], d[18], d[12], d[19], d[13], d[14], d[15], d[16]);
+            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld | stage=%lld(%lld) cross=%lld(%lld) hc=%lld(%lld) find=%lld(%lld) "
+                            "partA=%lld(%lld) partB=%lld(%lld) | publish=%lld(nbulk %lld) frame_end=%lld(%lld) | quietrun=%lld(%lld) quietlisted=%lld(%lld) busytop_total=%lld(%lld)\n",
+                    d[0], d[7], d[1], d[13], d[2], d[14], d[3], d[15], d[4], d[16], d[5], d[17], d[6], d[18], d[8], d[20], d[9], d[21],
+                    d[10], d[22], d[11], d[23], d[12], d[24]);
+
+
 
 
         }

@@ -127,26 +127,37 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
 
 enum { CMD_EXIT = 0, CMD_BULK = 1, CMD_VALIDATE = 2, CMD_ZERO = 3 };
 constexpr int kFastMaxActive = 64;      // active bursts live in the leader's lanes; more -> dense fallback
-constexpr int kStageCap = 4096;         // list entries staged in LDS per batch
-constexpr int kStageFrames = 16;
-constexpr int kGoneLds = 256;           // gone records buffered in LDS between flushes        // frames per batch (lane k <-> frame k, lane k+1 holds its end offset)
+constexpr int kStageCap = 2048;         // list entries staged in LDS per batch
+constexpr int kStageFrames = 32;        // frames per batch: one bit per frame in the 32-bit frame masks
+constexpr int kMaxBins = 2048;          // distinct crossing bins per batch
+constexpr int kCandCap = 512;
+constexpr int kGoneLds = 64;            // gone records buffered in LDS between flushes
+constexpr int kFastThreads = 512;       // 8 wavefronts (2 per SIMD, 256 VGPRs each): wavefront 0 leads, all execute dense commands
 
 struct FastShared {
     int cmd, f0, run, detect, hist_idx, primed;
     int abort;
 };
 
-constexpr int kFastThreads = 256;   // 4 wavefronts: one per SIMD, the full VGPR budget each (no spills)
+enum { S_TOP = 0, S_CPLX_A = 1, S_CPLX_B = 2, S_FRAME_END = 3 };
 
-enum { S_TOP = 0, S_CPLX_B = 1, S_FRAME_END = 2 };
-
-// Q = float4 groups per thread; thread t owns bins (q*256 + t)*4 .. +3, so every global
-// access of a dense command is a fully coalesced 1 KiB row segment per wavefront.
+// ---------------------------------------------------------------------------
+// Sparse detector scan, "frame-mask" form.
 //
-// Control structure: wavefront 0 ("leader") runs the sequential state machine and, whenever
-// dense per-bin work is needed, publishes ONE command; all four wavefronts execute it between
-// two barriers.  There is exactly one call site of the command body and one of the leader
-// step, so everything inlines and the leader's state lives in registers.
+// Cost model measured on gfx950: a lone wavefront running branchy sequential code retires roughly
+// one instruction per 10-20 cycles, so the design minimises the leader's instruction count:
+//   * a batch = up to 32 frames; for every bin that crosses the threshold somewhere in the batch,
+//     s_crossT[bin] holds a 32-bit mask of the frames in which it crosses (exact test, built by one
+//     pass over the batch's staged list entries);
+//   * an active burst (one per leader lane) gets its hit mask in O(1): crossT[cb-1]|crossT[cb]|crossT[cb+1]
+//     (update_bursts, burst_detect.c:458-469);
+//   * the frame of the next event (a burst expiring / growing too long, :498-505, or a peak candidate
+//     appearing, :522-548) is found with bit arithmetic on those masks -- no per-frame loop;
+//   * only event frames (about two per burst) run the list logic of delete_gone_bursts /
+//     create_new_bursts (:490-632).
+// Dense per-bin work (baseline updates while no burst is active, :438-454) is a command executed by
+// all eight wavefronts.  Q = float4 groups per thread; thread t owns bins (q*512 + t)*4 .. +3.
+// ---------------------------------------------------------------------------
 template <int Q>
 __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     DetParams P, DetState *__restrict__ st, float *__restrict__ sum_g, float *__restrict__ hist,
@@ -158,43 +169,47 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     constexpr int J = 4 * Q;
     const int N = P.n;
     float *s_sum = reinterpret_cast<float *>(smem_raw);                                   // N
-    unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_sum + N);                 // N bytes
-    ActiveBurst *s_act = reinterpret_cast<ActiveBurst *>(s_mask + N);                     // kFastMaxActive
-    PeakCand *s_cand = reinterpret_cast<PeakCand *>(s_act + kFastMaxActive);              // kListCap
-    ListEntry *s_ent = reinterpret_cast<ListEntry *>(s_cand + kListCap);                  // kStageCap
-    unsigned char *s_flag = reinterpret_cast<unsigned char *>(s_ent + kStageCap);         // kStageCap
-    GoneBurst *s_gone = reinterpret_cast<GoneBurst *>(s_flag + kStageCap);                // kGoneLds
-    unsigned long long *s_hit = reinterpret_cast<unsigned long long *>(s_gone + kGoneLds); // 64
-    unsigned *s_cnd = reinterpret_cast<unsigned *>(s_hit + 64);                           // 64
-    FastShared &sh = *reinterpret_cast<FastShared *>(s_cnd + 64);
-    // NOTE: never `volatile` here -- a volatile access through a generic pointer compiles to a
-    // system-coherent FLAT load (microseconds); LDS ops of one wavefront execute in order, so a
-    // compiler barrier between the write and read phases is all the ordering that is needed.
-    unsigned char *vmask = s_mask;
+    unsigned *s_crossT = reinterpret_cast<unsigned *>(s_sum + N);                         // N frame masks
+    unsigned *s_mbits = s_crossT + N;                                                     // N/32: 1 = not masked
+    ListEntry *s_ent = reinterpret_cast<ListEntry *>(s_mbits + N / 32);                   // kStageCap
+    PeakCand *s_cand = reinterpret_cast<PeakCand *>(s_ent + kStageCap);                   // kCandCap
+    GoneBurst *s_gone = reinterpret_cast<GoneBurst *>(s_cand + kCandCap);                 // kGoneLds
+    ActiveBurst *s_act = reinterpret_cast<ActiveBurst *>(s_gone + kGoneLds);              // kFastMaxActive
+    unsigned short *s_bins = reinterpret_cast<unsigned short *>(s_act + kFastMaxActive);  // kMaxBins
+    FastShared &sh = *reinterpret_cast<FastShared *>(s_bins + kMaxBins);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const float thr = P.threshold;
     const int half_bw = P.width / 2;
     const int dc = N / 2;
+    const int log_n = P.log_n;
     const uint64_t index0 = st->index;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int gap_frames = (P.post_len + N - 1) >> log_n;   // frames without a hit until last_active + post_len <= index
 
+    // NOTE: never `volatile` LDS pointers (they compile to system-coherent FLAT accesses, microseconds each);
+    // LDS ops of one wavefront execute in order, a compiler barrier between phases is all that is needed.
 #define WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define BIN_OF(j) ((((j) >> 2) * kFastThreads + tid) * 4 + ((j) & 3))
 #define VALID_BIN(b) ((b) >= half_bw && (b) < N - half_bw && !((b) >= dc - 3 && (b) <= dc + 3))
-#define MASK_RANGE(cb)                                                   \
-    do {                                                                 \
-        int lo_ = (cb) - half_bw, hi_ = (cb) + half_bw;                  \
-        if (lo_ < 0) lo_ = 0;                                            \
-        if (hi_ >= N) hi_ = N - 1;                                       \
-        for (int b_ = lo_ + lane; b_ <= hi_; b_ += 64) vmask[b_] = 0;    \
+#define UNMASKED(b) ((s_mbits[(b) >> 5] >> ((b) & 31)) & 1u)
+    // set (SETV=1) or clear (SETV=0) the mask bits of [cb-half_bw, cb+half_bw] (mask_burst, :473-480)
+#define MASK_EDIT(cb, SETV)                                                                         \
+    do {                                                                                            \
+        int lo_ = (cb) - half_bw, hi_ = (cb) + half_bw;                                             \
+        if (lo_ < 0) lo_ = 0;                                                                       \
+        if (hi_ >= N) hi_ = N - 1;                                                                  \
+        for (int w_ = (lo_ >> 5) + lane; w_ <= (hi_ >> 5); w_ += 64) {                              \
+            const int b0_ = w_ << 5;                                                                \
+            const int l_ = lo_ > b0_ ? lo_ - b0_ : 0, h_ = hi_ < b0_ + 31 ? hi_ - b0_ : 31;         \
+            const unsigned m_ = (h_ == 31 ? ~0u : ((1u << (h_ + 1)) - 1u)) & ~((1u << l_) - 1u);   \
+            if (SETV) s_mbits[w_] |= m_; else s_mbits[w_] &= ~m_;                                   \
+        }                                                                                           \
     } while (0)
-#define MASK_ALL_ONES()                                                  \
-    do {                                                                 \
-        unsigned *m32_ = reinterpret_cast<unsigned *>(s_mask);           \
-        for (int i_ = lane; i_ < N / 4; i_ += 64) m32_[i_] = 0x01010101u;\
-    } while (0)
+#define MASK_ALL_ONES() do { for (int i_ = lane; i_ < N / 32; i_ += 64) s_mbits[i_] = ~0u; } while (0)
+#define RL64(v, l) (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((v) >> 32), (l)) << 32) | \
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
 #define PUSH_GONE(b, stopv, slot)                                                                  \
     do {                                                                                           \
         const unsigned ls_ = (slot) - gone_base;                                                   \
@@ -221,21 +236,15 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 #pragma unroll
     for (int j = 0; j < J; j++) {
         s_sum[BIN_OF(j)] = sum_g[BIN_OF(j)];
-        s_mask[BIN_OF(j)] = 1;
+        s_crossT[BIN_OF(j)] = 0u;
     }
+    for (int i = tid; i < N / 32; i += kFastThreads) s_mbits[i] = ~0u;
     const int n_act_in = st->n_act;
     if (tid == 0) {
         sh.cmd = CMD_EXIT;
         sh.abort = n_act_in > kFastMaxActive ? 4 : 0;
     }
     for (int i = tid; i < n_act_in && i < kFastMaxActive; i += kFastThreads) s_act[i] = st->act[i];
-    __syncthreads();
-    for (int i = tid; i < n_act_in && i < kFastMaxActive; i += kFastThreads) {
-        int lo = s_act[i].center_bin - half_bw, hi = s_act[i].center_bin + half_bw;
-        if (lo < 0) lo = 0;
-        if (hi >= N) hi = N - 1;
-        for (int b = lo; b <= hi; b++) s_mask[b] = 0;
-    }
     __syncthreads();
 
     // ---- leader state (registers of wavefront 0) ----
@@ -259,23 +268,31 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         r_start = s_act[lane].start;
         r_id = s_act[lane].id;
     }
+    if (tid < 64) {
+        unsigned long long o = occ;
+        while (o) {
+            const int sl = __builtin_ctzll(o);
+            o &= o - 1;
+            MASK_EDIT(__builtin_amdgcn_readlane(r_cb, sl), 0);
+            WAVE_SYNC();
+        }
+    }
     int sb = 0, snf = 0;                   // staged batch: frames [sb, sb+snf)
     unsigned r_off = 0;                    // lane k: offset of frame sb+k in s_ent (lane snf: total)
-    bool flags_valid = false;              // s_flag[] (exact crossing test) valid from flags_from on
-    bool summ_valid = false;               // per-frame summaries valid for frames >= current
-    unsigned h_lo = 0, h_hi = 0, cndv = 0; // lane k: summary of staged frame k (hit bits per slot, candidate flag)
+    int n_bins = 0;                        // distinct crossing bins recorded in s_bins
+    bool cross_valid = false;              // s_crossT holds the exact crossings of frames >= f of the batch
+    bool hc_valid = false;                 // H / C below are current
+    unsigned H = 0;                        // lane s: frames of the batch in which slot s sees a crossing near its centre
+    unsigned C = 0;                        // frames of the batch that hold a peak candidate under the current mask
     int f = 0, state = S_TOP;
-    long long t_cmd[4] = {0, 0, 0, 0}, t_lead = 0, tS = 0, tF = 0, tB = 0, tL = 0, tA = 0, tC = 0, tQ = 0;
-    int nS = 0, nF = 0, nBd = 0;
-    int n_cmd[4] = {0, 0, 0, 0}, n_cplx = 0, n_sparse = 0;
-    const long long t_begin = IRDM_TICK();
     int e0 = 0, e1 = 0, n_cand = 0, hist_before = 0;
     bool any_cand = false, was_quiet = false;
-    unsigned long long ev_del = 0, new_slots = 0;
-    bool need_light = false;
-
-#define RL64(v, l) (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((v) >> 32), (l)) << 32) | \
-                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
+    unsigned long long ev_del = 0;
+    long long tk[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+    int nk[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+    const long long t_begin = IRDM_TICK();
+    (void)t_begin;
+#define TK(i, t0) do { tk[i] += IRDM_TICK() - (t0); nk[i]++; } while (0)
 
     for (;;) {
         const long long t_l0 = IRDM_TICK();
@@ -285,6 +302,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             while (cmd < 0) {
                 if (abort_code || (state == S_TOP && f >= n_frames)) { cmd = CMD_EXIT; break; }
                 if (state == S_TOP) {
+                    const long long tT_ = IRDM_TICK();
                     if (!primed) {
                         // update_filters_pre returns 0 (:427-428): updates only, up to the priming frame
                         int run = kHistory - hist_idx;
@@ -293,9 +311,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         f += run;
                         break;
                     }
-                    const long long tt0 = IRDM_TICK();
                     if (f < sb || f >= sb + snf) {
-                        nS++;
+                        const long long t0_ = IRDM_TICK();
                         // ---- stage the compact lists of up to kStageFrames frames starting at f ----
                         const int nf = n_frames - f < kStageFrames ? n_frames - f : kStageFrames;
                         unsigned g = 0, c = 0;
@@ -320,15 +337,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                                 if (i + 64 * u < total) s_ent[i + 64 * u] = t[u];
                         }
                         WAVE_SYNC();
-                        flags_valid = false;
-                        summ_valid = false;
+                        cross_valid = false;
+                        TK(0, t0_);
                     }
-                    const long long tt1 = IRDM_TICK();
-                    tS += tt1 - tt0;
                     const int k0 = f - sb;
-                    e0 = __builtin_amdgcn_readlane((int)r_off, k0);
-                    e1 = __builtin_amdgcn_readlane((int)r_off, k0 + 1);
-                    const uint64_t index = index0 + (uint64_t)f * N;
                     was_quiet = occ == 0;
                     hist_before = hist_idx;
 
@@ -344,10 +356,13 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             cmd = CMD_BULK; c_f0 = f; c_run = run; c_detect = 1;
                             squelch = squelch > run ? squelch - run : 0;
                             f += run;
+                            TK(9, tT_);
                             break;
                         }
                         // a listed frame: exact test of ITS entries against the live sums; with no burst
-                        // active the mask is all ones, so a valid crossing is a peak (burst_detect.c:529-548)
+                        // active the mask is all ones, so a valid crossing is a peak (:529-548)
+                        e0 = __builtin_amdgcn_readlane((int)r_off, k0);
+                        e1 = __builtin_amdgcn_readlane((int)r_off, k0 + 1);
                         n_cand = 0;
                         for (int base = e0; base < e1; base += 64) {
                             const int i = base + lane;
@@ -363,195 +378,213 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                                 cand = c.rel > thr && VALID_BIN(bin);
                             }
                             const unsigned long long cm = __ballot(cand);
-                            if (cand) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
+                            if (cand && n_cand + __popcll(cm & lt_mask) < kCandCap) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
                             n_cand += __popcll(cm);
                         }
+                        if (n_cand > kCandCap) { abort_code |= 32; continue; }
                         WAVE_SYNC();
-                        tQ += IRDM_TICK() - tt1;
+                        TK(10, tT_);
                         if (n_cand == 0) {
                             if (squelch > 0) squelch--;                           // :629-630
                             state = S_FRAME_END;
                             continue;
                         }
-                        n_cplx++;
                         ev_del = 0;
                         state = S_CPLX_B;                                         // nothing to delete
                         continue;
                     }
 
                     // ---------------- busy ----------------
-                    if (!flags_valid) {
-                        nF++;
-                        // exact threshold test of the staged entries from this frame on
-                        // (simd_relative_mag + `> threshold`); the baseline is frozen while busy
-                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
-                        for (int i = e0 + lane; i < total; i += 64) {
-                            const ListEntry e = s_ent[i];
-                            const float sv = s_sum[e.bin & 0x3FFF];
-                            const float rel = sv > 0 ? e.mag / sv : 0.0f;
-                            s_flag[i] = rel > thr ? 1 : 0;
-                        }
+                    const int total = __builtin_amdgcn_readlane((int)r_off, snf);
+                    if (!cross_valid) {
+                        const long long t0_ = IRDM_TICK();
+                        // s_crossT[bin] = frames (>= f) of the batch in which `bin` crosses: exact
+                        // simd_relative_mag + `> threshold` with the (frozen) baseline
+                        for (int i = lane; i < n_bins; i += 64) s_crossT[s_bins[i]] = 0u;
                         WAVE_SYNC();
-                        flags_valid = true;
-                        summ_valid = false;
-                    }
-                    const long long tt2 = IRDM_TICK();
-                    tF += tt2 - tt1;
-                    if (!summ_valid) {
-                        nBd++;
-                        // per-frame summaries for frames k0.. of the batch: which slots see a crossing within
-                        // +-1 bin of their centre (update_bursts, :458-469) and whether the frame holds a
-                        // peak candidate under the current mask (:522-548)
-                        if (lane >= k0 && lane < 64) {
-                            s_hit[lane] = 0ull;
-                            s_cnd[lane] = 0u;
-                        }
-                        WAVE_SYNC();
-                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
-                        for (int base = e0; base < total; base += 64) {
+                        n_bins = 0;
+                        const int ef = __builtin_amdgcn_readlane((int)r_off, k0);
+                        for (int base = ef; base < total; base += 64) {
                             const int i = base + lane;
-                            bool cross = false;
-                            int bin = -100, k = 0;
-                            if (i < total && s_flag[i]) {
-                                const int pk = s_ent[i].bin;
-                                cross = true;
-                                bin = pk & 0x3FFF;
-                                k = (pk >> 14) - sb;
+                            bool first = false;
+                            int bin = 0;
+                            if (i < total) {
+                                const ListEntry e = s_ent[i];
+                                bin = e.bin & 0x3FFF;
+                                const int k = (e.bin >> 14) - sb;
+                                const float sv = s_sum[bin];
+                                const float rel = sv > 0 ? e.mag / sv : 0.0f;
+                                if (rel > thr) first = atomicOr(&s_crossT[bin], 1u << k) == 0u;
                             }
-                            if (__any(cross)) {
-                                unsigned long long o = occ;
-                                while (o) {
-                                    const int sl = __builtin_ctzll(o);
-                                    o &= o - 1;
-                                    const int cb = __builtin_amdgcn_readlane(r_cb, sl);
-                                    if (cross && bin >= cb - 1 && bin <= cb + 1)
-                                        atomicOr(reinterpret_cast<unsigned long long *>(&s_hit[k]), 1ull << sl);
-                                }
-                                if (cross && vmask[bin < 0 ? 0 : bin] && VALID_BIN(bin)) atomicOr(&s_cnd[k], 1u);
-                            }
+                            const unsigned long long fm = __ballot(first);
+                            if (first && n_bins + __popcll(fm & lt_mask) < kMaxBins)
+                                s_bins[n_bins + __popcll(fm & lt_mask)] = (unsigned short)bin;
+                            n_bins += __popcll(fm);
                         }
+                        if (n_bins > kMaxBins) { abort_code |= 64; continue; }
                         WAVE_SYNC();
-                        const unsigned long long hv = s_hit[lane];
-                        h_lo = (unsigned)hv;
-                        h_hi = (unsigned)(hv >> 32);
-                        cndv = s_cnd[lane];
-                        summ_valid = true;
+                        cross_valid = true;
+                        hc_valid = false;
+                        TK(1, t0_);
                     }
-                    const long long tt3 = IRDM_TICK();
-                    tB += tt3 - tt2;
-                    // ---- simple frames: nothing but last_active refreshes ----
-                    {
-                        int k = k0;
-                        bool ev = false;
-                        const unsigned long long mybit = 1ull << lane;
-                        while (k < snf) {
-                            const uint64_t idx = index0 + (uint64_t)f * N;
-                            const unsigned hl = (unsigned)__builtin_amdgcn_readlane((int)h_lo, k);
-                            const unsigned hh = (unsigned)__builtin_amdgcn_readlane((int)h_hi, k);
-                            const unsigned cn = (unsigned)__builtin_amdgcn_readlane((int)cndv, k);
-                            const unsigned long long hk = ((unsigned long long)hh << 32) | hl;
-                            if (hk & mybit) r_la = idx;
-                            const bool too_long = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
-                            const bool del = (occ & mybit) && ((r_la + (uint64_t)P.post_len <= idx) || too_long);
-                            const unsigned long long dm = __ballot(del);
-                            n_sparse++;
-                            if (cn | (dm != 0)) {
-                                ev = true;
-                                ev_del = dm;
-                                any_cand = cn != 0;
-                                break;
-                            }
-                            if (squelch > 0) squelch--;                           // :629-630
-                            f++;
-                            k++;
+                    const long long t2_ = IRDM_TICK();
+                    if (!hc_valid) {
+                        H = 0;
+                        if ((occ >> lane) & 1) {
+                            H = s_crossT[r_cb];
+                            if (r_cb > 0) H |= s_crossT[r_cb - 1];
+                            if (r_cb < N - 1) H |= s_crossT[r_cb + 1];
                         }
-                        tL += IRDM_TICK() - tt3;
-                        if (!ev) continue;                                        // batch exhausted: restage
+                        unsigned acc = 0;
+                        for (int i = lane; i < n_bins; i += 64) {
+                            const int bin = s_bins[i];
+                            if (UNMASKED(bin) && VALID_BIN(bin)) acc |= s_crossT[bin];
+                        }
+                        for (int off = 32; off > 0; off >>= 1) acc |= __shfl_xor(acc, off);
+                        C = acc;
+                        hc_valid = true;
+                        TK(2, t2_);
                     }
-                    const long long tt4 = IRDM_TICK();
-                    // ---- a burst ends or may start in frame f (burst_detect.c:490-632), part A ----
-                    n_cplx++;
+                    const long long t3_ = IRDM_TICK();
+                    // ---- find the next event frame with bit arithmetic on the frame masks ----
+                    const unsigned rm = (snf >= 32 ? ~0u : ((1u << snf) - 1u)) & ~((1u << k0) - 1u);
+                    const uint64_t idx_base = index0 + (uint64_t)sb * N;
+                    int Ej = 32;
+                    const unsigned Hm = H & rm;
+                    if ((occ >> lane) & 1) {
+                        // expiry (:505): first frame k with no hit in (k - gap, k] and k >= last_active + gap
+                        unsigned D;
+                        if (gap_frames >= 32) {
+                            D = Hm ? ~((1u << __builtin_ctz(Hm)) - 1u) : 0u;     // no expiry at or after a hit within one batch
+                        } else {
+                            D = Hm;
+                            int filled = 1;
+                            while (filled * 2 <= gap_frames) { D |= D << filled; filled *= 2; }
+                            if (gap_frames > filled) D |= D << (gap_frames - filled);
+                        }
+                        const long long la_f = ((long long)(r_la - idx_base)) >> log_n;       // frames, may be < 0
+                        const long long kmin = la_f + gap_frames;
+                        const unsigned low = kmin <= 0 ? ~0u : (kmin >= 32 ? 0u : ~((1u << (int)kmin) - 1u));
+                        const unsigned X = ~D & low & rm;
+                        int Eexp = X ? __builtin_ctz(X) : 32;
+                        // too long (:499-502): first hit frame whose index - start > max_len
+                        int Elong = 32;
+                        if (P.max_len > 0) {
+                            const long long kl = (((long long)(r_start + (uint64_t)P.max_len - idx_base)) >> log_n) + 1;
+                            const unsigned T = Hm & (kl <= 0 ? ~0u : (kl >= 32 ? 0u : ~((1u << (int)kl) - 1u)));
+                            Elong = T ? __builtin_ctz(T) : 32;
+                        }
+                        Ej = Eexp < Elong ? Eexp : Elong;
+                    }
+                    int Ed = Ej;
+                    for (int off = 32; off > 0; off >>= 1) {
+                        const int o = __shfl_xor(Ed, off);
+                        Ed = o < Ed ? o : Ed;
+                    }
+                    const unsigned Cm = C & rm;
+                    const int Ec = Cm ? __builtin_ctz(Cm) : 32;
+                    const int E = Ed < Ec ? Ed : Ec;
+                    // update_bursts for the frames up to and including E
                     {
-                        const int k = f - sb;
-                        e0 = __builtin_amdgcn_readlane((int)r_off, k);
-                        e1 = __builtin_amdgcn_readlane((int)r_off, k + 1);
-                        const uint64_t idx = index0 + (uint64_t)f * N;
-                        n_cand = 0;
-                        if (any_cand) {
-                            for (int base = e0; base < e1; base += 64) {
-                                const int i = base + lane;
-                                bool cand = false;
-                                PeakCand c;
-                                c.rel = 0.0f; c.bin = 0;
-                                if (i < e1 && s_flag[i]) {
-                                    const ListEntry e = s_ent[i];
-                                    const int bin = e.bin & 0x3FFF;
-                                    cand = vmask[bin] && VALID_BIN(bin);
+                        const unsigned up = Hm & (E >= 31 ? ~0u : ((1u << (E + 1)) - 1u));
+                        if (up) r_la = idx_base + ((uint64_t)(31 - __builtin_clz(up)) << log_n);
+                    }
+                    TK(3, t3_);
+                    if (E >= snf) {
+                        const int cnt = snf - k0;
+                        squelch = squelch > cnt ? squelch - cnt : 0;                  // :629-630 per frame
+                        f = sb + snf;
+                        continue;
+                    }
+                    {
+                        const int cnt = E - k0;
+                        squelch = squelch > cnt ? squelch - cnt : 0;
+                    }
+                    f = sb + E;
+                    ev_del = __ballot(((occ >> lane) & 1) && Ej == E);
+                    any_cand = (Cm >> E) & 1u;
+                    state = S_CPLX_A;
+                    TK(11, tT_);
+                    continue;
+                }
+                if (state == S_CPLX_A) {
+                    const long long t4_ = IRDM_TICK();
+                    // ---- a burst ends or may start in frame f (burst_detect.c:490-632), part A ----
+                    const int k = f - sb;
+                    e0 = __builtin_amdgcn_readlane((int)r_off, k);
+                    e1 = __builtin_amdgcn_readlane((int)r_off, k + 1);
+                    const uint64_t idx = index0 + (uint64_t)f * N;
+                    n_cand = 0;
+                    if (any_cand) {
+                        // peaks of this frame under the PREVIOUS frame's mask (remove_peaks_around_bursts, :522-525)
+                        for (int base = e0; base < e1; base += 64) {
+                            const int i = base + lane;
+                            bool cand = false;
+                            PeakCand c;
+                            c.rel = 0.0f; c.bin = 0;
+                            if (i < e1) {
+                                const ListEntry e = s_ent[i];
+                                const int bin = e.bin & 0x3FFF;
+                                if (((s_crossT[bin] >> k) & 1u) && UNMASKED(bin) && VALID_BIN(bin)) {
+                                    cand = true;
                                     c.bin = bin;
                                     c.rel = e.mag / s_sum[bin];
                                 }
-                                const unsigned long long cm = __ballot(cand);
-                                if (cand) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
-                                n_cand += __popcll(cm);
                             }
+                            const unsigned long long cm = __ballot(cand);
+                            if (cand && n_cand + __popcll(cm & lt_mask) < kCandCap) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
+                            n_cand += __popcll(cm);
+                        }
+                        if (n_cand > kCandCap) { abort_code |= 32; continue; }
+                        WAVE_SYNC();
+                    }
+                    // delete_gone_bursts (:490-518): emitted in list order == ascending id
+                    bool force = false;
+                    if (ev_del) {
+                        const bool mine = (ev_del >> lane) & 1;
+                        int rank = 0;
+                        unsigned long long d2 = ev_del;
+                        while (d2) {
+                            const int sl = __builtin_ctzll(d2);
+                            d2 &= d2 - 1;
+                            rank += (RL64(r_id, sl) < r_id) ? 1 : 0;
+                        }
+                        if (mine) {
+                            ActiveBurst b = s_act[lane];
+                            b.last_active = r_la;
+                            force = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
+                            PUSH_GONE(b, idx, n_gone + rank);
+                        }
+                        n_gone += __popcll(ev_del);
+                        force = __any(force) != 0;
+                        // update_burst_mask (:482-486): only the deleted bursts' ranges can change
+                        d2 = ev_del;
+                        while (d2) {
+                            const int sl = __builtin_ctzll(d2);
+                            d2 &= d2 - 1;
+                            MASK_EDIT(__builtin_amdgcn_readlane(r_cb, sl), 1);
                             WAVE_SYNC();
                         }
-                        // delete_gone_bursts (:490-518): emitted in list order == ascending id
-                        bool force = false;
-                        if (ev_del) {
-                            const bool mine = (ev_del >> lane) & 1;
-                            int rank = 0;
-                            unsigned long long d2 = ev_del;
-                            while (d2) {
-                                const int sl = __builtin_ctzll(d2);
-                                d2 &= d2 - 1;
-                                const unsigned long long oid = RL64(r_id, sl);
-                                rank += (oid < r_id) ? 1 : 0;
-                            }
-                            if (mine) {
-                                ActiveBurst b = s_act[lane];
-                                b.last_active = r_la;
-                                force = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
-                                PUSH_GONE(b, idx, n_gone + rank);
-                            }
-                            n_gone += __popcll(ev_del);
-                            force = __any(force) != 0;
-                            // update_burst_mask (:482-486): only the deleted bursts' ranges can change
-                            d2 = ev_del;
-                            while (d2) {
-                                const int sl = __builtin_ctzll(d2);
-                                d2 &= d2 - 1;
-                                const int cbd = __builtin_amdgcn_readlane(r_cb, sl);
-                                int lo_ = cbd - half_bw, hi_ = cbd + half_bw;
-                                if (lo_ < 0) lo_ = 0;
-                                if (hi_ >= N) hi_ = N - 1;
-                                for (int b_ = lo_ + lane; b_ <= hi_; b_ += 64) vmask[b_] = 1;
-                            }
-                            occ &= ~ev_del;
+                        occ &= ~ev_del;
+                        d2 = occ;
+                        while (d2) {
+                            const int sl = __builtin_ctzll(d2);
+                            d2 &= d2 - 1;
+                            MASK_EDIT(__builtin_amdgcn_readlane(r_cb, sl), 0);
                             WAVE_SYNC();
-                            d2 = occ;
-                            while (d2) {
-                                const int sl = __builtin_ctzll(d2);
-                                d2 &= d2 - 1;
-                                MASK_RANGE(__builtin_amdgcn_readlane(r_cb, sl));
-                            }
-                            WAVE_SYNC();
-                            // freed slots: drop their hit bits in the frames still ahead; candidate flags are
-                            // recomputed by the light pass below (bins they masked are peaks again)
-                            if (lane > f - sb && lane < 64) s_hit[lane] &= ~ev_del;
-                            need_light = true;
                         }
-                        tA += IRDM_TICK() - tt4;
-                        state = S_CPLX_B;
-                        if (force) {                                              // update_filters_post(d, 1)
-                            cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0;
-                            break;
-                        }
+                        hc_valid = false;
+                    }
+                    state = S_CPLX_B;
+                    TK(4, t4_);
+                    if (force) {                                                  // update_filters_post(d, 1)
+                        cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0;
+                        break;
                     }
                     continue;
                 }
                 if (state == S_CPLX_B) {
-                    const long long tt5 = IRDM_TICK();
+                    const long long t5_ = IRDM_TICK();
                     const uint64_t index = index0 + (uint64_t)f * N;
                     // create_new_bursts (:556-591): descending magnitude, ties by ascending bin, skipping
                     // bins masked by bursts created earlier in the same frame == repeated arg-max
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         int bb = 0x7fffffff;
                         for (int k = lane; k < n_cand; k += 64) {
                             const PeakCand c = s_cand[k];
-                            if (vmask[c.bin] && (c.rel > br || (c.rel == br && c.bin < bb))) { br = c.rel; bb = c.bin; }
+                            if (UNMASKED(c.bin) && (c.rel > br || (c.rel == br && c.bin < bb))) { br = c.rel; bb = c.bin; }
                         }
                         for (int off = 32; off > 0; off >>= 1) {
                             const float orr = __shfl_xor(br, off);
@@ -586,11 +619,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             r_id = burst_id;
                         }
                         occ |= 1ull << sl;
-                        new_slots |= 1ull << sl;
                         burst_id += 10;
-                        MASK_RANGE(bb);
+                        MASK_EDIT(bb, 0);
                         WAVE_SYNC();
-                        need_light = true;
+                        hc_valid = false;
                     }
                     if (abort_code) continue;
                     bool reset = false;
@@ -619,64 +651,26 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             squelch = 0;
                             reset = true;
                         }
-                        summ_valid = false;
-                        need_light = false;
+                        hc_valid = false;
                     } else if (squelch > 0) {
                         squelch--;
                     }
                     WAVE_SYNC();
-                    if (need_light && summ_valid && flags_valid && occ != 0) {
-                        // incremental summary update for the frames after f: hit bits of the slots created in
-                        // this frame, and every candidate flag (the mask changed)
-                        const int kf = f - sb;
-                        if (lane > kf && lane < 64) s_cnd[lane] = 0u;
-                        WAVE_SYNC();
-                        const int ee = __builtin_amdgcn_readlane((int)r_off, kf + 1);
-                        const int total = __builtin_amdgcn_readlane((int)r_off, snf);
-                        for (int base = ee; base < total; base += 64) {
-                            const int i = base + lane;
-                            bool cross = false;
-                            int bin = -100, k = 0;
-                            if (i < total && s_flag[i]) {
-                                const int pk = s_ent[i].bin;
-                                cross = true;
-                                bin = pk & 0x3FFF;
-                                k = (pk >> 14) - sb;
-                            }
-                            if (__any(cross)) {
-                                unsigned long long o = new_slots;
-                                while (o) {
-                                    const int sl = __builtin_ctzll(o);
-                                    o &= o - 1;
-                                    const int cb = __builtin_amdgcn_readlane(r_cb, sl);
-                                    if (cross && bin >= cb - 1 && bin <= cb + 1)
-                                        atomicOr(reinterpret_cast<unsigned long long *>(&s_hit[k]), 1ull << sl);
-                                }
-                                if (cross && vmask[bin < 0 ? 0 : bin] && VALID_BIN(bin)) atomicOr(&s_cnd[k], 1u);
-                            }
-                        }
-                        WAVE_SYNC();
-                        const unsigned long long hv = s_hit[lane];
-                        h_lo = (unsigned)hv;
-                        h_hi = (unsigned)(hv >> 32);
-                        cndv = s_cnd[lane];
-                    } else if (need_light) {
-                        summ_valid = false;
-                    }
-                    need_light = false;
-                    new_slots = 0;
                     state = S_FRAME_END;
-                    tC += IRDM_TICK() - tt5;
+                    TK(5, t5_);
                     if (reset) { cmd = CMD_ZERO; break; }
                     continue;
                 }
                 // S_FRAME_END: update_filters_post(d, 0) (:698)
+                const long long tE_ = IRDM_TICK();
                 state = S_TOP;
                 if (occ == 0 || !primed) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
                 else if (was_quiet || hist_idx != hist_before) { cmd = CMD_VALIDATE; }
-                if (n_gone - gone_base > (unsigned)(kGoneLds - 80)) { WAVE_SYNC(); FLUSH_GONE(); }
+                if (n_gone - gone_base > (unsigned)(kGoneLds - 40)) { WAVE_SYNC(); FLUSH_GONE(); }
                 f++;
+                TK(8, tE_);
             }
+            const long long tP_ = IRDM_TICK();
             if (lane == 0) {
                 sh.cmd = cmd; sh.f0 = c_f0; sh.run = c_run; sh.detect = c_detect;
                 sh.hist_idx = hist_idx; sh.primed = primed;
@@ -685,15 +679,14 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 const int tot = hist_idx + c_run;
                 if (tot >= kHistory) primed = 1;
                 hist_idx = tot % kHistory;
-                flags_valid = false;                 // the baseline moves
-                summ_valid = false;
+                cross_valid = false;                 // the baseline moves
             } else if (cmd == CMD_ZERO) {
-                flags_valid = false;
-                summ_valid = false;
+                cross_valid = false;
             }
+            tk[7] += IRDM_TICK() - tP_;
         }
         const long long t_l1 = IRDM_TICK();
-        t_lead += t_l1 - t_l0;
+        tk[6] += t_l1 - t_l0;
         __syncthreads();
         const int cmd = sh.cmd;
         if (cmd == CMD_EXIT) break;
@@ -709,7 +702,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             bool bad = false;
             // groups of G frames with every load of the group in flight at once; the history rows of a
             // group are distinct (G <= 512), so reads never alias the group's writes
-            constexpr int G = (64 / J) > 0 ? (64 / J) : 1;
+            constexpr int G = (32 / J) > 8 ? 8 : ((32 / J) > 0 ? (32 / J) : 1);
             for (int k0 = 0; k0 < run; k0 += G) {
                 float4 m[G][Q], old[G][Q];
                 int hrow_idx[G];
@@ -749,8 +742,12 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             for (int u = 0; u < 4; u++) {
                                 const int j = 4 * q + u;
                                 if (detect) {
-                                    const float rel = s[j] > 0 ? mv[u] / s[j] : 0.0f;
-                                    if (rel > thr && VALID_BIN(BIN_OF(j))) bad = true;   // safety net
+                                    // safety net: mag / sum > thr is impossible while mag <= 0.99 * thr * sum;
+                                    // only the rare near-threshold bins pay for the exact division
+                                    if (mv[u] > 0.99f * thr * s[j]) {
+                                        const float rel = s[j] > 0 ? mv[u] / s[j] : 0.0f;
+                                        if (rel > thr && VALID_BIN(BIN_OF(j))) bad = true;
+                                    }
                                 }
                                 const float d = s[j] - ov[u];
                                 s[j] = d + mv[u];
@@ -787,8 +784,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         }
         __syncthreads();
         if (tid < 64) abort_code |= sh.abort;
-        t_cmd[cmd & 3] += IRDM_TICK() - t_l1;
-        n_cmd[cmd & 3]++;
+        if (cmd == CMD_BULK) { tk[6] += 0; nk[7]++; }
     }
 
     if (tid < 64) {
@@ -811,9 +807,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         if (lane == 0) {
 #ifdef IRDM_SCAN_PROFILE
             long long *dbg = reinterpret_cast<long long *>(status + 4);
-            dbg[0] = IRDM_TICK() - t_begin; dbg[1] = t_lead; dbg[2] = t_cmd[1]; dbg[3] = t_cmd[2]; dbg[4] = t_cmd[3];
-            dbg[5] = n_cmd[1]; dbg[6] = n_cmd[2]; dbg[7] = n_cmd[3]; dbg[8] = n_cplx; dbg[9] = n_sparse;
-            dbg[10] = tS; dbg[11] = tF; dbg[12] = tB; dbg[13] = tL; dbg[14] = tA; dbg[15] = tC; dbg[16] = tQ; dbg[17] = nS; dbg[18] = nF; dbg[19] = nBd;
+            dbg[0] = IRDM_TICK() - t_begin;
+            for (int i = 0; i < 12; i++) { dbg[1 + i] = tk[i]; dbg[13 + i] = nk[i]; }
 #endif
             status[0] = abort_code | sh.abort;
             if (n_gone > (unsigned)gone_cap) st->overflow = 1;
@@ -829,10 +824,12 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < J; j++) sum_g[BIN_OF(j)] = s_sum[BIN_OF(j)];
+#undef TK
 #undef WAVE_SYNC
 #undef BIN_OF
 #undef VALID_BIN
-#undef MASK_RANGE
+#undef UNMASKED
+#undef MASK_EDIT
 #undef MASK_ALL_ONES
 #undef RL64
 #undef PUSH_GONE
@@ -841,8 +838,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 
 size_t scan_fast_lds_bytes(int n)
 {
-    return (size_t)n * 4 + (size_t)n + sizeof(ActiveBurst) * kFastMaxActive + sizeof(PeakCand) * kListCap +
-           sizeof(ListEntry) * kStageCap + kStageCap + sizeof(GoneBurst) * kGoneLds + 64 * 12 + sizeof(FastShared) + 16;
+    return (size_t)n * 4 + (size_t)n * 4 + (size_t)n / 8 + sizeof(ListEntry) * kStageCap + sizeof(PeakCand) * kCandCap +
+           sizeof(GoneBurst) * kGoneLds + sizeof(ActiveBurst) * kFastMaxActive + 2 * kMaxBins + sizeof(FastShared) + 16;
 }
 
 int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
@@ -851,6 +848,7 @@ int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float 
                             int *status, hipStream_t stream)
 {
     const int Q = P.n / (4 * kFastThreads);
+    if (Q < 1) return -1;
     const size_t lds = scan_fast_lds_bytes(P.n);
 #define IRDM_LAUNCH_FAST(JJ)                                                                     \
     do {                                                                                         \
