@@ -48,6 +48,157 @@ __global__ __launch_bounds__(NT) void fft_mag_kernel(const void *__restrict__ iq
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1 (fast form, N = 4096 / 8192 / 16384): the same pinned radix-2 DIT arithmetic, evaluated as
+// three radix-16 register passes (+ a final 1- or 2-stage pass for N > 4096) instead of log2 N
+// LDS round trips.  N/16 threads, 16 points per thread.
+//
+//   pass A  stages 1-4   thread t loads x[t + T*r] (coalesced), i.e. the bit-reversed positions
+//                        16*rev(t) + q; twiddles are compile-time indices
+//   pass B  stages 5-8   positions hi2*256 + q*16 + lo2
+//   pass C  stages 9-12  positions h3*4096 + q*256 + lo3
+//   pass D  stages 13..  positions p + q*4096, fused with fftshift + |.|^2
+// Every butterfly is a' = a + W.b, b' = a - W.b with W.b in four-product form and the table
+// twiddle of the radix-2 flow graph, so the result is bit-identical to fft_lds_radix2 (products by
+// the exact twiddles (1,0) and (0,-1) differ from the copy/swap only in the sign of zeros, which
+// |.|^2 cannot see).  LDS exchange layouts are chosen so that both the writes and the reads of each
+// exchange touch consecutive (or odd-stride) addresses: no bank conflicts.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int rev4c(int q) { return ((q & 1) << 3) | ((q & 2) << 1) | ((q & 4) >> 1) | ((q & 8) >> 3); }
+
+template <int LOGN, int K>
+__device__ __forceinline__ void dit_stages(float2 (&v)[1 << K], int c, int s0, const float2 *__restrict__ tw)
+{
+#pragma unroll
+    for (int i = 1; i <= K; i++) {
+        const int half = 1 << (i - 1);
+#pragma unroll
+        for (int q0 = 0; q0 < (1 << K); q0++) {
+            if (q0 & half) continue;
+            const int jq = q0 & (half - 1);
+            const int tix = (c + (jq << s0)) << (LOGN - s0 - i);
+            const float2 t = cmul(tw[tix], v[q0 + half]);
+            const float2 a = v[q0];
+            v[q0] = make_float2(a.x + t.x, a.y + t.y);
+            v[q0 + half] = make_float2(a.x - t.x, a.y - t.y);
+        }
+        // keep each stage's twiddle loads inside the stage (otherwise all of them are hoisted and the
+        // kernel needs ~250 VGPRs = one workgroup per CU)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// stages 1..4 on bit-reversed-loaded points: twiddle indices are compile-time; the exact
+// twiddles are applied as copy / swap
+template <int LOGN>
+__device__ __forceinline__ void dit_first16(float2 (&v)[16], const float2 *__restrict__ tw)
+{
+    constexpr int N = 1 << LOGN;
+#pragma unroll
+    for (int i = 1; i <= 4; i++) {
+        const int half = 1 << (i - 1);
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0++) {
+            if (q0 & half) continue;
+            const int tix = (q0 & (half - 1)) << (LOGN - i);
+            const float2 b = v[q0 + half];
+            float2 t;
+            if (tix == 0) t = b;
+            else if (tix == N / 4) t = make_float2(b.y, -b.x);
+            else t = cmul(tw[tix], b);
+            const float2 a = v[q0];
+            v[q0] = make_float2(a.x + t.x, a.y + t.y);
+            v[q0 + half] = make_float2(a.x - t.x, a.y - t.y);
+        }
+    }
+}
+
+template <int LOGN, int FMT>
+__global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const void *__restrict__ iq,
+                                                                       const float *__restrict__ window,
+                                                                       const float2 *__restrict__ tw,
+                                                                       float *__restrict__ mag, int n_frames)
+{
+    constexpr int N = 1 << LOGN, T = N / 16, LB = LOGN - 8, NB = 1 << LB, ROW = NB + 1, RD = LOGN - 12;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *X = reinterpret_cast<float2 *>(smem_raw);
+    const int t = threadIdx.x;
+    const int lo2 = t >> LB, hb = t & (NB - 1);
+    const int lo3 = t & 255, h3 = t >> 8;
+    const int h3r = (int)(bitrev((unsigned)h3, LB - 4 > 0 ? LB - 4 : 1)) & ((1 << (LB - 4)) - 1);
+
+    // one frame per workgroup (no grid-stride loop: a persistent loop makes the compiler hoist every
+    // frame-invariant address into registers, ~250 VGPRs)
+    {
+        const int frame = blockIdx.x;
+        if (frame >= n_frames) return;
+        const size_t base = (size_t)frame * N;
+        float2 v[16];
+        // ---- pass A ----
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int idx = t + T * r;
+            float2 x;
+            if (FMT == 2) {
+                x = reinterpret_cast<const float2 *>(iq)[base + idx];
+            } else {
+                const char2 c8 = reinterpret_cast<const char2 *>(iq)[base + idx];
+                x = make_float2((float)c8.x / 128.0f, (float)c8.y / 128.0f);
+            }
+            const float w = window[idx];
+            v[rev4c(r)] = make_float2(x.x * w, x.y * w);
+        }
+        dit_first16<LOGN>(v, tw);
+#pragma unroll
+        for (int q = 0; q < 16; q++) X[q * T + t] = v[q];
+        __syncthreads();
+        // ---- pass B ----
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = X[lo2 * T + rev4c(q) * NB + hb];
+        __syncthreads();
+        dit_stages<LOGN, 4>(v, lo2, 4, tw);
+#pragma unroll
+        for (int q = 0; q < 16; q++) X[(q * 16 + lo2) * ROW + hb] = v[q];
+        __syncthreads();
+        // ---- pass C ----
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = X[lo3 * ROW + rev4c(q) * (NB / 16) + h3r];
+        dit_stages<LOGN, 4>(v, lo3, 8, tw);
+        if (RD == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int p = q * 256 + lo3;
+                mag[base + ((p + N / 2) & (N - 1))] = mag2(v[q]);
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 16; q++) X[h3 * 4096 + q * 256 + lo3] = v[q];
+            __syncthreads();
+            // ---- pass D: stages 13.. on points p + q*4096, fused with fftshift + |.|^2 ----
+            constexpr int RQ = 1 << RD;                 // points per group
+            constexpr int GP = 16 / RQ;                 // groups per thread
+#pragma unroll
+            for (int i = 0; i < GP; i++) {
+                const int pp = t + T * i;               // < 4096
+                float2 d[RQ];
+#pragma unroll
+                for (int q = 0; q < RQ; q++) d[q] = X[pp + q * 4096];
+                dit_stages<LOGN, RD>(d, pp, 12, tw);
+#pragma unroll
+                for (int q = 0; q < RQ; q++) {
+                    const int k = pp + q * 4096;
+                    mag[base + ((k + N / 2) & (N - 1))] = mag2(d[q]);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+int g_fft_force_radix2 = 0;   // test hook: 1 = always use the radix-2 LDS kernel
+
 int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
                    float *mag, int n_frames, hipStream_t stream)
 {
@@ -69,6 +220,32 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
                                stream, iq, window, tw, mag, n_frames);                         \
         }                                                                                      \
     } while (0)
+#define IRDM_LAUNCH_R16(LOGN)                                                                  \
+    do {                                                                                       \
+        constexpr int NB_ = 1 << (LOGN - 8);                                                   \
+        size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN)           \
+                                           ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));   \
+        if (f == 2) {                                                                          \
+            (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, 2>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+            hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, 2>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
+                               stream, iq, window, tw, mag, n_frames);                         \
+        } else {                                                                               \
+            (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, 0>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+            hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, 0>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
+                               stream, iq, window, tw, mag, n_frames);                         \
+        }                                                                                      \
+    } while (0)
+    if (!g_fft_force_radix2) {
+        switch (log_n) {
+        case 12: IRDM_LAUNCH_R16(12); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 13: IRDM_LAUNCH_R16(13); return hipGetLastError() == hipSuccess ? 0 : -1;
+        case 14: IRDM_LAUNCH_R16(14); return hipGetLastError() == hipSuccess ? 0 : -1;
+        default: break;
+        }
+    }
+#undef IRDM_LAUNCH_R16
     switch (log_n) {
     case 8:  IRDM_LAUNCH_FFT(8, 64); break;
     case 9:  IRDM_LAUNCH_FFT(9, 128); break;

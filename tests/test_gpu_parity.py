@@ -31,7 +31,7 @@ def _oracle_mags(fs, frames):
     return out
 
 
-@pytest.mark.parametrize("fs,n", [(2_000_000, 2048), (10_000_000, 8192), (12_000_000, 16384)])
+@pytest.mark.parametrize("fs,n", [(2_000_000, 2048), (4_000_000, 4096), (10_000_000, 8192), (12_000_000, 16384)])
 def test_gpu_burst_fft_bit_exact(fs, n):
     """a3/a12: gpu_burst_fft_process == window + pinned FFT + fftshift |.|^2, bit for bit."""
     rng = np.random.default_rng(n)
