@@ -84,7 +84,8 @@ int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ck
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
-    int decim, int row, const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
+    int decim, int row, const float *__restrict__ taps, const int *__restrict__ tap_off,
+    const float2 *__restrict__ rot_incr,
     const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -105,12 +106,28 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
         float2 ph = ck[seg];
         const int k0 = seg * kRotSeg;
         int p = k0 % decim, q = k0 / decim;
-#pragma unroll 4
+        const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
+        float2 x[kRotSeg];
+        if (src.fmt == 2 && a0 >= src.chunk_start && a0 + kRotSeg <= w.avail_end && k0 + kRotSeg <= span) {
+            // fast path: the whole segment lies in the chunk being fed -> 8 x 16-byte loads in flight
+            const float4 *g = reinterpret_cast<const float4 *>(
+                reinterpret_cast<const float2 *>(src.chunk) + (a0 - src.chunk_start));
+#pragma unroll
+            for (int u = 0; u < kRotSeg / 2; u++) {
+                const float4 v = g[u];
+                x[2 * u] = make_float2(v.x, v.y);
+                x[2 * u + 1] = make_float2(v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kRotSeg; u++)
+                x[u] = (k0 + u < span) ? burst_sample(src, w.start, w.avail_end, s0 + k0 + u)
+                                       : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
         for (int u = 0; u < kRotSeg; u++) {
-            const int k = k0 + u;
-            if (k < span) {
-                const float2 x = burst_sample(src, w.start, w.avail_end, s0 + k);
-                s[p * row + q] = cmul(x, ph);        // out[i] = in[i] * phase (rotator.h:38)
+            if (k0 + u < span) {
+                s[p * row + q] = cmul(x[u], ph);     // out[i] = in[i] * phase (rotator.h:38)
                 ph = cmul(ph, inc);                  // phase *= incr          (rotator.h:39)
             }
             if (++p == decim) { p = 0; q++; }
@@ -119,23 +136,40 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     __syncthreads();
 
     if (tid < n_out) {
+        // 801 taps, k ascending, two independent mul+add chains (simd_generic.c:86-96).  Eight LDS reads
+        // are issued ahead of the eight dependent accumulations; (p, q) walk the polyphase tile in
+        // scalar registers.
         float ar = 0.0f, ai = 0.0f;
-        int k = 0;
-        for (int q = 0; k < kFirTaps; q++) {
-            const float2 *col = s + tid + q;
-            const int pmax = (kFirTaps - k) < decim ? (kFirTaps - k) : decim;
-            for (int p = 0; p < pmax; p++, k++) {
-                const float t = taps[k];
-                const float2 v = col[p * row];
-                ar += t * v.x;
-                ai += t * v.y;
+        const unsigned char *col = reinterpret_cast<const unsigned char *>(s + tid);
+        constexpr int U = 8;
+        static_assert(kFirTaps % U == 1, "tail handles exactly one tap");
+        // tap_off[k] = byte offset of polyphase slot (k % M, k / M): wavefront-uniform, fetched with
+        // scalar loads together with the taps
+        for (int k0 = 0; k0 < kFirTaps - 1; k0 += U) {
+            float2 v[U];
+            float t[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                v[u] = *reinterpret_cast<const float2 *>(col + tap_off[k0 + u]);
+                t[u] = taps[k0 + u];
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                ar += t[u] * v[u].x;
+                ai += t[u] * v[u].y;
+            }
+        }
+        {
+            const float2 v = *reinterpret_cast<const float2 *>(col + tap_off[kFirTaps - 1]);
+            const float t = taps[kFirTaps - 1];
+            ar += t * v.x;
+            ai += t * v.y;
         }
         dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(ar, ai);
     }
 }
 
-static int fir_row(int decim)
+int fir_tile_row(int decim)
 {
     int r = kFirTileOut + kFirTaps / decim + 2;
     while ((r & 15) != 1) r++;
@@ -143,18 +177,18 @@ static int fir_row(int decim)
 }
 
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
-                        int n_tiles, int decim, const float *taps, const float2 *rot_incr,
+                        int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream)
 {
     if (n_tiles <= 0) return 0;
-    const int row = fir_row(decim);
+    const int row = fir_tile_row(decim);
     const size_t lds = sizeof(float2) * (size_t)row * decim;
     if (lds > 160 * 1024) return -1;
     (void)hipFuncSetAttribute((const void *)fir_decimate_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
-                       tiles, decim, row, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);
+                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

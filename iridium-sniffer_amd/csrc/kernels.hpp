@@ -34,8 +34,9 @@ struct SampleSource {
 
 // downmix.hip
 int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream);
+int fir_tile_row(int decim);
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
-                        int n_tiles, int decim, const float *taps, const float2 *rot_incr,
+                        int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream);
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,

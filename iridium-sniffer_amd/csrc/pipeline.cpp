@@ -162,6 +162,7 @@ struct irdm_pipeline {
     PeakCand *d_cand_a, *d_cand_b;
     void *d_ring, *d_stage;
     float *d_in_taps, *d_noise_taps, *d_start_taps, *d_rrc_taps, *d_cfo_window;
+    int *d_fir_off;
     BurstWork *d_work;
     FirTile *d_tiles;
     size_t tiles_cap;
@@ -208,7 +209,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod,
-                     p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
+                     p->d_fir_off, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -329,6 +330,13 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     UP(p->d_start_taps, start_taps);
     UP(p->d_rrc_taps, rrc);
     UP(p->d_cfo_window, cfo_window);
+    {
+        // byte offset of tap k in the decimator's polyphase LDS tile: slot (k % M, k / M)
+        const int row = fir_tile_row(p->decim);
+        std::vector<int> off(kFirTaps);
+        for (int k = 0; k < kFirTaps; k++) off[k] = ((k % p->decim) * row + k / p->decim) * (int)sizeof(float2);
+        UP(p->d_fir_off, off);
+    }
     AL(p->d_hist, float, (size_t)kHistory * P.n);
     AL(p->d_sum, float, (size_t)P.n);
     AL(p->d_mag, float, p->max_chunk);
@@ -484,7 +492,7 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
                                           hipMemcpyHostToDevice, p->stream));
         IRDM_HIP_CHECK(hipEventRecord(p->ev[3], p->stream));
         if (launch_fir_decimate(src, p->d_work, p->d_tiles, (int)p->h_tiles.size(), p->decim, p->d_in_taps,
-                                p->d_rot_incr, p->d_rot_table, p->n_ckpt, p->d_dec, p->dec_stride,
+                                p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, p->d_dec, p->dec_stride,
                                 p->stream) != 0)
             return -1;
         IRDM_HIP_CHECK(hipEventRecord(p->ev[4], p->stream));
