@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--samples", type=int, default=64 * 1024 * 1024, help="samples per chunk per GPU")
     ap.add_argument("--density", type=float, default=10.0, help="bursts per Msample")
     ap.add_argument("--sample-rate", type=int, default=10_000_000)
+    ap.add_argument("--depth", type=int, default=1,
+                    help="pipeline_depth: 1 = per-burst stages of chunk k overlap the detector scan of chunk k+1")
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
     args = ap.parse_args()
@@ -93,7 +95,7 @@ def main():
     torch.cuda.synchronize()
 
     pipe = irdm.Pipeline(fs, fmt=irdm.FMT_CF32, max_chunk_samples=n, max_bursts_per_chunk=8192,
-                         device=local)
+                         device=local, pipeline_depth=args.depth)
     pipe.L.irdm_feed_device.restype = C.c_int
     stream = torch.cuda.current_stream().cuda_stream
     REC = C.sizeof(irdm.Demod)
@@ -137,12 +139,22 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    if args.depth:
+        pipe.flush()
+        pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    if args.depth:
+        # drain: the last chunk's per-burst stages belong to the timed work
+        pipe.flush()
+        pipe.poll_bursts_raw()
+        pipe.drop_frames()
+        tail = pipe.poll_demods_raw()
+        totals["demods"] += len(tail)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

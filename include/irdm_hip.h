@@ -74,6 +74,9 @@ typedef struct {
     int device;                /* HIP device ordinal */
     size_t max_chunk_samples;  /* largest chunk passed to irdm_feed_*; 0 -> 64 Mi */
     int max_bursts_per_chunk;  /* 0 -> 8192 */
+    int pipeline_depth;        /* 0: irdm_feed_* returns with the chunk's results pollable.
+                                  1: the per-burst stages of chunk k run during irdm_feed_*(k+1), overlapped
+                                     with its detector scan (results one chunk later; irdm_flush drains). */
 } irdm_config_t;
 
 /* burst_info_t (burst_detect.h:29-37) + what emit_gone_bursts adds (burst_detect.c:703-742) */
@@ -149,6 +152,8 @@ void irdm_destroy(irdm_pipeline_t *p);
  * Returns the number of bursts emitted by this chunk, or -1 on error. */
 int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
 int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples);
+/* pipeline_depth 1: run the per-burst stages of the last fed chunk now.  Returns bursts processed or -1. */
+int irdm_flush(irdm_pipeline_t *p);
 
 /* Results of all chunks fed so far, in burst-emission order; each call drains up to max
  * entries.  bursts: one per emitted burst (burst_callback_t payload minus samples).

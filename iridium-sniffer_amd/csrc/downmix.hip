@@ -118,6 +118,17 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
                 x[2 * u] = make_float2(v.x, v.y);
                 x[2 * u + 1] = make_float2(v.z, v.w);
             }
+        } else if (src.fmt == 2 && a0 + kRotSeg <= src.chunk_start && a0 + kRotSeg <= w.avail_end &&
+                   k0 + kRotSeg <= span) {
+            // same from the history ring: ring_len is a multiple of 16 and a0 is too, so no wrap inside
+            const float4 *g = reinterpret_cast<const float4 *>(
+                reinterpret_cast<const float2 *>(src.ring) + (a0 % src.ring_len));
+#pragma unroll
+            for (int u = 0; u < kRotSeg / 2; u++) {
+                const float4 v = g[u];
+                x[2 * u] = make_float2(v.x, v.y);
+                x[2 * u + 1] = make_float2(v.z, v.w);
+            }
         } else {
 #pragma unroll
             for (int u = 0; u < kRotSeg; u++)

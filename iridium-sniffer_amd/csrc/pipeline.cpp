@@ -71,7 +71,12 @@ struct gpu_burst_fft {
     float2 *d_tw;
     float2 *d_in;
     float *d_out;
-    hipStream_t stream;
+    hipStream_t stream;      // detector (K1, prefilter, K2)
+    hipStream_t bstream;     // per-burst stages + history ring (== stream unless pipeline_depth 1)
+    hipStream_t stream2;
+    hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream confined to one CU (CU mask), so that the
+                             // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
+    hipEvent_t ev_scan_in, ev_scan_out;
 };
 
 extern "C" gpu_burst_fft_t *gpu_burst_fft_create(int fft_size, int batch_size, const float *window)
@@ -152,7 +157,12 @@ struct irdm_pipeline {
     int search_depth, pre_start;
     int in_ntaps, noise_ntaps, start_ntaps, rrc_ntaps, dl_len, ul_len;
 
-    hipStream_t stream;
+    hipStream_t stream;      // detector (K1, prefilter, K2)
+    hipStream_t bstream;     // per-burst stages + history ring (== stream unless pipeline_depth 1)
+    hipStream_t stream2;
+    hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream confined to one CU (CU mask), so that the
+                             // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
+    hipEvent_t ev_scan_in, ev_scan_out;
     hipEvent_t ev[10];   // 0 start,1 fft,2 scan,3 pre-fir,4 fir,5 post,6 demod,7 end,8 caller sync
 
     float *d_window, *d_hist, *d_sum, *d_mag;
@@ -179,6 +189,12 @@ struct irdm_pipeline {
     int host_primed, host_hist_idx;
 
     std::vector<GoneBurst> h_gone;
+    // pipeline_depth 1: bursts of the last fed chunk, processed during the next feed / irdm_flush
+    std::vector<GoneBurst> pend_gone;
+    bool has_pending;
+    uint64_t pend_c1;
+    int depth;
+    int deferred_emitted;
     std::vector<BurstWork> h_work;
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
@@ -215,6 +231,10 @@ static void pipeline_free(irdm_pipeline *p)
         if (q) (void)hipFree(q);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
+    if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
+    if (p->ev_scan_in) (void)hipEventDestroy(p->ev_scan_in);
+    if (p->ev_scan_out) (void)hipEventDestroy(p->ev_scan_out);
+    if (p->stream2) (void)hipStreamDestroy(p->stream2);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -277,7 +297,10 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     if (p->ref_ring < (uint64_t)2 * fs) p->ref_ring = (uint64_t)2 * fs;
     // longest possible burst window: stop - start < max_len + post_len + N, plus pre_len
     p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
+    p->depth = cfg->pipeline_depth > 0 ? 1 : 0;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
+    if (p->depth) p->ring_len += p->max_chunk;      // the whole previous chunk must still be readable
+    p->ring_len = (p->ring_len + 15) / 16 * 16;     // 16-sample segments never straddle the wrap
     p->n_ckpt = (int)(p->l_cap / kRotSeg) + 2;
 
     // ---- downmix constants (burst_downmix.c:223-373) ----
@@ -314,7 +337,35 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
                         tw2048 = design_twiddles(kCorrN);
     std::vector<cfloat> rot_incr = design_rotator_incr(P.n);
 
-    bool ok = hipStreamCreate(&p->stream) == hipSuccess;
+    bool ok = hipStreamCreate(&p->stream) == hipSuccess && hipStreamCreate(&p->stream2) == hipSuccess;
+    p->bstream = p->depth ? p->stream2 : p->stream;
+    p->sstream = p->stream;
+    p->ev_scan_in = p->ev_scan_out = nullptr;
+    if (ok && p->depth) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 8) {
+            const int words = (prop.multiProcessorCount + 31) / 32;
+            std::vector<uint32_t> one(words, 0u), rest(words, 0xffffffffu);
+            one[0] = 1u;                    // CU 0 for the scan ...
+            rest[0] &= ~1u;                 // ... every other CU for the per-burst stages
+            if (prop.multiProcessorCount % 32) rest[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+            hipStream_t s_scan = nullptr, s_rest = nullptr;
+            if (hipExtStreamCreateWithCUMask(&s_scan, words, one.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&s_rest, words, rest.data()) == hipSuccess) {
+                p->sstream = s_scan;
+                (void)hipStreamDestroy(p->stream2);
+                p->stream2 = s_rest;
+                p->bstream = s_rest;
+                ok = hipEventCreateWithFlags(&p->ev_scan_in, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&p->ev_scan_out, hipEventDisableTiming) == hipSuccess;
+            } else {
+                if (s_scan) (void)hipStreamDestroy(s_scan);
+                fprintf(stderr, "irdm_hip: CU-masked streams unavailable, scan shares the chip\n");
+            }
+        }
+    }
+    p->has_pending = false;
+    p->pend_c1 = 0;
     for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
 #define UP(dst, vec) ok = ok && ((dst = reinterpret_cast<decltype(dst)>(dev_upload((vec).data(), (vec).size()))) != nullptr)
 #define AL(dst, T, count) ok = ok && ((dst = dev_alloc<T>(count)) != nullptr)
@@ -406,9 +457,10 @@ extern "C" int irdm_fft_size(const irdm_pipeline_t *p) { return p ? p->P.n : -1;
 
 static SampleSource make_source(const irdm_pipeline *p, const void *chunk, uint64_t c0, uint64_t c1)
 {
+    // chunk == nullptr: every sample comes from the history ring (pipeline_depth 1)
     SampleSource s;
     s.chunk = chunk;
-    s.chunk_start = c0;
+    s.chunk_start = chunk ? c0 : ~0ull;
     s.chunk_end = c1;
     s.ring = p->d_ring;
     s.ring_len = p->ring_len;
@@ -426,13 +478,13 @@ static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t
         const uint64_t run = std::min<uint64_t>(c1 - a0, p->ring_len - pos);
         IRDM_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(p->d_ring) + pos * p->bps,
                                       static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
-                                      run * p->bps, hipMemcpyDeviceToDevice, p->stream));
+                                      run * p->bps, hipMemcpyDeviceToDevice, p->bstream));
         a0 += run;
     }
     return 0;
 }
 
-static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
+static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneBurst *gone_list, int n_gone)
 {
     const DetParams &P = p->P;
     const int fs = p->cfg.sample_rate;
@@ -442,7 +494,7 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
         p->h_tiles.clear();
         std::vector<irdm_burst_t> recs(nb);
         for (int i = 0; i < nb; i++) {
-            const GoneBurst &g = p->h_gone[base + i];
+            const GoneBurst &g = gone_list[base + i];
             irdm_burst_t &r = recs[i];
             r.id = g.id; r.start = g.start; r.stop = g.stop; r.last_active = g.last_active;
             r.center_bin = g.center_bin;
@@ -486,23 +538,23 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
             if (!p->d_tiles) return -1;
         }
         IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb,
-                                      hipMemcpyHostToDevice, p->stream));
+                                      hipMemcpyHostToDevice, p->bstream));
         if (!p->h_tiles.empty())
             IRDM_HIP_CHECK(hipMemcpyAsync(p->d_tiles, p->h_tiles.data(), sizeof(FirTile) * p->h_tiles.size(),
-                                          hipMemcpyHostToDevice, p->stream));
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[3], p->stream));
+                                          hipMemcpyHostToDevice, p->bstream));
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[3], p->bstream));
         if (launch_fir_decimate(src, p->d_work, p->d_tiles, (int)p->h_tiles.size(), p->decim, p->d_in_taps,
                                 p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, p->d_dec, p->dec_stride,
-                                p->stream) != 0)
+                                p->bstream) != 0)
             return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[4], p->stream));
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[4], p->bstream));
         if (launch_downmix_post1(p->d_work, nb, p->d_dec, p->dec_stride, p->d_lpf, p->d_noise_taps,
                                  p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
-                                 p->pre_start, p->d_cfo_window, p->d_tw4096, p->stream) != 0)
+                                 p->pre_start, p->d_cfo_window, p->d_tw4096, p->bstream) != 0)
             return -1;
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
-                                      hipMemcpyDeviceToHost, p->stream));
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+                                      hipMemcpyDeviceToHost, p->bstream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
 
         // host: fine-CFO increment with the host libm; centre frequency (burst_downmix.c:663-671, :716-719)
         std::vector<double> cfreq(nb);
@@ -521,28 +573,28 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
             w.simplex = cf > 1626000000 ? 1 : 0;                             // iridium.h:18
         }
         IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb,
-                                      hipMemcpyHostToDevice, p->stream));
+                                      hipMemcpyHostToDevice, p->bstream));
         if (launch_downmix_post2(p->d_work, nb, p->d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
                                  p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
-                                 p->d_rrc_ws, p->d_frames, p->stream) != 0)
+                                 p->d_rrc_ws, p->d_frames, p->bstream) != 0)
             return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[5], p->stream));
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[5], p->bstream));
         if (launch_demod(p->d_work, nb, p->d_frames, p->cfg.use_gardner, p->sps, p->d_demod_ws,
-                         p->d_demod, p->stream) != 0)
+                         p->d_demod, p->bstream) != 0)
             return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[6], p->stream));
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[6], p->bstream));
         p->h_demod.resize(nb);
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
-                                      hipMemcpyDeviceToHost, p->stream));
+                                      hipMemcpyDeviceToHost, p->bstream));
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_demod.data(), p->d_demod, sizeof(DemodOut) * nb,
-                                      hipMemcpyDeviceToHost, p->stream));
+                                      hipMemcpyDeviceToHost, p->bstream));
         if (p->keep_frame_samples) {
             p->h_frames.resize((size_t)nb * kMaxFrameSamples * 2);
             IRDM_HIP_CHECK(hipMemcpyAsync(p->h_frames.data(), p->d_frames,
                                           sizeof(float2) * (size_t)nb * kMaxFrameSamples,
-                                          hipMemcpyDeviceToHost, p->stream));
+                                          hipMemcpyDeviceToHost, p->bstream));
         }
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
 
         for (int i = 0; i < nb; i++) {
             const BurstWork &w = p->h_work[i];
@@ -615,6 +667,38 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, int n_gone)
     return 0;
 }
 
+// pipeline_depth 1: per-burst stages of the previously fed chunk (reading the history ring only), then
+// the copy of the chunk being fed into the ring -- all on bstream, concurrent with the detector.
+static int run_deferred(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1)
+{
+    p->deferred_emitted = 0;
+    p->last_bursts.clear();
+    for (int i = 3; i <= 6; i++) IRDM_HIP_CHECK(hipEventRecord(p->ev[i], p->bstream));
+    if (p->has_pending) {
+        const SampleSource src = make_source(p, nullptr, 0, p->pend_c1);
+        const int n = (int)p->pend_gone.size();
+        if (process_bursts(p, src, p->pend_gone.data(), n) != 0) return -1;
+        p->deferred_emitted = n;
+        p->has_pending = false;
+    }
+    if (d_iq) {
+        // the ring copy reads the caller's buffer: order it after the caller's producer
+        IRDM_HIP_CHECK(hipStreamWaitEvent(p->bstream, p->ev[8], 0));
+        if (ring_update(p, d_iq, c0, c1) != 0) return -1;
+    }
+    return 0;
+}
+
+extern "C" int irdm_flush(irdm_pipeline_t *p)
+{
+    if (!p) return -1;
+    if (!p->depth || !p->has_pending) return 0;
+    (void)hipSetDevice(p->cfg.device);
+    if (run_deferred(p, nullptr, 0, 0) != 0) return -1;
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
+    return p->deferred_emitted;
+}
+
 extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
 {
     if (!p || (!d_iq && n_samples)) return -1;
@@ -630,10 +714,8 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     (void)hipSetDevice(p->cfg.device);
     // order after the caller's stream (the producer of d_iq)
     hipStream_t caller = static_cast<hipStream_t>(stream_v);
-    if (caller != p->stream) {
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[8], caller));
-        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[8], 0));
-    }
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[8], caller));
+    if (caller != p->stream) IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[8], 0));
     const DetParams &P = p->P;
     const uint64_t c0 = p->total_samples, c1 = c0 + n_samples;
     const int n_frames = (int)(n_samples / (size_t)P.n);
@@ -644,7 +726,21 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->stream));
     // ---- detector scan: sparse kernel with the dense kernel as exact fallback ----
+    // the scan kernels run on sstream (== stream unless pipeline_depth 1 confined it to one CU)
+    auto scan_begin = [&]() -> int {
+        if (p->sstream == p->stream) return 0;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev_scan_in, p->stream));
+        IRDM_HIP_CHECK(hipStreamWaitEvent(p->sstream, p->ev_scan_in, 0));
+        return 0;
+    };
+    auto scan_end = [&]() -> int {
+        if (p->sstream == p->stream) return 0;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev_scan_out, p->sstream));
+        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_scan_out, 0));
+        return 0;
+    };
     bool need_dense_all = p->scan_mode == 1;
+    bool deferred_done = false;
     if (!need_dense_all) {
         // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts
         IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
@@ -656,9 +752,11 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         if (!p->host_primed) {
             // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428)
             done = std::min(n_frames, kHistory - p->host_hist_idx);
+            if (scan_begin() != 0) return -1;
             if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, done, p->d_gone, p->gone_cap,
-                                   p->d_cand_a, p->d_cand_b, p->stream) != 0)
+                                   p->d_cand_a, p->d_cand_b, p->sstream) != 0)
                 return -1;
+            if (scan_end() != 0) return -1;
             p->stat_dense_frames += done;
         }
         if (done < n_frames) {
@@ -666,14 +764,21 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
             if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
                                  p->d_goff, p->d_compact, n_frames - done, p->stream) != 0)
                 return -1;
+            if (scan_begin() != 0) return -1;
             if (launch_detect_scan_fast(P, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done,
                                         p->d_counts, p->d_goff, p->d_compact, p->d_pre, p->d_gone,
-                                        p->gone_cap, p->d_status, p->stream) != 0)
+                                        p->gone_cap, p->d_status, p->sstream) != 0)
                 return -1;
+            if (scan_end() != 0) return -1;
         }
         int status = 0;
         int status_buf[64];
         IRDM_HIP_CHECK(hipMemcpyAsync(status_buf, p->d_status, sizeof(status_buf), hipMemcpyDeviceToHost, p->stream));
+        if (p->depth) {
+            // while the detector of chunk k runs (one CU), the rest of the chip does chunk k-1's bursts
+            if (run_deferred(p, d_iq, c0, c1) != 0) return -1;
+            deferred_done = true;
+        }
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
         status = status_buf[0];
         if (getenv("IRDM_SCAN_DEBUG")) {
@@ -700,11 +805,14 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         }
     }
     if (need_dense_all) {
+        if (scan_begin() != 0) return -1;
         if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, n_frames, p->d_gone, p->gone_cap,
-                               p->d_cand_a, p->d_cand_b, p->stream) != 0)
+                               p->d_cand_a, p->d_cand_b, p->sstream) != 0)
             return -1;
+        if (scan_end() != 0) return -1;
         p->stat_dense_frames += n_frames;
     }
+    if (p->depth && !deferred_done && run_deferred(p, d_iq, c0, c1) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
     uint32_t counters[2] = { 0, 0 };
     int32_t hdr[2] = { 0, 0 };
@@ -721,25 +829,39 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     if (n_gone > 0)
         IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));
 
-    p->last_bursts.clear();
     p->last_frames = n_frames;
-    p->last_chunk = d_iq;
-    p->last_chunk_start = c0;
-    p->last_chunk_end = c1;
-    const SampleSource src = make_source(p, d_iq, c0, c1);
-    // events 3..6 are re-recorded per sub-batch; record them once so an empty chunk has valid timings
-    for (int i = 3; i <= 6; i++) IRDM_HIP_CHECK(hipEventRecord(p->ev[i], p->stream));
-    if (process_bursts(p, src, n_gone) != 0) return -1;
-    if (ring_update(p, d_iq, c0, c1) != 0) return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->stream));
-    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    int emitted = 0;
+    if (!p->depth) {
+        p->last_bursts.clear();
+        p->last_chunk = d_iq;
+        p->last_chunk_start = c0;
+        p->last_chunk_end = c1;
+        const SampleSource src = make_source(p, d_iq, c0, c1);
+        // events 3..6 are re-recorded per sub-batch; record them once so an empty chunk has valid timings
+        for (int i = 3; i <= 6; i++) IRDM_HIP_CHECK(hipEventRecord(p->ev[i], p->bstream));
+        if (process_bursts(p, src, p->h_gone.data(), n_gone) != 0) return -1;
+        if (ring_update(p, d_iq, c0, c1) != 0) return -1;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        emitted = n_gone;
+    } else {
+        // the previous chunk's per-burst work and this chunk's ring copy were issued on bstream before
+        // the detector was waited for (see above); here only the hand-over of this chunk's bursts remains
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
+        emitted = p->deferred_emitted;
+        p->pend_gone.assign(p->h_gone.begin(), p->h_gone.begin() + n_gone);
+        p->has_pending = true;
+        p->pend_c1 = c1;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    }
     p->total_samples = c1;
 
     float ms = 0;
     const int pairs[6][2] = { { 0, 1 }, { 1, 2 }, { 3, 4 }, { 4, 5 }, { 5, 6 }, { 0, 7 } };
     for (int i = 0; i < 6; i++)
         p->last_ms[i] = hipEventElapsedTime(&ms, p->ev[pairs[i][0]], p->ev[pairs[i][1]]) == hipSuccess ? ms : -1.0f;
-    return n_gone;
+    return emitted;
 }
 
 extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples)
@@ -821,12 +943,13 @@ extern "C" int irdm_baseline_sum(irdm_pipeline_t *p, float *out)
 
 extern "C" int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float *out, size_t max_samples)
 {
-    if (!p || !out || burst_in_chunk < 0 || burst_in_chunk >= (int)p->last_bursts.size() || !p->last_chunk)
+    if (!p || !out || burst_in_chunk < 0 || burst_in_chunk >= (int)p->last_bursts.size() || (!p->depth && !p->last_chunk))
         return -1;
     const irdm_burst_t &r = p->last_bursts[burst_in_chunk];
     const size_t n = std::min<size_t>(std::min<size_t>(max_samples, r.num_samples), p->l_cap);
     // NOTE: valid only until the next feed (the chunk pointer and ring are read again)
-    SampleSource src = make_source(p, p->last_chunk, p->last_chunk_start, p->last_chunk_end);
+    SampleSource src = p->depth ? make_source(p, nullptr, 0, r.avail_end)
+                                : make_source(p, p->last_chunk, p->last_chunk_start, p->last_chunk_end);
     // the ring already holds the chunk tail; reading through the chunk pointer is equivalent
     if (launch_gather_burst(src, r.start, r.avail_end, (int)n, p->d_probe, p->stream) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpyAsync(out, p->d_probe, n * sizeof(float2), hipMemcpyDeviceToHost, p->stream));

@@ -125,6 +125,51 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---- wavefront reductions on the DPP network (no LDS round trips: __shfl_xor compiles to
+// ds_bpermute, ~100+ cycles each for a lone wavefront) ----
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v, unsigned identity)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, 0xf, 0xf, false);
+}
+#define IRDM_DPP_REDUCE(v, OP, IDENT)                                  \
+    do {                                                               \
+        v = OP(v, dpp_u32<0x111>(v, IDENT));   /* row_shr:1  */        \
+        v = OP(v, dpp_u32<0x112>(v, IDENT));   /* row_shr:2  */        \
+        v = OP(v, dpp_u32<0x114>(v, IDENT));   /* row_shr:4  */        \
+        v = OP(v, dpp_u32<0x118>(v, IDENT));   /* row_shr:8  */        \
+        v = OP(v, dpp_u32<0x142>(v, IDENT));   /* row_bcast:15 */      \
+        v = OP(v, dpp_u32<0x143>(v, IDENT));   /* row_bcast:31 */      \
+    } while (0)
+__device__ __forceinline__ unsigned op_min_u32(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned op_or_u32(unsigned a, unsigned b) { return a | b; }
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    IRDM_DPP_REDUCE(v, op_min_u32, 0xffffffffu);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
+{
+    IRDM_DPP_REDUCE(v, op_or_u32, 0u);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// max of 64-bit keys (hi word compared first)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+    unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+#define IRDM_STEP(CTRL)                                                                  \
+    do {                                                                                 \
+        const unsigned olo = dpp_u32<CTRL>(lo, 0u), ohi = dpp_u32<CTRL>(hi, 0u);         \
+        const bool take = ohi > hi || (ohi == hi && olo > lo);                           \
+        lo = take ? olo : lo;                                                            \
+        hi = take ? ohi : hi;                                                            \
+    } while (0)
+    IRDM_STEP(0x111); IRDM_STEP(0x112); IRDM_STEP(0x114); IRDM_STEP(0x118); IRDM_STEP(0x142); IRDM_STEP(0x143);
+#undef IRDM_STEP
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
 enum { CMD_EXIT = 0, CMD_BULK = 1, CMD_VALIDATE = 2, CMD_ZERO = 3 };
 constexpr int kFastMaxActive = 64;      // active bursts live in the leader's lanes; more -> dense fallback
 constexpr int kStageCap = 2048;         // list entries staged in LDS per batch
@@ -440,8 +485,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             const int bin = s_bins[i];
                             if (UNMASKED(bin) && VALID_BIN(bin)) acc |= s_crossT[bin];
                         }
-                        for (int off = 32; off > 0; off >>= 1) acc |= __shfl_xor(acc, off);
-                        C = acc;
+                        C = wave_or_u32(acc);
                         hc_valid = true;
                         TK(2, t2_);
                     }
@@ -476,11 +520,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         }
                         Ej = Eexp < Elong ? Eexp : Elong;
                     }
-                    int Ed = Ej;
-                    for (int off = 32; off > 0; off >>= 1) {
-                        const int o = __shfl_xor(Ed, off);
-                        Ed = o < Ed ? o : Ed;
-                    }
+                    const int Ed = (int)wave_min_u32((unsigned)Ej);
                     const unsigned Cm = C & rm;
                     const int Ec = Cm ? __builtin_ctz(Cm) : 32;
                     const int E = Ed < Ec ? Ed : Ec;
@@ -589,18 +629,21 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     // create_new_bursts (:556-591): descending magnitude, ties by ascending bin, skipping
                     // bins masked by bursts created earlier in the same frame == repeated arg-max
                     while (n_cand > 0) {
-                        float br = -1.0f;
-                        int bb = 0x7fffffff;
+                        // key = (rel bits, ~bin): rel > 0, so its IEEE bits order like the value; the larger key
+                        // is the larger rel, ties the smaller bin
+                        unsigned long long key = 0ull;
                         for (int k = lane; k < n_cand; k += 64) {
                             const PeakCand c = s_cand[k];
-                            if (UNMASKED(c.bin) && (c.rel > br || (c.rel == br && c.bin < bb))) { br = c.rel; bb = c.bin; }
+                            if (UNMASKED(c.bin)) {
+                                const unsigned long long kk =
+                                    ((unsigned long long)__float_as_uint(c.rel) << 32) | (unsigned)(~c.bin);
+                                key = kk > key ? kk : key;
+                            }
                         }
-                        for (int off = 32; off > 0; off >>= 1) {
-                            const float orr = __shfl_xor(br, off);
-                            const int ob = __shfl_xor(bb, off);
-                            if (orr > br || (orr == br && ob < bb)) { br = orr; bb = ob; }
-                        }
-                        if (bb == 0x7fffffff) break;
+                        key = wave_max_u64(key);
+                        if (key == 0ull) break;
+                        const float br = __uint_as_float((unsigned)(key >> 32));
+                        const int bb = (int)~(unsigned)key;
                         if (occ == ~0ull) { abort_code |= 4; break; }
                         const int sl = __builtin_ctzll(~occ);
                         if (lane == sl) {

@@ -22,7 +22,8 @@ class Config(C.Structure):
     _fields_ = [("center_frequency", C.c_double), ("sample_rate", C.c_int),
                 ("threshold_db", C.c_float), ("format", C.c_int), ("feed_block", C.c_int),
                 ("use_gardner", C.c_int), ("start_time_ns", C.c_uint64), ("device", C.c_int),
-                ("max_chunk_samples", C.c_size_t), ("max_bursts_per_chunk", C.c_int)]
+                ("max_chunk_samples", C.c_size_t), ("max_bursts_per_chunk", C.c_int),
+                ("pipeline_depth", C.c_int)]
 
 
 class Burst(C.Structure):
@@ -80,6 +81,7 @@ def lib():
         L.irdm_destroy.argtypes = [C.c_void_p]
         L.irdm_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.irdm_feed_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_flush.argtypes = [C.c_void_p]
         L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
@@ -153,10 +155,11 @@ class Pipeline:
 
     def __init__(self, sample_rate, fmt=FMT_CF32, center_frequency=1622000000.0, threshold_db=0.0,
                  feed_block=0, use_gardner=1, start_time_ns=1700000000 * 10**9, device=0,
-                 max_chunk_samples=0, max_bursts_per_chunk=0):
+                 max_chunk_samples=0, max_bursts_per_chunk=0, pipeline_depth=0):
         self.L = lib()
         self.cfg = Config(center_frequency, int(sample_rate), threshold_db, fmt, feed_block,
-                          use_gardner, start_time_ns, device, max_chunk_samples, max_bursts_per_chunk)
+                          use_gardner, start_time_ns, device, max_chunk_samples, max_bursts_per_chunk,
+                          pipeline_depth)
         self.h = self.L.irdm_create(C.byref(self.cfg))
         if not self.h:
             raise RuntimeError("irdm_create failed (no GPU, or bad config)")
@@ -182,6 +185,12 @@ class Pipeline:
         rc = self.L.irdm_feed_device(self.h, C.c_void_p(ptr), n_samples, C.c_void_p(stream or 0))
         if rc < 0:
             raise RuntimeError("irdm_feed_device failed")
+        return rc
+
+    def flush(self):
+        rc = self.L.irdm_flush(self.h)
+        if rc < 0:
+            raise RuntimeError("irdm_flush failed")
         return rc
 
     def _poll(self, fn, typ, chunk=256):

@@ -11,11 +11,12 @@ def bits_of(x):
     return np.float32(x).view(np.uint32)
 
 
-def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, **kw):
+def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, **kw):
     """Feed `iq` through the HIP pipeline in the given chunk sizes (samples)."""
     n = len(iq) if fmt == irdm.FMT_CF32 else len(iq) // 2
     max_chunk = max(chunks) if chunks else n
-    p = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=max_chunk, max_bursts_per_chunk=1024, **kw)
+    p = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=max_chunk, max_bursts_per_chunk=1024,
+                      pipeline_depth=depth, **kw)
     p.set_option("keep_frame_samples", 1)
     p.set_option("scan_mode", scan_mode)
     per = 1 if fmt == irdm.FMT_CF32 else 2
@@ -24,6 +25,8 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, **kw):
         p.feed_host(iq[off * per:(off + c) * per])
         off += c
     assert off == n
+    if depth:
+        p.flush()
     bursts = p.poll_bursts()
     infos, samples = p.poll_frames()
     demods = p.poll_demods()

@@ -265,3 +265,22 @@ def test_time_chunk_handoff_equals_single_context():
     assert any(bb.start < cut < bb.start + bb.num_samples for bb in got["bursts"])
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("fmt", ["cf32", "ci8"])
+def test_pipeline_depth_1_overlapped_equals_synchronous(fmt):
+    """pipeline_depth 1: the per-burst stages of chunk k run during feed(k+1) from the history ring,
+    overlapped with the detector; after irdm_flush the records equal the synchronous ones."""
+    fs, iq = _scene_2m(seed=19, n_bursts=12, secs=3.0)
+    blk = 32768
+    n = len(iq)
+    chunks = [blk * 30, blk * 41, blk * 50, n - blk * 121]
+    if fmt == "cf32":
+        ref = orc.run_stream(iq, fs)
+        got = parity.run_gpu(iq, fs, chunks=chunks, depth=1)
+    else:
+        i8 = siggen.to_ci8(iq * 8)
+        ref = orc.run_stream(i8, fs, fmt=0)
+        got = parity.run_gpu(i8, fs, fmt=irdm.FMT_CI8, chunks=chunks, depth=1)
+    s = parity.compare(got, ref)
+    assert s["bursts"] >= 12
