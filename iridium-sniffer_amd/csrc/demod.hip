@@ -1,6 +1,6 @@
 // demod.hip -- stage C on gfx950 (qpsk_demod.c:393-535): Gardner-timed DQPSK
-// demodulation, one lane per frame (every loop in this stage is a sequential
-// per-symbol recurrence of <= 445 steps; frames are independent).
+// demodulation, one wavefront per frame (the loops of this stage are sequential per-symbol
+// recurrences of <= 445 steps run by lane 0 out of LDS; frames are independent).
 //
 // Numerics: float32 in the reference's operation order.  cabsf is reproduced
 // exactly (double sqrt); cargf/atan2f, cosf, sinf come from the device libm and
@@ -39,187 +39,210 @@ __device__ float2 cubic_interp(const float2 *in, int n, float pos)
     return cadd(cadd(cadd(cscale(mu3, a), cscale(mu2, b)), cscale(mu, c)), s1);
 }
 
-__global__ void demod_kernel(const BurstWork *__restrict__ work, int n_bursts,
-                             const float2 *__restrict__ frames, int use_gardner, float sps,
-                             float2 *__restrict__ ws, DemodOut *__restrict__ out)
+// One wavefront per frame.  The frame (<= 4440 samples) and the per-symbol work arrays live in LDS;
+// lane 0 runs the sequential recurrences (Gardner loop, PLL, end-of-frame rule, the float sums whose
+// order matters), the other lanes stage the frame and write the per-symbol outputs.
+__global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__ work, int n_bursts,
+                                                   const float2 *__restrict__ frames, int use_gardner, float sps,
+                                                   float2 *__restrict__ ws, DemodOut *__restrict__ out)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float2 s_fr[kMaxFrameSamples];
+    __shared__ float2 s_dec[kMaxSymbols];
+    __shared__ float2 s_po[kMaxSymbols];
+    __shared__ int s_sym[kMaxSymbols];
+    __shared__ int s_res[4];          // ok, direction, ns, confidence
+    __shared__ float s_resf[3];       // level, total_phase, llr scale
+    (void)ws;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
     if (b >= n_bursts) return;
     DemodOut &o = out[b];
-    o.ok = 0;
     const BurstWork w = work[b];
-    if (w.drop_reason != 0) return;
+    if (w.drop_reason != 0) {
+        if (lane == 0) o.ok = 0;
+        return;
+    }
     const int n_samples = w.num_samples;
-    const float2 *in = frames + (size_t)b * kMaxFrameSamples;
-    float2 *dec = ws + (size_t)b * (2 * kMaxSymbols);
-    float2 *po = dec + kMaxSymbols;
+    const float2 *gin = frames + (size_t)b * kMaxFrameSamples;
+    for (int i = lane; i < n_samples; i += 64) s_fr[i] = gin[i];
+    __syncthreads();
 
-    // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
-    int n = 0;
-    if (use_gardner) {
-        float pos = 0.0f, toff = 0.0f;
-        float2 prev = make_float2(0.0f, 0.0f);
-        while (pos < (float)(n_samples - 3) && n < kMaxSymbols) {
-            const float2 on = cubic_interp(in, n_samples, pos);
-            dec[n] = on;
-            if (n > 0) {
-                const float mid_pos = pos - sps * 0.5f;
-                if (mid_pos >= 1.0f) {
-                    const float2 mid = cubic_interp(in, n_samples, mid_pos);
-                    const float2 diff = csub(prev, on);
-                    // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
-                    const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
-                    float err = p0 - p1;
-                    if (err > 1.0f) err = 1.0f;
-                    if (err < -1.0f) err = -1.0f;
-                    toff += 0.0002f * err;
-                    float adj = 0.02f * err + toff;
-                    if (adj > 0.5f) adj = 0.5f;
-                    if (adj < -0.5f) adj = -0.5f;
-                    pos += adj;
+    if (lane == 0) {
+        const float2 *in = s_fr;
+        float2 *dec = s_dec, *po = s_po;
+        int *sym = s_sym;
+        // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
+        int n = 0;
+        if (use_gardner) {
+            float pos = 0.0f, toff = 0.0f;
+            float2 prev = make_float2(0.0f, 0.0f);
+            while (pos < (float)(n_samples - 3) && n < kMaxSymbols) {
+                const float2 on = cubic_interp(in, n_samples, pos);
+                dec[n] = on;
+                if (n > 0) {
+                    const float mid_pos = pos - sps * 0.5f;
+                    if (mid_pos >= 1.0f) {
+                        const float2 mid = cubic_interp(in, n_samples, mid_pos);
+                        const float2 diff = csub(prev, on);
+                        // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
+                        const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
+                        float err = p0 - p1;
+                        if (err > 1.0f) err = 1.0f;
+                        if (err < -1.0f) err = -1.0f;
+                        toff += 0.0002f * err;
+                        float adj = 0.02f * err + toff;
+                        if (adj > 0.5f) adj = 0.5f;
+                        if (adj < -0.5f) adj = -0.5f;
+                        pos += adj;
+                    }
                 }
+                prev = on;
+                n++;
+                pos += sps;
             }
-            prev = on;
-            n++;
-            pos += sps;
-        }
-    } else {
-        for (int i = 0; i < n_samples && n < kMaxSymbols; i += (int)sps) dec[n++] = in[i];
-    }
-
-    // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
-    float2 phi = make_float2(1.0f, 0.0f);
-    float total_phase = 0.0f;
-    for (int i = 0; i < n; i++) {
-        const float2 v = cmul(dec[i], phi);
-        po[i] = v;
-        float2 xh;
-        if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
-        else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
-        else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
-        else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
-        const float2 er = cmul(make_float2(xh.x, -xh.y), v);
-        const float em = cabs_f(er);
-        if (em < 1e-10f) continue;
-        const float2 unit = make_float2(er.x / em, er.y / em);
-        const float ang = atan2f(unit.y, unit.x);
-        const float sa = 0.2f * ang;
-        const float2 corr = make_float2(cosf(sa), sinf(sa));
-        total_phase += sa;
-        phi = cmul(make_float2(corr.x, -corr.y), phi);
-        const float pm = cabs_f(phi);
-        if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
-    }
-
-    // step 3: demod_qpsk (qpsk_demod.c:199-260)
-    int sym[kMaxSymbols];
-    float max_mag = 0.0f, sum = 0.0f;
-    int low = 0, ns = 0, n_ok = 0;
-    // first pass decides n (end-of-frame rule), second accumulates level/confidence over [0, n)
-    for (int i = 0; i < n; i++) {
-        const float re = po[i].x, im = po[i].y;
-        const float a = re * re, bq = im * im;
-        const float mag = sqrtf(a + bq);
-        if (mag > max_mag) max_mag = mag;
-        ns++;
-        if (mag < max_mag / 8.0f) {
-            if (++low >= 3) { ns -= 3; break; }
         } else {
-            low = 0;
+            for (int i = 0; i < n_samples && n < kMaxSymbols; i += (int)sps) dec[n++] = in[i];
         }
-    }
-    for (int i = 0; i < ns; i++) {
-        const float re = po[i].x, im = po[i].y;
-        const float a = re * re, bq = im * im;
-        sum += sqrtf(a + bq);
-        int s;
-        if (re >= 0 && im >= 0) s = 0;
-        else if (re < 0 && im >= 0) s = 1;
-        else if (re < 0) s = 2;
-        else s = 3;
-        sym[i] = s;
-        const float phase = (atan2f(im, re) + IRDM_PI_F) * 180.0f / IRDM_PI_F;
-        const float offs = 45.0f - fmodf(phase, 90.0f);
-        if (fabsf(offs) <= 22.0f) n_ok++;
-    }
-    const float level = ns > 0 ? sum / (float)ns : 0.0f;
-    const int confidence = ns > 0 ? (100 * n_ok) / ns : 0;
 
-    // step 4: unique word (qpsk_demod.c:277-325, :429-465)
-    const int UW_DL[12] = { 0, 2, 2, 2, 2, 0, 0, 0, 2, 0, 0, 2 };
-    const int UW_UL[12] = { 2, 2, 0, 0, 0, 2, 0, 0, 2, 0, 2, 2 };
-    int direction = w.direction;
-    int dl_ok = 0, ul_ok = 0;
-    if (ns >= 12) {
-        int dd = 0, du = 0;
-        for (int i = 0; i < 12; i++) {
-            int a = abs(sym[i] - UW_DL[i]); if (a == 3) a = 1; dd += a;
-            int c = abs(sym[i] - UW_UL[i]); if (c == 3) c = 1; du += c;
+        // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
+        float2 phi = make_float2(1.0f, 0.0f);
+        float total_phase = 0.0f;
+        for (int i = 0; i < n; i++) {
+            const float2 v = cmul(dec[i], phi);
+            po[i] = v;
+            float2 xh;
+            if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
+            else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
+            else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
+            else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
+            const float2 er = cmul(make_float2(xh.x, -xh.y), v);
+            const float em = cabs_f(er);
+            if (em < 1e-10f) continue;
+            const float2 unit = make_float2(er.x / em, er.y / em);
+            const float ang = atan2f(unit.y, unit.x);
+            const float sa = 0.2f * ang;
+            const float2 corr = make_float2(cosf(sa), sinf(sa));
+            total_phase += sa;
+            phi = cmul(make_float2(corr.x, -corr.y), phi);
+            const float pm = cabs_f(phi);
+            if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
         }
-        dl_ok = dd <= 2;
-        ul_ok = du <= 2;
-    }
-    if (!dl_ok && !ul_ok) {
-        float de = 999.0f, ue = 999.0f;
-        if (ns >= 12) {
-            de = 0.0f; ue = 0.0f;
-            for (int i = 0; i < 12; i++) {
-                float actual = atan2f(po[i].y, po[i].x);
-                if (actual < 0) actual += 2.0f * IRDM_PI_F;
-                {
-                    const float expect = IRDM_PI_F * 0.25f + (float)UW_DL[i] * IRDM_PI_F * 0.5f;
-                    float df = actual - expect;
-                    if (df > IRDM_PI_F) df -= 2.0f * IRDM_PI_F;
-                    if (df < -IRDM_PI_F) df += 2.0f * IRDM_PI_F;
-                    de += fabsf(df) * (float)(2.0 / 3.14159265358979323846);
-                }
-                {
-                    const float expect = IRDM_PI_F * 0.25f + (float)UW_UL[i] * IRDM_PI_F * 0.5f;
-                    float df = actual - expect;
-                    if (df > IRDM_PI_F) df -= 2.0f * IRDM_PI_F;
-                    if (df < -IRDM_PI_F) df += 2.0f * IRDM_PI_F;
-                    ue += fabsf(df) * (float)(2.0 / 3.14159265358979323846);
-                }
+
+        // step 3: demod_qpsk (qpsk_demod.c:199-260): the end-of-frame rule fixes ns, then level and
+        // confidence are accumulated over [0, ns) in order
+        float max_mag = 0.0f, sum = 0.0f;
+        int low = 0, ns = 0, n_ok = 0;
+        for (int i = 0; i < n; i++) {
+            const float re = po[i].x, im = po[i].y;
+            const float a = re * re, bq = im * im;
+            const float mag = sqrtf(a + bq);
+            if (mag > max_mag) max_mag = mag;
+            ns++;
+            if (mag < max_mag / 8.0f) {
+                if (++low >= 3) { ns -= 3; break; }
+            } else {
+                low = 0;
             }
         }
-        const float mn = de < ue ? de : ue;
-        if (mn > 3.0f) return;                                   // UW failed: no frame
-        direction = ue < de ? 2 : 1;
-    } else {
-        if (ul_ok && !dl_ok) direction = 2;
-        else if (dl_ok && !ul_ok) direction = 1;
-    }
+        for (int i = 0; i < ns; i++) {
+            const float re = po[i].x, im = po[i].y;
+            const float a = re * re, bq = im * im;
+            sum += sqrtf(a + bq);
+            int sq;
+            if (re >= 0 && im >= 0) sq = 0;
+            else if (re < 0 && im >= 0) sq = 1;
+            else if (re < 0) sq = 2;
+            else sq = 3;
+            sym[i] = sq;
+            const float phase = (atan2f(im, re) + IRDM_PI_F) * 180.0f / IRDM_PI_F;
+            const float offs = 45.0f - fmodf(phase, 90.0f);
+            if (fabsf(offs) <= 22.0f) n_ok++;
+        }
+        const float level = ns > 0 ? sum / (float)ns : 0.0f;
+        const int confidence = ns > 0 ? (100 * n_ok) / ns : 0;
 
-    // steps 5-7: decode_dqpsk (:264-273), bits MSB first (:329-335), LLR (:489-503)
-    const int dq[4] = { 0, 2, 3, 1 };
-    int old = 0;
-    float sm = 0.0f;
-    for (int i = 0; i < ns; i++) {
-        const int s = sym[i];
-        const int v = dq[(s - old + 4) % 4];
-        old = s;
+        // step 4: unique word (qpsk_demod.c:277-325, :429-465)
+        const int UW_DL[12] = { 0, 2, 2, 2, 2, 0, 0, 0, 2, 0, 0, 2 };
+        const int UW_UL[12] = { 2, 2, 0, 0, 0, 2, 0, 0, 2, 0, 2, 2 };
+        int direction = w.direction;
+        int ok = 1;
+        int dl_ok = 0, ul_ok = 0;
+        if (ns >= 12) {
+            int dd = 0, du = 0;
+            for (int i = 0; i < 12; i++) {
+                int a = abs(sym[i] - UW_DL[i]); if (a == 3) a = 1; dd += a;
+                int c = abs(sym[i] - UW_UL[i]); if (c == 3) c = 1; du += c;
+            }
+            dl_ok = dd <= 2;
+            ul_ok = du <= 2;
+        }
+        if (!dl_ok && !ul_ok) {
+            float de = 999.0f, ue = 999.0f;
+            if (ns >= 12) {
+                de = 0.0f; ue = 0.0f;
+                for (int i = 0; i < 12; i++) {
+                    float actual = atan2f(po[i].y, po[i].x);
+                    if (actual < 0) actual += 2.0f * IRDM_PI_F;
+                    {
+                        const float expect = IRDM_PI_F * 0.25f + (float)UW_DL[i] * IRDM_PI_F * 0.5f;
+                        float df = actual - expect;
+                        if (df > IRDM_PI_F) df -= 2.0f * IRDM_PI_F;
+                        if (df < -IRDM_PI_F) df += 2.0f * IRDM_PI_F;
+                        de += fabsf(df) * (float)(2.0 / 3.14159265358979323846);
+                    }
+                    {
+                        const float expect = IRDM_PI_F * 0.25f + (float)UW_UL[i] * IRDM_PI_F * 0.5f;
+                        float df = actual - expect;
+                        if (df > IRDM_PI_F) df -= 2.0f * IRDM_PI_F;
+                        if (df < -IRDM_PI_F) df += 2.0f * IRDM_PI_F;
+                        ue += fabsf(df) * (float)(2.0 / 3.14159265358979323846);
+                    }
+                }
+            }
+            const float mn = de < ue ? de : ue;
+            if (mn > 3.0f) ok = 0;                                     // UW failed: no frame
+            direction = ue < de ? 2 : 1;
+        } else {
+            if (ul_ok && !dl_ok) direction = 2;
+            else if (dl_ok && !ul_ok) direction = 1;
+        }
+        // LLR normalisation (:489-497): sum of |.| in symbol order
+        float sm = 0.0f;
+        if (ok)
+            for (int i = 0; i < ns; i++) sm += cabs_f(po[i]);
+        s_res[0] = ok; s_res[1] = direction; s_res[2] = ns; s_res[3] = confidence;
+        s_resf[0] = level; s_resf[1] = total_phase;
+        s_resf[2] = (ns > 0 && sm > 0) ? (kSqrt1_2 / (sm / (float)ns)) : 1.0f;
+    }
+    __syncthreads();
+    const int ok = s_res[0], ns = s_res[2];
+    if (lane == 0) {
+        o.ok = ok;
+        o.direction = s_res[1];
+        o.confidence = s_res[3];
+        o.n_symbols = ns;
+        o.level = s_resf[0];
+        o.total_phase = s_resf[1];
+    }
+    if (!ok) return;
+    // steps 5-7: decode_dqpsk (:264-273), bits MSB first (:329-335), LLR (:498-503): per-symbol independent
+    const float scale = s_resf[2];
+    for (int i = lane; i < ns; i += 64) {
+        const int dq[4] = { 0, 2, 3, 1 };
+        const int sq = s_sym[i], old = i > 0 ? s_sym[i - 1] : 0;
+        const int v = dq[(sq - old + 4) % 4];
         o.bits[2 * i] = (uint8_t)((v >> 1) & 1);
         o.bits[2 * i + 1] = (uint8_t)(v & 1);
-        sm += cabs_f(po[i]);
+        o.llr[2 * i] = fabsf(s_po[i].x) * scale;
+        o.llr[2 * i + 1] = fabsf(s_po[i].y) * scale;
     }
-    const float scale = (ns > 0 && sm > 0) ? (kSqrt1_2 / (sm / (float)ns)) : 1.0f;
-    for (int i = 0; i < ns; i++) {
-        o.llr[2 * i] = fabsf(po[i].x) * scale;
-        o.llr[2 * i + 1] = fabsf(po[i].y) * scale;
-    }
-    o.direction = direction;
-    o.confidence = confidence;
-    o.n_symbols = ns;
-    o.level = level;
-    o.total_phase = total_phase;
-    o.ok = 1;
 }
 
 int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,
                  float sps, float2 *ws, DemodOut *out, hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
-    hipLaunchKernelGGL(demod_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts,
+    hipLaunchKernelGGL(demod_kernel, dim3(n_bursts), dim3(64), 0, stream, work, n_bursts,
                        frames, use_gardner, sps, ws, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

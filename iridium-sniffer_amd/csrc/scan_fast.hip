@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             const int b0_ = w_ << 5;                                                                \
             const int l_ = lo_ > b0_ ? lo_ - b0_ : 0, h_ = hi_ < b0_ + 31 ? hi_ - b0_ : 31;         \
             const unsigned m_ = (h_ == 31 ? ~0u : ((1u << (h_ + 1)) - 1u)) & ~((1u << l_) - 1u);   \
-            if (SETV) s_mbits[w_] |= m_; else s_mbits[w_] &= ~m_;                                   \
+            if (SETV) atomicOr(&s_mbits[w_], m_); else atomicAnd(&s_mbits[w_], ~m_);  /* no return value: no LDS round trip */ \
         }                                                                                           \
     } while (0)
 #define MASK_ALL_ONES() do { for (int i_ = lane; i_ < N / 32; i_ += 64) s_mbits[i_] = ~0u; } while (0)
