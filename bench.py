@@ -67,10 +67,11 @@ def main():
     ap.add_argument("--samples", type=int, default=64 * 1024 * 1024, help="samples per chunk per GPU")
     ap.add_argument("--density", type=float, default=10.0, help="bursts per Msample")
     ap.add_argument("--sample-rate", type=int, default=10_000_000)
-    ap.add_argument("--depth", type=int, default=1,
+    ap.add_argument("--depth", type=int, default=0,
                     help="pipeline_depth: 1 = per-burst stages of chunk k overlap the detector scan of chunk k+1")
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--cpu-passes", type=int, default=4, help="oracle passes over that prefix (~3 s each)")
     args = ap.parse_args()
 
     import torch
@@ -151,10 +152,13 @@ def main():
     if args.depth:
         # drain: the last chunk's per-burst stages belong to the timed work
         pipe.flush()
-        pipe.poll_bursts_raw()
+        tb_ = pipe.poll_bursts_raw()
         pipe.drop_frames()
         tail = pipe.poll_demods_raw()
         totals["demods"] += len(tail)
+        totals["bursts"] += len(tb_)
+        ns_off = irdm.Burst.num_samples.offset
+        totals["burst_samples"] += int(tb_[:, ns_off:ns_off + 8].copy().view(np.uint64).sum()) if len(tb_) else 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -176,11 +180,25 @@ def main():
         "scan": 8.0 * n,                          # history row read + write per bin-frame (B_det = 16 B/sample with K1)
         "fir": 8.0 * lb + 8.0 * lb / decim,       # burst-window re-read + decimated write
     }
-    kernels = {"fft_mag": "fft_mag_kernel", "scan": "detect_scan_kernel", "fir": "fir_decimate_kernel"}
+    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "detect_scan_fast_kernel", "fir": "fir_decimate_kernel"}
     dom = max(alg_bytes, key=lambda k: ms[k])
     ach = alg_bytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+    # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs and
+    # corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py -> profiles/<round>_pmc.json)
+    traffic = None
+    try:
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        if files:
+            pmc = json.load(open(files[-1]))
+            for kname, d in pmc.items():
+                if kernels[dom] in kname:
+                    traffic = round(d["traffic_bytes"])
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": kernels[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes": round(alg_bytes[dom]),
                 "ms_per_launch": round(ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in ms.items()},
                 "host_ms": {k: round(v / K, 3) for k, v in host.items()},
@@ -193,12 +211,14 @@ def main():
         m = min(n, args.cpu_samples) // 32768 * 32768
         host = x[:m].cpu().numpy().view(np.complex64).reshape(-1)
         t1 = time.perf_counter()
-        ref = orc.run_stream(host, fs, cap_bursts=8192)
+        for _ in range(max(args.cpu_passes, 1)):
+            ref = orc.run_stream(host, fs, cap_bursts=8192)
         cdt = time.perf_counter() - t1
-        cpu = {"value": round(m / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-               "sample": "first %d samples of the rank-0 stream (%.2f s of CPU), scalar C oracle "
-                         "(reference --no-simd --no-gpu algorithm, pinned FFT), %d bursts -> %d RAW frames"
-                         % (m, cdt, ref.n_tagged, len(ref.demods))}
+        cpu = {"value": round(max(args.cpu_passes, 1) * m / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+               "kind": "port",
+               "sample": "%d passes over the first %d samples of the rank-0 stream (%.1f s of CPU), scalar C oracle "
+                         "(reference --no-simd --no-gpu algorithm, pinned FFT), %d bursts -> %d RAW frames per pass"
+                         % (max(args.cpu_passes, 1), m, cdt, ref.n_tagged, len(ref.demods))}
 
     if rank == 0:
         out = {
