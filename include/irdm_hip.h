@@ -175,6 +175,14 @@ int irdm_baseline_sum(irdm_pipeline_t *p, float *out);
 /* burst_data_t.samples of the i-th burst emitted by the LAST chunk (re-gathered) */
 int irdm_burst_samples(irdm_pipeline_t *p, int burst_in_chunk, float *out, size_t max_samples);
 
+/* Stage B alone for one burst: burst_downmix_process() (burst_downmix.h:70).  `info` carries the
+ * burst_info_t fields (id, start, center_bin, magnitude, noise are used), `samples` the burst_data_t IQ
+ * (host, num_samples complex floats).  Fills *frame (drop_reason 0 = frame produced, 1..5 = the reference's
+ * early returns) and, when a frame was produced, frame_samples (2 * IRDM_MAX_FRAME_SAMPLES floats).
+ * cf32 contexts only.  Returns 1 (frame), 0 (dropped) or -1 (error). */
+int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, const float *samples, size_t num_samples,
+                       irdm_frame_info_t *frame, float *frame_samples);
+
 /* Stage C alone, batched: qpsk_demod() (qpsk_demod.h:42) for n downmixed frames.
  * samples: n rows of 2*IRDM_MAX_FRAME_SAMPLES floats (re,im interleaved, row-padded);
  * num_samples[i] <= IRDM_MAX_FRAME_SAMPLES; direction[i] = the downmixer's ir_direction_t.

@@ -1037,6 +1037,49 @@ extern "C" int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_
     return 0;
 }
 
+extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, const float *samples,
+                                  size_t num_samples, irdm_frame_info_t *frame, float *frame_samples)
+{
+    if (!p || !info || !samples || !frame || p->dev_fmt != 2) return -1;
+    if (num_samples > p->l_cap) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    IRDM_HIP_CHECK(hipMemcpy(p->d_probe, samples, num_samples * sizeof(float2), hipMemcpyHostToDevice));
+    // the burst window is presented as a "chunk" that starts at info->start
+    SampleSource src = make_source(p, p->d_probe, info->start, info->start + num_samples);
+    GoneBurst g;
+    memset(&g, 0, sizeof(g));
+    g.id = info->id;
+    g.start = info->start;
+    g.stop = info->start + num_samples - (uint64_t)p->P.pre_len;     // num_samples = stop + pre_len - start
+    g.last_active = info->last_active;
+    g.center_bin = info->center_bin;
+    g.peak_rel = info->peak_rel;
+    g.base_sum = info->base_sum;
+    // keep the result queues of the stream untouched: run on private queues
+    std::deque<irdm_burst_t> qb; std::deque<irdm_frame_info_t> qf; std::deque<std::vector<float>> qs;
+    std::deque<irdm_demod_t> qd;
+    qb.swap(p->q_bursts); qf.swap(p->q_frames); qs.swap(p->q_frame_samples); qd.swap(p->q_demods);
+    const int keep = p->keep_frame_samples;
+    const uint64_t tagged = p->tagged;
+    std::vector<irdm_burst_t> last; last.swap(p->last_bursts);
+    p->keep_frame_samples = 1;
+    const int rc = process_bursts(p, src, &g, 1);
+    int ret = -1;
+    if (rc == 0 && !p->q_frames.empty()) {
+        *frame = p->q_frames.front();
+        frame->magnitude = info->magnitude;
+        frame->noise = info->noise;
+        if (frame->drop_reason == 0 && frame_samples && !p->q_frame_samples.empty())
+            memcpy(frame_samples, p->q_frame_samples.front().data(), p->q_frame_samples.front().size() * sizeof(float));
+        ret = frame->drop_reason == 0 ? 1 : 0;
+    }
+    p->q_bursts.swap(qb); p->q_frames.swap(qf); p->q_frame_samples.swap(qs); p->q_demods.swap(qd);
+    p->keep_frame_samples = keep;
+    p->tagged = tagged;
+    p->last_bursts.swap(last);
+    return ret;
+}
+
 extern "C" int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, const int *num_samples,
                                      const int *direction, int n, irdm_demod_t *out)
 {

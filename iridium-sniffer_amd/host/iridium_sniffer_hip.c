@@ -1,0 +1,108 @@
+/*
+ * iridium_sniffer_hip.c -- file-mode command line over the MI355X hot path, plain C99.
+ *
+ * Mirrors the reference's file-mode surface (options.c:186-551, main.c:223-284, frame_output.c:160-199):
+ *     iridium-sniffer-hip -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB]
+ *                         [--file-info STR] [--no-gardner] [--chunk SAMPLES] [-v]
+ * IQ file in, iridium-toolkit "RAW:" lines on stdout, "burst_detect: tagged N bursts total" on stderr
+ * (burst_detect.c:350-351, the line test-configurations.sh:140 greps).  Everything between the file
+ * read and the line printer runs on the GPU through the C-ABI in include/irdm_hip.h; there is no CPU
+ * path here (the reference's own --no-gpu binary is the CPU path).
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "irdm_hip.h"
+
+static const char *ext_of(const char *p)
+{
+    const char *d = strrchr(p, '.');
+    return d ? d + 1 : "";
+}
+
+int main(int argc, char **argv)
+{
+    const char *file = NULL, *file_info = NULL, *format = NULL;
+    double rate = 0, freq = 1622000000.0, db = 0;
+    int gardner = 1, verbose = 0;
+    size_t chunk = (size_t)16 << 20;
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i];
+#define NEXT() (i + 1 < argc ? argv[++i] : (fprintf(stderr, "missing value for %s\n", a), exit(2), ""))
+        if (!strcmp(a, "-f") || !strcmp(a, "--file")) file = NEXT();
+        else if (!strcmp(a, "-r") || !strcmp(a, "--sample-rate")) rate = atof(NEXT());
+        else if (!strcmp(a, "-c") || !strcmp(a, "--center-freq")) freq = atof(NEXT());
+        else if (!strcmp(a, "-d") || !strcmp(a, "--threshold")) db = atof(NEXT());
+        else if (!strcmp(a, "--format")) format = NEXT();
+        else if (!strcmp(a, "--file-info")) file_info = NEXT();
+        else if (!strcmp(a, "--chunk")) chunk = (size_t)atoll(NEXT());
+        else if (!strcmp(a, "--no-gardner")) gardner = 0;
+        else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) verbose = 1;
+        else if (!strcmp(a, "--no-simd") || !strcmp(a, "--no-gpu")) {
+            fprintf(stderr, "%s: this binary is the GPU path; use the reference binary for the CPU path\n", a);
+            return 2;
+        } else {
+            fprintf(stderr, "unknown option %s\n", a);
+            return 2;
+        }
+    }
+    if (!file || rate <= 0) {
+        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR]\n", argv[0]);
+        return 2;
+    }
+    if (!format) format = ext_of(file);              /* autodetect by extension, options.c:533-544 */
+    int fmt = IRDM_FMT_CI8;
+    size_t bps = 2;
+    if (!strcmp(format, "cf32") || !strcmp(format, "fc32") || !strcmp(format, "cfile")) { fmt = IRDM_FMT_CF32; bps = 8; }
+    else if (!strcmp(format, "ci16") || !strcmp(format, "cs16")) { fmt = IRDM_FMT_CI16; bps = 4; }
+
+    irdm_config_t c;
+    memset(&c, 0, sizeof(c));
+    c.center_frequency = freq;
+    c.sample_rate = (int)rate;
+    c.threshold_db = (float)db;
+    c.format = fmt;
+    c.feed_block = 32768;
+    c.use_gardner = gardner;
+    chunk = chunk / 32768 * 32768;
+    if (chunk == 0) chunk = 32768;
+    c.max_chunk_samples = chunk;
+    irdm_pipeline_t *p = irdm_create(&c);
+    if (!p) {
+        fprintf(stderr, "irdm_create failed (no MI355X / bad parameters)\n");
+        return 1;
+    }
+    if (verbose) fprintf(stderr, "%s: fft_size=%d chunk=%zu samples\n", irdm_version(), irdm_fft_size(p), chunk);
+
+    FILE *f = strcmp(file, "-") ? fopen(file, "rb") : stdin;
+    if (!f) { perror(file); return 1; }
+    void *buf = malloc(chunk * bps);
+    irdm_demod_t *d = malloc(sizeof(*d) * 256);
+    char line[4096];
+    uint64_t t0 = 0;
+    size_t r;
+    int rc = 0;
+    while ((r = fread(buf, bps, chunk, f)) > 0) {
+        if (irdm_feed_host(p, buf, r) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; break; }
+        int n;
+        while ((n = irdm_poll_demods(p, d, 256)) > 0)
+            for (int i = 0; i < n; i++) {
+                const int len = irdm_format_raw(&d[i], file_info, &t0, line, sizeof line);
+                if (len > 0) fwrite(line, 1, (size_t)len, stdout);
+            }
+        irdm_burst_t tmp[256];
+        while (irdm_poll_bursts(p, tmp, 256) > 0) {}
+        irdm_frame_info_t fi[256];
+        while (irdm_poll_frames(p, fi, NULL, 256) > 0) {}
+        if (r < chunk) break;
+    }
+    fflush(stdout);
+    fprintf(stderr, "burst_detect: tagged %lu bursts total\n", (unsigned long)irdm_tagged_bursts(p));
+    irdm_destroy(p);
+    free(buf);
+    free(d);
+    if (f != stdin) fclose(f);
+    return rc;
+}

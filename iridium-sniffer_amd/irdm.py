@@ -93,6 +93,8 @@ def lib():
         L.irdm_last_magnitudes.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]
         L.irdm_baseline_sum.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.irdm_burst_samples.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]
+        L.irdm_downmix_burst.argtypes = [C.c_void_p, C.POINTER(Burst), C.POINTER(C.c_float), C.c_size_t,
+                                         C.POINTER(FrameInfo), C.POINTER(C.c_float)]
         L.irdm_qpsk_demod_batch.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int),
                                             C.POINTER(C.c_int), C.c_int, C.POINTER(Demod)]
         L.irdm_state_bytes.argtypes = [C.c_void_p]
@@ -255,6 +257,16 @@ class Pipeline:
                 infos.append(fi)
                 samples.append(sb[i, :2 * fi.num_samples].copy().view(np.complex64))
         return infos, samples
+
+    def downmix_burst(self, info, samples):
+        """burst_downmix_process for one burst (host samples, complex64) -> (FrameInfo, complex64 frame | None)."""
+        x = np.ascontiguousarray(samples, np.complex64)
+        fi = FrameInfo()
+        out = np.zeros(2 * MAX_FRAME_SAMPLES, np.float32)
+        rc = self.L.irdm_downmix_burst(self.h, C.byref(info), _fp(x.view(np.float32)), len(x), C.byref(fi), _fp(out))
+        if rc < 0:
+            raise RuntimeError("irdm_downmix_burst failed")
+        return fi, (out[:2 * fi.num_samples].view(np.complex64).copy() if rc == 1 else None)
 
     def qpsk_demod_batch(self, frames, directions):
         """frames: list of complex64 arrays (<= 4440 samples); returns list of Demod."""
