@@ -795,6 +795,7 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         if (status != 0) {
             // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
             p->stat_fallbacks++;
+            if (getenv("IRDM_SCAN_DEBUG")) fprintf(stderr, "irdm_hip: sparse scan aborted with status 0x%x -> dense scan\n", status);
             IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
             IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
                                           hipMemcpyDeviceToDevice, p->stream));
