@@ -558,6 +558,100 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     e1 = __builtin_amdgcn_readlane((int)r_off, k + 1);
                     const uint64_t idx = index0 + (uint64_t)f * N;
                     n_cand = 0;
+                    if (!any_cand && ev_del && (ev_del & (ev_del - 1)) == 0) {
+                        // ---- common case 1: exactly one burst ends, nothing can start ----
+                        const int sl = __builtin_ctzll(ev_del);
+                        const int cbd = __builtin_amdgcn_readlane(r_cb, sl);
+                        bool force = false;
+                        if (lane == sl) {
+                            ActiveBurst b = s_act[lane];
+                            b.last_active = r_la;
+                            force = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
+                            PUSH_GONE(b, idx, n_gone);
+                            H = 0;
+                        }
+                        n_gone += 1;
+                        force = __any(force) != 0;
+                        occ &= ~ev_del;
+                        MASK_EDIT(cbd, 1);                                        // its range is free again ...
+                        WAVE_SYNC();
+                        {   // ... except where a surviving burst's range overlaps it
+                            const bool ov = ((occ >> lane) & 1) && r_cb >= cbd - P.width - 1 && r_cb <= cbd + P.width + 1;
+                            unsigned long long om = __ballot(ov);
+                            while (om) {
+                                const int s2 = __builtin_ctzll(om);
+                                om &= om - 1;
+                                MASK_EDIT(__builtin_amdgcn_readlane(r_cb, s2), 0);
+                                WAVE_SYNC();
+                            }
+                        }
+                        if (hc_valid && !force) {
+                            // candidate frames can only gain the later crossings of the freed bins
+                            int lo_ = cbd - half_bw, hi_ = cbd + half_bw;
+                            if (lo_ < 0) lo_ = 0;
+                            if (hi_ >= N) hi_ = N - 1;
+                            unsigned acc = 0;
+                            for (int b_ = lo_ + lane; b_ <= hi_; b_ += 64)
+                                if (UNMASKED(b_) && VALID_BIN(b_)) acc |= s_crossT[b_];
+                            C |= wave_or_u32(acc);
+                        } else {
+                            hc_valid = false;
+                        }
+                        if (squelch > 0) squelch--;                               // create_new_bursts' else branch (:629-630)
+                        state = S_FRAME_END;
+                        if (force) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; break; }
+                        continue;
+                    }
+                    if (any_cand && e1 - e0 <= 64 && !ev_del) {
+                        // ---- common case 2: bursts may start, none ends; the frame's entries fit the lanes ----
+                        const int i = e0 + lane;
+                        float c_rel = -1.0f;
+                        int c_bin = 0;
+                        if (i < e1) {
+                            const ListEntry e = s_ent[i];
+                            const int bin = e.bin & 0x3FFF;
+                            if (((s_crossT[bin] >> k) & 1u) && UNMASKED(bin) && VALID_BIN(bin)) {
+                                c_bin = bin;
+                                c_rel = e.mag / s_sum[bin];
+                            }
+                        }
+                        // create_new_bursts (:556-591) == repeated arg-max over the candidates not yet masked by a
+                        // burst created in this frame (rel > 0: its IEEE bits order like the value)
+                        while (true) {
+                            unsigned long long key = c_rel > 0.0f
+                                ? (((unsigned long long)__float_as_uint(c_rel) << 32) | (unsigned)(~c_bin)) : 0ull;
+                            key = wave_max_u64(key);
+                            if (key == 0ull) break;
+                            const float br = __uint_as_float((unsigned)(key >> 32));
+                            const int bb = (int)~(unsigned)key;
+                            if (occ == ~0ull) { abort_code |= 4; break; }
+                            const int sl = __builtin_ctzll(~occ);
+                            if (lane == sl) {
+                                ActiveBurst b;
+                                b.id = burst_id;
+                                b.center_bin = bb;
+                                b.peak_rel = br;
+                                b.start = idx - (uint64_t)P.pre_len;
+                                b.last_active = b.start;
+                                b.base_sum = s_sum[bb];
+                                b.pad = 0;
+                                s_act[sl] = b;
+                                r_cb = bb;
+                                r_start = b.start;
+                                r_la = b.start;
+                                r_id = burst_id;
+                            }
+                            occ |= 1ull << sl;
+                            burst_id += 10;
+                            MASK_EDIT(bb, 0);
+                            if (c_bin >= bb - half_bw && c_bin <= bb + half_bw) c_rel = -1.0f;   // now masked
+                            hc_valid = false;
+                        }
+                        WAVE_SYNC();
+                        n_cand = 0;
+                        state = S_CPLX_B;                                         // squelch check / decay only
+                        continue;
+                    }
                     if (any_cand) {
                         // peaks of this frame under the PREVIOUS frame's mask (remove_peaks_around_bursts, :522-525)
                         for (int base = e0; base < e1; base += 64) {
