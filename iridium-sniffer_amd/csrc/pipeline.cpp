@@ -194,7 +194,18 @@ struct irdm_pipeline {
     bool has_pending;
     uint64_t pend_c1;
     int depth;
+    int *h_pin;              // pinned host words: [0..63] scan status, [64..65] n_gone/overflow, [66..67] hist_idx/primed.
+                             // (a D2H copy into pageable memory blocks the host until the stream drains -- that would
+                             // serialise pipeline_depth 1's deferred work behind the detector scan)
     int deferred_emitted;
+    // detector scan in flight (scan_launch .. scan_finish)
+    bool fl_active, fl_sparse;
+    const float *fl_mag, *d_mag_last;
+    int fl_frames;
+    uint64_t fl_c1;
+    hipStream_t fstream;     // K1 (== stream unless pipeline_depth 1)
+    float *d_mag2;           // pipeline_depth 1: second magnitude buffer
+    int mag_parity;
     std::vector<BurstWork> h_work;
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
@@ -225,15 +236,17 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod,
-                     p->d_fir_off, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
+                     p->d_fir_off, p->d_mag2, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p->h_pin) (void)hipHostFree(p->h_pin);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
     if (p->ev_scan_in) (void)hipEventDestroy(p->ev_scan_in);
     if (p->ev_scan_out) (void)hipEventDestroy(p->ev_scan_out);
+    if (p->fstream && p->fstream != p->stream) (void)hipStreamDestroy(p->fstream);
     if (p->stream2) (void)hipStreamDestroy(p->stream2);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
@@ -340,6 +353,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     bool ok = hipStreamCreate(&p->stream) == hipSuccess && hipStreamCreate(&p->stream2) == hipSuccess;
     p->bstream = p->depth ? p->stream2 : p->stream;
     p->sstream = p->stream;
+    p->fstream = p->stream;
     p->ev_scan_in = p->ev_scan_out = nullptr;
     if (ok && p->depth) {
         hipDeviceProp_t prop;
@@ -349,10 +363,12 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             one[0] = 1u;                    // CU 0 for the scan ...
             rest[0] &= ~1u;                 // ... every other CU for the per-burst stages
             if (prop.multiProcessorCount % 32) rest[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
-            hipStream_t s_scan = nullptr, s_rest = nullptr;
+            hipStream_t s_scan = nullptr, s_rest = nullptr, s_fft = nullptr;
             if (hipExtStreamCreateWithCUMask(&s_scan, words, one.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&s_rest, words, rest.data()) == hipSuccess) {
+                hipExtStreamCreateWithCUMask(&s_rest, words, rest.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&s_fft, words, rest.data()) == hipSuccess) {
                 p->sstream = s_scan;
+                p->fstream = s_fft;
                 (void)hipStreamDestroy(p->stream2);
                 p->stream2 = s_rest;
                 p->bstream = s_rest;
@@ -360,12 +376,16 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
                      hipEventCreateWithFlags(&p->ev_scan_out, hipEventDisableTiming) == hipSuccess;
             } else {
                 if (s_scan) (void)hipStreamDestroy(s_scan);
+                if (s_rest) (void)hipStreamDestroy(s_rest);
                 fprintf(stderr, "irdm_hip: CU-masked streams unavailable, scan shares the chip\n");
             }
         }
     }
     p->has_pending = false;
     p->pend_c1 = 0;
+    p->h_pin = nullptr;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_pin), sizeof(int) * 128, hipHostMallocDefault) == hipSuccess;
+    if (ok) memset(p->h_pin, 0, sizeof(int) * 128);
     for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
 #define UP(dst, vec) ok = ok && ((dst = reinterpret_cast<decltype(dst)>(dev_upload((vec).data(), (vec).size()))) != nullptr)
 #define AL(dst, T, count) ok = ok && ((dst = dev_alloc<T>(count)) != nullptr)
@@ -391,6 +411,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_hist, float, (size_t)kHistory * P.n);
     AL(p->d_sum, float, (size_t)P.n);
     AL(p->d_mag, float, p->max_chunk);
+    if (p->depth) AL(p->d_mag2, float, p->max_chunk);
     AL(p->d_state, DetState, 1);
     AL(p->d_gone, GoneBurst, (size_t)p->gone_cap);
     AL(p->d_cand_a, PeakCand, (size_t)P.n);
@@ -667,6 +688,148 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
     return 0;
 }
 
+// ---- detector scan of one chunk: sparse kernel with the dense kernel as exact fallback ----
+// scan_launch only enqueues (detector stream; the scan kernels themselves hop to sstream, which pipeline_depth 1
+// confines to one CU); scan_finish waits, falls back to the dense scan if the sparse one aborted, and fetches the
+// finished bursts into h_gone.  pipeline_depth 0 calls them back to back; pipeline_depth 1 calls scan_finish at the
+// start of the NEXT feed, so the detector of chunk k runs while the host returns, the caller produces chunk k+1 and
+// the FFT of chunk k+1 executes.
+static int scan_hop_in(irdm_pipeline *p)
+{
+    if (p->sstream == p->stream) return 0;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_scan_in, p->stream));
+    IRDM_HIP_CHECK(hipStreamWaitEvent(p->sstream, p->ev_scan_in, 0));
+    return 0;
+}
+
+static int scan_hop_out(irdm_pipeline *p)
+{
+    if (p->sstream == p->stream) return 0;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_scan_out, p->sstream));
+    IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_scan_out, 0));
+    return 0;
+}
+
+static int scan_dense(irdm_pipeline *p, const float *mag, int n_frames)
+{
+    if (scan_hop_in(p) != 0) return -1;
+    if (launch_detect_scan(p->P, p->d_state, p->d_sum, p->d_hist, mag, n_frames, p->d_gone, p->gone_cap,
+                           p->d_cand_a, p->d_cand_b, p->sstream) != 0)
+        return -1;
+    if (scan_hop_out(p) != 0) return -1;
+    p->stat_dense_frames += n_frames;
+    return 0;
+}
+
+static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_t c1)
+{
+    const DetParams &P = p->P;
+    IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[9], p->stream));
+    p->fl_sparse = p->scan_mode != 1;
+    if (p->fl_sparse) {
+        // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
+                                      hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 64, p->stream));
+        int done = 0;
+        if (!p->host_primed) {
+            // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428)
+            done = std::min(n_frames, kHistory - p->host_hist_idx);
+            if (scan_dense(p, mag, done) != 0) return -1;
+        }
+        if (done < n_frames) {
+            const float *mag_rest = mag + (size_t)done * P.n;
+            if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
+                                 p->d_goff, p->d_compact, n_frames - done, p->stream) != 0)
+                return -1;
+            if (scan_hop_in(p) != 0) return -1;
+            if (launch_detect_scan_fast(P, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done,
+                                        p->d_counts, p->d_goff, p->d_compact, p->d_pre, p->d_gone,
+                                        p->gone_cap, p->d_status, p->sstream) != 0)
+                return -1;
+            if (scan_hop_out(p) != 0) return -1;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_pin, p->d_status, sizeof(int) * 64, hipMemcpyDeviceToHost, p->stream));
+    } else {
+        if (scan_dense(p, mag, n_frames) != 0) return -1;
+    }
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
+    p->fl_active = true;
+    p->fl_mag = mag;
+    p->fl_frames = n_frames;
+    p->fl_c1 = c1;
+    return 0;
+}
+
+static int scan_finish(irdm_pipeline *p, int *n_gone_out)
+{
+    const DetParams &P = p->P;
+    *n_gone_out = 0;
+    if (!p->fl_active) return 0;
+    p->fl_active = false;
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (p->fl_sparse) {
+        const int status = p->h_pin[0];
+        if (getenv("IRDM_SCAN_DEBUG")) {
+            const long long *d = reinterpret_cast<const long long *>(p->h_pin + 4);
+            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld | stage=%lld(%lld) cross=%lld(%lld) hc=%lld(%lld) find=%lld(%lld) "
+                            "partA=%lld(%lld) partB=%lld(%lld) | publish=%lld(nbulk %lld) frame_end=%lld(%lld) | quietrun=%lld(%lld) quietlisted=%lld(%lld) busytop_total=%lld(%lld)\n",
+                    d[0], d[7], d[1], d[13], d[2], d[14], d[3], d[15], d[4], d[16], d[5], d[17], d[6], d[18], d[8], d[20], d[9], d[21],
+                    d[10], d[22], d[11], d[23], d[12], d[24]);
+        }
+        if (status != 0) {
+            // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
+            p->stat_fallbacks++;
+            if (getenv("IRDM_SCAN_DEBUG")) fprintf(stderr, "irdm_hip: sparse scan aborted with status 0x%x -> dense scan\n", status);
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
+                                          hipMemcpyDeviceToDevice, p->stream));
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+            if (scan_dense(p, p->fl_mag, p->fl_frames) != 0) return -1;
+            IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
+        } else {
+            p->stat_fast_chunks++;
+        }
+    }
+    uint32_t *counters = reinterpret_cast<uint32_t *>(p->h_pin + 64);
+    int32_t *hdr = p->h_pin + 66;
+    IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    p->host_hist_idx = hdr[0];
+    p->host_primed = hdr[1];
+    const int n_gone = (int)counters[0];
+    if (counters[1] || n_gone > p->gone_cap) {
+        fprintf(stderr, "irdm_hip: detector capacity exceeded (%d bursts in one chunk, cap %d)\n", n_gone, p->gone_cap);
+        return -1;
+    }
+    if (n_gone > 0)
+        IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));
+    float ms = 0;
+    p->last_ms[1] = hipEventElapsedTime(&ms, p->ev[9], p->ev[2]) == hipSuccess ? ms : -1.0f;
+    p->last_frames = p->fl_frames;
+    p->d_mag_last = p->fl_mag;
+    *n_gone_out = n_gone;
+    return 0;
+}
+
+// pipeline_depth 1: a detector scan still in flight is completed and its bursts become the pending list
+static int settle(irdm_pipeline *p)
+{
+    if (!p->fl_active) return 0;
+    (void)hipSetDevice(p->cfg.device);
+    const uint64_t c1 = p->fl_c1;
+    int n_gone = 0;
+    if (scan_finish(p, &n_gone) != 0) return -1;
+    p->pend_gone.assign(p->h_gone.begin(), p->h_gone.begin() + n_gone);
+    p->has_pending = true;
+    p->pend_c1 = c1;
+    return 0;
+}
+
 // pipeline_depth 1: per-burst stages of the previously fed chunk (reading the history ring only), then
 // the copy of the chunk being fed into the ring -- all on bstream, concurrent with the detector.
 static int run_deferred(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1)
@@ -692,8 +855,10 @@ static int run_deferred(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_
 extern "C" int irdm_flush(irdm_pipeline_t *p)
 {
     if (!p) return -1;
-    if (!p->depth || !p->has_pending) return 0;
+    if (!p->depth) return 0;
     (void)hipSetDevice(p->cfg.device);
+    if (settle(p) != 0) return -1;
+    if (!p->has_pending) return 0;
     if (run_deferred(p, nullptr, 0, 0) != 0) return -1;
     IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
     return p->deferred_emitted;
@@ -715,124 +880,28 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     // order after the caller's stream (the producer of d_iq)
     hipStream_t caller = static_cast<hipStream_t>(stream_v);
     IRDM_HIP_CHECK(hipEventRecord(p->ev[8], caller));
-    if (caller != p->stream) IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[8], 0));
+    if (caller != p->fstream) IRDM_HIP_CHECK(hipStreamWaitEvent(p->fstream, p->ev[8], 0));
     const DetParams &P = p->P;
     const uint64_t c0 = p->total_samples, c1 = c0 + n_samples;
     const int n_frames = (int)(n_samples / (size_t)P.n);
+    float ms = 0;
 
-    IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[0], p->stream));
-    if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, p->d_mag, n_frames, p->stream) != 0)
+    // K1 of this chunk.  pipeline_depth 1: on its own stream and into the other magnitude buffer, while the detector
+    // scan of the previous chunk may still be running
+    float *mag = p->d_mag;
+    if (p->depth) {
+        p->mag_parity ^= 1;
+        mag = p->mag_parity ? p->d_mag2 : p->d_mag;
+    }
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[0], p->fstream));
+    if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream) != 0)
         return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->stream));
-    // ---- detector scan: sparse kernel with the dense kernel as exact fallback ----
-    // the scan kernels run on sstream (== stream unless pipeline_depth 1 confined it to one CU)
-    auto scan_begin = [&]() -> int {
-        if (p->sstream == p->stream) return 0;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev_scan_in, p->stream));
-        IRDM_HIP_CHECK(hipStreamWaitEvent(p->sstream, p->ev_scan_in, 0));
-        return 0;
-    };
-    auto scan_end = [&]() -> int {
-        if (p->sstream == p->stream) return 0;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev_scan_out, p->sstream));
-        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_scan_out, 0));
-        return 0;
-    };
-    bool need_dense_all = p->scan_mode == 1;
-    bool deferred_done = false;
-    if (!need_dense_all) {
-        // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
-                                      hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 64, p->stream));
-        int done = 0;
-        if (!p->host_primed) {
-            // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428)
-            done = std::min(n_frames, kHistory - p->host_hist_idx);
-            if (scan_begin() != 0) return -1;
-            if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, done, p->d_gone, p->gone_cap,
-                                   p->d_cand_a, p->d_cand_b, p->sstream) != 0)
-                return -1;
-            if (scan_end() != 0) return -1;
-            p->stat_dense_frames += done;
-        }
-        if (done < n_frames) {
-            const float *mag_rest = p->d_mag + (size_t)done * P.n;
-            if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
-                                 p->d_goff, p->d_compact, n_frames - done, p->stream) != 0)
-                return -1;
-            if (scan_begin() != 0) return -1;
-            if (launch_detect_scan_fast(P, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done,
-                                        p->d_counts, p->d_goff, p->d_compact, p->d_pre, p->d_gone,
-                                        p->gone_cap, p->d_status, p->sstream) != 0)
-                return -1;
-            if (scan_end() != 0) return -1;
-        }
-        int status = 0;
-        int status_buf[64];
-        IRDM_HIP_CHECK(hipMemcpyAsync(status_buf, p->d_status, sizeof(status_buf), hipMemcpyDeviceToHost, p->stream));
-        if (p->depth) {
-            // while the detector of chunk k runs (one CU), the rest of the chip does chunk k-1's bursts
-            if (run_deferred(p, d_iq, c0, c1) != 0) return -1;
-            deferred_done = true;
-        }
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-        status = status_buf[0];
-        if (getenv("IRDM_SCAN_DEBUG")) {
-            const long long *d = reinterpret_cast<const long long *>(status_buf + 4);
-            fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld | stage=%lld(%lld) cross=%lld(%lld) hc=%lld(%lld) find=%lld(%lld) "
-                            "partA=%lld(%lld) partB=%lld(%lld) | publish=%lld(nbulk %lld) frame_end=%lld(%lld) | quietrun=%lld(%lld) quietlisted=%lld(%lld) busytop_total=%lld(%lld)\n",
-                    d[0], d[7], d[1], d[13], d[2], d[14], d[3], d[15], d[4], d[16], d[5], d[17], d[6], d[18], d[8], d[20], d[9], d[21],
-                    d[10], d[22], d[11], d[23], d[12], d[24]);
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->fstream));
 
-
-
-
-        }
-        if (status != 0) {
-            // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
-            p->stat_fallbacks++;
-            if (getenv("IRDM_SCAN_DEBUG")) fprintf(stderr, "irdm_hip: sparse scan aborted with status 0x%x -> dense scan\n", status);
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
-                                          hipMemcpyDeviceToDevice, p->stream));
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
-            need_dense_all = true;
-        } else {
-            p->stat_fast_chunks++;
-        }
-    }
-    if (need_dense_all) {
-        if (scan_begin() != 0) return -1;
-        if (launch_detect_scan(P, p->d_state, p->d_sum, p->d_hist, p->d_mag, n_frames, p->d_gone, p->gone_cap,
-                               p->d_cand_a, p->d_cand_b, p->sstream) != 0)
-            return -1;
-        if (scan_end() != 0) return -1;
-        p->stat_dense_frames += n_frames;
-    }
-    if (p->depth && !deferred_done && run_deferred(p, d_iq, c0, c1) != 0) return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
-    uint32_t counters[2] = { 0, 0 };
-    int32_t hdr[2] = { 0, 0 };
-    IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(counters), hipMemcpyDeviceToHost, p->stream));
-    IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(hdr), hipMemcpyDeviceToHost, p->stream));
-    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-    p->host_hist_idx = hdr[0];
-    p->host_primed = hdr[1];
-    const int n_gone = (int)counters[0];
-    if (counters[1] || n_gone > p->gone_cap) {
-        fprintf(stderr, "irdm_hip: detector capacity exceeded (%d bursts in one chunk, cap %d)\n", n_gone, p->gone_cap);
-        return -1;
-    }
-    if (n_gone > 0)
-        IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));
-
-    p->last_frames = n_frames;
     int emitted = 0;
     if (!p->depth) {
+        int n_gone = 0;
+        if (scan_launch(p, mag, n_frames, c1) != 0 || scan_finish(p, &n_gone) != 0) return -1;
         p->last_bursts.clear();
         p->last_chunk = d_iq;
         p->last_chunk_start = c0;
@@ -846,22 +915,25 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
         emitted = n_gone;
     } else {
-        // the previous chunk's per-burst work and this chunk's ring copy were issued on bstream before
-        // the detector was waited for (see above); here only the hand-over of this chunk's bursts remains
+        // 1. the previous chunk's detector must be done before this chunk's can start: collect its bursts
+        if (settle(p) != 0) return -1;
+        // 2. this chunk's detector (needs K1's output)
+        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[1], 0));
+        if (scan_launch(p, mag, n_frames, c1) != 0) return -1;
+        // 3. while it runs on its CU: the previous chunk's per-burst stages and this chunk's ring copy (bstream)
+        if (run_deferred(p, d_iq, c0, c1) != 0) return -1;
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->bstream));
         IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
+        IRDM_HIP_CHECK(hipEventSynchronize(p->ev[1]));     // the caller may overwrite d_iq once we return
         emitted = p->deferred_emitted;
-        p->pend_gone.assign(p->h_gone.begin(), p->h_gone.begin() + n_gone);
-        p->has_pending = true;
-        p->pend_c1 = c1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->stream));
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
     }
     p->total_samples = c1;
 
-    float ms = 0;
-    const int pairs[6][2] = { { 0, 1 }, { 1, 2 }, { 3, 4 }, { 4, 5 }, { 5, 6 }, { 0, 7 } };
-    for (int i = 0; i < 6; i++)
+    const int pairs[6][2] = { { 0, 1 }, { 9, 2 }, { 3, 4 }, { 4, 5 }, { 5, 6 }, { 0, 7 } };
+    for (int i = 0; i < 6; i++) {
+        if (i == 1) continue;           // set by scan_finish (pipeline_depth 1: the previous chunk's scan)
         p->last_ms[i] = hipEventElapsedTime(&ms, p->ev[pairs[i][0]], p->ev[pairs[i][1]]) == hipSuccess ? ms : -1.0f;
+    }
     return emitted;
 }
 
@@ -930,14 +1002,16 @@ extern "C" int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max)
 extern "C" int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_frames)
 {
     if (!p || !out) return -1;
+    if (settle(p) != 0) return -1;
     const size_t nf = std::min<size_t>(max_frames, (size_t)p->last_frames);
-    IRDM_HIP_CHECK(hipMemcpy(out, p->d_mag, nf * p->P.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (!nf) return 0;
+    IRDM_HIP_CHECK(hipMemcpy(out, p->d_mag_last, nf * p->P.n * sizeof(float), hipMemcpyDeviceToHost));
     return (int)nf;
 }
 
 extern "C" int irdm_baseline_sum(irdm_pipeline_t *p, float *out)
 {
-    if (!p || !out) return -1;
+    if (!p || !out || settle(p) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpy(out, p->d_sum, p->P.n * sizeof(float), hipMemcpyDeviceToHost));
     return p->P.n;
 }
@@ -972,7 +1046,7 @@ extern "C" size_t irdm_state_bytes(const irdm_pipeline_t *p)
 
 extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap)
 {
-    if (!p || !buf || cap < irdm_state_bytes(p)) return -1;
+    if (!p || !buf || cap < irdm_state_bytes(p) || settle(p) != 0) return -1;
     (void)hipSetDevice(p->cfg.device);
     char *o = static_cast<char *>(buf);
     StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
@@ -989,7 +1063,7 @@ extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap
 
 extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
 {
-    if (!p || !buf || n < irdm_state_bytes(p)) return -1;
+    if (!p || !buf || n < irdm_state_bytes(p) || settle(p) != 0) return -1;
     (void)hipSetDevice(p->cfg.device);
     const char *i = static_cast<const char *>(buf);
     StateHeader h;
