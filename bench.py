@@ -62,13 +62,15 @@ def build_scene(torch, device, fs, n, density_per_msample, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=64 * 1024 * 1024, help="samples per chunk per GPU")
     ap.add_argument("--density", type=float, default=10.0, help="bursts per Msample")
     ap.add_argument("--sample-rate", type=int, default=10_000_000)
-    ap.add_argument("--depth", type=int, default=0,
-                    help="pipeline_depth: 1 = per-burst stages of chunk k overlap the detector scan of chunk k+1")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="pipeline_depth: 1 (default) = the detector scan of chunk k stays in flight while chunk k-1's "
+                         "per-burst stages and chunk k+1's FFT run (results one chunk later, identical); 0 = every "
+                         "feed returns its own chunk's results")
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=4, help="oracle passes over that prefix (~3 s each)")
@@ -231,6 +233,7 @@ def main():
                                    % (fs // 1_000_000, pipe.fft_size, n, args.density),
                        "samples_per_step_per_gpu": n, "bursts_per_step": totals["bursts"] / K,
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
+                       "pipeline_depth": args.depth,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames")}},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -776,9 +776,9 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         if (getenv("IRDM_SCAN_DEBUG")) {
             const long long *d = reinterpret_cast<const long long *>(p->h_pin + 4);
             fprintf(stderr, "scan dbg (10ns ticks): all=%lld leader=%lld | stage=%lld(%lld) cross=%lld(%lld) hc=%lld(%lld) find=%lld(%lld) "
-                            "partA=%lld(%lld) partB=%lld(%lld) | publish=%lld(nbulk %lld) frame_end=%lld(%lld) | quietrun=%lld(%lld) quietlisted=%lld(%lld) busytop_total=%lld(%lld)\n",
+                            "partA=%lld(%lld) partB=%lld(%lld) | publish=%lld(nbulk %lld) frame_end=%lld(%lld) | cmdcross=%lld(%lld) cmdbulk=%lld(%lld) busytop_total=%lld(%lld) fast1=%lld(%lld) fast2=%lld(%lld) bulk_frames=%lld\n",
                     d[0], d[7], d[1], d[13], d[2], d[14], d[3], d[15], d[4], d[16], d[5], d[17], d[6], d[18], d[8], d[20], d[9], d[21],
-                    d[10], d[22], d[11], d[23], d[12], d[24]);
+                    d[10], d[22], d[11], d[23], d[12], d[24], d[25], d[26], d[27], d[28], d[29]);
         }
         if (status != 0) {
             // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan

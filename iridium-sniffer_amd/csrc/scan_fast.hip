@@ -173,7 +173,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
-enum { CMD_EXIT = 0, CMD_BULK = 1, CMD_VALIDATE = 2, CMD_ZERO = 3 };
+enum { CMD_EXIT = 0, CMD_BULK = 1, CMD_VALIDATE = 2, CMD_ZERO = 3, CMD_CROSS = 4 };
 constexpr int kFastMaxActive = 64;      // active bursts live in the leader's lanes; more -> dense fallback
 constexpr int kStageCap = 2048;         // list entries staged in LDS per batch
 constexpr int kStageFrames = 32;        // frames per batch: one bit per frame in the 32-bit frame masks
@@ -182,9 +182,61 @@ constexpr int kCandCap = 512;
 constexpr int kGoneLds = 64;            // gone records buffered in LDS between flushes
 constexpr int kFastThreads = 512;       // 8 wavefronts (2 per SIMD, 256 VGPRs each): wavefront 0 leads, all execute dense commands
 
+// G consecutive baseline updates of one thread's bins (simd_baseline_update + memcpy, burst_detect.c:441-452):
+// sum = (sum - oldest) + mag per frame, the magnitude row replaces the oldest history row.  The history rows of a
+// group are distinct (G <= 512), so reads never alias the group's writes.
+template <int Q, int G>
+__device__ __forceinline__ void bulk_group(const float *__restrict__ mag, float *__restrict__ hist, int N, int f0,
+                                           int &hidx, int &prm, float (&s)[4 * Q], int detect, float thr, int tid,
+                                           int half_bw, int dc, bool &bad)
+{
+    float4 m[G][Q], old[G][Q];
+    int row[G], prm_g[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        row[g] = hidx;
+        prm_g[g] = prm;
+        const float4 *mrow = reinterpret_cast<const float4 *>(mag + (size_t)(f0 + g) * N);
+        const float4 *hrow = reinterpret_cast<const float4 *>(hist + (size_t)hidx * N);
+#pragma unroll
+        for (int q = 0; q < Q; q++) m[g][q] = mrow[q * kFastThreads + tid];
+#pragma unroll
+        for (int q = 0; q < Q; q++) old[g][q] = hrow[q * kFastThreads + tid];
+        if (++hidx == kHistory) { prm = 1; hidx = 0; }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        float4 *hrow = reinterpret_cast<float4 *>(hist + (size_t)row[g] * N);
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            // rows not yet rewritten since a reset read as zero (:623-624)
+            const float4 o = prm_g[g] ? old[g][q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float mv[4] = { m[g][q].x, m[g][q].y, m[g][q].z, m[g][q].w };
+            const float ov[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = 4 * q + u;
+                if (detect) {
+                    // safety net: mag / sum > thr is impossible while mag <= 0.99 * thr * sum;
+                    // only the rare near-threshold bins pay for the exact division
+                    if (mv[u] > 0.99f * thr * s[j]) {
+                        const float rel = s[j] > 0 ? mv[u] / s[j] : 0.0f;
+                        const int b = (q * kFastThreads + tid) * 4 + u;
+                        if (rel > thr && b >= half_bw && b < N - half_bw && !(b >= dc - 3 && b <= dc + 3)) bad = true;
+                    }
+                }
+                const float d = s[j] - ov[u];
+                s[j] = d + mv[u];
+            }
+            hrow[q * kFastThreads + tid] = m[g][q];
+        }
+    }
+}
+
 struct FastShared {
     int cmd, f0, run, detect, hist_idx, primed;
     int abort;
+    int n_bins_old, n_bins;   // CMD_CROSS: distinct crossing bins recorded in s_bins (in: to clear, out: new count)
 };
 
 enum { S_TOP = 0, S_CPLX_A = 1, S_CPLX_B = 2, S_FRAME_END = 3 };
@@ -238,6 +290,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 
     // NOTE: never `volatile` LDS pointers (they compile to system-coherent FLAT accesses, microseconds each);
     // LDS ops of one wavefront execute in order, a compiler barrier between phases is all that is needed.
+    // workgroup barrier that orders LDS only: the history-row stores of a bulk command stay in flight (each thread
+    // re-reads only rows it wrote itself, in program order), __syncthreads() would wait ~1 us for their acknowledgement
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define BIN_OF(j) ((((j) >> 2) * kFastThreads + tid) * 4 + ((j) & 3))
 #define VALID_BIN(b) ((b) >= half_bw && (b) < N - half_bw && !((b) >= dc - 3 && (b) <= dc + 3))
@@ -309,8 +364,11 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     unsigned long long burst_id = st->burst_id;
     int abort_code = sh.abort;
     int r_cb = 0;
+    float r_peak = 0.0f, r_base = 0.0f;
     uint64_t r_la = 0, r_start = 0, r_id = 0;
     if ((occ >> lane) & 1) {
+        r_peak = s_act[lane].peak_rel;
+        r_base = s_act[lane].base_sum;
         r_cb = s_act[lane].center_bin;
         r_la = s_act[lane].last_active;
         r_start = s_act[lane].start;
@@ -328,6 +386,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     int sb = 0, snf = 0;                   // staged batch: frames [sb, sb+snf)
     unsigned r_off = 0;                    // lane k: offset of frame sb+k in s_ent (lane snf: total)
     int n_bins = 0;                        // distinct crossing bins recorded in s_bins
+    bool cross_cmd_done = false;           // CMD_CROSS just rebuilt s_crossT / s_bins for the frames >= f
     bool cross_valid = false;              // s_crossT holds the exact crossings of frames >= f of the batch
     bool hc_valid = false;                 // H / C below are current
     unsigned H = 0;                        // lane s: frames of the batch in which slot s sees a crossing near its centre
@@ -336,8 +395,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     int e0 = 0, e1 = 0, n_cand = 0, hist_before = 0;
     bool any_cand = false, was_quiet = false;
     unsigned long long ev_del = 0;
-    long long tk[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
-    int nk[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+    long long tk[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+    int nk[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+    long long bulk_frames = 0;
+    (void)bulk_frames;
     const long long t_begin = IRDM_TICK();
     (void)t_begin;
 #define TK(i, t0) do { tk[i] += IRDM_TICK() - (t0); nk[i]++; } while (0)
@@ -404,7 +465,6 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             cmd = CMD_BULK; c_f0 = f; c_run = run; c_detect = 1;
                             squelch = squelch > run ? squelch - run : 0;
                             f += run;
-                            TK(9, tT_);
                             break;
                         }
                         // a listed frame: exact test of ITS entries against the live sums; with no burst
@@ -431,7 +491,6 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         }
                         if (n_cand > kCandCap) { abort_code |= 32; continue; }
                         WAVE_SYNC();
-                        TK(10, tT_);
                         if (n_cand == 0) {
                             if (squelch > 0) squelch--;                           // :629-630
                             state = S_FRAME_END;
@@ -447,11 +506,18 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     if (!cross_valid) {
                         const long long t0_ = IRDM_TICK();
                         // s_crossT[bin] = frames (>= f) of the batch in which `bin` crosses: exact
-                        // simd_relative_mag + `> threshold` with the (frozen) baseline
+                        // simd_relative_mag + `> threshold` with the (frozen) baseline.  One pass over the
+                        // batch's staged entries: a dense command when there are enough of them to pay for
+                        // the two barriers, the leader alone otherwise.
+                        const int ef = __builtin_amdgcn_readlane((int)r_off, k0);
+                        if (!cross_cmd_done && total - ef + n_bins > 192) {
+                            cmd = CMD_CROSS; c_f0 = ef; c_run = total; c_detect = sb;
+                            break;
+                        }
+                        if (!cross_cmd_done) {
                         for (int i = lane; i < n_bins; i += 64) s_crossT[s_bins[i]] = 0u;
                         WAVE_SYNC();
                         n_bins = 0;
-                        const int ef = __builtin_amdgcn_readlane((int)r_off, k0);
                         for (int base = ef; base < total; base += 64) {
                             const int i = base + lane;
                             bool first = false;
@@ -469,6 +535,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                                 s_bins[n_bins + __popcll(fm & lt_mask)] = (unsigned short)bin;
                             n_bins += __popcll(fm);
                         }
+                        }
+                        cross_cmd_done = false;
                         if (n_bins > kMaxBins) { abort_code |= 64; continue; }
                         WAVE_SYNC();
                         cross_valid = true;
@@ -564,7 +632,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         const int cbd = __builtin_amdgcn_readlane(r_cb, sl);
                         bool force = false;
                         if (lane == sl) {
-                            ActiveBurst b = s_act[lane];
+                            ActiveBurst b;
+                            b.id = r_id; b.center_bin = r_cb; b.peak_rel = r_peak; b.start = r_start; b.base_sum = r_base; b.pad = 0;
                             b.last_active = r_la;
                             force = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
                             PUSH_GONE(b, idx, n_gone);
@@ -599,6 +668,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         }
                         if (squelch > 0) squelch--;                               // create_new_bursts' else branch (:629-630)
                         state = S_FRAME_END;
+                        TK(12, t4_);
                         if (force) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; break; }
                         continue;
                     }
@@ -627,18 +697,11 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (occ == ~0ull) { abort_code |= 4; break; }
                             const int sl = __builtin_ctzll(~occ);
                             if (lane == sl) {
-                                ActiveBurst b;
-                                b.id = burst_id;
-                                b.center_bin = bb;
-                                b.peak_rel = br;
-                                b.start = idx - (uint64_t)P.pre_len;
-                                b.last_active = b.start;
-                                b.base_sum = s_sum[bb];
-                                b.pad = 0;
-                                s_act[sl] = b;
                                 r_cb = bb;
-                                r_start = b.start;
-                                r_la = b.start;
+                                r_peak = br;
+                                r_base = s_sum[bb];
+                                r_start = idx - (uint64_t)P.pre_len;
+                                r_la = r_start;
                                 r_id = burst_id;
                             }
                             occ |= 1ull << sl;
@@ -650,6 +713,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         WAVE_SYNC();
                         n_cand = 0;
                         state = S_CPLX_B;                                         // squelch check / decay only
+                        TK(13, t4_);
                         continue;
                     }
                     if (any_cand) {
@@ -687,7 +751,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             rank += (RL64(r_id, sl) < r_id) ? 1 : 0;
                         }
                         if (mine) {
-                            ActiveBurst b = s_act[lane];
+                            ActiveBurst b;
+                            b.id = r_id; b.center_bin = r_cb; b.peak_rel = r_peak; b.start = r_start; b.base_sum = r_base; b.pad = 0;
                             b.last_active = r_la;
                             force = P.max_len > 0 && (r_la - r_start > (uint64_t)P.max_len);
                             PUSH_GONE(b, idx, n_gone + rank);
@@ -744,18 +809,11 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         if (occ == ~0ull) { abort_code |= 4; break; }
                         const int sl = __builtin_ctzll(~occ);
                         if (lane == sl) {
-                            ActiveBurst b;
-                            b.id = burst_id;
-                            b.center_bin = bb;
-                            b.peak_rel = br;
-                            b.start = index - (uint64_t)P.pre_len;
-                            b.last_active = b.start;
-                            b.base_sum = s_sum[bb];
-                            b.pad = 0;
-                            s_act[sl] = b;
                             r_cb = bb;
-                            r_start = b.start;
-                            r_la = b.start;
+                            r_peak = br;
+                            r_base = s_sum[bb];
+                            r_start = index - (uint64_t)P.pre_len;
+                            r_la = r_start;
                             r_id = burst_id;
                         }
                         occ |= 1ull << sl;
@@ -777,7 +835,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             rank += (RL64(r_id, sl) < r_id) ? 1 : 0;
                         }
                         if (mine) {
-                            ActiveBurst b = s_act[lane];
+                            ActiveBurst b;
+                            b.id = r_id; b.center_bin = r_cb; b.peak_rel = r_peak; b.start = r_start; b.base_sum = r_base; b.pad = 0;
                             b.last_active = r_la;
                             PUSH_GONE(b, index, n_gone + rank);
                         }
@@ -814,6 +873,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             if (lane == 0) {
                 sh.cmd = cmd; sh.f0 = c_f0; sh.run = c_run; sh.detect = c_detect;
                 sh.hist_idx = hist_idx; sh.primed = primed;
+                sh.n_bins_old = n_bins; sh.n_bins = 0;
             }
             if (cmd == CMD_BULK) {
                 const int tot = hist_idx + c_run;
@@ -827,7 +887,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         }
         const long long t_l1 = IRDM_TICK();
         tk[6] += t_l1 - t_l0;
-        __syncthreads();
+        LDS_BARRIER();
         const int cmd = sh.cmd;
         if (cmd == CMD_EXIT) break;
 
@@ -840,65 +900,19 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 #pragma unroll
             for (int j = 0; j < J; j++) s[j] = s_sum[BIN_OF(j)];
             bool bad = false;
-            // groups of G frames with every load of the group in flight at once; the history rows of a
-            // group are distinct (G <= 512), so reads never alias the group's writes
-            constexpr int G = (32 / J) > 8 ? 8 : ((32 / J) > 0 ? (32 / J) : 1);
-            for (int k0 = 0; k0 < run; k0 += G) {
-                float4 m[G][Q], old[G][Q];
-                int hrow_idx[G];
-                int hx = hidx, px = prm;
-                // all loads are issued unconditionally (a register-or-load select makes hipcc branch
-                // around every load and serialise them); frames past the run re-read the last frame
-                int prm_g[G];
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    const int kk = k0 + g < run ? k0 + g : run - 1;
-                    hrow_idx[g] = hx;
-                    prm_g[g] = px;
-                    const float4 *mrow = reinterpret_cast<const float4 *>(mag + (size_t)(f0 + kk) * N);
-                    const float4 *hrow = reinterpret_cast<const float4 *>(hist + (size_t)hx * N);
-#pragma unroll
-                    for (int q = 0; q < Q; q++) m[g][q] = mrow[q * kFastThreads + tid];
-#pragma unroll
-                    for (int q = 0; q < Q; q++) old[g][q] = hrow[q * kFastThreads + tid];
-                    if (k0 + g < run && ++hx == kHistory) { px = 1; hx = 0; }
-                }
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    if (!prm_g[g]) {      // rows not yet rewritten since a reset read as zero (:623-624)
-#pragma unroll
-                        for (int q = 0; q < Q; q++) old[g][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    }
-                }
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    if (k0 + g < run) {
-                        float4 *hrow = reinterpret_cast<float4 *>(hist + (size_t)hrow_idx[g] * N);
-#pragma unroll
-                        for (int q = 0; q < Q; q++) {
-                            const float mv[4] = { m[g][q].x, m[g][q].y, m[g][q].z, m[g][q].w };
-                            const float ov[4] = { old[g][q].x, old[g][q].y, old[g][q].z, old[g][q].w };
-#pragma unroll
-                            for (int u = 0; u < 4; u++) {
-                                const int j = 4 * q + u;
-                                if (detect) {
-                                    // safety net: mag / sum > thr is impossible while mag <= 0.99 * thr * sum;
-                                    // only the rare near-threshold bins pay for the exact division
-                                    if (mv[u] > 0.99f * thr * s[j]) {
-                                        const float rel = s[j] > 0 ? mv[u] / s[j] : 0.0f;
-                                        if (rel > thr && VALID_BIN(BIN_OF(j))) bad = true;
-                                    }
-                                }
-                                const float d = s[j] - ov[u];
-                                s[j] = d + mv[u];
-                            }
-                            hrow[q * kFastThreads + tid] = m[g][q];
-                        }
-                    }
-                }
-                hidx = hx;
-                prm = px;
-            }
+            // One CU moves ~64 B/clk through its L1, i.e. ~0.6 us per frame (mag row + history row in, history row
+            // out); runs are short (4 frames on average), so groups are sized to the run -- 4, 2, then 1 frame(s)
+            // with every load of the group in flight at once and nothing loaded twice.
+            int k0 = 0;
+            constexpr int GMAX = (64 / J) > 4 ? 4 : ((64 / J) > 0 ? (64 / J) : 1);
+            if (GMAX >= 4)
+                for (; run - k0 >= 4; k0 += 4)
+                    bulk_group<Q, 4>(mag, hist, N, f0 + k0, hidx, prm, s, detect, thr, tid, half_bw, dc, bad);
+            if (GMAX >= 2)
+                for (; run - k0 >= 2; k0 += 2)
+                    bulk_group<Q, 2>(mag, hist, N, f0 + k0, hidx, prm, s, detect, thr, tid, half_bw, dc, bad);
+            for (; k0 < run; k0++)
+                bulk_group<Q, 1>(mag, hist, N, f0 + k0, hidx, prm, s, detect, thr, tid, half_bw, dc, bad);
 #pragma unroll
             for (int j = 0; j < J; j++) s_sum[BIN_OF(j)] = s[j];
             if (bad) atomicOr(&sh.abort, 1);
@@ -921,10 +935,40 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         } else if (cmd == CMD_ZERO) {
 #pragma unroll
             for (int j = 0; j < J; j++) s_sum[BIN_OF(j)] = 0.0f;
+        } else if (cmd == CMD_CROSS) {
+            // rebuild the frame masks of the staged entries [ef, total) with the live baseline, 512 entries at a time
+            const int ef = sh.f0, total = sh.run, sb_ = sh.detect, nb_old = sh.n_bins_old;
+            for (int i = tid; i < nb_old; i += kFastThreads) s_crossT[s_bins[i]] = 0u;
+            __syncthreads();
+            for (int base = ef; base < total; base += kFastThreads) {
+                const int i = base + tid;
+                bool first = false;
+                int bin = 0;
+                if (i < total) {
+                    const ListEntry e = s_ent[i];
+                    bin = e.bin & 0x3FFF;
+                    const int k = (e.bin >> 14) - sb_;
+                    const float sv = s_sum[bin];
+                    const float rel = sv > 0 ? e.mag / sv : 0.0f;
+                    if (rel > thr) first = atomicOr(&s_crossT[bin], 1u << k) == 0u;
+                }
+                const unsigned long long fm = __ballot(first);
+                if (fm) {
+                    int slot0 = 0;
+                    if (lane == 0) slot0 = atomicAdd(&sh.n_bins, __popcll(fm));
+                    slot0 = __builtin_amdgcn_readfirstlane(slot0);
+                    const int slot = slot0 + __popcll(fm & lt_mask);
+                    if (first && slot < kMaxBins) s_bins[slot] = (unsigned short)bin;
+                }
+            }
         }
-        __syncthreads();
-        if (tid < 64) abort_code |= sh.abort;
-        if (cmd == CMD_BULK) { tk[6] += 0; nk[7]++; }
+        LDS_BARRIER();
+        if (cmd == CMD_CROSS) { TK(9, t_l1); } else if (cmd == CMD_BULK) { TK(10, t_l1); }
+        if (tid < 64) {
+            abort_code |= sh.abort;
+            if (cmd == CMD_CROSS) { n_bins = sh.n_bins; cross_cmd_done = true; }
+        }
+        if (cmd == CMD_BULK) { nk[7]++; bulk_frames += sh.run; }
     }
 
     if (tid < 64) {
@@ -940,7 +984,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             rank += (RL64(r_id, sl) < r_id) ? 1 : 0;
         }
         if (mine) {
-            ActiveBurst b = s_act[lane];
+            ActiveBurst b;
+                            b.id = r_id; b.center_bin = r_cb; b.peak_rel = r_peak; b.start = r_start; b.base_sum = r_base; b.pad = 0;
             b.last_active = r_la;
             st->act[rank] = b;
         }
@@ -949,6 +994,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             long long *dbg = reinterpret_cast<long long *>(status + 4);
             dbg[0] = IRDM_TICK() - t_begin;
             for (int i = 0; i < 12; i++) { dbg[1 + i] = tk[i]; dbg[13 + i] = nk[i]; }
+            dbg[29] = bulk_frames; dbg[25] = tk[12]; dbg[26] = nk[12]; dbg[27] = tk[13]; dbg[28] = nk[13];
 #endif
             status[0] = abort_code | sh.abort;
             if (n_gone > (unsigned)gone_cap) st->overflow = 1;
@@ -966,6 +1012,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     for (int j = 0; j < J; j++) sum_g[BIN_OF(j)] = s_sum[BIN_OF(j)];
 #undef TK
 #undef WAVE_SYNC
+#undef LDS_BARRIER
 #undef BIN_OF
 #undef VALID_BIN
 #undef UNMASKED
