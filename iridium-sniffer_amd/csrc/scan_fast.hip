@@ -173,6 +173,17 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
 }
 
+// Values that are wave-uniform by construction but arrive through a vector load (LDS / global) must be moved to
+// SGPRs explicitly: otherwise hipcc treats every branch of the leader's state machine as divergent (exec-mask
+// bookkeeping on each transition instead of a scalar compare-and-branch).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 enum { CMD_EXIT = 0, CMD_BULK = 1, CMD_VALIDATE = 2, CMD_ZERO = 3, CMD_CROSS = 4 };
 constexpr int kFastMaxActive = 64;      // active bursts live in the leader's lanes; more -> dense fallback
 constexpr int kStageCap = 2048;         // list entries staged in LDS per batch
@@ -280,11 +291,12 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const bool leader = uni(tid) < 64;                   // wavefront 0 (scalar predicate)
     const float thr = P.threshold;
     const int half_bw = P.width / 2;
     const int dc = N / 2;
     const int log_n = P.log_n;
-    const uint64_t index0 = st->index;
+    const uint64_t index0 = uni((unsigned long long)st->index);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int gap_frames = (P.post_len + N - 1) >> log_n;   // frames without a hit until last_active + post_len <= index
 
@@ -322,10 +334,11 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             g_.center_bin = (b).center_bin; g_.peak_rel = (b).peak_rel; g_.base_sum = (b).base_sum;    \
             g_.pad = 0;                                                                            \
             s_gone[ls_] = g_;                                                                      \
-        } else {                                                                                   \
-            abort_code |= 16;                                                                      \
         }                                                                                          \
     } while (0)
+    // PUSH_GONE runs inside per-lane branches; the overflow check is made on the uniform counter afterwards
+    // (abort_code must stay a scalar: it steers the state machine)
+#define CHECK_GONE() do { if (n_gone - gone_base > (unsigned)kGoneLds) abort_code |= 16; } while (0)
     // gone records collect in LDS (no global store, hence no vmcnt wait, inside the frame loop)
 #define FLUSH_GONE()                                                                               \
     do {                                                                                           \
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         s_crossT[BIN_OF(j)] = 0u;
     }
     for (int i = tid; i < N / 32; i += kFastThreads) s_mbits[i] = ~0u;
-    const int n_act_in = st->n_act;
+    const int n_act_in = uni(st->n_act);
     if (tid == 0) {
         sh.cmd = CMD_EXIT;
         sh.abort = n_act_in > kFastMaxActive ? 4 : 0;
@@ -353,16 +366,16 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     // ---- leader state (registers of wavefront 0) ----
     // Active bursts live in fixed lane slots: lane s mirrors slot s while bit s of `occ` is set.
     // The reference's list order (burst_detect.c:148-160) is creation order == ascending id.
-    int hist_idx = st->hist_idx, primed = st->primed, squelch = st->squelch;
+    int hist_idx = uni(st->hist_idx), primed = uni(st->primed), squelch = uni(st->squelch);
     unsigned long long occ = 0;
     {
         const int na = n_act_in < kFastMaxActive ? n_act_in : kFastMaxActive;
         occ = na >= 64 ? ~0ull : ((1ull << na) - 1ull);
     }
-    unsigned n_gone = st->n_gone;
+    unsigned n_gone = uni(st->n_gone);
     unsigned gone_base = n_gone;
-    unsigned long long burst_id = st->burst_id;
-    int abort_code = sh.abort;
+    unsigned long long burst_id = uni((unsigned long long)st->burst_id);
+    int abort_code = uni(sh.abort);
     int r_cb = 0;
     float r_peak = 0.0f, r_base = 0.0f;
     uint64_t r_la = 0, r_start = 0, r_id = 0;
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         r_start = s_act[lane].start;
         r_id = s_act[lane].id;
     }
-    if (tid < 64) {
+    if (leader) {
         unsigned long long o = occ;
         while (o) {
             const int sl = __builtin_ctzll(o);
@@ -405,7 +418,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 
     for (;;) {
         const long long t_l0 = IRDM_TICK();
-        if (tid < 64) {
+        if (leader) {
             // ================= leader step: run until a dense command is needed =================
             int cmd = -1, c_f0 = 0, c_run = 0, c_detect = 0;
             while (cmd < 0) {
@@ -640,6 +653,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             H = 0;
                         }
                         n_gone += 1;
+                        CHECK_GONE();
                         force = __any(force) != 0;
                         occ &= ~ev_del;
                         MASK_EDIT(cbd, 1);                                        // its range is free again ...
@@ -758,6 +772,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             PUSH_GONE(b, idx, n_gone + rank);
                         }
                         n_gone += __popcll(ev_del);
+                        CHECK_GONE();
                         force = __any(force) != 0;
                         // update_burst_mask (:482-486): only the deleted bursts' ranges can change
                         d2 = ev_del;
@@ -841,6 +856,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             PUSH_GONE(b, index, n_gone + rank);
                         }
                         n_gone += __popcll(om);
+                        CHECK_GONE();
                         occ = 0;
                         MASK_ALL_ONES();
                         squelch += 3;
@@ -888,14 +904,14 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         const long long t_l1 = IRDM_TICK();
         tk[6] += t_l1 - t_l0;
         LDS_BARRIER();
-        const int cmd = sh.cmd;
+        const int cmd = uni(sh.cmd);
         if (cmd == CMD_EXIT) break;
 
         // ================= dense command, all threads =================
         if (cmd == CMD_BULK) {
             // consecutive baseline updates (simd_baseline_update + memcpy, burst_detect.c:441-452)
-            const int f0 = sh.f0, run = sh.run, detect = sh.detect;
-            int hidx = sh.hist_idx, prm = sh.primed;
+            const int f0 = uni(sh.f0), run = uni(sh.run), detect = uni(sh.detect);
+            int hidx = uni(sh.hist_idx), prm = uni(sh.primed);
             float s[J];
 #pragma unroll
             for (int j = 0; j < J; j++) s[j] = s_sum[BIN_OF(j)];
@@ -937,7 +953,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             for (int j = 0; j < J; j++) s_sum[BIN_OF(j)] = 0.0f;
         } else if (cmd == CMD_CROSS) {
             // rebuild the frame masks of the staged entries [ef, total) with the live baseline, 512 entries at a time
-            const int ef = sh.f0, total = sh.run, sb_ = sh.detect, nb_old = sh.n_bins_old;
+            const int ef = uni(sh.f0), total = uni(sh.run), sb_ = uni(sh.detect), nb_old = uni(sh.n_bins_old);
             for (int i = tid; i < nb_old; i += kFastThreads) s_crossT[s_bins[i]] = 0u;
             __syncthreads();
             for (int base = ef; base < total; base += kFastThreads) {
@@ -964,14 +980,14 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         }
         LDS_BARRIER();
         if (cmd == CMD_CROSS) { TK(9, t_l1); } else if (cmd == CMD_BULK) { TK(10, t_l1); }
-        if (tid < 64) {
-            abort_code |= sh.abort;
-            if (cmd == CMD_CROSS) { n_bins = sh.n_bins; cross_cmd_done = true; }
+        if (leader) {
+            abort_code |= uni(sh.abort);
+            if (cmd == CMD_CROSS) { n_bins = uni(sh.n_bins); cross_cmd_done = true; }
         }
-        if (cmd == CMD_BULK) { nk[7]++; bulk_frames += sh.run; }
+        if (cmd == CMD_BULK) { nk[7]++; bulk_frames += uni(sh.run); }
     }
 
-    if (tid < 64) {
+    if (leader) {
         WAVE_SYNC();
         FLUSH_GONE();
         // carried bursts go back in list order (ascending id)
@@ -1020,6 +1036,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 #undef MASK_ALL_ONES
 #undef RL64
 #undef PUSH_GONE
+#undef CHECK_GONE
 #undef FLUSH_GONE
 }
 
