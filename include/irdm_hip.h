@@ -59,7 +59,8 @@ int gpu_burst_fft_process_device(gpu_burst_fft_t *g, const void *d_input, void *
 /* ------------------------------------------------------------------ */
 
 #define IRDM_FMT_CI8  0   /* options.c FMT_CI8  */
-#define IRDM_FMT_CI16 1   /* options.c FMT_CI16: ingested as (int8)(v >> 8), main.c:245-246 */
+#define IRDM_FMT_CI16 1   /* options.c FMT_CI16: raw int16 pairs; narrowed to (int8)(v >> 8) (main.c:245-246) in the
+                             kernels' load stage, on the device */
 #define IRDM_FMT_CF32 2   /* options.c FMT_CF32 */
 
 typedef struct {
@@ -75,8 +76,11 @@ typedef struct {
     size_t max_chunk_samples;  /* largest chunk passed to irdm_feed_*; 0 -> 64 Mi */
     int max_bursts_per_chunk;  /* 0 -> 8192 */
     int pipeline_depth;        /* 0: irdm_feed_* returns with the chunk's results pollable.
-                                  1: the per-burst stages of chunk k run during irdm_feed_*(k+1), overlapped
-                                     with its detector scan (results one chunk later; irdm_flush drains). */
+                                  1: throughput mode.  irdm_feed_*(k) returns once chunk k is ingested (FFT done,
+                                     samples in the history ring) and its detector scan is launched; the scan stays in
+                                     flight while the caller produces chunk k+1.  The bursts of chunk k are demodulated
+                                     during irdm_feed_*(k+1) (or irdm_flush), so results arrive one chunk later --
+                                     identical records, same order. */
 } irdm_config_t;
 
 /* burst_info_t (burst_detect.h:29-37) + what emit_gone_bursts adds (burst_detect.c:703-742) */
@@ -147,13 +151,20 @@ void irdm_destroy(irdm_pipeline_t *p);
 
 /* burst_detector_feed / _feed_cf32 (burst_detect.h:74-79) for a whole chunk.
  * n_samples must be a multiple of feed_block except for the last chunk of the stream.
- * _device: d_iq is a device pointer in the configured format, stream = hipStream_t or NULL;
- * the call returns after the chunk is fully processed (results pollable).
- * Returns the number of bursts emitted by this chunk, or -1 on error. */
+ * _device: d_iq is a device pointer to raw samples in the configured format (cf32 pairs, int16 pairs or int8
+ * pairs), stream = the hipStream_t that produced them (or NULL).  The buffer may be reused when the call returns.
+ * pipeline_depth 0: returns after the chunk is fully processed (results pollable); pipeline_depth 1: see above.
+ * _host: the same for a host buffer; the H2D copy is asynchronous DMA when the buffer is pinned
+ * (irdm_host_alloc, hipHostMalloc, hipHostRegister) and overlaps the previous chunk's detector scan.
+ * Returns the number of bursts whose records became pollable, or -1 on error. */
 int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
 int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples);
-/* pipeline_depth 1: run the per-burst stages of the last fed chunk now.  Returns bursts processed or -1. */
+/* pipeline_depth 1: finish the detector scan in flight and run the per-burst stages of the last fed chunk now.
+ * Returns bursts processed or -1. */
 int irdm_flush(irdm_pipeline_t *p);
+/* Pinned (page-locked) host memory for feed buffers, for hosts without HIP headers.  NULL on failure. */
+void *irdm_host_alloc(size_t bytes);
+void irdm_host_free(void *ptr);
 
 /* Results of all chunks fed so far, in burst-emission order; each call drains up to max
  * entries.  bursts: one per emitted burst (burst_callback_t payload minus samples).

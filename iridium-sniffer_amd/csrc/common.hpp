@@ -105,4 +105,27 @@ __host__ __device__ __forceinline__ unsigned bitrev(unsigned v, int bits)
 #endif
 }
 
+
+// One IQ sample of the device-resident input in the configured format -> cf32, exactly as the reference ingests it:
+//   fmt 2: cf32 as is (burst_detector_feed_cf32, burst_detect.c:846)
+//   fmt 0: ci8, int8 / 128.0f (simd_convert_i8_cf, simd_generic.c:147-153)
+//   fmt 1: ci16, narrowed to int8 by (int8_t)(v >> 8) (spewer_thread, main.c:245-246), then as ci8
+template <int FMT>
+__device__ __forceinline__ float2 load_iq(const void *__restrict__ iq, size_t i)
+{
+    if (FMT == 2) {
+        return reinterpret_cast<const float2 *>(iq)[i];
+    } else if (FMT == 1) {
+        const short2 v = reinterpret_cast<const short2 *>(iq)[i];
+        return make_float2((float)(v.x >> 8) / 128.0f, (float)(v.y >> 8) / 128.0f);
+    } else {
+        const char2 v = reinterpret_cast<const char2 *>(iq)[i];
+        return make_float2((float)v.x / 128.0f, (float)v.y / 128.0f);
+    }
+}
+__device__ __forceinline__ float2 load_iq(int fmt, const void *__restrict__ iq, size_t i)
+{
+    return fmt == 2 ? load_iq<2>(iq, i) : (fmt == 1 ? load_iq<1>(iq, i) : load_iq<0>(iq, i));
+}
+
 }  // namespace irdm

@@ -27,14 +27,7 @@ __global__ __launch_bounds__(NT) void fft_mag_kernel(const void *__restrict__ iq
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         const size_t base = (size_t)frame * N;
         for (int i = tid; i < N; i += NT) {
-            float2 x;
-            if (FMT == 2) {
-                x = reinterpret_cast<const float2 *>(iq)[base + i];
-            } else {
-                // simd_convert_i8_cf (simd_generic.c:147-153): int8 / 128.0f
-                char2 v = reinterpret_cast<const char2 *>(iq)[base + i];
-                x = make_float2((float)v.x / 128.0f, (float)v.y / 128.0f);
-            }
+            const float2 x = load_iq<FMT>(iq, base + i);
             const float w = window[i];
             s[bitrev((unsigned)i, LOGN)] = make_float2(x.x * w, x.y * w);
         }
@@ -138,13 +131,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int idx = t + T * r;
-            float2 x;
-            if (FMT == 2) {
-                x = reinterpret_cast<const float2 *>(iq)[base + idx];
-            } else {
-                const char2 c8 = reinterpret_cast<const char2 *>(iq)[base + idx];
-                x = make_float2((float)c8.x / 128.0f, (float)c8.y / 128.0f);
-            }
+            const float2 x = load_iq<FMT>(iq, base + idx);
             const float w = window[idx];
             v[rev4c(r)] = make_float2(x.x * w, x.y * w);
         }
@@ -204,38 +191,37 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
 {
     if (n_frames <= 0) return 0;
     int grid = n_frames < 4096 ? n_frames : 4096;
-    const int f = fmt == 2 ? 2 : 0;
-#define IRDM_LAUNCH_FFT(LOGN, NT)                                                              \
+    const int f = fmt;
+    if (f < 0 || f > 2) return -1;
+#define IRDM_LAUNCH_FFT_F(LOGN, NT, F)                                                         \
     do {                                                                                       \
         size_t lds = sizeof(float2) << LOGN;                                                   \
-        if (f == 2) {                                                                          \
-            (void)hipFuncSetAttribute((const void *)fft_mag_kernel<LOGN, NT, 2>,                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-            hipLaunchKernelGGL((fft_mag_kernel<LOGN, NT, 2>), dim3(grid), dim3(NT), lds,       \
-                               stream, iq, window, tw, mag, n_frames);                         \
-        } else {                                                                               \
-            (void)hipFuncSetAttribute((const void *)fft_mag_kernel<LOGN, NT, 0>,                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-            hipLaunchKernelGGL((fft_mag_kernel<LOGN, NT, 0>), dim3(grid), dim3(NT), lds,       \
-                               stream, iq, window, tw, mag, n_frames);                         \
-        }                                                                                      \
+        (void)hipFuncSetAttribute((const void *)fft_mag_kernel<LOGN, NT, F>,                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL((fft_mag_kernel<LOGN, NT, F>), dim3(grid), dim3(NT), lds,           \
+                           stream, iq, window, tw, mag, n_frames);                             \
     } while (0)
-#define IRDM_LAUNCH_R16(LOGN)                                                                  \
+#define IRDM_LAUNCH_FFT(LOGN, NT)                                                              \
+    do {                                                                                       \
+        if (f == 2) IRDM_LAUNCH_FFT_F(LOGN, NT, 2);                                            \
+        else if (f == 1) IRDM_LAUNCH_FFT_F(LOGN, NT, 1);                                       \
+        else IRDM_LAUNCH_FFT_F(LOGN, NT, 0);                                                   \
+    } while (0)
+#define IRDM_LAUNCH_R16_F(LOGN, F)                                                             \
     do {                                                                                       \
         constexpr int NB_ = 1 << (LOGN - 8);                                                   \
         size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN)           \
                                            ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));   \
-        if (f == 2) {                                                                          \
-            (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, 2>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-            hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, 2>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
-                               stream, iq, window, tw, mag, n_frames);                         \
-        } else {                                                                               \
-            (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, 0>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
-            hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, 0>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
-                               stream, iq, window, tw, mag, n_frames);                         \
-        }                                                                                      \
+        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F>,                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
+                           stream, iq, window, tw, mag, n_frames);                             \
+    } while (0)
+#define IRDM_LAUNCH_R16(LOGN)                                                                  \
+    do {                                                                                       \
+        if (f == 2) IRDM_LAUNCH_R16_F(LOGN, 2);                                                \
+        else if (f == 1) IRDM_LAUNCH_R16_F(LOGN, 1);                                           \
+        else IRDM_LAUNCH_R16_F(LOGN, 0);                                                       \
     } while (0)
     if (!g_fft_force_radix2) {
         switch (log_n) {
@@ -246,6 +232,7 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
         }
     }
 #undef IRDM_LAUNCH_R16
+#undef IRDM_LAUNCH_R16_F
     switch (log_n) {
     case 8:  IRDM_LAUNCH_FFT(8, 64); break;
     case 9:  IRDM_LAUNCH_FFT(9, 128); break;
@@ -257,6 +244,7 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
     default: return -1;
     }
 #undef IRDM_LAUNCH_FFT
+#undef IRDM_LAUNCH_FFT_F
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

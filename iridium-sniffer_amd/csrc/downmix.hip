@@ -17,18 +17,8 @@ namespace irdm {
 // ring length earlier (or the zero page before the ring first wrapped).
 __device__ __forceinline__ float2 load_abs(const SampleSource &src, uint64_t a)
 {
-    if (src.fmt == 2) {
-        if (a >= src.chunk_start)
-            return reinterpret_cast<const float2 *>(src.chunk)[a - src.chunk_start];
-        return reinterpret_cast<const float2 *>(src.ring)[a % src.ring_len];
-    } else {
-        char2 v;
-        if (a >= src.chunk_start)
-            v = reinterpret_cast<const char2 *>(src.chunk)[a - src.chunk_start];
-        else
-            v = reinterpret_cast<const char2 *>(src.ring)[a % src.ring_len];
-        return make_float2((float)v.x / 128.0f, (float)v.y / 128.0f);
-    }
+    if (a >= src.chunk_start) return load_iq(src.fmt, src.chunk, (size_t)(a - src.chunk_start));
+    return load_iq(src.fmt, src.ring, (size_t)(a % src.ring_len));
 }
 
 __device__ __forceinline__ float2 burst_sample(const SampleSource &src, uint64_t start,

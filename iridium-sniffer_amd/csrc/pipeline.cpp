@@ -146,7 +146,8 @@ extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, flo
 struct irdm_pipeline {
     irdm_config_t cfg;
     DetParams P;
-    int dev_fmt;                // 0 ci8, 2 cf32 (ci16 is narrowed to ci8 on ingest, main.c:245-246)
+    int dev_fmt;                // device sample format == cfg.format: 0 ci8, 1 ci16 (narrowed in the load stage,
+                                // main.c:245-246), 2 cf32
     size_t bps;                 // bytes per device sample
     int feed_block, decim, out_rate;
     float sps;
@@ -292,8 +293,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         delete p;
         return nullptr;
     }
-    p->dev_fmt = cfg->format == IRDM_FMT_CF32 ? 2 : 0;
-    p->bps = p->dev_fmt == 2 ? 8 : 2;
+    p->dev_fmt = cfg->format;
+    p->bps = p->dev_fmt == 2 ? 8 : (p->dev_fmt == 1 ? 4 : 2);
     p->max_chunk = cfg->max_chunk_samples ? cfg->max_chunk_samples : ((size_t)64 << 20);
     p->max_chunk = (p->max_chunk + p->feed_block - 1) / p->feed_block * p->feed_block;
     p->burst_cap = cfg->max_bursts_per_chunk > 0 ? cfg->max_bursts_per_chunk : 4096;
@@ -937,6 +938,20 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     return emitted;
 }
 
+// Pinned host memory for irdm_feed_host callers that have no HIP headers (the C99 host): H2D copies from pinned
+// memory are asynchronous DMA at PCIe rate; from pageable memory they are staged and block the host.
+extern "C" void *irdm_host_alloc(size_t bytes)
+{
+    void *q = nullptr;
+    if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return q;
+}
+
+extern "C" void irdm_host_free(void *q)
+{
+    if (q) (void)hipHostFree(q);
+}
+
 extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples)
 {
     if (!p || (!h_iq && n_samples)) return -1;
@@ -945,16 +960,12 @@ extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_sam
     if (!p->d_stage) {
         if (hipMalloc(&p->d_stage, p->max_chunk * p->bps) != hipSuccess) return -1;
     }
-    if (p->cfg.format == IRDM_FMT_CI16) {
-        // spewer_thread's ci16 narrowing (main.c:245-246): (int8_t)(v >> 8)
-        std::vector<int8_t> tmp(2 * n_samples);
-        const int16_t *s = static_cast<const int16_t *>(h_iq);
-        for (size_t i = 0; i < 2 * n_samples; i++) tmp[i] = (int8_t)(s[i] >> 8);
-        IRDM_HIP_CHECK(hipMemcpy(p->d_stage, tmp.data(), n_samples * p->bps, hipMemcpyHostToDevice));
-    } else {
-        IRDM_HIP_CHECK(hipMemcpy(p->d_stage, h_iq, n_samples * p->bps, hipMemcpyHostToDevice));
-    }
-    return irdm_feed_device(p, p->d_stage, n_samples, p->stream);
+    // Raw bytes in the configured format (the ci16 narrowing of main.c:245-246 happens in the kernels' load stage).
+    // The copy goes on K1's stream, never the null stream: with pipeline_depth 1 the previous chunk's detector scan is
+    // still running and must not be waited for.  irdm_feed_device returns only after K1 and the history-ring copy of
+    // its chunk are done, so one staging buffer is enough.
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_stage, h_iq, n_samples * p->bps, hipMemcpyHostToDevice, p->fstream));
+    return irdm_feed_device(p, p->d_stage, n_samples, p->fstream);
 }
 
 template <typename T>
@@ -1088,17 +1099,10 @@ extern "C" int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_
     if (!p || (!h_iq && n_samples) || n_samples > abs_start) return -1;
     (void)hipSetDevice(p->cfg.device);
     if (n_samples > p->ring_len) {       // only the most recent ring_len samples can matter
-        h_iq = static_cast<const char *>(h_iq) + (n_samples - p->ring_len) * (p->cfg.format == IRDM_FMT_CI16 ? 4 : p->bps);
+        h_iq = static_cast<const char *>(h_iq) + (n_samples - p->ring_len) * p->bps;
         n_samples = p->ring_len;
     }
-    std::vector<int8_t> narrowed;
     const char *src = static_cast<const char *>(h_iq);
-    if (p->cfg.format == IRDM_FMT_CI16) {
-        narrowed.resize(2 * n_samples);
-        const int16_t *s16 = static_cast<const int16_t *>(h_iq);
-        for (size_t k = 0; k < 2 * n_samples; k++) narrowed[k] = (int8_t)(s16[k] >> 8);
-        src = reinterpret_cast<const char *>(narrowed.data());
-    }
     uint64_t a0 = abs_start - n_samples;
     size_t done = 0;
     while (done < n_samples) {

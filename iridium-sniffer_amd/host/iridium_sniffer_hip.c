@@ -22,12 +22,28 @@ static const char *ext_of(const char *p)
     return d ? d + 1 : "";
 }
 
+/* print every finished frame (frame_output_print, frame_output.c:160-199) and discard the other record queues */
+static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, uint64_t *t0, char *line, size_t cap)
+{
+    int n;
+    while ((n = irdm_poll_demods(p, d, 256)) > 0)
+        for (int i = 0; i < n; i++) {
+            const int len = irdm_format_raw(&d[i], file_info, t0, line, cap);
+            if (len > 0) fwrite(line, 1, (size_t)len, stdout);
+        }
+    irdm_burst_t tmp[256];
+    while (irdm_poll_bursts(p, tmp, 256) > 0) {}
+    irdm_frame_info_t fi[256];
+    while (irdm_poll_frames(p, fi, NULL, 256) > 0) {}
+}
+
 int main(int argc, char **argv)
 {
     const char *file = NULL, *file_info = NULL, *format = NULL;
     double rate = 0, freq = 1622000000.0, db = 0;
     int gardner = 1, verbose = 0;
     size_t chunk = (size_t)16 << 20;
+    int depth = 1;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
 #define NEXT() (i + 1 < argc ? argv[++i] : (fprintf(stderr, "missing value for %s\n", a), exit(2), ""))
@@ -39,6 +55,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--file-info")) file_info = NEXT();
         else if (!strcmp(a, "--chunk")) chunk = (size_t)atoll(NEXT());
         else if (!strcmp(a, "--no-gardner")) gardner = 0;
+        else if (!strcmp(a, "--depth")) depth = atoi(NEXT());       /* 0: per-chunk latency, 1: throughput (default) */
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) verbose = 1;
         else if (!strcmp(a, "--no-simd") || !strcmp(a, "--no-gpu")) {
             fprintf(stderr, "%s: this binary is the GPU path; use the reference binary for the CPU path\n", a);
@@ -69,6 +86,7 @@ int main(int argc, char **argv)
     chunk = chunk / 32768 * 32768;
     if (chunk == 0) chunk = 32768;
     c.max_chunk_samples = chunk;
+    c.pipeline_depth = depth;
     irdm_pipeline_t *p = irdm_create(&c);
     if (!p) {
         fprintf(stderr, "irdm_create failed (no MI355X / bad parameters)\n");
@@ -78,7 +96,9 @@ int main(int argc, char **argv)
 
     FILE *f = strcmp(file, "-") ? fopen(file, "rb") : stdin;
     if (!f) { perror(file); return 1; }
-    void *buf = malloc(chunk * bps);
+    /* pinned read buffer: the H2D copy of chunk k+1 is DMA that overlaps chunk k's detector scan */
+    void *buf = irdm_host_alloc(chunk * bps);
+    if (!buf) { fprintf(stderr, "irdm_host_alloc failed\n"); return 1; }
     irdm_demod_t *d = malloc(sizeof(*d) * 256);
     char line[4096];
     uint64_t t0 = 0;
@@ -86,22 +106,15 @@ int main(int argc, char **argv)
     int rc = 0;
     while ((r = fread(buf, bps, chunk, f)) > 0) {
         if (irdm_feed_host(p, buf, r) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; break; }
-        int n;
-        while ((n = irdm_poll_demods(p, d, 256)) > 0)
-            for (int i = 0; i < n; i++) {
-                const int len = irdm_format_raw(&d[i], file_info, &t0, line, sizeof line);
-                if (len > 0) fwrite(line, 1, (size_t)len, stdout);
-            }
-        irdm_burst_t tmp[256];
-        while (irdm_poll_bursts(p, tmp, 256) > 0) {}
-        irdm_frame_info_t fi[256];
-        while (irdm_poll_frames(p, fi, NULL, 256) > 0) {}
+        drain(p, d, file_info, &t0, line, sizeof line);
         if (r < chunk) break;
     }
+    if (rc == 0 && irdm_flush(p) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; }
+    drain(p, d, file_info, &t0, line, sizeof line);
     fflush(stdout);
     fprintf(stderr, "burst_detect: tagged %lu bursts total\n", (unsigned long)irdm_tagged_bursts(p));
     irdm_destroy(p);
-    free(buf);
+    irdm_host_free(buf);
     free(d);
     if (f != stdin) fclose(f);
     return rc;

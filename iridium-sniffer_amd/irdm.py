@@ -82,6 +82,10 @@ def lib():
         L.irdm_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.irdm_feed_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_flush.argtypes = [C.c_void_p]
+        L.irdm_host_alloc.argtypes = [C.c_size_t]
+        L.irdm_host_alloc.restype = C.c_void_p
+        L.irdm_host_free.argtypes = [C.c_void_p]
+        L.irdm_host_free.restype = None
         L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
@@ -115,6 +119,20 @@ def lib():
 
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def host_alloc(nbytes):
+    """Pinned host buffer (irdm_host_alloc) as (pointer, numpy uint8 view); release with host_free(pointer)."""
+    L = lib()
+    ptr = L.irdm_host_alloc(nbytes)
+    if not ptr:
+        raise MemoryError("irdm_host_alloc(%d) failed" % nbytes)
+    view = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
+    return ptr, view
+
+
+def host_free(ptr):
+    lib().irdm_host_free(C.c_void_p(ptr))
 
 
 class GpuBurstFFT:
@@ -179,6 +197,13 @@ class Pipeline:
         iq = np.ascontiguousarray(iq)
         n = len(iq) if self.fmt == FMT_CF32 else len(iq) // 2
         rc = self.L.irdm_feed_host(self.h, iq.ctypes.data_as(C.c_void_p), n)
+        if rc < 0:
+            raise RuntimeError("irdm_feed_host failed")
+        return rc
+
+    def feed_host_ptr(self, ptr, n_samples):
+        """irdm_feed_host on a raw host pointer (e.g. a pinned buffer from host_alloc)."""
+        rc = self.L.irdm_feed_host(self.h, C.c_void_p(ptr), n_samples)
         if rc < 0:
             raise RuntimeError("irdm_feed_host failed")
         return rc
