@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libirdm_hip.so")
+# IRDM_LIB: another build of the same library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("IRDM_LIB") or os.path.join(PKG_DIR, "libirdm_hip.so")
 
 FMT_CI8, FMT_CI16, FMT_CF32 = 0, 1, 2
 MAX_FRAME_SAMPLES = 4440
