@@ -514,6 +514,10 @@ __global__ __launch_bounds__(kScanThreads) void detect_scan_kernel(
                 if (sh.squelch >= 10) {
                     reset = 1;
                     sh.squelch = 0;
+                    // the un-primed frames that follow skip the candidate pass and with it the re-arming of the
+                    // rotating counters: clear them here, or this frame's count would be taken for real
+                    // candidates when detection resumes 512 frames later
+                    sh.n_cand[0] = sh.n_cand[1] = sh.n_cand[2] = 0;
                 }
                 sh.flag_deleted = 2;      // mask must be cleared to all-ones
             } else if (sh.squelch > 0) {

@@ -1,0 +1,86 @@
+"""Edge-case scenes for the detector state machine (SURVEY.md 8c "negative cases"): squelch + history reset,
+bursts longer than max_burst_len, carriers on DC / in the guard bands, simultaneous strong bursts, more concurrent
+bursts than the sparse scan keeps in its lanes.  Seeded, generated with siggen; the oracle decides what is right."""
+import numpy as np
+
+import siggen
+
+
+def _payload(rng, n=150):
+    return rng.integers(0, 4, n).tolist()
+
+
+def squelch(fs=2_000_000, seed=21):
+    """44 carriers start within 2 ms: more than max_bursts (40 @ 2 MHz) -> squelch dumps them, squelch_count reaches
+    10 -> noise-floor history reset and re-priming (burst_detect.c:594-631); a second wave after re-priming decodes."""
+    n = int(2.7 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    chans = [c for c in range(-22, 23) if c != 0]
+    bursts = [dict(start=first + 4000 + 37 * i, freq_hz=siggen.channel_freq(ch), payload=_payload(rng), amp=0.03)
+              for i, ch in enumerate(chans)]
+    for i, ch in enumerate(chans[:6]):
+        bursts.append(dict(start=first + 2_400_000 + 70_000 * i, freq_hz=siggen.channel_freq(ch), payload=_payload(rng)))
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+def too_long(fs=2_000_000, seed=22):
+    """A 0.36 s carrier: ended by max_burst_len (burst_detect.c:499-502) with the forced baseline update, re-created,
+    while normal bursts come and go beside it."""
+    n = int(1.5 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    bursts = [dict(start=first + 1000, freq_hz=siggen.channel_freq(5), quads=_payload(rng, 9000)),
+              dict(start=first + 150_000, freq_hz=siggen.channel_freq(-7), payload=_payload(rng, 160)),
+              dict(start=first + 420_000, freq_hz=siggen.channel_freq(12), payload=_payload(rng, 160)),
+              dict(start=first + 1_200_000, freq_hz=siggen.channel_freq(-3), payload=_payload(rng, 160))]
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+def dc_and_edges(fs=2_000_000, seed=23):
+    """Carriers on DC (bins dc+-3 never produce peaks, burst_detect.c:537-542), beside the notch, inside the guard
+    bands (peaks only in [w/2, N-w/2))."""
+    n = int(1.3 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    bursts = [dict(start=first + 1000, freq_hz=300.0, payload=_payload(rng)),
+              dict(start=first + 200_000, freq_hz=-2500.0, payload=_payload(rng)),
+              dict(start=first + 400_000, freq_hz=fs / 2 - 15_000.0, payload=_payload(rng)),
+              dict(start=first + 600_000, freq_hz=-fs / 2 + 30_000.0, payload=_payload(rng)),
+              dict(start=first + 800_000, freq_hz=siggen.channel_freq(9), payload=_payload(rng))]
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+def strong_simultaneous(fs=2_000_000, seed=24):
+    """Five strong bursts with the same start and length (created and deleted in the same frames, long prefilter
+    lists), an adjacent-channel pile-up with a weak neighbour in a strong burst's skirt, two near-threshold bursts."""
+    n = int(1.3 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    bursts = [dict(start=first + 5000, freq_hz=siggen.channel_freq(ch),
+                   quads=siggen.frame_quadrants(_payload(rng, 170)), amp=0.4) for ch in (-15, -6, 4, 11, 18)]
+    for i, ch in enumerate((-12, 2, 14)):
+        bursts.append(dict(start=first + 300_000 + 3000 * i, freq_hz=siggen.channel_freq(ch), payload=_payload(rng, 170), amp=0.3))
+    bursts.append(dict(start=first + 301_500, freq_hz=siggen.channel_freq(3), payload=_payload(rng, 170), amp=0.02))
+    bursts.append(dict(start=first + 700_000, freq_hz=siggen.channel_freq(-20), payload=_payload(rng, 170), amp=0.004))
+    bursts.append(dict(start=first + 900_000, freq_hz=siggen.channel_freq(20), payload=_payload(rng, 170), amp=0.006))
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+def many_active_10m(fs=10_000_000, seed=25, n_sim=70):
+    """70 concurrent bursts at 10 MHz: below max_bursts (200) so no squelch, above the 64 lane slots of the sparse
+    scan -> it must abort and the dense scan must take over for that chunk."""
+    n = int(0.75 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 8192
+    chans = [c for c in range(-110, 111, 3) if c != 0][:n_sim]
+    bursts = [dict(start=first + 3000 + 211 * i, freq_hz=siggen.channel_freq(ch), payload=_payload(rng, 160), amp=0.03)
+              for i, ch in enumerate(chans)]
+    for i in range(6):
+        bursts.append(dict(start=first + 1_500_000 + 150_000 * i,
+                           freq_hz=siggen.channel_freq(int(rng.integers(-100, 100)) or 1), payload=_payload(rng, 160)))
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+ALL = dict(squelch=squelch, too_long=too_long, dc_and_edges=dc_and_edges,
+           strong_simultaneous=strong_simultaneous, many_active_10m=many_active_10m)
