@@ -84,3 +84,53 @@ def many_active_10m(fs=10_000_000, seed=25, n_sim=70):
 
 ALL = dict(squelch=squelch, too_long=too_long, dc_and_edges=dc_and_edges,
            strong_simultaneous=strong_simultaneous, many_active_10m=many_active_10m)
+
+
+def frame_lengths(fs=2_000_000, seed=26, simplex=False):
+    """Payload lengths around the frame-length rules (burst_downmix.c:763-777): shorter than the minimum (dropped),
+    exactly minimum / maximum, longer than the maximum (cut).  simplex=True is meant to be run with a capture centre
+    above 1626 MHz (80..444 symbols instead of 131..191)."""
+    n = int(1.9 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    lens = (40, 67, 68, 69, 300, 431, 432, 433, 640) if simplex else (60, 118, 119, 120, 150, 178, 179, 180, 320)
+    bursts = [dict(start=first + 2000 + 290_000 * i, freq_hz=siggen.channel_freq(3 + 2 * i), payload=_payload(rng, p))
+              for i, p in enumerate(lens)]
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+def junk(fs=2_000_000, seed=27):
+    """Things that are detected but are not Iridium frames: an unmodulated carrier, a 1 ms blip, QPSK without preamble
+    or unique word, a burst whose unique word is damaged in 1 / 2 / 3 symbols (hard check tolerance, soft rescue,
+    rejection: qpsk_demod.c:277-325), two bursts on the same channel 3 ms apart."""
+    n = int(1.9 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    bursts = [dict(start=first + 2000, freq_hz=siggen.channel_freq(-9), quads=[0] * 400),
+              dict(start=first + 150_000, freq_hz=siggen.channel_freq(6), quads=_payload(rng, 25)),
+              dict(start=first + 300_000, freq_hz=siggen.channel_freq(-4), quads=_payload(rng, 200))]
+    for k, nbad in enumerate((1, 2, 3, 5)):
+        q = siggen.frame_quadrants(_payload(rng, 160))
+        for j in range(nbad):
+            q[16 + 2 * j + 1] = (q[16 + 2 * j + 1] + 1 + (j & 1)) % 4
+        bursts.append(dict(start=first + 450_000 + 150_000 * k, freq_hz=siggen.channel_freq(10 - 3 * k), quads=q))
+    bursts.append(dict(start=first + 1_100_000, freq_hz=siggen.channel_freq(15), payload=_payload(rng, 150)))
+    bursts.append(dict(start=first + 1_100_000 + 6000 + 16_000, freq_hz=siggen.channel_freq(15), payload=_payload(rng, 150)))
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+def cfo_spread(fs=2_000_000, seed=28):
+    """Carriers off the channel grid by up to +-12 kHz (coarse bin rounding, the 4096-point CFO estimate and its
+    parabolic refinement, burst_downmix.c:482-535), at amplitudes from near-threshold to strong."""
+    n = int(1.9 * fs) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 530 * 2048
+    offs = (-12_000.0, -7_300.0, -488.3, 0.0, 244.1, 488.28125, 3_111.0, 9_765.0, 11_999.0)
+    amps = (0.05, 0.007, 0.2, 0.05, 0.011, 0.05, 0.6, 0.05, 0.02)
+    bursts = [dict(start=first + 2000 + 200_000 * i, freq_hz=siggen.channel_freq(int(rng.integers(-20, 21)) or 2, extra=o),
+                   payload=_payload(rng, 140 + 4 * i), amp=a, uplink=bool(i % 3 == 2))
+              for i, (o, a) in enumerate(zip(offs, amps))]
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+ALL.update(frame_lengths=frame_lengths, junk=junk, cfo_spread=cfo_spread)

@@ -26,16 +26,23 @@ def _chunks(n, parts):
     return out
 
 
-@pytest.mark.parametrize("name", sorted(scenes.ALL))
-def test_scene_parity_sparse_dense_and_chunked(name):
-    fs, iq = scenes.ALL[name]()
-    ref = orc.run_stream(iq, fs)
-    got = parity.run_gpu(iq, fs)                                   # sparse scan (dense fallback if it aborts)
+CASES = {name: ({}, {}) for name in scenes.ALL}
+# capture centred above 1626 MHz: the simplex frame-length rules (burst_downmix.c:764-767)
+CASES["frame_lengths_simplex"] = (dict(simplex=True), dict(center_frequency=1626.4e6))
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_scene_parity_sparse_dense_and_chunked(case):
+    name = case.replace("_simplex", "")
+    skw, ckw = CASES[case]
+    fs, iq = scenes.ALL[name](**skw)
+    ref = orc.run_stream(iq, fs, **ckw)
+    got = parity.run_gpu(iq, fs, **ckw)                            # sparse scan (dense fallback if it aborts)
     s = parity.compare(got, ref)
-    dense = parity.run_gpu(iq, fs, scan_mode=1)
+    dense = parity.run_gpu(iq, fs, scan_mode=1, **ckw)
     parity.compare(dense, ref)
     assert dense["stats"]["scan_fast_chunks"] == 0
-    chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 5), depth=1)
+    chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 5), depth=1, **ckw)
     parity.compare(chunked, ref)
     if name in ("many_active_10m", "squelch"):
         # > 64 concurrent bursts / > 1024 listed bins per frame: the sparse scan gives up, the dense scan redoes the chunk
