@@ -134,3 +134,32 @@ def cfo_spread(fs=2_000_000, seed=28):
 
 
 ALL.update(frame_lengths=frame_lengths, junk=junk, cfo_spread=cfo_spread)
+
+
+def random_scene(seed, fs=2_000_000, secs=1.6):
+    """Randomised differential-test scene: 10-60 emitters with log-uniform amplitudes (near-threshold .. very strong),
+    random lengths (a few symbols .. longer than max_burst_len), random off-grid carriers (adjacent-channel pile-ups
+    included), starts clustered in a few groups so that many bursts are born and die in the same frames."""
+    rng = np.random.default_rng(10_000 + seed)
+    nfft = 1 << int(round(np.log2(fs / 1000.0)))
+    n = int(secs * fs) // 32768 * 32768
+    first = 530 * nfft
+    n_em = int(rng.integers(10, 61))
+    groups = np.sort(rng.integers(first, n - int(0.25 * fs), size=int(rng.integers(2, 7))))
+    bursts = []
+    for _ in range(n_em):
+        g = int(rng.choice(groups))
+        start = g + int(rng.integers(0, int(0.02 * fs))) if rng.random() < 0.7 else int(rng.integers(first, n - int(0.05 * fs)))
+        kind = rng.random()
+        if kind < 0.6:
+            quads = siggen.frame_quadrants(_payload(rng, int(rng.integers(100, 200))), uplink=bool(rng.random() < 0.3))
+        elif kind < 0.8:
+            quads = _payload(rng, int(rng.integers(5, 400)))
+        elif kind < 0.92:
+            quads = [0] * int(rng.integers(20, 1500))
+        else:
+            quads = _payload(rng, int(rng.integers(2300, 4000)))          # longer than max_burst_len (2250 symbols)
+        f = float(rng.uniform(-fs / 2 + 25e3, fs / 2 - 25e3))
+        amp = float(np.exp(rng.uniform(np.log(0.0035), np.log(0.5))))
+        bursts.append(dict(start=start, freq_hz=f, quads=quads, amp=amp))
+    return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]

@@ -61,3 +61,24 @@ def test_squelch_scene_ci8():
     got = parity.run_gpu(i8, fs, fmt=irdm.FMT_CI8, chunks=_chunks(len(iq), 3), depth=1)
     parity.compare(got, ref)
     assert len(ref.bursts) >= 30
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes_differential(seed):
+    """randomised emitters (scenes.random_scene): sparse scan in one chunk, and 7 ragged chunks in throughput mode,
+    against the oracle; every third seed also through the dense scan"""
+    fs, iq = scenes.random_scene(seed)
+    ref = orc.run_stream(iq, fs)
+    assert len(ref.bursts) >= 10
+    parity.compare(parity.run_gpu(iq, fs), ref)
+    parity.compare(parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 7), depth=1), ref)
+    if seed % 3 == 0:
+        parity.compare(parity.run_gpu(iq, fs, scan_mode=1), ref)
+
+
+@pytest.mark.parametrize("seed", (100, 101))
+def test_random_scenes_10mhz(seed):
+    fs, iq = scenes.random_scene(seed, fs=10_000_000, secs=0.8)
+    ref = orc.run_stream(iq, fs)
+    parity.compare(parity.run_gpu(iq, fs), ref)
+    parity.compare(parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1), ref)
