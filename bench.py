@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=4, help="oracle passes over that prefix (~3 s each)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="irdm_set_option before the run (kernel-variant A/B: fir_generic=1, fft_radix2=1, scan_mode=1)")
     ap.add_argument("--host-steps", type=int, default=6,
                     help="extra, separately timed steps fed from pinned HOST memory (PCIe-inclusive rate; 0 = skip)")
     args = ap.parse_args()
@@ -102,11 +104,19 @@ def main():
     pipe = irdm.Pipeline(fs, fmt=irdm.FMT_CF32, max_chunk_samples=n, max_bursts_per_chunk=8192,
                          device=local, pipeline_depth=args.depth)
     pipe.L.irdm_feed_device.restype = C.c_int
+    for kv in args.opt:
+        key, val = kv.split("=")
+        pipe.set_option(key, int(val))
     stream = torch.cuda.current_stream().cuda_stream
     REC = C.sizeof(irdm.Demod)
     cap = 2048
-    gather_buf = torch.zeros((cap * REC,), dtype=torch.uint8, device=device)
-    gather_list = [torch.zeros_like(gather_buf) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # record gather to rank 0 (RCCL over xGMI): fixed-size padded buffers, double-buffered and asynchronous so the
+    # collective of step i overlaps the detector scan of step i+1
+    gather_bufs = [torch.zeros((cap * REC,), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+    gather_lists = ([[torch.zeros((cap * REC,), dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(2)]
+                    if (world > 1 and rank == 0) else [None, None])
+    gather_work = [None, None]
+    step_no = [0]
     counts = torch.zeros((3,), dtype=torch.int64, device=device)
 
     stage = {k: 0.0 for k in ("fft_mag", "scan", "fir", "post", "demod", "total")}
@@ -126,13 +136,18 @@ def main():
             host["feed_call"] += (tb - ta) * 1e3
             host["poll"] += (tc - tb) * 1e3
         if world > 1:
-            # gather of demodulated frame records to rank 0 (RCCL over xGMI); fixed-size, padded
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            if gather_work[slot] is not None:
+                gather_work[slot].wait()
             k = min(len(demods), cap)
             if k:
-                gather_buf[:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(device)
-            counts[0], counts[1], counts[2] = nb_step, len(demods), k
-            dist.gather(gather_buf, gather_list, dst=0)
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+                gather_bufs[slot][:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(device, non_blocking=True)
+            gather_work[slot] = dist.gather(gather_bufs[slot], gather_lists[slot], dst=0, async_op=True)
+            if record:
+                counts[0] += nb_step
+                counts[1] += len(demods)
+                counts[2] += k
         if record:
             t = pipe.timings()
             for kk in stage:
@@ -163,6 +178,11 @@ def main():
         totals["bursts"] += len(tb_)
         ns_off = irdm.Burst.num_samples.offset
         totals["burst_samples"] += int(tb_[:, ns_off:ns_off + 8].copy().view(np.uint64).sum()) if len(tb_) else 0
+    if world > 1:
+        for w in gather_work:
+            if w is not None:
+                w.wait()
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # whole-job burst / record counts
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -260,6 +280,7 @@ def main():
                                    % (fs // 1_000_000, pipe.fft_size, n, args.density),
                        "samples_per_step_per_gpu": n, "bursts_per_step": totals["bursts"] / K,
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
+                       "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
                        "pipeline_depth": args.depth,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames")}},
             "roofline": roofline,

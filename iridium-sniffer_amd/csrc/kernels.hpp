@@ -35,6 +35,8 @@ struct SampleSource {
 // downmix.hip
 int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream);
 int fir_tile_row(int decim);
+extern int g_fir_force_generic;   // 1: always the runtime-M decimator kernel
+extern int g_fft_force_radix2;    // 1: always the radix-2 LDS FFT kernel
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,

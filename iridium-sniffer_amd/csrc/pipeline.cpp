@@ -1211,6 +1211,9 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
+    // kernel-variant hooks (process-wide; parity tests and A/B timing): generic runtime-M decimator, radix-2 FFT
+    if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
+    if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
     return -1;
 }
 

@@ -148,6 +148,27 @@ def test_ci16_device_resident_and_pinned_host_feed():
     parity.compare(got, ref)
 
 
+def test_kernel_variants_agree():
+    """The runtime-M decimator and the radix-2 FFT kernels (fallbacks for sizes without a specialised kernel) give the
+    same records as the specialised ones and the oracle."""
+    fs, iq = _scene_2m(seed=19, n_bursts=6, secs=2.0)
+    ref = orc.run_stream(iq, fs)
+    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}):
+        p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)
+        p.set_option("keep_frame_samples", 1)
+        try:
+            for k, v in opts.items():
+                p.set_option(k, v)
+            p.feed_host(iq)
+            infos, samples = p.poll_frames()
+            got = dict(bursts=p.poll_bursts(), infos=infos, samples=samples, demods=p.poll_demods(), tagged=p.tagged)
+        finally:
+            for k in opts:
+                p.set_option(k, 0)
+            p.close()
+        parity.compare(got, ref)
+
+
 def test_known_answer_bits_from_reference_docs():
     """ARCHITECTURE.md:264/:270 -- the documented PRBS15 RAW line: 179 payload symbols, same bits."""
     fs = 2_000_000
