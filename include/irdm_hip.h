@@ -233,6 +233,12 @@ int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n);
  * file_info NULL/"" -> "i-<t0 s>-t1".  Returns the line length incl. '\n', or -1. */
 int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uint64_t *t0_io,
                     char *buf, size_t cap);
+/* The same for n frames, lines concatenated in buf (NUL-terminated): one write per batch instead of the
+ * reference's fflush per line (frame_output.c:196-198).  cap >= n * IRDM_RAW_LINE_MAX always suffices.
+ * Returns the total length or -1. */
+#define IRDM_RAW_LINE_MAX 1280          /* 256 B of prefix (file_info <= 128 chars) + IRDM_MAX_BITS + newline, rounded up */
+long long irdm_format_raw_batch(const irdm_demod_t *f, int n, const char *file_info, uint64_t *t0_io,
+                                char *buf, size_t cap);
 
 const char *irdm_version(void);
 

@@ -1260,4 +1260,19 @@ extern "C" int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uin
     return pos;
 }
 
+// many lines into one buffer: one write()/fwrite() per poll batch instead of the reference's fflush per line
+// (frame_output.c:196-198), which is the sink bottleneck at >= 1e5 lines/s; the bytes are identical
+extern "C" long long irdm_format_raw_batch(const irdm_demod_t *f, int n, const char *file_info, uint64_t *t0_io,
+                                           char *buf, size_t cap)
+{
+    if (!f || n < 0 || !t0_io || !buf) return -1;
+    size_t pos = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = irdm_format_raw(&f[i], file_info, t0_io, buf + pos, cap - pos);
+        if (len < 0) return -1;          // cap too small (IRDM_RAW_LINE_MAX bytes per frame always suffice)
+        pos += (size_t)len;
+    }
+    return (long long)pos;
+}
+
 extern "C" const char *irdm_version(void) { return "irdm_hip 0.1 (gfx950)"; }

@@ -26,11 +26,10 @@ static const char *ext_of(const char *p)
 static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, uint64_t *t0, char *line, size_t cap)
 {
     int n;
-    while ((n = irdm_poll_demods(p, d, 256)) > 0)
-        for (int i = 0; i < n; i++) {
-            const int len = irdm_format_raw(&d[i], file_info, t0, line, cap);
-            if (len > 0) fwrite(line, 1, (size_t)len, stdout);
-        }
+    while ((n = irdm_poll_demods(p, d, 256)) > 0) {
+        const long long len = irdm_format_raw_batch(d, n, file_info, t0, line, cap);     /* one write per batch */
+        if (len > 0) fwrite(line, 1, (size_t)len, stdout);
+    }
     irdm_burst_t tmp[256];
     while (irdm_poll_bursts(p, tmp, 256) > 0) {}
     irdm_frame_info_t fi[256];
@@ -100,7 +99,7 @@ int main(int argc, char **argv)
     void *buf = irdm_host_alloc(chunk * bps);
     if (!buf) { fprintf(stderr, "irdm_host_alloc failed\n"); return 1; }
     irdm_demod_t *d = malloc(sizeof(*d) * 256);
-    char line[4096];
+    static char line[256 * IRDM_RAW_LINE_MAX];
     uint64_t t0 = 0;
     size_t r;
     int rc = 0;

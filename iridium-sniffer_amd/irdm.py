@@ -383,3 +383,19 @@ def format_raw(demods, file_info="golden"):
             raise RuntimeError("irdm_format_raw failed")
         out.append(buf.value.decode())
     return out
+
+
+def format_raw_batch(demods, file_info="golden"):
+    """irdm_format_raw_batch: all lines in one buffer (one write per batch); returns the text."""
+    L = lib()
+    L.irdm_format_raw_batch.restype = C.c_longlong
+    n = len(demods)
+    arr = (Demod * n)(*demods)
+    cap = max(n, 1) * 1280
+    buf = C.create_string_buffer(cap)
+    t0 = C.c_uint64(0)
+    rc = L.irdm_format_raw_batch(arr, n, file_info.encode() if file_info else None, C.byref(t0), buf, cap)
+    if rc < 0:
+        raise RuntimeError("irdm_format_raw_batch failed")
+    return buf.raw[:rc].decode()
+

@@ -60,3 +60,21 @@ def test_format_raw_matches_oracle_format():
         orc.lib().orc_format_raw(C.byref(o), fi.encode(), C.byref(t0), buf, 4096)
         assert ours == buf.value.decode()
     assert ours.startswith("RAW: i-1700000000-t1 0000533.0720 1622209568 N:23.80-114.13 I:00000000120  97% 0.01681 179 ")
+
+
+def test_format_raw_batch_is_the_concatenation_of_lines():
+    """irdm_format_raw_batch (one write per poll batch) produces exactly the per-line bytes, t0 carried across."""
+    ds = []
+    for k in range(5):
+        d = irdm.Demod()
+        d.id = 10 * k
+        d.timestamp = 1700000000 * 10**9 + 533072000 + 90_000_000 * k
+        d.center_frequency = 1622209567.6 + 41666.7 * k
+        d.magnitude, d.noise, d.confidence, d.level = 20.0 + k, -114.1, 90 + k, 0.016 + 0.001 * k
+        d.n_symbols, d.n_payload_symbols, d.n_bits, d.ok = 191, 179, 382 - 2 * k, 1
+        for i in range(d.n_bits):
+            d.bits[i] = (i * (k + 3) // 5) & 1
+        ds.append(d)
+    for fi in ("golden", ""):
+        assert irdm.format_raw_batch(ds, fi) == "".join(irdm.format_raw(ds, fi))
+    assert irdm.format_raw_batch([], "x") == ""
