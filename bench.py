@@ -89,11 +89,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # IRDM_BENCH_BACKEND=gloo + IRDM_BENCH_SHARE_GPU=1: functional check of the multi-rank code path on a one-GPU box
+    # (all ranks on device 0, collectives through host tensors); never used for reported numbers
+    backend = os.environ.get("IRDM_BENCH_BACKEND", "nccl")
+    if os.environ.get("IRDM_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    cdev = device if backend == "nccl" else torch.device("cpu")      # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     fs = args.sample_rate
     n = args.samples // 32768 * 32768
@@ -112,12 +121,12 @@ def main():
     cap = 2048
     # record gather to rank 0 (RCCL over xGMI): fixed-size padded buffers, double-buffered and asynchronous so the
     # collective of step i overlaps the detector scan of step i+1
-    gather_bufs = [torch.zeros((cap * REC,), dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
-    gather_lists = ([[torch.zeros((cap * REC,), dtype=torch.uint8, device=device) for _ in range(world)] for _ in range(2)]
+    gather_bufs = [torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) for _ in range(2)] if world > 1 else None
+    gather_lists = ([[torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
                     if (world > 1 and rank == 0) else [None, None])
     gather_work = [None, None]
     step_no = [0]
-    counts = torch.zeros((3,), dtype=torch.int64, device=device)
+    counts = torch.zeros((3,), dtype=torch.int64, device=cdev)
 
     stage = {k: 0.0 for k in ("fft_mag", "scan", "fir", "post", "demod", "total")}
     totals = dict(bursts=0, demods=0, burst_samples=0)
@@ -142,7 +151,7 @@ def main():
                 gather_work[slot].wait()
             k = min(len(demods), cap)
             if k:
-                gather_bufs[slot][:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(device, non_blocking=True)
+                gather_bufs[slot][:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(cdev, non_blocking=True)
             gather_work[slot] = dist.gather(gather_bufs[slot], gather_lists[slot], dst=0, async_op=True)
             if record:
                 counts[0] += nb_step
@@ -176,6 +185,9 @@ def main():
         tail = pipe.poll_demods_raw()
         totals["demods"] += len(tail)
         totals["bursts"] += len(tb_)
+        if world > 1:
+            counts[0] += len(tb_)
+            counts[1] += len(tail)
         ns_off = irdm.Burst.num_samples.offset
         totals["burst_samples"] += int(tb_[:, ns_off:ns_off + 8].copy().view(np.uint64).sum()) if len(tb_) else 0
     if world > 1:
@@ -188,7 +200,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
