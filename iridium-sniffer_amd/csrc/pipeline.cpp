@@ -156,7 +156,7 @@ struct irdm_pipeline {
     hipStream_t stream;      // detector (K1, prefilter, K2)
     hipStream_t bstream;     // per-burst stages + history ring (== stream unless pipeline_depth 1)
     hipStream_t stream2;
-    hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream confined to one CU (CU mask), so that the
+    hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream with CUs of its own (CU mask), so that the
                              // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
     hipEvent_t ev_scan_in, ev_scan_out;
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
@@ -359,9 +359,16 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 8) {
             const int words = (prop.multiProcessorCount + 31) / 32;
             std::vector<uint32_t> one(words, 0u), rest(words, 0xffffffffu);
-            one[0] = 1u;                    // CU 0 for the scan ...
-            rest[0] &= ~1u;                 // ... every other CU for the per-burst stages
+            // CU-mask bits are dealt round-robin to the XCDs, and a workgroup is placed on whichever XCD the dispatcher
+            // picks: a one-bit mask does not confine it (measured: with only bit 0 reserved the scan still shared its CU
+            // with the per-burst kernels, 7.7 ms; with one bit per XCD reserved, 6.9 ms; alone 6.45 ms).  So the scan
+            // stream gets the first `xcds` bits -- one CU in every XCD -- and every other stream the remaining CUs.
             if (prop.multiProcessorCount % 32) rest[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
+            const int xcds = prop.multiProcessorCount >= 64 ? 8 : 1;
+            for (int b = 0; b < xcds; b++) {
+                one[b / 32] |= 1u << (b % 32);
+                rest[b / 32] &= ~(1u << (b % 32));
+            }
             hipStream_t s_scan = nullptr, s_rest = nullptr, s_fft = nullptr;
             if (hipExtStreamCreateWithCUMask(&s_scan, words, one.data()) == hipSuccess &&
                 hipExtStreamCreateWithCUMask(&s_rest, words, rest.data()) == hipSuccess &&
