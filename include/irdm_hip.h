@@ -120,6 +120,9 @@ typedef struct {
     float corr_re, corr_im;
     int32_t drop_reason;       /* 0 = frame produced; 1..5 = the reference's five early returns
                                   (burst_downmix.c:645, :677, :702, :744, :773) */
+    int32_t demod_ok;          /* qpsk_demod()'s return value for this frame (0 when no frame was produced) */
+    int32_t demod_direction;   /* in->direction as qpsk_demod leaves it (qpsk_demod.c:444, :454-463): DIR_UNDEF (0)
+                                  when the unique word was rejected, else the verified direction */
 } irdm_frame_info_t;
 
 /* demod_frame_t (qpsk_demod.h:24-38), bits/llr inline */
@@ -239,6 +242,12 @@ int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uint64_t *t0_i
 #define IRDM_RAW_LINE_MAX 1280          /* 256 B of prefix (file_info <= 128 chars) + IRDM_MAX_BITS + newline, rounded up */
 long long irdm_format_raw_batch(const irdm_demod_t *f, int n, const char *file_info, uint64_t *t0_io,
                                 char *buf, size_t cap);
+
+/* --save-bursts (qpsk_demod.c:339-389): writes <dir>/<timestamp>_<freq>_<id>_<DL|UL|UN>.cf32 (the frame's cf32 samples at
+ * 250 kHz) and the matching .meta text file for one downmixed frame (info->drop_reason == 0), creating dir if needed.
+ * samples: 2 * info->num_samples floats as returned by irdm_poll_frames with "keep_frame_samples" = 1.
+ * Returns 0, or -1 (no frame / I/O error, message on stderr as the reference prints). */
+int irdm_save_burst(const irdm_frame_info_t *info, const float *samples, const char *dir);
 
 const char *irdm_version(void);
 

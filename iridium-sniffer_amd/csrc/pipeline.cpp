@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <errno.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <deque>
@@ -656,6 +658,10 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
                 f.uw_start = w.uw_corr;
                 f.num_samples = w.num_samples;
             }
+            if (w.drop_reason == 0) {
+                f.demod_ok = p->h_demod[i].ok ? 1 : 0;
+                f.demod_direction = p->h_demod[i].ok ? p->h_demod[i].direction : 0;      // DIR_UNDEF, qpsk_demod.c:444
+            }
             p->q_frames.push_back(f);
             if (p->keep_frame_samples) {
                 std::vector<float> s;
@@ -1265,6 +1271,50 @@ extern "C" int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uin
     buf[pos++] = '\n';
     buf[pos] = 0;
     return pos;
+}
+
+// ===========================================================================
+// 4. --save-bursts (qpsk_demod.c:339-389)
+// ===========================================================================
+extern "C" int irdm_save_burst(const irdm_frame_info_t *info, const float *samples, const char *dir)
+{
+    if (!info || !samples || !dir || info->drop_reason != 0 || info->num_samples <= 0) return -1;
+    struct stat st;
+    memset(&st, 0, sizeof(st));
+    if (stat(dir, &st) == -1) {
+        if (mkdir(dir, 0755) == -1 && errno != EEXIST) {
+            fprintf(stderr, "Warning: failed to create burst save directory: %s\n", strerror(errno));
+            return -1;
+        }
+    }
+    const char *dir_str = info->demod_direction == 1 ? "DL" : info->demod_direction == 2 ? "UL" : "UN";
+    char base[512];
+    snprintf(base, sizeof(base), "%s/%020lu_%011.0f_%lu_%s", dir, (unsigned long)info->timestamp,
+             info->center_frequency, (unsigned long)info->id, dir_str);
+    char path[520];
+    snprintf(path, sizeof(path), "%s.cf32", base);
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        fprintf(stderr, "Warning: failed to save burst IQ: %s\n", strerror(errno));
+        return -1;
+    }
+    fwrite(samples, 2 * sizeof(float), (size_t)info->num_samples, f);
+    fclose(f);
+    snprintf(path, sizeof(path), "%s.meta", base);
+    f = fopen(path, "w");
+    if (!f) return -1;
+    fprintf(f, "burst_id: %lu\n", (unsigned long)info->id);
+    fprintf(f, "timestamp_ns: %lu\n", (unsigned long)info->timestamp);
+    fprintf(f, "center_freq_hz: %.0f\n", info->center_frequency);
+    fprintf(f, "sample_rate_hz: %.0f\n", info->sample_rate);
+    fprintf(f, "samples_per_symbol: %.2f\n", info->samples_per_symbol);
+    fprintf(f, "direction: %s\n", dir_str);
+    fprintf(f, "magnitude_db: %.2f\n", info->magnitude);
+    fprintf(f, "noise_dbfs_hz: %.2f\n", info->noise);
+    fprintf(f, "num_samples: %zu\n", (size_t)info->num_samples);
+    fprintf(f, "uw_start_offset: %.2f\n", info->uw_start);
+    fclose(f);
+    return 0;
 }
 
 // many lines into one buffer: one write()/fwrite() per poll batch instead of the reference's fflush per line

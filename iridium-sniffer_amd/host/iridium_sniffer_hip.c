@@ -23,6 +23,8 @@ static const char *ext_of(const char *p)
 }
 
 /* print every finished frame (frame_output_print, frame_output.c:160-199) and discard the other record queues */
+static const char *g_save_dir;
+
 static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, uint64_t *t0, char *line, size_t cap)
 {
     int n;
@@ -32,8 +34,17 @@ static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, ui
     }
     irdm_burst_t tmp[256];
     while (irdm_poll_bursts(p, tmp, 256) > 0) {}
-    irdm_frame_info_t fi[256];
-    while (irdm_poll_frames(p, fi, NULL, 256) > 0) {}
+    if (g_save_dir) {
+        /* every frame handed to the demodulator is saved, accepted or not (qpsk_demod.c:443-445, :468-470) */
+        static irdm_frame_info_t fi[16];
+        static float fs[16 * 2 * IRDM_MAX_FRAME_SAMPLES];
+        while ((n = irdm_poll_frames(p, fi, fs, 16)) > 0)
+            for (int i = 0; i < n; i++)
+                if (fi[i].drop_reason == 0) irdm_save_burst(&fi[i], fs + (size_t)i * 2 * IRDM_MAX_FRAME_SAMPLES, g_save_dir);
+    } else {
+        irdm_frame_info_t fi[256];
+        while (irdm_poll_frames(p, fi, NULL, 256) > 0) {}
+    }
 }
 
 int main(int argc, char **argv)
@@ -43,6 +54,7 @@ int main(int argc, char **argv)
     int gardner = 1, verbose = 0;
     size_t chunk = (size_t)16 << 20;
     int depth = 1;
+    const char *save_dir = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
 #define NEXT() (i + 1 < argc ? argv[++i] : (fprintf(stderr, "missing value for %s\n", a), exit(2), ""))
@@ -54,6 +66,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--file-info")) file_info = NEXT();
         else if (!strcmp(a, "--chunk")) chunk = (size_t)atoll(NEXT());
         else if (!strcmp(a, "--no-gardner")) gardner = 0;
+        else if (!strcmp(a, "--save-bursts")) save_dir = NEXT();   /* options.c --save-bursts: IQ + .meta per downmixed frame */
         else if (!strcmp(a, "--depth")) depth = atoi(NEXT());       /* 0: per-chunk latency, 1: throughput (default) */
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) verbose = 1;
         else if (!strcmp(a, "--no-simd") || !strcmp(a, "--no-gpu")) {
@@ -65,7 +78,7 @@ int main(int argc, char **argv)
         }
     }
     if (!file || rate <= 0) {
-        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR]\n", argv[0]);
+        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR] [--save-bursts DIR]\n", argv[0]);
         return 2;
     }
     if (!format) format = ext_of(file);              /* autodetect by extension, options.c:533-544 */
@@ -91,6 +104,8 @@ int main(int argc, char **argv)
         fprintf(stderr, "irdm_create failed (no MI355X / bad parameters)\n");
         return 1;
     }
+    if (save_dir) irdm_set_option(p, "keep_frame_samples", 1);
+    g_save_dir = save_dir;
     if (verbose) fprintf(stderr, "%s: fft_size=%d chunk=%zu samples\n", irdm_version(), irdm_fft_size(p), chunk);
 
     FILE *f = strcmp(file, "-") ? fopen(file, "rb") : stdin;

@@ -42,7 +42,8 @@ class FrameInfo(C.Structure):
                 ("magnitude", C.c_float), ("noise", C.c_float), ("uw_start", C.c_float),
                 ("num_samples", C.c_int32), ("dec_len", C.c_int32), ("start", C.c_int32),
                 ("center_offset", C.c_float), ("uw_start_idx", C.c_int32),
-                ("corr_re", C.c_float), ("corr_im", C.c_float), ("drop_reason", C.c_int32)]
+                ("corr_re", C.c_float), ("corr_im", C.c_float), ("drop_reason", C.c_int32),
+                ("demod_ok", C.c_int32), ("demod_direction", C.c_int32)]
 
 
 class Demod(C.Structure):
@@ -398,4 +399,12 @@ def format_raw_batch(demods, file_info="golden"):
     if rc < 0:
         raise RuntimeError("irdm_format_raw_batch failed")
     return buf.raw[:rc].decode()
+
+
+def save_burst(info, samples, dirname):
+    """irdm_save_burst: the reference's --save-bursts file pair for one frame (qpsk_demod.c:339-389)."""
+    L = lib()
+    L.irdm_save_burst.argtypes = [C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_char_p]
+    s = np.ascontiguousarray(samples, np.float32)
+    return L.irdm_save_burst(C.byref(info), s.ctypes.data_as(C.POINTER(C.c_float)), dirname.encode())
 

@@ -37,7 +37,7 @@ def test_struct_sizes_match_header():
     # sizeof() of the C structs in include/irdm_hip.h, x86-64 SysV (checked with gcc)
     assert C.sizeof(irdm.Burst) == 72
     assert C.sizeof(irdm.Demod) == 4544
-    assert C.sizeof(irdm.FrameInfo) == 80
+    assert C.sizeof(irdm.FrameInfo) == 88
     assert C.sizeof(irdm.Config) == 64
 
 
@@ -78,3 +78,26 @@ def test_format_raw_batch_is_the_concatenation_of_lines():
     for fi in ("golden", ""):
         assert irdm.format_raw_batch(ds, fi) == "".join(irdm.format_raw(ds, fi))
     assert irdm.format_raw_batch([], "x") == ""
+
+
+def test_save_burst_writes_the_reference_file_pair(tmp_path):
+    """irdm_save_burst == save_burst_iq (qpsk_demod.c:339-389): file names, .meta text, raw cf32 payload."""
+    import numpy as np
+    f = irdm.FrameInfo()
+    f.id, f.timestamp, f.center_frequency = 130, 1700000000533072000, 1626270833.0
+    f.sample_rate, f.samples_per_symbol = 250000.0, 10.0
+    f.magnitude, f.noise, f.uw_start, f.num_samples = 23.456, -114.127, 3.25, 1910
+    f.drop_reason, f.demod_ok, f.demod_direction = 0, 1, 2
+    x = (np.arange(2 * 1910, dtype=np.float32) * 0.001).astype(np.float32)
+    d = str(tmp_path / "bursts")
+    assert irdm.save_burst(f, x, d) == 0
+    base = "%s/%020d_%011.0f_%d_UL" % (d, f.timestamp, f.center_frequency, f.id)
+    assert np.array_equal(np.fromfile(base + ".cf32", np.float32), x)
+    assert open(base + ".meta").read() == (
+        "burst_id: 130\ntimestamp_ns: 1700000000533072000\ncenter_freq_hz: 1626270833\nsample_rate_hz: 250000\n"
+        "samples_per_symbol: 10.00\ndirection: UL\nmagnitude_db: 23.46\nnoise_dbfs_hz: -114.13\nnum_samples: 1910\n"
+        "uw_start_offset: 3.25\n")
+    f.demod_ok, f.demod_direction = 0, 0
+    assert irdm.save_burst(f, x, d) == 0 and os.path.exists(base[:-2] + "UN.meta")
+    f.drop_reason = 3
+    assert irdm.save_burst(f, x, d) == -1

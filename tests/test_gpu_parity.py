@@ -413,3 +413,38 @@ def test_cli_binary_raw_lines(tmp_path):
             # field 2 (timestamp) differs by the wall-clock base the binary reads; all else equal
             assert fa[0] == fb[0] and fa[3:6] == fb[3:6] and fa[7:] == fb[7:]
             assert abs(fa[2] - fb[2]) <= 1 and abs(fa[6] - fb[6]) <= 1e-4
+
+
+def test_cli_save_bursts_dumps_every_downmixed_frame(tmp_path):
+    """--save-bursts (qpsk_demod.c:339-389): one .cf32/.meta pair per frame handed to the demodulator, named with the
+    direction the demodulator settled on (UN when the unique word was rejected); payload == the frame samples."""
+    import glob
+    import subprocess
+    import scenes
+    exe = os.path.join(os.path.dirname(irdm.LIB_PATH), "iridium-sniffer-hip")
+    if not os.path.exists(exe):
+        irdm.build(force=True)
+    fs, iq = scenes.junk()                       # accepted, rescued and rejected unique words
+    ref = orc.run_stream(iq, fs)
+    path = tmp_path / "junk.cf32"
+    np.ascontiguousarray(iq).tofile(path)
+    d = tmp_path / "dump"
+    out = subprocess.run([exe, "-f", str(path), "-r", str(fs), "--save-bursts", str(d), "--chunk", str(32768 * 24)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    metas = sorted(glob.glob(str(d / "*.meta")))
+    frames = [f for f in ref.frames if f.drop_reason == 0]
+    assert len(metas) == len(frames) == len(glob.glob(str(d / "*.cf32"))) >= 5
+    ok_ids = {dm.id: dm.direction for dm in ref.demods}
+    by_id = {}
+    for m in metas:
+        txt = dict(l.split(": ") for l in open(m).read().splitlines())
+        by_id[int(txt["burst_id"])] = (m, txt)
+    for f in frames:
+        m, txt = by_id[f.id]
+        want_dir = {1: "DL", 2: "UL"}[ok_ids[f.id]] if f.id in ok_ids else "UN"
+        assert txt["direction"] == want_dir and m.endswith("_%d_%s.meta" % (f.id, want_dir))
+        assert int(txt["num_samples"]) == f.num_samples
+        got = np.fromfile(m[:-5] + ".cf32", np.float32)
+        assert np.array_equal(got.view(np.uint32), np.ctypeslib.as_array(f.samples)[:2 * f.num_samples].view(np.uint32))
+    assert any(f.id not in ok_ids for f in frames)            # the scene really has rejected frames
