@@ -155,7 +155,8 @@ void irdm_destroy(irdm_pipeline_t *p);
 /* burst_detector_feed / _feed_cf32 (burst_detect.h:74-79) for a whole chunk.
  * n_samples must be a multiple of feed_block except for the last chunk of the stream.
  * _device: d_iq is a device pointer to raw samples in the configured format (cf32 pairs, int16 pairs or int8
- * pairs), stream = the hipStream_t that produced them (or NULL).  The buffer may be reused when the call returns.
+ * pairs), stream = the hipStream_t that produced them, or NULL when the data is already complete (no ordering is
+ * established then; NULL does not mean the legacy default stream).  The buffer may be reused when the call returns.
  * pipeline_depth 0: returns after the chunk is fully processed (results pollable); pipeline_depth 1: see above.
  * _host: the same for a host buffer; the H2D copy is asynchronous DMA when the buffer is pinned
  * (irdm_host_alloc, hipHostMalloc, hipHostRegister) and overlaps the previous chunk's detector scan.

@@ -197,6 +197,7 @@ struct irdm_pipeline {
                              // (a D2H copy into pageable memory blocks the host until the stream drains -- that would
                              // serialise pipeline_depth 1's deferred work behind the detector scan)
     int deferred_emitted;
+    bool caller_ordered;     // the current chunk was handed over on a stream (ev[8] recorded)
     // detector scan in flight (scan_launch .. scan_finish)
     bool fl_active, fl_sparse;
     const float *fl_mag, *d_mag_last;
@@ -864,7 +865,7 @@ static int run_deferred(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_
     }
     if (d_iq) {
         // the ring copy reads the caller's buffer: order it after the caller's producer
-        IRDM_HIP_CHECK(hipStreamWaitEvent(p->bstream, p->ev[8], 0));
+        if (p->caller_ordered) IRDM_HIP_CHECK(hipStreamWaitEvent(p->bstream, p->ev[8], 0));
         if (ring_update(p, d_iq, c0, c1) != 0) return -1;
     }
     return 0;
@@ -897,8 +898,15 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     (void)hipSetDevice(p->cfg.device);
     // order after the caller's stream (the producer of d_iq)
     hipStream_t caller = static_cast<hipStream_t>(stream_v);
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[8], caller));
-    if (caller != p->fstream) IRDM_HIP_CHECK(hipStreamWaitEvent(p->fstream, p->ev[8], 0));
+    // stream == NULL: the chunk is already complete in memory, nothing to order against.  (Not the legacy null stream,
+    // which would wait for every other stream including the detector scan in flight; and no event on a foreign stream
+    // when it is not needed: streams share hardware queues, and an event recorded on a stream that shares one with the
+    // detector's sits behind the scan -- measured: K1 of the next chunk then started only after the scan had ended.)
+    p->caller_ordered = caller != nullptr;
+    if (p->caller_ordered) {
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[8], caller));
+        if (caller != p->fstream) IRDM_HIP_CHECK(hipStreamWaitEvent(p->fstream, p->ev[8], 0));
+    }
     const DetParams &P = p->P;
     const uint64_t c0 = p->total_samples, c1 = c0 + n_samples;
     const int n_frames = (int)(n_samples / (size_t)P.n);
