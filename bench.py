@@ -283,7 +283,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "IQ Msamples/s end-to-end (detect->demod), 10 MHz cf32",
+            "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz cf32" % (fs // 1_000_000),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
