@@ -13,14 +13,60 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdio.h>
+#include <unistd.h>
+
 #include "qpsk_demod.h"   /* reference header (burst_detect.h neutralised by the recipe's -D flags) */
+#include "frame_output.h" /* reference header */
 #include "rotator.h"      /* reference header */
 #include "simd_kernels.h" /* reference header */
 
 char *save_bursts_dir = NULL;   /* main.c global read by qpsk_demod.c:34 */
 int use_gardner = 1;            /* main.c:143 global read by qpsk_demod.c:35 */
 
+int diagnostic_mode = 0;        /* main.c globals read by frame_output.c:36-38 */
+int parsed_mode = 0;
+int acars_enabled = 0;
+
 void ref_set_use_gardner(int v) { use_gardner = v; }
+
+/* frame_output_print (frame_output.c:160-199) writes the RAW line to stdout; this shim hands it the fields through a
+ * demod_frame_t and returns what it printed (fd 1 is pointed at a temporary file for the duration of the call).
+ * frame_output.c keeps file_info and t0 in statics set by the FIRST frame of the process: call frame_output_init
+ * through ref_frame_output_init before the first line, in a fresh process per stream. */
+void ref_frame_output_init(const char *file_info) { frame_output_init(file_info); }
+
+int ref_frame_output_line(uint64_t id, uint64_t timestamp, double center_frequency, float magnitude, float noise,
+                          int confidence, float level, int n_payload_symbols, int n_bits, const uint8_t *bits,
+                          char *out, int cap)
+{
+    demod_frame_t f;
+    memset(&f, 0, sizeof(f));
+    f.id = id;
+    f.timestamp = timestamp;
+    f.center_frequency = center_frequency;
+    f.magnitude = magnitude;
+    f.noise = noise;
+    f.confidence = confidence;
+    f.level = level;
+    f.n_payload_symbols = n_payload_symbols;
+    f.n_bits = n_bits;
+    f.bits = (uint8_t *)bits;
+    FILE *tmp = tmpfile();
+    if (!tmp) return -1;
+    fflush(stdout);
+    const int saved = dup(1);
+    dup2(fileno(tmp), 1);
+    frame_output_print(&f);
+    fflush(stdout);
+    dup2(saved, 1);
+    close(saved);
+    rewind(tmp);
+    const int n = (int)fread(out, 1, (size_t)cap - 1, tmp);
+    out[n > 0 ? n : 0] = 0;
+    fclose(tmp);
+    return n;
+}
 
 /* rotator.h:36-46 (static inline in the reference) */
 void ref_rotator_rotate_n(float *phase, const float *incr, float *out, const float *in, int n)

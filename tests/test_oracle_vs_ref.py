@@ -203,3 +203,75 @@ def test_avx2_variant_differs_only_in_float_rounding(reflib):
     reflib.generic_fir_ccf_dec(fp(pad), 801, fp(x), fp(a), 64, 40)
     reflib.avx2_fir_ccf_dec(fp(pad), 801, fp(x), fp(b), 64, 40)
     assert np.allclose(a, b, rtol=1e-4, atol=1e-4)
+
+
+_RAW_CHILD = r'''
+import ctypes as C, json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import orc, irdm
+R = orc.ref()
+R.ref_frame_output_line.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_float, C.c_float, C.c_int, C.c_float,
+                                    C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_char_p, C.c_int]
+file_info = sys.argv[3]
+fi_keep = C.create_string_buffer(file_info.encode())      # frame_output_init keeps the POINTER (frame_output.c:101-104)
+R.ref_frame_output_init(fi_keep if file_info else None)
+rng = np.random.default_rng(int(sys.argv[4]))
+out = []
+t = 1700000000 * 10**9 + int(rng.integers(0, 10**9))
+demods = []
+for k in range(40):
+    d = irdm.Demod()
+    d.id = int(rng.integers(0, 10**7)) * 10
+    t += int(rng.integers(1, 10**9))
+    d.timestamp = t
+    d.center_frequency = float(rng.uniform(1.616e9, 1.6265e9))
+    d.magnitude = float(np.float32(rng.uniform(-5, 60)))
+    d.noise = float(np.float32(rng.uniform(-140, -80)))
+    d.confidence = int(rng.integers(0, 101))
+    d.level = float(np.float32(rng.uniform(0, 2)))
+    d.n_symbols = int(rng.integers(20, 445))
+    d.n_payload_symbols = d.n_symbols - 12
+    d.n_bits = 2 * d.n_symbols
+    d.ok = 1
+    bits = rng.integers(0, 2, d.n_bits).astype(np.uint8)
+    for i, b in enumerate(bits):
+        d.bits[i] = int(b)
+    demods.append(d)
+    buf = C.create_string_buffer(4096)
+    n = R.ref_frame_output_line(d.id, d.timestamp, d.center_frequency, d.magnitude, d.noise, d.confidence, d.level,
+                                d.n_payload_symbols, d.n_bits, bits.ctypes.data_as(C.POINTER(C.c_uint8)), buf, 4096)
+    assert n > 0
+    out.append(buf.value.decode())
+ours = irdm.format_raw(demods, file_info)                 # product (host C in libirdm_hip.so)
+batch = irdm.format_raw_batch(demods, file_info)
+oracle = []
+t0 = C.c_uint64(0)
+for d in demods:
+    o = orc.Demod.from_buffer_copy(bytes(d))
+    b = C.create_string_buffer(4096)
+    orc.lib().orc_format_raw(C.byref(o), file_info.encode(), C.byref(t0), b, 4096)
+    oracle.append(b.value.decode())
+print(json.dumps(dict(ref=out, ours=ours, oracle=oracle, batch=batch)))
+'''
+
+
+@pytest.mark.parametrize("file_info,seed", [("golden", 1), ("", 2)])
+def test_raw_line_printer_matches_frame_output_c(reflib, file_info, seed):
+    """frame_output_print (frame_output.c:160-199, the reference's object code, stdout captured) vs the oracle's
+    orc_format_raw vs the product's irdm_format_raw / _batch: byte-identical lines for random records, including the
+    automatic "i-<t0>-t1" file info.  Runs in a child process: frame_output.c latches t0 and file_info in statics."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pkg = os.path.join(os.path.dirname(here), "iridium-sniffer_amd")
+    r = subprocess.run([sys.executable, "-c", _RAW_CHILD, here, pkg, file_info, str(seed)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(d["ref"]) == 40
+    assert d["ref"] == d["oracle"] == d["ours"]
+    assert d["batch"] == "".join(d["ref"])
+    assert d["ref"][0].startswith("RAW: golden " if file_info else "RAW: i-17000000")
