@@ -144,6 +144,25 @@ typedef struct {
     float llr[IRDM_MAX_BITS];
 } irdm_demod_t;
 
+/* decoded_frame_t (frame_decode.h:26-60), flattened: the post-demod bit layer's result for one demodulated frame */
+typedef struct {
+    int32_t type;              /* frame_type_t: 0 FRAME_UNKNOWN, 1 FRAME_IRA, 2 FRAME_IBC */
+    int32_t sat_id, beam_id;
+    int32_t pos_xyz[3];        /* ira_data_t */
+    int32_t alt;
+    int32_t n_pages;
+    double lat, lon;
+    uint32_t page_tmsi[12];
+    int32_t page_msc[12];
+    int32_t timeslot, sv_blocking, bc_type;    /* ibc_data_t */
+    uint32_t iri_time;
+    int32_t bch_len;           /* decoded data bits assembled (probe; not in the reference's struct) */
+    int32_t pad;
+    uint64_t id;               /* the frame's burst id */
+    uint64_t timestamp;        /* decoded_frame_t.timestamp */
+    double frequency;          /* decoded_frame_t.frequency = the refined centre frequency */
+} irdm_decoded_t;
+
 typedef struct irdm_pipeline irdm_pipeline_t;
 
 /* burst_detector_create + burst_downmix_create (burst_detect.c:174, burst_downmix.c:223):
@@ -206,6 +225,15 @@ int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, const float
 int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, const int *num_samples,
                           const int *direction, int n, irdm_demod_t *out);
 
+/* Post-demod bit layer alone, batched: frame_decode() (frame_decode.h:63) for n demodulated frames -- access code,
+ * de-interleave, BCH(31,21)/(7,3) syndromes, Chase decoding on the LLRs (use_llr = 0: hard decisions only, as
+ * frame->llr == NULL), IRA / IBC fields.  in[i].bits / llr / n_bits / id / timestamp / center_frequency are read.
+ * out[i].type is 0 when frame_decode() returns 0.  Returns 0 or -1.
+ * With the option "decode_frames" = 1 the pipeline runs the same kernel behind the demodulator and
+ * irdm_poll_decoded returns one record per irdm_poll_demods record, in the same order. */
+int irdm_frame_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_decoded_t *out);
+int irdm_poll_decoded(irdm_pipeline_t *p, irdm_decoded_t *out, int max);
+
 /* ---- time-chunk sharding of ONE stream across GPUs ----
  * The detector is sequential across frames (noise-floor ring, active bursts, ids); exact
  * sharding hands its state from the rank that scanned chunk k to the rank that scans chunk k+1.
@@ -220,7 +248,8 @@ long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap);
 int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n);
 int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start);
 
-/* Options: "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
+/* Options: "decode_frames" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded),
+ * "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
  * "scan_mode" (0 = sparse detector scan with exact dense fallback, 1 = dense scan only).
  * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */
 int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);

@@ -177,6 +177,12 @@ struct irdm_pipeline {
     size_t tiles_cap;
     float2 *d_dec, *d_lpf, *d_rrc_ws, *d_frames, *d_demod_ws, *d_probe;
     DemodOut *d_demod;
+    DecodedOut *d_decoded;      // post-demod bit layer (bitlayer.hip)
+    int2 *d_syn_ra, *d_syn_hdr; // BCH syndrome -> (error count, locator) tables (frame_decode.c:95-135)
+    int *d_nbits;
+    int decode_frames;
+    std::vector<DecodedOut> h_decoded;
+    std::deque<irdm_decoded_t> q_decoded;
     // sparse scan (scan_fast.hip): prefilter lists, status word, pre-chunk snapshot for the dense fallback
     unsigned *d_counts, *d_goff;
     ListEntry *d_entries, *d_compact;
@@ -235,7 +241,8 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_dl_fft, p->d_ul_fft, p->d_rot_incr, p->d_rot_table, p->d_state, p->d_gone,
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
-                     p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod,
+                     p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
+                     p->d_syn_hdr, p->d_nbits,
                      p->d_fir_off, p->d_mag2, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status };
     for (void *q : ptrs)
@@ -436,6 +443,35 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
     AL(p->d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
     AL(p->d_demod, DemodOut, (size_t)p->burst_cap);
+    AL(p->d_decoded, DecodedOut, (size_t)p->burst_cap);
+    AL(p->d_nbits, int, (size_t)p->burst_cap);
+    {
+        // build_syndrome_table (frame_decode.c:95-129): remainder of every 1- and 2-bit error pattern
+        auto rem = [](unsigned poly, unsigned v) {
+            if (!v) return 0u;
+            const int pb = 32 - __builtin_clz(poly);
+            for (int i = 31; i >= pb - 1; i--)
+                if (v & (1u << i)) v ^= poly << (i - pb + 1);
+            return v;
+        };
+        auto build = [&](unsigned poly, int nbits, int max_err, int size) {
+            std::vector<int2> t((size_t)size, make_int2(-1, 0));
+            for (int b1 = 0; b1 < nbits; b1++) {
+                const unsigned v = 1u << b1, r = rem(poly, v);
+                if (r < (unsigned)size) t[r] = make_int2(1, (int)v);
+            }
+            if (max_err >= 2)
+                for (int b1 = 0; b1 < nbits; b1++)
+                    for (int b2 = b1 + 1; b2 < nbits; b2++) {
+                        const unsigned v = (1u << b1) | (1u << b2), r = rem(poly, v);
+                        if (r < (unsigned)size && t[r].x < 0) t[r] = make_int2(2, (int)v);
+                    }
+            return t;
+        };
+        std::vector<int2> ra = build(1207u, 31, 2, 1024), hdr = build(29u, 7, 1, 16);
+        UP(p->d_syn_ra, ra);
+        UP(p->d_syn_hdr, hdr);
+    }
     AL(p->d_probe, float2, p->l_cap);
     {
         const size_t max_frames = p->max_chunk / P.n;
@@ -513,6 +549,36 @@ static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t
         a0 += run;
     }
     return 0;
+}
+
+// DecodedOut (device) -> irdm_decoded_t: lat / lon / alt with the host libm, exactly parse_ira's expressions
+// (frame_decode.c:336-342); they stay zero when fewer than 63 data bits were assembled (:321-322)
+static irdm_decoded_t finish_decoded(const DecodedOut &d, uint64_t id, uint64_t timestamp, double frequency)
+{
+    irdm_decoded_t o;
+    memset(&o, 0, sizeof(o));
+    o.type = d.type;
+    o.sat_id = d.sat_id;
+    o.beam_id = d.beam_id;
+    o.n_pages = d.n_pages;
+    for (int k = 0; k < 3; k++) o.pos_xyz[k] = d.pos_xyz[k];
+    for (int k = 0; k < 12; k++) { o.page_tmsi[k] = d.page_tmsi[k]; o.page_msc[k] = d.page_msc[k]; }
+    o.timeslot = d.timeslot;
+    o.sv_blocking = d.sv_blocking;
+    o.bc_type = d.bc_type;
+    o.iri_time = d.iri_time;
+    o.bch_len = d.bch_len;
+    if (d.type == 1 && d.bch_len >= 63) {
+        const int x = d.pos_xyz[0], y = d.pos_xyz[1], z = d.pos_xyz[2];
+        const double xy = sqrt((double)x * x + (double)y * y);
+        o.lat = atan2((double)z, xy) * 180.0 / M_PI;
+        o.lon = atan2((double)y, (double)x) * 180.0 / M_PI;
+        o.alt = (int)(sqrt((double)x * x + (double)y * y + (double)z * z) * 4.0) - 6378 + 23;
+    }
+    o.id = id;
+    o.timestamp = timestamp;               // decoded_frame_t.timestamp / .frequency (frame_decode.c:418-419)
+    o.frequency = frequency;
+    return o;
 }
 
 static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneBurst *gone_list, int n_gone)
@@ -617,6 +683,15 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
         p->h_demod.resize(nb);
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
                                       hipMemcpyDeviceToHost, p->bstream));
+        if (p->decode_frames) {
+            // post-demod bit layer on the demodulator's device-resident output (frames that failed the unique word
+            // have ok = 0 and decode to FRAME_UNKNOWN)
+            if (launch_frame_decode(p->d_demod, nb, p->d_syn_ra, p->d_syn_hdr, 1, nullptr, p->d_decoded, p->bstream) != 0)
+                return -1;
+            p->h_decoded.resize(nb);
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->h_decoded.data(), p->d_decoded, sizeof(DecodedOut) * nb,
+                                          hipMemcpyDeviceToHost, p->bstream));
+        }
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_demod.data(), p->d_demod, sizeof(DemodOut) * nb,
                                       hipMemcpyDeviceToHost, p->bstream));
         if (p->keep_frame_samples) {
@@ -696,6 +771,7 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
                     o.center_frequency = f.center_frequency;
                 }
                 p->q_demods.push_back(o);
+                if (p->decode_frames) p->q_decoded.push_back(finish_decoded(p->h_decoded[i], o.id, o.timestamp, o.center_frequency));
             }
         }
     }
@@ -1163,7 +1239,8 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     std::deque<irdm_burst_t> qb; std::deque<irdm_frame_info_t> qf; std::deque<std::vector<float>> qs;
     std::deque<irdm_demod_t> qd;
     qb.swap(p->q_bursts); qf.swap(p->q_frames); qs.swap(p->q_frame_samples); qd.swap(p->q_demods);
-    const int keep = p->keep_frame_samples;
+    const int keep = p->keep_frame_samples, dec = p->decode_frames;
+    p->decode_frames = 0;
     const uint64_t tagged = p->tagged;
     std::vector<irdm_burst_t> last; last.swap(p->last_bursts);
     p->keep_frame_samples = 1;
@@ -1179,6 +1256,7 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     }
     p->q_bursts.swap(qb); p->q_frames.swap(qf); p->q_frame_samples.swap(qs); p->q_demods.swap(qd);
     p->keep_frame_samples = keep;
+    p->decode_frames = dec;
     p->tagged = tagged;
     p->last_bursts.swap(last);
     return ret;
@@ -1227,11 +1305,52 @@ extern "C" int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, c
     return 0;
 }
 
+extern "C" int irdm_poll_decoded(irdm_pipeline_t *p, irdm_decoded_t *out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    return drain(p->q_decoded, out, max);
+}
+
+extern "C" int irdm_frame_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_decoded_t *out)
+{
+    if (!p || !in || !out || n < 0) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    std::vector<int> nbits;
+    for (int base = 0; base < n; base += p->burst_cap) {
+        const int nb = std::min(p->burst_cap, n - base);
+        p->h_demod.assign(nb, DemodOut());
+        nbits.assign(nb, 0);
+        for (int i = 0; i < nb; i++) {
+            const irdm_demod_t &f = in[base + i];
+            if (f.n_bits < 0 || f.n_bits > kMaxBits) return -1;
+            DemodOut &d = p->h_demod[i];
+            d.ok = 1;
+            d.n_symbols = f.n_bits / 2;
+            memcpy(d.bits, f.bits, sizeof(d.bits));
+            memcpy(d.llr, f.llr, sizeof(d.llr));
+            nbits[i] = f.n_bits;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_demod, p->h_demod.data(), sizeof(DemodOut) * nb, hipMemcpyHostToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_nbits, nbits.data(), sizeof(int) * nb, hipMemcpyHostToDevice, p->stream));
+        if (launch_frame_decode(p->d_demod, nb, p->d_syn_ra, p->d_syn_hdr, use_llr ? 1 : 0, p->d_nbits, p->d_decoded,
+                                p->stream) != 0)
+            return -1;
+        p->h_decoded.resize(nb);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_decoded.data(), p->d_decoded, sizeof(DecodedOut) * nb, hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        for (int i = 0; i < nb; i++)
+            out[base + i] = finish_decoded(p->h_decoded[i], in[base + i].id, in[base + i].timestamp,
+                                           in[base + i].center_frequency);
+    }
+    return 0;
+}
+
 extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
 {
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
+    if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
     // kernel-variant hooks (process-wide; parity tests and A/B timing): generic runtime-M decimator, radix-2 FFT
     if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }

@@ -89,4 +89,14 @@ struct DemodOut {
     float llr[kMaxBits];
 };
 
+// frame_decode() result per demodulated frame (bitlayer.hip); lat / lon / alt are completed on the host
+struct DecodedOut {
+    int32_t type, sat_id, beam_id, pos_xyz[3], n_pages;
+    uint32_t page_tmsi[12];
+    int32_t page_msc[12];
+    int32_t timeslot, sv_blocking, bc_type;
+    uint32_t iri_time;
+    int32_t bch_len;
+};
+
 }  // namespace irdm

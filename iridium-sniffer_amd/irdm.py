@@ -56,6 +56,15 @@ class Demod(C.Structure):
                 ("llr", C.c_float * MAX_BITS)]
 
 
+class Decoded(C.Structure):
+    _fields_ = [("type", C.c_int32), ("sat_id", C.c_int32), ("beam_id", C.c_int32), ("pos_xyz", C.c_int32 * 3),
+                ("alt", C.c_int32), ("n_pages", C.c_int32), ("lat", C.c_double), ("lon", C.c_double),
+                ("page_tmsi", C.c_uint32 * 12), ("page_msc", C.c_int32 * 12), ("timeslot", C.c_int32),
+                ("sv_blocking", C.c_int32), ("bc_type", C.c_int32), ("iri_time", C.c_uint32),
+                ("bch_len", C.c_int32), ("pad", C.c_int32), ("id", C.c_uint64), ("timestamp", C.c_uint64),
+                ("frequency", C.c_double)]
+
+
 _lib = None
 
 
@@ -91,6 +100,8 @@ def lib():
         L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
+        L.irdm_poll_decoded.argtypes = [C.c_void_p, C.POINTER(Decoded), C.c_int]
+        L.irdm_frame_decode_batch.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int, C.c_int, C.POINTER(Decoded)]
         L.irdm_tagged_bursts.argtypes = [C.c_void_p]
         L.irdm_tagged_bursts.restype = C.c_uint64
         L.irdm_sample_count.argtypes = [C.c_void_p]
@@ -202,6 +213,19 @@ class Pipeline:
         if rc < 0:
             raise RuntimeError("irdm_feed_host failed")
         return rc
+
+    def poll_decoded(self):
+        """irdm_poll_decoded: one Decoded per polled Demod (option "decode_frames" = 1)."""
+        return self._poll(self.L.irdm_poll_decoded, Decoded)
+
+    def frame_decode_batch(self, demods, use_llr=True):
+        """irdm_frame_decode_batch: frame_decode() for a list of Demod records."""
+        n = len(demods)
+        arr = (Demod * max(n, 1))(*demods)
+        out = (Decoded * max(n, 1))()
+        if self.L.irdm_frame_decode_batch(self.h, arr, n, 1 if use_llr else 0, out) != 0:
+            raise RuntimeError("irdm_frame_decode_batch failed")
+        return [out[i] for i in range(n)]
 
     def feed_host_ptr(self, ptr, n_samples):
         """irdm_feed_host on a raw host pointer (e.g. a pinned buffer from host_alloc)."""

@@ -1450,6 +1450,279 @@ int orc_format_raw(const orc_demod_t *f, const char *file_info, uint64_t *t0_io,
 }
 
 /* =====================================================================
+ * Post-demod bit layer: frame_decode() (frame_decode.c)
+ * ===================================================================== */
+#define BL_POLY_RA 1207u   /* BCH(31,21), frame_decode.c:36 */
+#define BL_POLY_HDR 29u    /* BCH(7,3),   frame_decode.c:37 */
+#define BL_CHASE 5         /* frame_decode.c:48 */
+
+static const uint8_t bl_access_dl[24] = { 0,0,1,1,0,0,0,0,0,0,1,1,0,0,0,0,1,1,1,1,0,0,1,1 };   /* :51-53 */
+static const uint8_t bl_access_ul[24] = { 1,1,0,0,1,1,0,0,0,0,1,1,1,1,0,0,1,1,1,1,1,1,0,0 };   /* :54-56 */
+
+typedef struct { int errs; uint32_t locator; } bl_syn_t;
+static bl_syn_t bl_syn_ra[1024], bl_syn_hdr[16];
+static int bl_ready;
+
+static uint32_t bl_bits_to_uint(const uint8_t *b, int n)               /* :66-72 */
+{
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) v = (v << 1) | (b[i] & 1u);
+    return v;
+}
+
+static void bl_uint_to_bits(uint32_t v, uint8_t *b, int n)             /* :74-80 */
+{
+    for (int i = n - 1; i >= 0; i--) { b[i] = (uint8_t)(v & 1u); v >>= 1; }
+}
+
+static uint32_t bl_rem(uint32_t poly, uint32_t val)                     /* gf2_remainder, :82-91 */
+{
+    if (!val) return 0;
+    int pb = 32 - __builtin_clz(poly);
+    for (int i = 31; i >= pb - 1; i--)
+        if (val & (1u << i)) val ^= poly << (i - pb + 1);
+    return val;
+}
+
+static void bl_build(uint32_t poly, int nbits, int max_err, bl_syn_t *syn, int size)   /* :95-129 */
+{
+    for (int i = 0; i < size; i++) { syn[i].errs = -1; syn[i].locator = 0; }
+    for (int b1 = 0; b1 < nbits; b1++) {
+        uint32_t v = 1u << b1, r = bl_rem(poly, v);
+        if (r < (uint32_t)size) { syn[r].errs = 1; syn[r].locator = v; }
+    }
+    if (max_err >= 2)
+        for (int b1 = 0; b1 < nbits; b1++)
+            for (int b2 = b1 + 1; b2 < nbits; b2++) {
+                uint32_t v = (1u << b1) | (1u << b2), r = bl_rem(poly, v);
+                if (r < (uint32_t)size && syn[r].errs < 0) { syn[r].errs = 2; syn[r].locator = v; }
+            }
+}
+
+static void bl_init(void)                                                /* frame_decode_init, :131-135 */
+{
+    if (bl_ready) return;
+    bl_build(BL_POLY_RA, 31, 2, bl_syn_ra, 1024);
+    bl_build(BL_POLY_HDR, 7, 1, bl_syn_hdr, 16);
+    bl_ready = 1;
+}
+
+/* de_interleave (:156-176): odd symbols in reverse -> out1, even symbols in reverse -> out2 */
+static void bl_deint2(const uint8_t *in, uint8_t *o1, uint8_t *o2)
+{
+    int p = 0;
+    for (int s = 31; s >= 1; s -= 2) { o1[p++] = in[2 * s]; o1[p++] = in[2 * s + 1]; }
+    p = 0;
+    for (int s = 30; s >= 0; s -= 2) { o2[p++] = in[2 * s]; o2[p++] = in[2 * s + 1]; }
+}
+
+static void bl_deint2f(const float *in, float *o1, float *o2)           /* :203-215 */
+{
+    int p = 0;
+    for (int s = 31; s >= 1; s -= 2) { o1[p++] = in[2 * s]; o1[p++] = in[2 * s + 1]; }
+    p = 0;
+    for (int s = 30; s >= 0; s -= 2) { o2[p++] = in[2 * s]; o2[p++] = in[2 * s + 1]; }
+}
+
+/* chase_bch_decode_p (:224-295) */
+static int bl_chase(const uint8_t *blk, const float *llr, uint8_t *data, uint8_t *chk)
+{
+    uint32_t val = bl_bits_to_uint(blk, 31);
+    uint32_t syn = bl_rem(BL_POLY_RA, val);
+    if (syn == 0) {
+        bl_uint_to_bits(val >> 10, data, 21);
+        bl_uint_to_bits(val & 0x3FF, chk, 10);
+        return 0;
+    }
+    if (syn < 1024 && bl_syn_ra[syn].errs >= 0) {
+        val ^= bl_syn_ra[syn].locator;
+        bl_uint_to_bits(val >> 10, data, 21);
+        bl_uint_to_bits(val & 0x3FF, chk, 10);
+        return bl_syn_ra[syn].errs;
+    }
+    if (!llr) return -1;
+    int pos[31];
+    for (int i = 0; i < 31; i++) pos[i] = i;
+    for (int i = 0; i < BL_CHASE; i++) {           /* partial selection sort, first minimum wins */
+        int mi = i;
+        for (int j = i + 1; j < 31; j++)
+            if (llr[pos[j]] < llr[pos[mi]]) mi = j;
+        int t = pos[i]; pos[i] = pos[mi]; pos[mi] = t;
+    }
+    uint32_t fm[BL_CHASE];
+    for (int i = 0; i < BL_CHASE; i++) fm[i] = 1u << (30 - pos[i]);
+    uint32_t base = bl_bits_to_uint(blk, 31);
+    for (int mask = 1; mask < (1 << BL_CHASE); mask++) {
+        uint32_t f = base;
+        for (int b = 0; b < BL_CHASE; b++)
+            if (mask & (1 << b)) f ^= fm[b];
+        syn = bl_rem(BL_POLY_RA, f);
+        if (syn == 0) {
+            bl_uint_to_bits(f >> 10, data, 21);
+            bl_uint_to_bits(f & 0x3FF, chk, 10);
+            return 0;
+        }
+        if (syn < 1024 && bl_syn_ra[syn].errs >= 0) {
+            f ^= bl_syn_ra[syn].locator;
+            bl_uint_to_bits(f >> 10, data, 21);
+            bl_uint_to_bits(f & 0x3FF, chk, 10);
+            return bl_syn_ra[syn].errs;
+        }
+    }
+    return -1;
+}
+
+static int bl_parity(const uint8_t *blk, const uint8_t *d, const uint8_t *c)   /* check_parity32, :399-407 */
+{
+    int ones = 0;
+    for (int i = 0; i < 21; i++) ones += d[i];
+    for (int i = 0; i < 10; i++) ones += c[i];
+    ones += blk[31];
+    return (ones % 2) == 0;
+}
+
+static int bl_uint(const uint8_t *b, int n)                              /* extract_uint, :309-315 */
+{
+    int v = 0;
+    for (int i = 0; i < n; i++) v = (v << 1) | b[i];
+    return v;
+}
+
+static int bl_s12(const uint8_t *b)                                       /* extract_signed12, :299-307 */
+{
+    int mag = 0;
+    for (int i = 1; i < 12; i++) mag = (mag << 1) | b[i];
+    return b[0] ? (mag - (1 << 11)) : mag;
+}
+
+/* remaining 64-bit blocks (:478-497, :569-588): appends 2 x 21 data bits per good block pair */
+static void bl_blocks(const uint8_t *data, const float *llr, int offset, int limit, uint8_t *stream, int cap,
+                      int *len)
+{
+    uint8_t di1[32], di2[32], d1[21], d2[21], c1[10], c2[10];
+    float l1[32], l2[32];
+    while (offset + 64 <= limit && *len + 42 <= cap) {
+        bl_deint2(data + offset, di1, di2);
+        if (llr) bl_deint2f(llr + offset, l1, l2);
+        int ea = bl_chase(di1, llr ? l1 : NULL, d1, c1);
+        int eb = bl_chase(di2, llr ? l2 : NULL, d2, c2);
+        if (ea < 0 || eb < 0) break;
+        if (!bl_parity(di1, d1, c1)) break;
+        if (!bl_parity(di2, d2, c2)) break;
+        memcpy(stream + *len, d1, 21); *len += 21;
+        memcpy(stream + *len, d2, 21); *len += 21;
+        offset += 64;
+    }
+}
+
+int orc_frame_decode(const uint8_t *bits, const float *llr_all, int n_bits, orc_decoded_t *out)
+{
+    bl_init();
+    memset(out, 0, sizeof(*out));
+    if (n_bits < 24) return 0;                                           /* :424-425 */
+    int is_dl = memcmp(bits, bl_access_dl, 24) == 0;
+    int is_ul = memcmp(bits, bl_access_ul, 24) == 0;
+    if (!is_dl && !is_ul) return 0;
+    const uint8_t *data = bits + 24;
+    const float *llr = llr_all ? llr_all + 24 : NULL;
+    int data_len = n_bits - 24;
+
+    if (data_len >= 6 + 64) {                                            /* IBC, :441-505 */
+        uint32_t hv = bl_bits_to_uint(data, 6);
+        uint32_t hs = bl_rem(BL_POLY_HDR, hv);
+        int hdr_ok = 0;
+        if (hs == 0) hdr_ok = 1;
+        else if (hs < 16 && bl_syn_hdr[hs].errs >= 0) { hv ^= bl_syn_hdr[hs].locator; hdr_ok = 1; }
+        if (hdr_ok) {
+            uint8_t hd[3], di1[32], di2[32], d1[21], d2[21], c1[10], c2[10];
+            float l1[32], l2[32];
+            bl_uint_to_bits(hv >> 4, hd, 3);
+            bl_deint2(data + 6, di1, di2);
+            if (llr) bl_deint2f(llr + 6, l1, l2);
+            int e1 = bl_chase(di1, llr ? l1 : NULL, d1, c1);
+            int e2 = bl_chase(di2, llr ? l2 : NULL, d2, c2);
+            if (e1 >= 0 && e2 >= 0 && bl_parity(di1, d1, c1) && bl_parity(di2, d2, c2)) {
+                int bc_type = bl_uint(hd, 3);
+                int ibc_max = data_len < 262 ? data_len : 262;
+                uint8_t st[256];
+                int len = 0;
+                memcpy(st, d1, 21); len += 21;
+                memcpy(st + len, d2, 21); len += 21;
+                bl_blocks(data, llr, 6 + 64, ibc_max, st, (int)sizeof(st), &len);
+                out->type = 2;
+                out->bch_len = len;
+                out->bc_type = bc_type;                                  /* parse_ibc, :368-393 */
+                if (len >= 42) {
+                    out->sat_id = bl_uint(st, 7);
+                    out->beam_id = bl_uint(st + 7, 6);
+                    out->timeslot = st[14];
+                    out->sv_blocking = st[15];
+                    if (len >= 84 && bl_uint(st + 42, 6) == 1) {
+                        uint32_t t = 0;
+                        for (int i = 52; i < 84; i++) t = (t << 1) | st[i];
+                        out->iri_time = t;
+                    }
+                }
+                return 1;
+            }
+        }
+    }
+
+    if (data_len >= 96) {                                                /* IRA, :514-595 */
+        uint8_t r1[32], r2[32], r3[32], d1[21], d2[21], d3[21], c1[10], c2[10], c3[10];
+        float a1[32], a2[32], a3[32];
+        int p1 = 0, p2 = 0, p3 = 0;                                      /* de_interleave3, :178-199 */
+        for (int s = 47; s >= 2; s -= 3) { r1[p1++] = data[2 * s]; r1[p1++] = data[2 * s + 1]; }
+        for (int s = 46; s >= 1; s -= 3) { r2[p2++] = data[2 * s]; r2[p2++] = data[2 * s + 1]; }
+        for (int s = 45; s >= 0; s -= 3) { r3[p3++] = data[2 * s]; r3[p3++] = data[2 * s + 1]; }
+        if (llr) {
+            p1 = p2 = p3 = 0;
+            for (int s = 47; s >= 2; s -= 3) { a1[p1++] = llr[2 * s]; a1[p1++] = llr[2 * s + 1]; }
+            for (int s = 46; s >= 1; s -= 3) { a2[p2++] = llr[2 * s]; a2[p2++] = llr[2 * s + 1]; }
+            for (int s = 45; s >= 0; s -= 3) { a3[p3++] = llr[2 * s]; a3[p3++] = llr[2 * s + 1]; }
+        }
+        int e1 = bl_chase(r1, llr ? a1 : NULL, d1, c1);
+        int e2 = bl_chase(r2, llr ? a2 : NULL, d2, c2);
+        int e3 = bl_chase(r3, llr ? a3 : NULL, d3, c3);
+        if (e1 >= 0 && e2 >= 0 && e3 >= 0 && bl_parity(r1, d1, c1) && bl_parity(r2, d2, c2) && bl_parity(r3, d3, c3)) {
+            uint8_t st[512];
+            int len = 0;
+            memcpy(st, d1, 21); len += 21;
+            memcpy(st + len, d2, 21); len += 21;
+            memcpy(st + len, d3, 21); len += 21;
+            bl_blocks(data, llr, 96, data_len, st, (int)sizeof(st), &len);
+            out->type = 1;
+            out->bch_len = len;
+            if (len >= 63) {                                             /* parse_ira, :317-366 */
+                out->sat_id = bl_uint(st, 7);
+                out->beam_id = bl_uint(st + 7, 6);
+                int x = bl_s12(st + 13), y = bl_s12(st + 25), z = bl_s12(st + 37);
+                out->pos_xyz[0] = x; out->pos_xyz[1] = y; out->pos_xyz[2] = z;
+                double xy = sqrt((double)x * x + (double)y * y);
+                out->lat = atan2((double)z, xy) * 180.0 / M_PI;
+                out->lon = atan2((double)y, (double)x) * 180.0 / M_PI;
+                out->alt = (int)(sqrt((double)x * x + (double)y * y + (double)z * z) * 4.0) - 6378 + 23;
+                int off = 63;
+                while (off + 42 <= len && out->n_pages < 12) {
+                    const uint8_t *pg = st + off;
+                    int all1 = 1;
+                    for (int i = 0; i < 42; i++) if (!pg[i]) { all1 = 0; break; }
+                    if (all1) break;
+                    uint32_t tmsi = 0;
+                    for (int i = 0; i < 32; i++) tmsi = (tmsi << 1) | pg[i];
+                    out->page_tmsi[out->n_pages] = tmsi;
+                    out->page_msc[out->n_pages] = bl_uint(pg + 34, 5);
+                    out->n_pages++;
+                    off += 42;
+                }
+            }
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* =====================================================================
  * Whole stream, reference file-mode plumbing (main.c:223-284 spewer,
  * burst_detect.c:941-956, burst_downmix.c:801-824, main.c:307-373)
  * ===================================================================== */

@@ -162,6 +162,28 @@ int orc_qpsk_demod(const orc_frame_t *in, int use_gardner, orc_demod_t *out);
 int orc_format_raw(const orc_demod_t *f, const char *file_info, uint64_t *t0_io,
                    char *buf, size_t cap);
 
+/* ---- post-demod bit layer: frame_decode() (frame_decode.c:414-598), SURVEY 8f row 3 ----
+ * access code, de-interleave, BCH(31,21)/BCH(7,3) syndromes, Chase decoding on the LLRs, IRA / IBC field
+ * extraction.  decoded_frame_t (frame_decode.h:26-60) flattened; bch_len = decoded data bits assembled. */
+typedef struct {
+    int32_t type;            /* frame_type_t: 0 unknown, 1 IRA, 2 IBC */
+    int32_t sat_id, beam_id;
+    int32_t pos_xyz[3];      /* IRA */
+    int32_t alt;
+    int32_t n_pages;
+    double lat, lon;
+    uint32_t page_tmsi[12];
+    int32_t page_msc[12];
+    int32_t timeslot, sv_blocking, bc_type;   /* IBC */
+    uint32_t iri_time;
+    int32_t bch_len;
+    int32_t pad;
+} orc_decoded_t;
+
+/* bits: n_bits hard bits (access code first), llr: n_bits reliabilities or NULL.  Returns frame_decode()'s
+ * return value (1 = IRA or IBC recognised). */
+int orc_frame_decode(const uint8_t *bits, const float *llr, int n_bits, orc_decoded_t *out);
+
 /* ---- whole stream: detect -> downmix -> demod, reference file-mode plumbing ---- */
 typedef struct {
     double center_frequency;

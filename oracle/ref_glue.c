@@ -18,6 +18,7 @@
 
 #include "qpsk_demod.h"   /* reference header (burst_detect.h neutralised by the recipe's -D flags) */
 #include "frame_output.h" /* reference header */
+#include "frame_decode.h" /* reference header */
 #include "rotator.h"      /* reference header */
 #include "simd_kernels.h" /* reference header */
 
@@ -121,3 +122,52 @@ int ref_qpsk_demod(const float *samples, int num_samples, float samples_per_symb
     free(out);
     return 1;
 }
+
+/* frame_decode() (frame_decode.c:414) through a flat interface; the layout of `out` is orc_decoded_t's (irdm_oracle.h) */
+typedef struct {
+    int32_t type, sat_id, beam_id, pos_xyz[3], alt, n_pages;
+    double lat, lon;
+    uint32_t page_tmsi[12];
+    int32_t page_msc[12];
+    int32_t timeslot, sv_blocking, bc_type;
+    uint32_t iri_time;
+    int32_t bch_len, pad;
+} ref_decoded_t;
+
+int ref_frame_decode(const uint8_t *bits, const float *llr, int n_bits, ref_decoded_t *out)
+{
+    static int init;
+    if (!init) { frame_decode_init(); init = 1; }
+    demod_frame_t f;
+    memset(&f, 0, sizeof(f));
+    f.bits = (uint8_t *)bits;
+    f.llr = (float *)llr;
+    f.n_bits = n_bits;
+    decoded_frame_t d;
+    const int r = frame_decode(&f, &d);
+    memset(out, 0, sizeof(*out));
+    out->type = (int32_t)d.type;
+    out->bch_len = -1;                       /* not exposed by the reference */
+    if (d.type == FRAME_IRA) {
+        out->sat_id = d.ira.sat_id;
+        out->beam_id = d.ira.beam_id;
+        out->lat = d.ira.lat;
+        out->lon = d.ira.lon;
+        out->alt = d.ira.alt;
+        for (int i = 0; i < 3; i++) out->pos_xyz[i] = d.ira.pos_xyz[i];
+        out->n_pages = d.ira.n_pages;
+        for (int i = 0; i < d.ira.n_pages && i < 12; i++) {
+            out->page_tmsi[i] = d.ira.pages[i].tmsi;
+            out->page_msc[i] = d.ira.pages[i].msc_id;
+        }
+    } else if (d.type == FRAME_IBC) {
+        out->sat_id = d.ibc.sat_id;
+        out->beam_id = d.ibc.beam_id;
+        out->timeslot = d.ibc.timeslot;
+        out->sv_blocking = d.ibc.sv_blocking;
+        out->bc_type = d.ibc.bc_type;
+        out->iri_time = d.ibc.iri_time;
+    }
+    return r;
+}
+
