@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--samples", type=int, default=64 * 1024 * 1024, help="samples per chunk per GPU")
     ap.add_argument("--density", type=float, default=10.0, help="bursts per Msample")
     ap.add_argument("--sample-rate", type=int, default=10_000_000)
+    ap.add_argument("--format", choices=("cf32", "ci16", "ci8"), default="cf32",
+                    help="device sample format of the chunk (the headline metric is cf32; ci16 / ci8 = the reference's "
+                         "integer file formats, quantised from the same scene)")
     ap.add_argument("--depth", type=int, default=1,
                     help="pipeline_depth: 1 (default) = the detector scan of chunk k stays in flight while chunk k-1's "
                          "per-burst stages and chunk k+1's FFT run (results one chunk later, identical); 0 = every "
@@ -110,7 +113,14 @@ def main():
     x, nb = build_scene(torch, device, fs, n, args.density, seed=2 + rank)
     torch.cuda.synchronize()
 
-    pipe = irdm.Pipeline(fs, fmt=irdm.FMT_CF32, max_chunk_samples=n, max_bursts_per_chunk=8192,
+    fmt = {"cf32": irdm.FMT_CF32, "ci16": irdm.FMT_CI16, "ci8": irdm.FMT_CI8}[args.format]
+    bps = {"cf32": 8, "ci16": 4, "ci8": 2}[args.format]
+    if args.format == "ci16":       # siggen.to_ci16: x * 131072, rounded, clipped
+        x = torch.clamp(torch.round(x * 131072.0), -32768, 32767).to(torch.int16)
+    elif args.format == "ci8":      # siggen.to_ci8 with headroom for the burst peaks
+        x = torch.clamp(torch.round(x * 512.0 * 4), -128, 127).to(torch.int8)
+    torch.cuda.synchronize()
+    pipe = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192,
                          device=local, pipeline_depth=args.depth)
     pipe.L.irdm_feed_device.restype = C.c_int
     for kv in args.opt:
@@ -212,9 +222,9 @@ def main():
     decim = int(round(fs / 250000.0))
     lb = totals["burst_samples"] / K
     alg_bytes = {
-        "fft_mag": 8.0 * n,                       # one read of every cf32 sample
+        "fft_mag": float(bps) * n,                # one read of every sample (B_det's b_in: 8 / 4 / 2 bytes)
         "scan": 8.0 * n,                          # history row read + write per bin-frame (B_det = 16 B/sample with K1)
-        "fir": 8.0 * lb + 8.0 * lb / decim,       # burst-window re-read + decimated write
+        "fir": float(bps) * lb + 8.0 * lb / decim,   # burst-window re-read + decimated (cf32) write
     }
     kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "detect_scan_fast_kernel", "fir": "fir_decimate_kernel"}
     dom = max(alg_bytes, key=lambda k: ms[k])
@@ -243,7 +253,7 @@ def main():
     # ---- PCIe-inclusive rate: the same chunk fed from pinned host memory (never `value`) ----
     pcie = None
     if rank == 0 and world == 1 and args.host_steps > 0:
-        nbytes = n * 8
+        nbytes = n * bps
         hptr, hview = irdm.host_alloc(nbytes)
         hview[:] = x.view(torch.uint8).reshape(-1).cpu().numpy()
         for _ in range(2):
@@ -261,7 +271,7 @@ def main():
         hdt = time.perf_counter() - th
         pcie = {"value": round(n * args.host_steps / hdt / 1e6, 2), "unit": "Msamples/s",
                 "h2d_GBps": round(nbytes * args.host_steps / hdt / 1e9, 2), "steps": args.host_steps,
-                "note": "irdm_feed_host from pinned host memory, cf32 (8 B/sample over PCIe); H2D of chunk k+1 "
+                "note": "irdm_feed_host from pinned host memory, %s (%d B/sample over PCIe); H2D of chunk k+1 " % (args.format, bps) +
                         "overlaps the detector scan of chunk k"}
         irdm.host_free(hptr)
 
@@ -270,10 +280,13 @@ def main():
     if rank == 0 and world == 1 and args.cpu_samples > 0:
         import orc
         m = min(n, args.cpu_samples) // 32768 * 32768
-        host = x[:m].cpu().numpy().view(np.complex64).reshape(-1)
+        if args.format == "cf32":
+            host = x[:m].cpu().numpy().view(np.complex64).reshape(-1)
+        else:
+            host = x[:m].cpu().numpy().reshape(-1)
         t1 = time.perf_counter()
         for _ in range(max(args.cpu_passes, 1)):
-            ref = orc.run_stream(host, fs, cap_bursts=8192)
+            ref = orc.run_stream(host, fs, fmt=int(fmt), cap_bursts=8192)
         cdt = time.perf_counter() - t1
         cpu = {"value": round(max(args.cpu_passes, 1) * m / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                "kind": "port",
@@ -283,13 +296,13 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz cf32" % (fs // 1_000_000),
+            "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz %s" % (fs // 1_000_000, args.format),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg3: %d MHz cf32 full pipeline (detect + downmix/FIR/CFO + Gardner DQPSK), "
+            "config": {"workload": "cfg3: %d MHz %s full pipeline (detect + downmix/FIR/CFO + Gardner DQPSK), "
                                    "%d-pt detect, %d samples/GPU/step resident in HBM, %.0f bursts/Msample"
-                                   % (fs // 1_000_000, pipe.fft_size, n, args.density),
+                                   % (fs // 1_000_000, args.format, pipe.fft_size, n, args.density),
                        "samples_per_step_per_gpu": n, "bursts_per_step": totals["bursts"] / K,
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
