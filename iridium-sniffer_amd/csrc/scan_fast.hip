@@ -305,6 +305,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     // workgroup barrier that orders LDS only: the history-row stores of a bulk command stay in flight (each thread
     // re-reads only rows it wrote itself, in program order), __syncthreads() would wait ~1 us for their acknowledgement
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // branch-layout hint: the rare paths (aborts, capacity checks, squelch, forced updates) are moved out of the
+    // leader's straight-line code
+#define RARE(c) __builtin_expect(!!(c), 0)
+#define LIKELY(c) __builtin_expect(!!(c), 1)
 #define WAVE_SYNC() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define BIN_OF(j) ((((j) >> 2) * kFastThreads + tid) * 4 + ((j) & 3))
 #define VALID_BIN(b) ((b) >= half_bw && (b) < N - half_bw && !((b) >= dc - 3 && (b) <= dc + 3))
@@ -422,10 +426,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             // ================= leader step: run until a dense command is needed =================
             int cmd = -1, c_f0 = 0, c_run = 0, c_detect = 0;
             while (cmd < 0) {
-                if (abort_code || (state == S_TOP && f >= n_frames)) { cmd = CMD_EXIT; break; }
+                if (RARE(abort_code || (state == S_TOP && f >= n_frames))) { cmd = CMD_EXIT; break; }
                 if (state == S_TOP) {
                     const long long tT_ = IRDM_TICK();
-                    if (!primed) {
+                    if (RARE(!primed)) {
                         // update_filters_pre returns 0 (:427-428): updates only, up to the priming frame
                         int run = kHistory - hist_idx;
                         if (run > n_frames - f) run = n_frames - f;
@@ -433,14 +437,14 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         f += run;
                         break;
                     }
-                    if (f < sb || f >= sb + snf) {
+                    if (RARE(f < sb || f >= sb + snf)) {
                         const long long t0_ = IRDM_TICK();
                         // ---- stage the compact lists of up to kStageFrames frames starting at f ----
                         const int nf = n_frames - f < kStageFrames ? n_frames - f : kStageFrames;
                         unsigned g = 0, c = 0;
                         if (lane <= nf) g = goff[f + lane];
                         if (lane < nf) c = counts[f + lane];
-                        if (__any(c > (unsigned)kListCap)) { abort_code |= 8; continue; }
+                        if (RARE(__any(c > (unsigned)kListCap))) { abort_code |= 8; continue; }
                         const unsigned g0 = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
                         r_off = g - g0;
                         const unsigned long long fit =
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (cand && n_cand + __popcll(cm & lt_mask) < kCandCap) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
                             n_cand += __popcll(cm);
                         }
-                        if (n_cand > kCandCap) { abort_code |= 32; continue; }
+                        if (RARE(n_cand > kCandCap)) { abort_code |= 32; continue; }
                         WAVE_SYNC();
                         if (n_cand == 0) {
                             if (squelch > 0) squelch--;                           // :629-630
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 
                     // ---------------- busy ----------------
                     const int total = __builtin_amdgcn_readlane((int)r_off, snf);
-                    if (!cross_valid) {
+                    if (RARE(!cross_valid)) {
                         const long long t0_ = IRDM_TICK();
                         // s_crossT[bin] = frames (>= f) of the batch in which `bin` crosses: exact
                         // simd_relative_mag + `> threshold` with the (frozen) baseline.  One pass over the
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         }
                         }
                         cross_cmd_done = false;
-                        if (n_bins > kMaxBins) { abort_code |= 64; continue; }
+                        if (RARE(n_bins > kMaxBins)) { abort_code |= 64; continue; }
                         WAVE_SYNC();
                         cross_valid = true;
                         hc_valid = false;
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     if ((occ >> lane) & 1) {
                         // expiry (:505): first frame k with no hit in (k - gap, k] and k >= last_active + gap
                         unsigned D;
-                        if (gap_frames >= 32) {
+                        if (RARE(gap_frames >= 32)) {
                             D = Hm ? ~((1u << __builtin_ctz(Hm)) - 1u) : 0u;     // no expiry at or after a hit within one batch
                         } else {
                             D = Hm;
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         if (up) r_la = idx_base + ((uint64_t)(31 - __builtin_clz(up)) << log_n);
                     }
                     TK(3, t3_);
-                    if (E >= snf) {
+                    if (RARE(E >= snf)) {
                         const int cnt = snf - k0;
                         squelch = squelch > cnt ? squelch - cnt : 0;                  // :629-630 per frame
                         f = sb + snf;
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     e1 = __builtin_amdgcn_readlane((int)r_off, k + 1);
                     const uint64_t idx = index0 + (uint64_t)f * N;
                     n_cand = 0;
-                    if (!any_cand && ev_del && (ev_del & (ev_del - 1)) == 0) {
+                    if (LIKELY(!any_cand && ev_del && (ev_del & (ev_del - 1)) == 0)) {
                         // ---- common case 1: exactly one burst ends, nothing can start ----
                         const int sl = __builtin_ctzll(ev_del);
                         const int cbd = __builtin_amdgcn_readlane(r_cb, sl);
@@ -683,10 +687,10 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         if (squelch > 0) squelch--;                               // create_new_bursts' else branch (:629-630)
                         state = S_FRAME_END;
                         TK(12, t4_);
-                        if (force) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; break; }
+                        if (RARE(force)) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; break; }
                         continue;
                     }
-                    if (any_cand && e1 - e0 <= 64 && !ev_del) {
+                    if (LIKELY(any_cand && e1 - e0 <= 64 && !ev_del)) {
                         // ---- common case 2: bursts may start, none ends; the frame's entries fit the lanes ----
                         const int i = e0 + lane;
                         float c_rel = -1.0f;
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (key == 0ull) break;
                             const float br = __uint_as_float((unsigned)(key >> 32));
                             const int bb = (int)~(unsigned)key;
-                            if (occ == ~0ull) { abort_code |= 4; break; }
+                            if (RARE(occ == ~0ull)) { abort_code |= 4; break; }
                             const int sl = __builtin_ctzll(~occ);
                             if (lane == sl) {
                                 r_cb = bb;
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (cand && n_cand + __popcll(cm & lt_mask) < kCandCap) s_cand[n_cand + __popcll(cm & lt_mask)] = c;
                             n_cand += __popcll(cm);
                         }
-                        if (n_cand > kCandCap) { abort_code |= 32; continue; }
+                        if (RARE(n_cand > kCandCap)) { abort_code |= 32; continue; }
                         WAVE_SYNC();
                     }
                     // delete_gone_bursts (:490-518): emitted in list order == ascending id
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     }
                     state = S_CPLX_B;
                     TK(4, t4_);
-                    if (force) {                                                  // update_filters_post(d, 1)
+                    if (RARE(force)) {                                            // update_filters_post(d, 1)
                         cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0;
                         break;
                     }
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         if (key == 0ull) break;
                         const float br = __uint_as_float((unsigned)(key >> 32));
                         const int bb = (int)~(unsigned)key;
-                        if (occ == ~0ull) { abort_code |= 4; break; }
+                        if (RARE(occ == ~0ull)) { abort_code |= 4; break; }
                         const int sl = __builtin_ctzll(~occ);
                         if (lane == sl) {
                             r_cb = bb;
@@ -837,9 +841,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         WAVE_SYNC();
                         hc_valid = false;
                     }
-                    if (abort_code) continue;
+                    if (RARE(abort_code)) continue;
                     bool reset = false;
-                    if (P.max_bursts > 0 && __popcll(occ) > P.max_bursts) {       // squelch (:594-631)
+                    if (RARE(P.max_bursts > 0 && __popcll(occ) > P.max_bursts)) { // squelch (:594-631)
                         const bool mine = ((occ >> lane) & 1) && r_start != index - (uint64_t)P.pre_len;
                         const unsigned long long om = __ballot(mine);
                         int rank = 0;
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     WAVE_SYNC();
                     state = S_FRAME_END;
                     TK(5, t5_);
-                    if (reset) { cmd = CMD_ZERO; break; }
+                    if (RARE(reset)) { cmd = CMD_ZERO; break; }
                     continue;
                 }
                 // S_FRAME_END: update_filters_post(d, 0) (:698)
@@ -881,7 +885,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 state = S_TOP;
                 if (occ == 0 || !primed) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
                 else if (was_quiet || hist_idx != hist_before) { cmd = CMD_VALIDATE; }
-                if (n_gone - gone_base > (unsigned)(kGoneLds - 40)) { WAVE_SYNC(); FLUSH_GONE(); }
+                if (RARE(n_gone - gone_base > (unsigned)(kGoneLds - 40))) { WAVE_SYNC(); FLUSH_GONE(); }
                 f++;
                 TK(8, tE_);
             }
@@ -1028,6 +1032,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     for (int j = 0; j < J; j++) sum_g[BIN_OF(j)] = s_sum[BIN_OF(j)];
 #undef TK
 #undef WAVE_SYNC
+#undef RARE
+#undef LIKELY
 #undef LDS_BARRIER
 #undef BIN_OF
 #undef VALID_BIN
