@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     was_quiet = occ == 0;
                     hist_before = hist_idx;
 
-                    if (occ == 0) {
+                    if (RARE(occ == 0)) {
                         // ---------------- quiet ----------------
                         // frames with an empty list are updated in bulk, every thread re-checking its own
                         // bins exactly (safety net)
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                                 WAVE_SYNC();
                             }
                         }
-                        if (hc_valid && !force) {
+                        if (LIKELY(hc_valid && !force)) {
                             // candidate frames can only gain the later crossings of the freed bins
                             int lo_ = cbd - half_bw, hi_ = cbd + half_bw;
                             if (lo_ < 0) lo_ = 0;
@@ -809,7 +809,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     const uint64_t index = index0 + (uint64_t)f * N;
                     // create_new_bursts (:556-591): descending magnitude, ties by ascending bin, skipping
                     // bins masked by bursts created earlier in the same frame == repeated arg-max
-                    while (n_cand > 0) {
+                    while (RARE(n_cand > 0)) {
                         // key = (rel bits, ~bin): rel > 0, so its IEEE bits order like the value; the larger key
                         // is the larger rel, ties the smaller bin
                         unsigned long long key = 0ull;
@@ -883,8 +883,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 // S_FRAME_END: update_filters_post(d, 0) (:698)
                 const long long tE_ = IRDM_TICK();
                 state = S_TOP;
-                if (occ == 0 || !primed) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
-                else if (was_quiet || hist_idx != hist_before) { cmd = CMD_VALIDATE; }
+                if (RARE(occ == 0 || !primed)) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
+                else if (RARE(was_quiet || hist_idx != hist_before)) { cmd = CMD_VALIDATE; }
                 if (RARE(n_gone - gone_base > (unsigned)(kGoneLds - 40))) { WAVE_SYNC(); FLUSH_GONE(); }
                 f++;
                 TK(8, tE_);
