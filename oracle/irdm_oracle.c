@@ -1723,6 +1723,346 @@ int orc_frame_decode(const uint8_t *bits, const float *llr_all, int n_bits, orc_
 }
 
 /* =====================================================================
+ * Post-demod bit layer: ida_decode() (ida_decode.c)
+ * ===================================================================== */
+#define DA_POLY 3545u      /* BCH(31,20), ida_decode.c:33 */
+static bl_syn_t da_syn[2048], da_syn1[16], da_syn2[256], da_syn3[32];
+static int da_ready;
+
+static const int da_perm[46] = {                                        /* ida_decode.c:54-60 */
+    40, 39, 36, 35, 32, 31, 28, 27, 24, 23, 20, 19, 16, 15, 12, 11, 8, 7, 4, 3,
+    41, 38, 37, 34, 33, 30, 29, 26, 25, 22, 21, 18, 17, 14, 13, 10, 9, 6, 5, 2,
+    1, 46, 45, 44, 43, 42
+};
+
+static void da_init(void)                                                /* ida_decode_init, :96-102 */
+{
+    if (da_ready) return;
+    bl_build(DA_POLY, 31, 2, da_syn, 2048);
+    bl_build(29u, 7, 1, da_syn1, 16);
+    bl_build(465u, 14, 1, da_syn2, 256);
+    bl_build(41u, 26, 2, da_syn3, 32);
+    da_ready = 1;
+}
+
+/* chase_bch_da (:107-172) */
+static int da_chase(const uint8_t *blk, const float *llr, uint8_t *data, int *fixed)
+{
+    uint32_t val = bl_bits_to_uint(blk, 31);
+    uint32_t syn = bl_rem(DA_POLY, val);
+    if (syn == 0) { bl_uint_to_bits(val >> 11, data, 20); *fixed = 0; return 0; }
+    if (syn < 2048 && da_syn[syn].errs >= 0) {
+        val ^= da_syn[syn].locator;
+        bl_uint_to_bits(val >> 11, data, 20);
+        *fixed = 1;
+        return da_syn[syn].errs;
+    }
+    if (!llr) return -1;
+    int pos[31];
+    for (int i = 0; i < 31; i++) pos[i] = i;
+    for (int i = 0; i < BL_CHASE; i++) {
+        int mi = i;
+        for (int j = i + 1; j < 31; j++)
+            if (llr[pos[j]] < llr[pos[mi]]) mi = j;
+        int t = pos[i]; pos[i] = pos[mi]; pos[mi] = t;
+    }
+    uint32_t fm[BL_CHASE];
+    for (int i = 0; i < BL_CHASE; i++) fm[i] = 1u << (30 - pos[i]);
+    uint32_t base = bl_bits_to_uint(blk, 31);
+    for (int mask = 1; mask < (1 << BL_CHASE); mask++) {
+        uint32_t f = base;
+        for (int b = 0; b < BL_CHASE; b++)
+            if (mask & (1 << b)) f ^= fm[b];
+        syn = bl_rem(DA_POLY, f);
+        if (syn == 0) { bl_uint_to_bits(f >> 11, data, 20); *fixed = 1; return 0; }
+        if (syn < 2048 && da_syn[syn].errs >= 0) {
+            f ^= da_syn[syn].locator;
+            bl_uint_to_bits(f >> 11, data, 20);
+            *fixed = 1;
+            return da_syn[syn].errs;
+        }
+    }
+    return -1;
+}
+
+static void da_deint(const uint8_t *in, int n_sym, uint8_t *o1, uint8_t *o2)   /* de_interleave_n, :259-272 */
+{
+    int p = 0;
+    for (int s = n_sym - 1; s >= 1; s -= 2) { o1[p++] = in[2 * s]; o1[p++] = in[2 * s + 1]; }
+    p = 0;
+    for (int s = n_sym - 2; s >= 0; s -= 2) { o2[p++] = in[2 * s]; o2[p++] = in[2 * s + 1]; }
+}
+
+static void da_deintf(const float *in, int n_sym, float *o1, float *o2)        /* :176-189 */
+{
+    int p = 0;
+    for (int s = n_sym - 1; s >= 1; s -= 2) { o1[p++] = in[2 * s]; o1[p++] = in[2 * s + 1]; }
+    p = 0;
+    for (int s = n_sym - 2; s >= 0; s -= 2) { o2[p++] = in[2 * s]; o2[p++] = in[2 * s + 1]; }
+}
+
+/* decode_lcw (:193-252) */
+static int da_lcw(const uint8_t *data, int data_len, orc_ida_t *o)
+{
+    if (data_len < 46) return 0;
+    uint8_t sw[46], lb[46];
+    for (int i = 0; i < 46; i += 2) { sw[i] = data[i + 1]; sw[i + 1] = data[i]; }
+    for (int i = 0; i < 46; i++) lb[i] = sw[da_perm[i] - 1];
+    uint32_t v1 = bl_bits_to_uint(lb, 7), s1 = bl_rem(29u, v1);
+    if (s1 != 0) {
+        if (s1 >= 16 || da_syn1[s1].errs < 0) return 0;
+        v1 ^= da_syn1[s1].locator;
+    }
+    int ft = (int)(v1 >> 4) & 7;
+    uint32_t v2 = bl_bits_to_uint(lb + 7, 13) << 1, s2 = bl_rem(465u, v2);
+    if (s2 != 0) {
+        if (s2 >= 256 || da_syn2[s2].errs < 0) return 0;
+        v2 ^= da_syn2[s2].locator;
+    }
+    uint32_t v3 = bl_bits_to_uint(lb + 20, 26), s3 = bl_rem(41u, v3);
+    if (s3 != 0) {
+        if (s3 >= 32 || da_syn3[s3].errs < 0) return 0;
+        v3 ^= da_syn3[s3].locator;
+    }
+    int d2 = (int)(v2 >> 8) & 0x3F;
+    o->ft = ft;
+    o->lcw_ft = (d2 >> 4) & 3;
+    o->lcw_code = d2 & 0xF;
+    o->lcw3_val = (uint32_t)((int)(v3 >> 5));
+    o->ec_lcw = (s1 != 0) + (s2 != 0) + (s3 != 0);
+    return 1;
+}
+
+/* descramble_payload (:276-377) */
+static int da_descramble(const uint8_t *data, const float *llr, int data_len, uint8_t *st, int max_bch, int *fixederrs)
+{
+    int len = 0;
+    *fixederrs = 0;
+    int n_full = data_len / 124, remain = data_len % 124;
+    for (int blk = 0; blk < n_full; blk++) {
+        const uint8_t *b = data + blk * 124;
+        const float *bl = llr ? llr + blk * 124 : NULL;
+        uint8_t comb[124];
+        float lcomb[124];
+        da_deint(b, 62, comb, comb + 62);
+        if (bl) da_deintf(bl, 62, lcomb, lcomb + 62);
+        static const int order[4] = { 3, 1, 2, 0 };
+        for (int c = 0; c < 4; c++) {
+            if (len + 20 > max_bch) break;
+            int off = order[c] * 31, fixed = 0;
+            uint8_t od[20];
+            int e = da_chase(comb + off, bl ? lcomb + off : NULL, od, &fixed);
+            if (e < 0) return len;
+            *fixederrs += fixed;
+            memcpy(st + len, od, 20);
+            len += 20;
+        }
+    }
+    if (remain >= 4 && len + 2 * (remain / 2 - 1) <= max_bch) {
+        int ns = remain / 2;
+        uint8_t h1[64], h2[64];
+        float l1[64], l2[64];
+        const float *ll = llr ? llr + n_full * 124 : NULL;
+        da_deint(data + n_full * 124, ns, h1, h2);
+        if (ll) da_deintf(ll, ns, l1, l2);
+        if (ns > 1 && len + 20 <= max_bch) {
+            uint8_t comb[128];
+            float lcomb[128];
+            int cl = 0;
+            for (int i = 1; i < ns && cl < 128; i++) { comb[cl] = h2[i]; if (ll) lcomb[cl] = l2[i]; cl++; }
+            for (int i = 1; i < ns && cl < 128; i++) { comb[cl] = h1[i]; if (ll) lcomb[cl] = l1[i]; cl++; }
+            int pos = 0;
+            while (pos + 31 <= cl && len + 20 <= max_bch) {
+                uint8_t od[20];
+                int fixed = 0;
+                int e = da_chase(comb + pos, ll ? lcomb + pos : NULL, od, &fixed);
+                if (e < 0) break;
+                *fixederrs += fixed;
+                memcpy(st + len, od, 20);
+                len += 20;
+                pos += 31;
+            }
+        }
+    }
+    return len;
+}
+
+static uint16_t da_crc(const uint8_t *d, int n)                          /* crc_ccitt, :381-394 */
+{
+    uint16_t crc = 0xFFFF;
+    for (int i = 0; i < n; i++) {
+        crc ^= (uint16_t)((uint16_t)d[i] << 8);
+        for (int j = 0; j < 8; j++)
+            crc = (crc & 0x8000) ? (uint16_t)((crc << 1) ^ 0x1021) : (uint16_t)(crc << 1);
+    }
+    return crc;
+}
+
+static int da_bits(const char *b, int from, int to)                      /* MSB-first field of the lcw3 bit string */
+{
+    int v = 0;
+    for (int i = from; i < to; i++) v = (v << 1) | (b[i] - '0');
+    return v;
+}
+
+/* format_lcw_header (:405-539) */
+void orc_format_lcw_header(int ft, int lcw_ft, int lcw_code, uint32_t lcw3_val, char *out, int outsz)
+{
+    char b[32], code[128], rem[64], raw[128];
+    const char *ty;
+    for (int i = 0; i < 21; i++) b[i] = (char)('0' + ((lcw3_val >> (20 - i)) & 1));
+    b[21] = 0;
+    switch (lcw_ft) {
+    case 0:
+        ty = "maint";
+        switch (lcw_code) {
+        case 0:
+            snprintf(code, sizeof(code), "sync[status:%d,dtoa:%d,dfoa:%d]", b[1] - '0', da_bits(b, 3, 13), da_bits(b, 13, 21));
+            snprintf(rem, sizeof(rem), "%c|%c", b[0], b[2]);
+            break;
+        case 1:
+            snprintf(code, sizeof(code), "switch[dtoa:%d,dfoa:%d]", da_bits(b, 3, 13), da_bits(b, 13, 21));
+            snprintf(rem, sizeof(rem), "%.3s", b);
+            break;
+        case 3:
+            snprintf(code, sizeof(code), "maint[2][lqi:%d,power:%d,f_dtoa:%d,f_dfoa:%d]",
+                     (b[1] - '0') * 2 + (b[2] - '0'), da_bits(b, 3, 6), da_bits(b, 6, 13), da_bits(b, 13, 20));
+            snprintf(rem, sizeof(rem), "%c|%c", b[0], b[20]);
+            break;
+        case 6:
+            snprintf(code, sizeof(code), "geoloc");
+            snprintf(rem, sizeof(rem), "%s", b);
+            break;
+        case 12:
+            snprintf(code, sizeof(code), "maint[1][lqi:%d,power:%d]", (b[19] - '0') * 2 + (b[20] - '0'), da_bits(b, 16, 19));
+            b[16] = 0;
+            snprintf(rem, sizeof(rem), "%s", b);
+            break;
+        case 15:
+            snprintf(code, sizeof(code), "<silent>");
+            snprintf(rem, sizeof(rem), "%s", b);
+            break;
+        default:
+            snprintf(code, sizeof(code), "rsrvd(%d)", lcw_code);
+            snprintf(rem, sizeof(rem), "%s", b);
+            break;
+        }
+        break;
+    case 1:
+        ty = "acchl";
+        if (lcw_code == 1) {
+            char segm[16];
+            memcpy(segm, b + 8, 8);
+            segm[8] = 0;
+            snprintf(code, sizeof(code), "acchl[msg_type:%01x,bloc_num:%01x,sapi_code:%01x,segm_list:%s]",
+                     da_bits(b, 1, 4), b[4] - '0', da_bits(b, 5, 8), segm);
+            snprintf(rem, sizeof(rem), "%c,%02x", b[0], da_bits(b, 16, 21));
+        } else {
+            snprintf(code, sizeof(code), "rsrvd(%d)", lcw_code);
+            snprintf(rem, sizeof(rem), "%s", b);
+        }
+        break;
+    case 2:
+        ty = "hndof";
+        switch (lcw_code) {
+        case 3:
+            snprintf(code, sizeof(code),
+                     "handoff_resp[cand:%c,denied:%d,ref:%d,slot:%d,sband_up:%d,sband_dn:%d,access:%d]",
+                     (b[2] - '0') == 0 ? 'P' : 'S', b[3] - '0', b[4] - '0', 1 + (b[6] - '0') * 2 + (b[7] - '0'),
+                     da_bits(b, 8, 13), da_bits(b, 13, 18), da_bits(b, 18, 21) + 1);
+            snprintf(rem, sizeof(rem), "%.2s,%c", b, b[5]);
+            break;
+        case 12: {
+            char first[12], second[11];
+            memcpy(first, b, 11); first[11] = 0;
+            memcpy(second, b + 11, 10); second[10] = 0;
+            snprintf(code, sizeof(code), "handoff_cand");
+            snprintf(rem, sizeof(rem), "%s,%s", first, second);
+            break;
+        }
+        case 15:
+            snprintf(code, sizeof(code), "<silent>");
+            snprintf(rem, sizeof(rem), "%s", b);
+            break;
+        default:
+            snprintf(code, sizeof(code), "rsrvd(%d)", lcw_code);
+            snprintf(rem, sizeof(rem), "%s", b);
+            break;
+        }
+        break;
+    default:
+        ty = "rsrvd";
+        snprintf(code, sizeof(code), "<%d>", lcw_code);
+        snprintf(rem, sizeof(rem), "%s", b);
+        break;
+    }
+    snprintf(raw, sizeof(raw), "LCW(%d,T:%s,C:%s,%s)", ft, ty, code, rem);
+    snprintf(out, (size_t)outsz, "%-110s ", raw);
+}
+
+int orc_ida_decode(const uint8_t *bits, const float *llr_all, int n_bits, int direction, orc_ida_t *o)
+{
+    bl_init();
+    da_init();
+    memset(o, 0, sizeof(*o));
+    if (n_bits < 24 + 46 + 124) return 0;                                /* :547-548 */
+    if (direction != 1 && direction != 2) return 0;                      /* :551-552 */
+    const uint8_t *data = bits + 24;
+    const float *llr = llr_all ? llr_all + 24 : NULL;
+    int data_len = n_bits - 24;
+    orc_ida_t lcw;
+    memset(&lcw, 0, sizeof(lcw));
+    if (!da_lcw(data, data_len, &lcw)) return 0;
+    if (lcw.ft != 2) return 0;
+    int payload_len = data_len - 46;
+    if (payload_len < 124) return 0;
+    uint8_t st[512];
+    int fixederrs = 0;
+    int len = da_descramble(data + 46, llr ? llr + 46 : NULL, payload_len, st, (int)sizeof(st), &fixederrs);
+    if (len < 196) return 0;                                             /* :577-578 */
+    int cont = st[3];
+    int da_ctr = (st[5] << 2) | (st[6] << 1) | st[7];
+    int da_len = (st[11] << 4) | (st[12] << 3) | (st[13] << 2) | (st[14] << 1) | st[15];
+    int zero1 = (st[17] << 2) | (st[18] << 1) | st[19];
+    if (zero1 != 0) return 0;
+    if (da_len > 20) return 0;
+    uint8_t payload[20];
+    for (int i = 0; i < 20; i++) {
+        uint8_t by = 0;
+        for (int b = 0; b < 8; b++) by = (uint8_t)((by << 1) | st[20 + i * 8 + b]);
+        payload[i] = by;
+    }
+    int crc_ok = 0;
+    uint16_t stored = 0, computed = 0;
+    if (da_len > 0 && len >= 196) {                                      /* :606-637 */
+        for (int i = 0; i < 16; i++) stored = (uint16_t)((stored << 1) | st[9 * 20 + i]);
+        int crc_bits = 20 + 12 + (len - 20 - 4);
+        int crc_bytes = (crc_bits + 7) / 8;
+        uint8_t buf[64];
+        if (crc_bytes <= (int)sizeof(buf)) {
+            memset(buf, 0, sizeof(buf));
+            int bp = 0;
+            for (int i = 0; i < 20; i++) { buf[bp / 8] |= (uint8_t)(st[i] << (7 - (bp % 8))); bp++; }
+            bp += 12;
+            for (int i = 20; i < len - 4; i++) { buf[bp / 8] |= (uint8_t)(st[i] << (7 - (bp % 8))); bp++; }
+            computed = da_crc(buf, (bp + 7) / 8);
+            crc_ok = computed == 0;
+        }
+    }
+    o->ok = 1;
+    o->ft = lcw.ft; o->lcw_ft = lcw.lcw_ft; o->lcw_code = lcw.lcw_code; o->ec_lcw = lcw.ec_lcw; o->lcw3_val = lcw.lcw3_val;
+    o->da_ctr = da_ctr; o->da_len = da_len; o->cont = cont; o->crc_ok = crc_ok;
+    o->stored_crc = stored; o->computed_crc = computed;
+    o->fixederrs = fixederrs;
+    o->payload_len = da_len > 0 ? da_len : 20;
+    memcpy(o->payload, payload, (size_t)o->payload_len);
+    o->bch_len = len;
+    memcpy(o->bch_stream, st, (size_t)(len < 256 ? len : 256));
+    orc_format_lcw_header(lcw.ft, lcw.lcw_ft, lcw.lcw_code, lcw.lcw3_val, o->lcw_header, (int)sizeof(o->lcw_header));
+    return 1;
+}
+
+/* =====================================================================
  * Whole stream, reference file-mode plumbing (main.c:223-284 spewer,
  * burst_detect.c:941-956, burst_downmix.c:801-824, main.c:307-373)
  * ===================================================================== */

@@ -184,6 +184,26 @@ typedef struct {
  * return value (1 = IRA or IBC recognised). */
 int orc_frame_decode(const uint8_t *bits, const float *llr, int n_bits, orc_decoded_t *out);
 
+/* ida_decode() (ida_decode.c:543-665): LCW extraction (3 BCH codes behind a 46-bit permutation), payload descramble
+ * (124-bit blocks -> 4 x BCH(31,20) with Chase decoding), IDA fields, CRC-CCITT, LCW header text.
+ * ida_burst_t (ida_decode.h:31-56) flattened, minus the fields copied from the demod record. */
+typedef struct {
+    int32_t ok;                 /* ida_decode()'s return value */
+    int32_t ft, lcw_ft, lcw_code, ec_lcw;
+    uint32_t lcw3_val;
+    int32_t da_ctr, da_len, cont, crc_ok;
+    uint32_t stored_crc, computed_crc;
+    int32_t fixederrs, payload_len, bch_len, pad;
+    uint8_t payload[32];
+    uint8_t bch_stream[256];
+    char lcw_header[128];
+} orc_ida_t;
+
+/* direction: the demodulator's ir_direction_t (0 undefined -> rejected, ida_decode.c:551-552) */
+int orc_ida_decode(const uint8_t *bits, const float *llr, int n_bits, int direction, orc_ida_t *out);
+/* format_lcw_header (ida_decode.c:405-539): "LCW(ft,T:..,C:..,..)" padded to 110 characters + one space */
+void orc_format_lcw_header(int ft, int lcw_ft, int lcw_code, uint32_t lcw3_val, char *out, int outsz);
+
 /* ---- whole stream: detect -> downmix -> demod, reference file-mode plumbing ---- */
 typedef struct {
     double center_frequency;

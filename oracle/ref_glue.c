@@ -19,6 +19,7 @@
 #include "qpsk_demod.h"   /* reference header (burst_detect.h neutralised by the recipe's -D flags) */
 #include "frame_output.h" /* reference header */
 #include "frame_decode.h" /* reference header */
+#include "ida_decode.h"   /* reference header */
 #include "rotator.h"      /* reference header */
 #include "simd_kernels.h" /* reference header */
 
@@ -169,5 +170,52 @@ int ref_frame_decode(const uint8_t *bits, const float *llr, int n_bits, ref_deco
         out->iri_time = d.ibc.iri_time;
     }
     return r;
+}
+
+/* ida_decode() (ida_decode.c:543) through a flat interface; the layout of `out` is orc_ida_t's (irdm_oracle.h) */
+typedef struct {
+    int32_t ok, ft, lcw_ft, lcw_code, ec_lcw;
+    uint32_t lcw3_val;
+    int32_t da_ctr, da_len, cont, crc_ok;
+    uint32_t stored_crc, computed_crc;
+    int32_t fixederrs, payload_len, bch_len, pad;
+    uint8_t payload[32];
+    uint8_t bch_stream[256];
+    char lcw_header[128];
+} ref_ida_t;
+
+int ref_ida_decode(const uint8_t *bits, const float *llr, int n_bits, int direction, ref_ida_t *out)
+{
+    static int init;
+    if (!init) { frame_decode_init(); ida_decode_init(); init = 1; }
+    demod_frame_t f;
+    memset(&f, 0, sizeof(f));
+    f.bits = (uint8_t *)bits;
+    f.llr = (float *)llr;
+    f.n_bits = n_bits;
+    f.direction = (ir_direction_t)direction;
+    ida_burst_t b;
+    const int r = ida_decode(&f, &b);
+    memset(out, 0, sizeof(*out));
+    out->ok = r;
+    if (!r) return 0;
+    out->ft = b.lcw.ft;
+    out->lcw_ft = b.lcw.lcw_ft;
+    out->lcw_code = b.lcw.lcw_code;
+    out->ec_lcw = b.lcw.ec_lcw;
+    out->lcw3_val = b.lcw.lcw3_val;
+    out->da_ctr = b.da_ctr;
+    out->da_len = b.da_len;
+    out->cont = b.cont;
+    out->crc_ok = b.crc_ok;
+    out->stored_crc = b.stored_crc;
+    out->computed_crc = b.computed_crc;
+    out->fixederrs = b.fixederrs;
+    out->payload_len = b.payload_len;
+    out->bch_len = b.bch_len;
+    memcpy(out->payload, b.payload, sizeof(out->payload));
+    memcpy(out->bch_stream, b.bch_stream, sizeof(out->bch_stream));
+    memcpy(out->lcw_header, b.lcw_header, sizeof(out->lcw_header));
+    return 1;
 }
 

@@ -115,3 +115,89 @@ def corrupt(bits, rng, n_errors, first=24, reliable=1.0, weak=0.05, mark=True, e
     for i in rng.choice(np.arange(first, len(bits)), size=min(extra_weak, len(bits) - first), replace=False):
         llr[i] = weak * float(rng.random())
     return bits, llr
+
+
+# ---------------------------------------------------------------- IDA (ida_decode.c) ----
+POLY_DA, POLY_LCW2, POLY_LCW3 = 3545, 465, 41
+LCW_PERM = [40, 39, 36, 35, 32, 31, 28, 27, 24, 23, 20, 19, 16, 15, 12, 11, 8, 7, 4, 3,
+            41, 38, 37, 34, 33, 30, 29, 26, 25, 22, 21, 18, 17, 14, 13, 10, 9, 6, 5, 2,
+            1, 46, 45, 44, 43, 42]
+
+
+def lcw_bits(ft, d5, lcw3):
+    """46 on-air LCW bits: lcw1 = BCH(7,3) of ft, lcw2 = 13-bit codeword of 5 data bits (generator 465; the decoder reads
+    its top 6 bits as lcw_ft (2) + lcw_code (4)), lcw3 = BCH(26,21) of lcw3; permuted and pair-swapped as the air
+    interface does (inverse of decode_lcw's two steps)"""
+    v1 = (ft << 4) | gf2_rem(POLY_HDR, ft << 4)
+    v2 = (d5 << 8) | gf2_rem(POLY_LCW2, d5 << 8)
+    v3 = (lcw3 << 5) | gf2_rem(POLY_LCW3, lcw3 << 5)
+    lb = to_bits(v1, 7) + to_bits(v2, 13) + to_bits(v3, 26)
+    swapped = [0] * 46
+    for i in range(46):
+        swapped[LCW_PERM[i] - 1] = lb[i]
+    data = [0] * 46
+    for i in range(0, 46, 2):
+        data[i + 1], data[i] = swapped[i], swapped[i + 1]
+    return data
+
+
+def crc_ccitt(data):
+    crc = 0xFFFF
+    for b in data:
+        crc ^= b << 8
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x1021) & 0xFFFF if crc & 0x8000 else (crc << 1) & 0xFFFF
+    return crc
+
+
+def ida_stream(da_ctr, da_len, cont, payload20, rng, good_crc=True):
+    """200 decoded bits: header (cont @3, ctr @5-7, len @11-15, zero @17-19), 20 payload bytes, CRC-CCITT, 4 spare"""
+    hdr = [int(b) for b in rng.integers(0, 2, 20)]
+    hdr[3] = cont
+    hdr[5:8] = to_bits(da_ctr, 3)
+    hdr[11:16] = to_bits(da_len, 5)
+    hdr[17:20] = [0, 0, 0]
+    pl = []
+    for by in payload20:
+        pl += to_bits(by, 8)
+    msg_bits = hdr + [0] * 12 + pl
+    msg = [int("".join(map(str, msg_bits[i:i + 8])), 2) for i in range(0, len(msg_bits), 8)]
+    crc = crc_ccitt(msg)
+    if not good_crc:
+        crc ^= 0x0101
+    return hdr + pl + to_bits(crc, 16) + [int(b) for b in rng.integers(0, 2, 4)]
+
+
+def da_block31(data20):
+    v = int("".join(map(str, data20)), 2)
+    return to_bits((v << 11) | gf2_rem(POLY_DA, v << 11), 31)
+
+
+def interleave_n(h1, h2, n_sym):
+    """inverse of de_interleave_n: h1 <- symbols n-1, n-3, ..; h2 <- symbols n-2, n-4, .."""
+    out = [0] * (2 * n_sym)
+    p = 0
+    for s in range(n_sym - 1, 0, -2):
+        out[2 * s], out[2 * s + 1] = h1[p], h1[p + 1]
+        p += 2
+    p = 0
+    for s in range(n_sym - 2, -1, -2):
+        out[2 * s], out[2 * s + 1] = h2[p], h2[p + 1]
+        p += 2
+    return out
+
+
+def ida_frame(lcw, stream200, rng, uplink=False):
+    """access code + LCW + two 124-bit blocks (chunks in air order 3,1,2,0) + the 64-bit tail block = 382 bits"""
+    assert len(stream200) == 200
+    ch = [da_block31(stream200[i:i + 20]) for i in range(0, 200, 20)]
+    bits = list(ACCESS_UL if uplink else ACCESS_DL) + list(lcw)
+    for blk in range(2):
+        s = ch[4 * blk:4 * blk + 4]
+        comb = s[3] + s[1] + s[2] + s[0]
+        bits += interleave_n(comb[:62], comb[62:], 62)
+    h2 = [int(rng.integers(0, 2))] + ch[8]
+    h1 = [int(rng.integers(0, 2))] + ch[9]
+    bits += interleave_n(h1, h2, 32)
+    assert len(bits) == 382
+    return bits

@@ -98,3 +98,91 @@ def test_oracle_matches_frame_decode_c(oracle, reflib, seed):
         assert ro == rr and as_tuple(do) == as_tuple(dr), (ro, rr, as_tuple(do), as_tuple(dr))
         kinds[do.type] += 1
     assert kinds[1] >= 20 and kinds[2] >= 10 and kinds[0] >= 20, kinds      # IRA, IBC and rejected frames all occur
+
+
+class Ida(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("ft", C.c_int32), ("lcw_ft", C.c_int32), ("lcw_code", C.c_int32),
+                ("ec_lcw", C.c_int32), ("lcw3_val", C.c_uint32), ("da_ctr", C.c_int32), ("da_len", C.c_int32),
+                ("cont", C.c_int32), ("crc_ok", C.c_int32), ("stored_crc", C.c_uint32), ("computed_crc", C.c_uint32),
+                ("fixederrs", C.c_int32), ("payload_len", C.c_int32), ("bch_len", C.c_int32), ("pad", C.c_int32),
+                ("payload", C.c_uint8 * 32), ("bch_stream", C.c_uint8 * 256), ("lcw_header", C.c_char * 128)]
+
+
+def ida_decode_with(fn, bits, llr, direction):
+    b = np.ascontiguousarray(bits, np.uint8)
+    d = Ida()
+    lp = None if llr is None else np.ascontiguousarray(llr, np.float32).ctypes.data_as(C.POINTER(C.c_float))
+    r = fn(b.ctypes.data_as(C.POINTER(C.c_uint8)), lp, len(b), direction, C.byref(d))
+    return r, d
+
+
+def make_ida_cases(seed, n=120):
+    rng = np.random.default_rng(1000 + seed)
+    cases = []
+    for k in range(n):
+        ft = 2 if k % 8 else int(rng.integers(0, 8))                    # mostly IDA (ft == 2)
+        lcw = bl.lcw_bits(ft, int(rng.integers(0, 32)), int(rng.integers(0, 1 << 21)))
+        da_len = int(rng.integers(0, 21)) if k % 9 else int(rng.integers(21, 32))
+        st = bl.ida_stream(int(rng.integers(0, 8)), da_len, int(rng.integers(0, 2)),
+                           [int(b) for b in rng.integers(0, 256, 20)], rng, good_crc=bool(k % 5))
+        if k % 11 == 0:
+            st[17 + int(rng.integers(0, 3))] = 1                          # the "zero" field set -> rejected
+        bits = bl.ida_frame(lcw, st, rng, uplink=bool(k % 3 == 0))
+        n_err = int(rng.choice([0, 0, 1, 2, 4, 7, 12, 25]))
+        bits, llr = bl.corrupt(bits, rng, n_err, mark=bool(rng.integers(0, 4)), extra_weak=int(rng.integers(0, 6)))
+        if rng.integers(0, 10) == 0:
+            cut = int(rng.integers(150, len(bits)))
+            bits, llr = bits[:cut], llr[:cut]
+        direction = 2 if k % 3 == 0 else (1 if k % 13 else 0)            # direction 0 = undefined -> rejected
+        cases.append((bits, None if rng.integers(0, 6) == 0 else llr, direction))
+    return cases
+
+
+def ida_tuple(d):
+    return (d.ok, d.ft, d.lcw_ft, d.lcw_code, d.ec_lcw, d.lcw3_val, d.da_ctr, d.da_len, d.cont, d.crc_ok, d.stored_crc,
+            d.computed_crc, d.fixederrs, d.payload_len, d.bch_len, bytes(d.payload), bytes(d.bch_stream), d.lcw_header)
+
+
+def test_ida_encoder_round_trip_through_the_oracle(oracle):
+    oracle.orc_ida_decode.restype = C.c_int
+    rng = np.random.default_rng(9)
+    payload = list(range(100, 120))
+    st = bl.ida_stream(5, 17, 1, payload, rng)
+    r, d = ida_decode_with(oracle.orc_ida_decode, bl.ida_frame(bl.lcw_bits(2, 0b00011, 0x12345), st, rng), None, 1)
+    assert r == 1 and (d.ft, d.da_ctr, d.da_len, d.cont, d.crc_ok, d.bch_len, d.fixederrs) == (2, 5, 17, 1, 1, 200, 0)
+    assert list(d.payload[:17]) == payload[:17] and d.lcw3_val == 0x12345 and d.ec_lcw == 0
+    assert d.lcw_header.decode().startswith("LCW(2,T:maint,C:") and len(d.lcw_header.decode()) == 111
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_matches_ida_decode_c(oracle, reflib, seed):
+    oracle.orc_ida_decode.restype = C.c_int
+    reflib.ref_ida_decode.restype = C.c_int
+    n_ok = n_crc = n_rej = 0
+    for bits, llr, direction in make_ida_cases(seed):
+        ro, do = ida_decode_with(oracle.orc_ida_decode, bits, llr, direction)
+        rr, dr = ida_decode_with(reflib.ref_ida_decode, bits, llr, direction)
+        assert ro == rr and ida_tuple(do) == ida_tuple(dr), (ida_tuple(do)[:16], ida_tuple(dr)[:16])
+        n_ok += ro
+        n_crc += do.crc_ok
+        n_rej += 1 - ro
+    assert n_ok >= 30 and n_crc >= 10 and n_rej >= 20, (n_ok, n_crc, n_rej)
+
+
+def test_lcw_header_text_for_every_type_and_code(oracle, reflib):
+    """format_lcw_header's switch (ida_decode.c:405-539): every (lcw_ft, lcw_code) pair with random lcw3 values, through
+    whole frames so the reference's own formatter runs"""
+    oracle.orc_ida_decode.restype = C.c_int
+    reflib.ref_ida_decode.restype = C.c_int
+    rng = np.random.default_rng(77)
+    seen = set()
+    for d5 in range(32):
+        for rep in range(6):
+            lcw3 = int(rng.integers(0, 1 << 21))
+            st = bl.ida_stream(1, 20, 0, [0] * 20, rng)
+            bits = bl.ida_frame(bl.lcw_bits(2, d5, lcw3), st, rng)
+            ro, do = ida_decode_with(oracle.orc_ida_decode, bits, None, 1)
+            rr, dr = ida_decode_with(reflib.ref_ida_decode, bits, None, 1)
+            assert ro == rr == 1 and do.lcw_header == dr.lcw_header, (d5, do.lcw_header, dr.lcw_header)
+            seen.add((do.lcw_ft, do.lcw_code))
+    assert len(seen) == 32          # the 5 encodable data bits reach 32 of the 64 (type, code) pairs
