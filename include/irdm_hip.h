@@ -163,6 +163,26 @@ typedef struct {
     double frequency;          /* decoded_frame_t.frequency = the refined centre frequency */
 } irdm_decoded_t;
 
+/* ida_burst_t (ida_decode.h:31-56), flattened: one IDA burst after LCW + BCH decoding, before multi-burst reassembly */
+typedef struct {
+    int32_t ok;                /* ida_decode()'s return value */
+    int32_t ft, lcw_ft, lcw_code, ec_lcw;      /* lcw_t */
+    uint32_t lcw3_val;
+    int32_t da_ctr, da_len, cont, crc_ok;
+    uint32_t stored_crc, computed_crc;
+    int32_t fixederrs, payload_len, bch_len;
+    int32_t direction;         /* ir_direction_t of the frame */
+    uint8_t payload[32];
+    uint8_t bch_stream[256];
+    char lcw_header[128];      /* "LCW(...)" padded to 110 characters + one space (format_lcw_header) */
+    uint64_t id;               /* the frame's burst id */
+    uint64_t timestamp;
+    double frequency;
+    float magnitude, noise, level;
+    int32_t confidence, n_symbols;             /* n_symbols = the frame's payload symbols (ida_decode.c:648) */
+    int32_t pad;
+} irdm_ida_t;
+
 typedef struct irdm_pipeline irdm_pipeline_t;
 
 /* burst_detector_create + burst_downmix_create (burst_detect.c:174, burst_downmix.c:223):
@@ -233,6 +253,12 @@ int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, const int *n
  * irdm_poll_decoded returns one record per irdm_poll_demods record, in the same order. */
 int irdm_frame_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_decoded_t *out);
 int irdm_poll_decoded(irdm_pipeline_t *p, irdm_decoded_t *out, int max);
+/* ida_decode() (ida_decode.h) the same way: LCW extraction, payload descramble, BCH(31,20) + Chase, CRC-CCITT.
+ * in[i].direction is the demodulator's direction.  Option "decode_ida" = 1 runs it in the pipeline;
+ * irdm_poll_ida returns one record per irdm_poll_demods record (ok = 0 when ida_decode() returns 0).
+ * Multi-burst reassembly (ida_reassemble) stays on the host and consumes these records. */
+int irdm_ida_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_ida_t *out);
+int irdm_poll_ida(irdm_pipeline_t *p, irdm_ida_t *out, int max);
 
 /* ---- time-chunk sharding of ONE stream across GPUs ----
  * The detector is sequential across frames (noise-floor ring, active bursts, ids); exact
@@ -248,7 +274,8 @@ long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap);
 int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n);
 int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start);
 
-/* Options: "decode_frames" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded),
+/* Options: "decode_frames" / "decode_ida" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded /
+ * irdm_poll_ida),
  * "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
  * "scan_mode" (0 = sparse detector scan with exact dense fallback, 1 = dense scan only).
  * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */

@@ -245,6 +245,233 @@ __global__ __launch_bounds__(64) void frame_decode_kernel(const DemodOut *__rest
     out[i] = o;
 }
 
+// ---------------------------------------------------------------------------
+// ida_decode() (ida_decode.c:543-665): Link Control Word (46 bits behind a pair swap and a permutation, three BCH
+// codes, :193-252), payload descramble (124-bit blocks = 62 symbols de-interleaved into two halves, four 31-bit
+// BCH(31,20) chunks in the order 3,1,2,0, then the short tail block with the first bit of each half dropped,
+// :276-377), Chase decoding on the LLRs (:107-172), IDA header fields and CRC-CCITT (:580-637).
+// One lane per frame; a chunk's 31 bits / LLRs are gathered through the index maps into registers / scratch.
+// ---------------------------------------------------------------------------
+namespace {
+
+__constant__ int c_lcw_perm[46] = {                                     // ida_decode.c:54-60
+    40, 39, 36, 35, 32, 31, 28, 27, 24, 23, 20, 19, 16, 15, 12, 11, 8, 7, 4, 3,
+    41, 38, 37, 34, 33, 30, 29, 26, 25, 22, 21, 18, 17, 14, 13, 10, 9, 6, 5, 2,
+    1, 46, 45, 44, 43, 42
+};
+
+// chase_bch_da (:107-172) on a gathered chunk: cw = 31 bits (first bit at position 30), l = its LLRs or nullptr
+__device__ int chase_da(unsigned cw, const float *l, const int2 *__restrict__ syn_da, unsigned *out, int *fixed)
+{
+    unsigned syn = gf2_rem(3545u, 12, cw);
+    if (syn == 0) { *out = cw; *fixed = 0; return 0; }
+    if (syn < 2048 && syn_da[syn].x >= 0) { *out = cw ^ (unsigned)syn_da[syn].y; *fixed = 1; return syn_da[syn].x; }
+    if (!l) return -1;
+    int pos[31];
+    for (int i = 0; i < 31; i++) pos[i] = i;
+    for (int i = 0; i < kChase; i++) {
+        int mi = i;
+        float mv = l[pos[i]];
+        for (int j = i + 1; j < 31; j++) {
+            const float v = l[pos[j]];
+            if (v < mv) { mv = v; mi = j; }
+        }
+        const int t = pos[i]; pos[i] = pos[mi]; pos[mi] = t;
+    }
+    unsigned fm[kChase];
+    for (int i = 0; i < kChase; i++) fm[i] = 1u << (30 - pos[i]);
+    for (int mask = 1; mask < (1 << kChase); mask++) {
+        unsigned f = cw;
+        for (int k = 0; k < kChase; k++)
+            if (mask & (1 << k)) f ^= fm[k];
+        syn = gf2_rem(3545u, 12, f);
+        if (syn == 0) { *out = f; *fixed = 1; return 0; }
+        if (syn < 2048 && syn_da[syn].x >= 0) { *out = f ^ (unsigned)syn_da[syn].y; *fixed = 1; return syn_da[syn].x; }
+    }
+    return -1;
+}
+
+// position j of de_interleave_n's out1 (half == 0) / out2 (half == 1) -> input bit index (:259-272)
+__device__ __forceinline__ int deint_index(int n_sym, int half, int j)
+{
+    const int s = (n_sym - 1 - half) - 2 * (j >> 1);
+    return 2 * s + (j & 1);
+}
+
+__device__ __forceinline__ void put20(uint8_t *stream, int &len, unsigned corrected)
+{
+    const unsigned d = (corrected >> 11) & 0xfffffu;
+    for (int i = 0; i < 20; i++) stream[len + i] = (uint8_t)((d >> (19 - i)) & 1u);
+    len += 20;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void ida_decode_kernel(const DemodOut *__restrict__ frames, int n_frames,
+                                                        const int2 *__restrict__ syn_da,
+                                                        const int2 *__restrict__ syn_l1, const int2 *__restrict__ syn_l2,
+                                                        const int2 *__restrict__ syn_l3, int use_llr,
+                                                        const int *__restrict__ n_bits_in,
+                                                        const int *__restrict__ direction_in,
+                                                        IdaOut *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_frames) return;
+    const DemodOut &f = frames[i];
+    IdaOut &o = out[i];
+    o.ok = 0;
+    const int n_bits = n_bits_in ? n_bits_in[i] : (f.ok ? 2 * f.n_symbols : 0);
+    const int direction = direction_in ? direction_in[i] : f.direction;
+    if (n_bits < 24 + 46 + 124) return;                                 // :547-548
+    if (direction != 1 && direction != 2) return;                       // :551-552
+    const uint8_t *data = f.bits + 24;
+    const float *llr = use_llr ? f.llr + 24 : nullptr;
+    const int data_len = n_bits - 24;
+
+    // ---- decode_lcw (:193-252): lcw_bits[i] = swapped[perm[i] - 1], swapped[k] = data[k ^ 1]
+    unsigned v1 = 0, v2 = 0, v3 = 0;
+    for (int k = 0; k < 46; k++) {
+        const unsigned b = (unsigned)(data[(c_lcw_perm[k] - 1) ^ 1] & 1);
+        if (k < 7) v1 = (v1 << 1) | b;
+        else if (k < 20) v2 = (v2 << 1) | b;
+        else v3 = (v3 << 1) | b;
+    }
+    v2 <<= 1;                                                           // 13 bits + trailing zero (:222)
+    const unsigned s1 = gf2_rem(29u, 5, v1), s2 = gf2_rem(465u, 9, v2), s3 = gf2_rem(41u, 6, v3);
+    if (s1 != 0) { if (s1 >= 16 || syn_l1[s1].x < 0) return; v1 ^= (unsigned)syn_l1[s1].y; }
+    if (s2 != 0) { if (s2 >= 256 || syn_l2[s2].x < 0) return; v2 ^= (unsigned)syn_l2[s2].y; }
+    if (s3 != 0) { if (s3 >= 32 || syn_l3[s3].x < 0) return; v3 ^= (unsigned)syn_l3[s3].y; }
+    const int ft = (int)(v1 >> 4) & 7;
+    if (ft != 2) return;                                                // :563-564
+    const int d2 = (int)(v2 >> 8) & 0x3F;
+    const int payload_len = data_len - 46;
+    if (payload_len < 124) return;
+    const uint8_t *pd = data + 46;
+    const float *pl = llr ? llr + 46 : nullptr;
+
+    // ---- descramble_payload (:276-377)
+    uint8_t st[512];                                                    // the reference's bch_stream[512] (:571); the record keeps 256
+    int len = 0, fixederrs = 0;
+    const int max_bch = 512;
+    const int n_full = payload_len / 124, remain = payload_len % 124;
+    bool failed = false;
+    for (int blk = 0; blk < n_full && !failed; blk++) {
+        const uint8_t *b = pd + blk * 124;
+        const float *bl = pl ? pl + blk * 124 : nullptr;
+        for (int c = 0; c < 4; c++) {
+            if (len + 20 > max_bch) break;
+            const int off = (c == 0 ? 3 : c == 1 ? 1 : c == 2 ? 2 : 0) * 31;
+            unsigned cw = 0;
+            float l[31];
+            for (int k = 0; k < 31; k++) {
+                const int j = off + k;
+                const int idx = j < 62 ? deint_index(62, 0, j) : deint_index(62, 1, j - 62);
+                cw = (cw << 1) | (unsigned)(b[idx] & 1);
+                l[k] = bl ? bl[idx] : 0.0f;
+            }
+            unsigned cor;
+            int fixed = 0;
+            if (chase_da(cw, bl ? l : nullptr, syn_da, &cor, &fixed) < 0) { failed = true; break; }
+            fixederrs += fixed;
+            put20(st, len, cor);
+        }
+    }
+    if (!failed && remain >= 4 && len + 2 * (remain / 2 - 1) <= max_bch) {
+        const int ns = remain / 2;
+        const uint8_t *b = pd + n_full * 124;
+        const float *bl = pl ? pl + n_full * 124 : nullptr;
+        if (ns > 1 && len + 20 <= max_bch) {
+            const int hl = ns - 1;                                      // each half without its first bit
+            int clen = 2 * hl;
+            if (clen > 128) clen = 128;
+            int pos = 0;
+            while (pos + 31 <= clen && len + 20 <= max_bch) {
+                unsigned cw = 0;
+                float l[31];
+                for (int k = 0; k < 31; k++) {
+                    const int t = pos + k;                              // combined = h2[1..] then h1[1..]
+                    const int idx = t < hl ? deint_index(ns, 1, t + 1) : deint_index(ns, 0, t - hl + 1);
+                    cw = (cw << 1) | (unsigned)(b[idx] & 1);
+                    l[k] = bl ? bl[idx] : 0.0f;
+                }
+                unsigned cor;
+                int fixed = 0;
+                if (chase_da(cw, bl ? l : nullptr, syn_da, &cor, &fixed) < 0) break;
+                fixederrs += fixed;
+                put20(st, len, cor);
+                pos += 31;
+            }
+        }
+    }
+    if (len < 196) return;                                              // :577-578
+
+    const int cont = st[3];
+    const int da_ctr = (st[5] << 2) | (st[6] << 1) | st[7];
+    const int da_len = (st[11] << 4) | (st[12] << 3) | (st[13] << 2) | (st[14] << 1) | st[15];
+    if (((st[17] << 2) | (st[18] << 1) | st[19]) != 0) return;
+    if (da_len > 20) return;
+    for (int k = 0; k < 32; k++) o.payload[k] = 0;
+    const int plen = da_len > 0 ? da_len : 20;
+    for (int k = 0; k < plen; k++) {
+        unsigned by = 0;
+        for (int b = 0; b < 8; b++) by = (by << 1) | st[20 + k * 8 + b];
+        o.payload[k] = (uint8_t)by;
+    }
+    int crc_ok = 0;
+    unsigned stored = 0, computed = 0;
+    if (da_len > 0) {                                                   // CRC-CCITT-FALSE over the re-packed bits (:606-637)
+        for (int k = 0; k < 16; k++) stored = (stored << 1) | st[9 * 20 + k];
+        const int crc_bits = 20 + 12 + (len - 20 - 4);
+        if ((crc_bits + 7) / 8 <= 64) {
+            unsigned crc = 0xFFFFu;
+            int nb = 0;
+            unsigned cur = 0;
+            // bit-serial: feed the message bits MSB-first, byte-wise zero padding at the end as the packed buffer has
+            const int total_bits = ((crc_bits + 7) / 8) * 8;
+            for (int bp = 0; bp < total_bits; bp++) {
+                unsigned bit = 0;
+                if (bp < 20) bit = st[bp];
+                else if (bp >= 32 && bp < crc_bits) bit = st[20 + (bp - 32)];
+                cur = (cur << 1) | bit;
+                if (++nb == 8) {
+                    crc ^= (cur & 0xffu) << 8;
+                    for (int j = 0; j < 8; j++) crc = (crc & 0x8000u) ? ((crc << 1) ^ 0x1021u) & 0xffffu : (crc << 1) & 0xffffu;
+                    nb = 0;
+                    cur = 0;
+                }
+            }
+            computed = crc;
+            crc_ok = computed == 0;
+        }
+    }
+    for (int k = 0; k < 256; k++) o.bch_stream[k] = k < len ? st[k] : (uint8_t)0;
+    o.ft = ft;
+    o.lcw_ft = (d2 >> 4) & 3;
+    o.lcw_code = d2 & 0xF;
+    o.lcw3_val = v3 >> 5;
+    o.ec_lcw = (s1 != 0) + (s2 != 0) + (s3 != 0);
+    o.da_ctr = da_ctr;
+    o.da_len = da_len;
+    o.cont = cont;
+    o.crc_ok = crc_ok;
+    o.stored_crc = stored;
+    o.computed_crc = computed;
+    o.fixederrs = fixederrs;
+    o.payload_len = plen;
+    o.bch_len = len;
+    o.ok = 1;
+}
+
+int launch_ida_decode(const DemodOut *frames, int n_frames, const int2 *syn_da, const int2 *syn_l1, const int2 *syn_l2,
+                      const int2 *syn_l3, int use_llr, const int *n_bits, const int *direction, IdaOut *out,
+                      hipStream_t stream)
+{
+    if (n_frames <= 0) return 0;
+    hipLaunchKernelGGL(ida_decode_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, stream, frames, n_frames, syn_da,
+                       syn_l1, syn_l2, syn_l3, use_llr, n_bits, direction, out);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_frame_decode(const DemodOut *frames, int n_frames, const int2 *syn_ra, const int2 *syn_hdr, int use_llr,
                         const int *n_bits, DecodedOut *out, hipStream_t stream)
 {

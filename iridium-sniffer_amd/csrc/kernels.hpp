@@ -53,6 +53,9 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int d
                          float sps, float2 *rrc_ws, float2 *frames, hipStream_t stream);
 
 // demod.hip
+int launch_ida_decode(const DemodOut *frames, int n_frames, const int2 *syn_da, const int2 *syn_l1, const int2 *syn_l2,
+                      const int2 *syn_l3, int use_llr, const int *n_bits, const int *direction, IdaOut *out,
+                      hipStream_t stream);
 int launch_frame_decode(const DemodOut *frames, int n_frames, const int2 *syn_ra, const int2 *syn_hdr, int use_llr,
                         const int *n_bits, DecodedOut *out, hipStream_t stream);
 int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,

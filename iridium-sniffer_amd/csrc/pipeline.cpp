@@ -180,7 +180,12 @@ struct irdm_pipeline {
     DecodedOut *d_decoded;      // post-demod bit layer (bitlayer.hip)
     int2 *d_syn_ra, *d_syn_hdr; // BCH syndrome -> (error count, locator) tables (frame_decode.c:95-135)
     int *d_nbits;
-    int decode_frames;
+    int decode_frames, decode_ida;
+    IdaOut *d_ida;
+    int2 *d_syn_da, *d_syn_l1, *d_syn_l2, *d_syn_l3;
+    int *d_dirs;
+    std::vector<IdaOut> h_ida;
+    std::deque<irdm_ida_t> q_ida;
     std::vector<DecodedOut> h_decoded;
     std::deque<irdm_decoded_t> q_decoded;
     // sparse scan (scan_fast.hip): prefilter lists, status word, pre-chunk snapshot for the dense fallback
@@ -242,7 +247,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
-                     p->d_syn_hdr, p->d_nbits,
+                     p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
                      p->d_fir_off, p->d_mag2, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status };
     for (void *q : ptrs)
@@ -471,6 +476,15 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         std::vector<int2> ra = build(1207u, 31, 2, 1024), hdr = build(29u, 7, 1, 16);
         UP(p->d_syn_ra, ra);
         UP(p->d_syn_hdr, hdr);
+        // ida_decode_init (ida_decode.c:96-102)
+        std::vector<int2> da = build(3545u, 31, 2, 2048), l1 = build(29u, 7, 1, 16), l2 = build(465u, 14, 1, 256),
+                          l3 = build(41u, 26, 2, 32);
+        UP(p->d_syn_da, da);
+        UP(p->d_syn_l1, l1);
+        UP(p->d_syn_l2, l2);
+        UP(p->d_syn_l3, l3);
+        AL(p->d_ida, IdaOut, (size_t)p->burst_cap);
+        AL(p->d_dirs, int, (size_t)p->burst_cap);
     }
     AL(p->d_probe, float2, p->l_cap);
     {
@@ -578,6 +592,97 @@ static irdm_decoded_t finish_decoded(const DecodedOut &d, uint64_t id, uint64_t 
     o.id = id;
     o.timestamp = timestamp;               // decoded_frame_t.timestamp / .frequency (frame_decode.c:418-419)
     o.frequency = frequency;
+    return o;
+}
+
+// format_lcw_header (ida_decode.c:405-539): "LCW(ft,T:<type>,C:<code>,<remaining bits>)" left-justified in 110 columns
+// plus one space.  Host text formatting of the four integers the kernel returns.
+static int lcw_field(const char *b, int from, int to)
+{
+    int v = 0;
+    for (int i = from; i < to; i++) v = (v << 1) | (b[i] - '0');
+    return v;
+}
+
+static void format_lcw_header(int ft, int lcw_ft, int lcw_code, uint32_t lcw3_val, char *out, size_t outsz)
+{
+    char b[32], code[128], rem[64], raw[128];
+    const char *ty = "rsrvd";
+    for (int i = 0; i < 21; i++) b[i] = (char)('0' + ((lcw3_val >> (20 - i)) & 1));
+    b[21] = 0;
+    snprintf(code, sizeof(code), "rsrvd(%d)", lcw_code);           // the default of the maint / acchl / hndof switches
+    snprintf(rem, sizeof(rem), "%s", b);
+    if (lcw_ft == 0) {
+        ty = "maint";
+        if (lcw_code == 0) {
+            snprintf(code, sizeof(code), "sync[status:%d,dtoa:%d,dfoa:%d]", b[1] - '0', lcw_field(b, 3, 13), lcw_field(b, 13, 21));
+            snprintf(rem, sizeof(rem), "%c|%c", b[0], b[2]);
+        } else if (lcw_code == 1) {
+            snprintf(code, sizeof(code), "switch[dtoa:%d,dfoa:%d]", lcw_field(b, 3, 13), lcw_field(b, 13, 21));
+            snprintf(rem, sizeof(rem), "%.3s", b);
+        } else if (lcw_code == 3) {
+            snprintf(code, sizeof(code), "maint[2][lqi:%d,power:%d,f_dtoa:%d,f_dfoa:%d]", (b[1] - '0') * 2 + (b[2] - '0'),
+                     lcw_field(b, 3, 6), lcw_field(b, 6, 13), lcw_field(b, 13, 20));
+            snprintf(rem, sizeof(rem), "%c|%c", b[0], b[20]);
+        } else if (lcw_code == 6) {
+            snprintf(code, sizeof(code), "geoloc");
+        } else if (lcw_code == 12) {
+            snprintf(code, sizeof(code), "maint[1][lqi:%d,power:%d]", (b[19] - '0') * 2 + (b[20] - '0'), lcw_field(b, 16, 19));
+            snprintf(rem, sizeof(rem), "%.16s", b);
+        } else if (lcw_code == 15) {
+            snprintf(code, sizeof(code), "<silent>");
+        }
+    } else if (lcw_ft == 1) {
+        ty = "acchl";
+        if (lcw_code == 1) {
+            snprintf(code, sizeof(code), "acchl[msg_type:%01x,bloc_num:%01x,sapi_code:%01x,segm_list:%.8s]",
+                     lcw_field(b, 1, 4), b[4] - '0', lcw_field(b, 5, 8), b + 8);
+            snprintf(rem, sizeof(rem), "%c,%02x", b[0], lcw_field(b, 16, 21));
+        }
+    } else if (lcw_ft == 2) {
+        ty = "hndof";
+        if (lcw_code == 3) {
+            snprintf(code, sizeof(code), "handoff_resp[cand:%c,denied:%d,ref:%d,slot:%d,sband_up:%d,sband_dn:%d,access:%d]",
+                     (b[2] - '0') == 0 ? 'P' : 'S', b[3] - '0', b[4] - '0', 1 + (b[6] - '0') * 2 + (b[7] - '0'),
+                     lcw_field(b, 8, 13), lcw_field(b, 13, 18), lcw_field(b, 18, 21) + 1);
+            snprintf(rem, sizeof(rem), "%.2s,%c", b, b[5]);
+        } else if (lcw_code == 12) {
+            snprintf(code, sizeof(code), "handoff_cand");
+            snprintf(rem, sizeof(rem), "%.11s,%.10s", b, b + 11);
+        } else if (lcw_code == 15) {
+            snprintf(code, sizeof(code), "<silent>");
+        }
+    } else {
+        snprintf(code, sizeof(code), "<%d>", lcw_code);
+    }
+    snprintf(raw, sizeof(raw), "LCW(%d,T:%s,C:%s,%s)", ft, ty, code, rem);
+    snprintf(out, outsz, "%-110s ", raw);
+}
+
+// IdaOut (device) -> irdm_ida_t: the fields ida_decode() copies from the demod record (ida_decode.c:641-648) and the
+// LCW header text
+static irdm_ida_t finish_ida(const IdaOut &d, const irdm_demod_t &f)
+{
+    irdm_ida_t o;
+    memset(&o, 0, sizeof(o));
+    o.id = f.id;
+    if (!d.ok) return o;
+    o.ok = 1;
+    o.ft = d.ft; o.lcw_ft = d.lcw_ft; o.lcw_code = d.lcw_code; o.ec_lcw = d.ec_lcw; o.lcw3_val = d.lcw3_val;
+    o.da_ctr = d.da_ctr; o.da_len = d.da_len; o.cont = d.cont; o.crc_ok = d.crc_ok;
+    o.stored_crc = d.stored_crc; o.computed_crc = d.computed_crc;
+    o.fixederrs = d.fixederrs; o.payload_len = d.payload_len; o.bch_len = d.bch_len;
+    memcpy(o.payload, d.payload, sizeof(o.payload));
+    memcpy(o.bch_stream, d.bch_stream, sizeof(o.bch_stream));
+    format_lcw_header(d.ft, d.lcw_ft, d.lcw_code, d.lcw3_val, o.lcw_header, sizeof(o.lcw_header));
+    o.direction = f.direction;
+    o.timestamp = f.timestamp;
+    o.frequency = f.center_frequency;
+    o.magnitude = f.magnitude;
+    o.noise = f.noise;
+    o.level = f.level;
+    o.confidence = f.confidence;
+    o.n_symbols = f.n_payload_symbols;
     return o;
 }
 
@@ -692,6 +797,13 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
             IRDM_HIP_CHECK(hipMemcpyAsync(p->h_decoded.data(), p->d_decoded, sizeof(DecodedOut) * nb,
                                           hipMemcpyDeviceToHost, p->bstream));
         }
+        if (p->decode_ida) {
+            if (launch_ida_decode(p->d_demod, nb, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, 1, nullptr, nullptr,
+                                  p->d_ida, p->bstream) != 0)
+                return -1;
+            p->h_ida.resize(nb);
+            IRDM_HIP_CHECK(hipMemcpyAsync(p->h_ida.data(), p->d_ida, sizeof(IdaOut) * nb, hipMemcpyDeviceToHost, p->bstream));
+        }
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_demod.data(), p->d_demod, sizeof(DemodOut) * nb,
                                       hipMemcpyDeviceToHost, p->bstream));
         if (p->keep_frame_samples) {
@@ -772,6 +884,7 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
                 }
                 p->q_demods.push_back(o);
                 if (p->decode_frames) p->q_decoded.push_back(finish_decoded(p->h_decoded[i], o.id, o.timestamp, o.center_frequency));
+                if (p->decode_ida) p->q_ida.push_back(finish_ida(p->h_ida[i], o));
             }
         }
     }
@@ -1239,8 +1352,9 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     std::deque<irdm_burst_t> qb; std::deque<irdm_frame_info_t> qf; std::deque<std::vector<float>> qs;
     std::deque<irdm_demod_t> qd;
     qb.swap(p->q_bursts); qf.swap(p->q_frames); qs.swap(p->q_frame_samples); qd.swap(p->q_demods);
-    const int keep = p->keep_frame_samples, dec = p->decode_frames;
+    const int keep = p->keep_frame_samples, dec = p->decode_frames, dec_ida = p->decode_ida;
     p->decode_frames = 0;
+    p->decode_ida = 0;
     const uint64_t tagged = p->tagged;
     std::vector<irdm_burst_t> last; last.swap(p->last_bursts);
     p->keep_frame_samples = 1;
@@ -1257,6 +1371,7 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     p->q_bursts.swap(qb); p->q_frames.swap(qf); p->q_frame_samples.swap(qs); p->q_demods.swap(qd);
     p->keep_frame_samples = keep;
     p->decode_frames = dec;
+    p->decode_ida = dec_ida;
     p->tagged = tagged;
     p->last_bursts.swap(last);
     return ret;
@@ -1345,12 +1460,54 @@ extern "C" int irdm_frame_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *i
     return 0;
 }
 
+extern "C" int irdm_poll_ida(irdm_pipeline_t *p, irdm_ida_t *out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    return drain(p->q_ida, out, max);
+}
+
+extern "C" int irdm_ida_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_ida_t *out)
+{
+    if (!p || !in || !out || n < 0) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    std::vector<int> nbits, dirs;
+    for (int base = 0; base < n; base += p->burst_cap) {
+        const int nb = std::min(p->burst_cap, n - base);
+        p->h_demod.assign(nb, DemodOut());
+        nbits.assign(nb, 0);
+        dirs.assign(nb, 0);
+        for (int i = 0; i < nb; i++) {
+            const irdm_demod_t &f = in[base + i];
+            if (f.n_bits < 0 || f.n_bits > kMaxBits) return -1;
+            DemodOut &d = p->h_demod[i];
+            d.ok = 1;
+            d.n_symbols = f.n_bits / 2;
+            memcpy(d.bits, f.bits, sizeof(d.bits));
+            memcpy(d.llr, f.llr, sizeof(d.llr));
+            nbits[i] = f.n_bits;
+            dirs[i] = f.direction;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_demod, p->h_demod.data(), sizeof(DemodOut) * nb, hipMemcpyHostToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_nbits, nbits.data(), sizeof(int) * nb, hipMemcpyHostToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_dirs, dirs.data(), sizeof(int) * nb, hipMemcpyHostToDevice, p->stream));
+        if (launch_ida_decode(p->d_demod, nb, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, use_llr ? 1 : 0,
+                              p->d_nbits, p->d_dirs, p->d_ida, p->stream) != 0)
+            return -1;
+        p->h_ida.resize(nb);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_ida.data(), p->d_ida, sizeof(IdaOut) * nb, hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        for (int i = 0; i < nb; i++) out[base + i] = finish_ida(p->h_ida[i], in[base + i]);
+    }
+    return 0;
+}
+
 extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
 {
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
     if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
+    if (!strcmp(key, "decode_ida")) { p->decode_ida = value; return 0; }
     // kernel-variant hooks (process-wide; parity tests and A/B timing): generic runtime-M decimator, radix-2 FFT
     if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }

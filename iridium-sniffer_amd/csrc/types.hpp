@@ -99,4 +99,15 @@ struct DecodedOut {
     int32_t bch_len;
 };
 
+// ida_decode() result per demodulated frame (bitlayer.hip); the LCW header text is formatted on the host
+struct IdaOut {
+    int32_t ok, ft, lcw_ft, lcw_code, ec_lcw;
+    uint32_t lcw3_val;
+    int32_t da_ctr, da_len, cont, crc_ok;
+    uint32_t stored_crc, computed_crc;
+    int32_t fixederrs, payload_len, bch_len;
+    uint8_t payload[32];
+    uint8_t bch_stream[256];
+};
+
 }  // namespace irdm

@@ -65,6 +65,17 @@ class Decoded(C.Structure):
                 ("frequency", C.c_double)]
 
 
+class Ida(C.Structure):
+    _fields_ = [("ok", C.c_int32), ("ft", C.c_int32), ("lcw_ft", C.c_int32), ("lcw_code", C.c_int32),
+                ("ec_lcw", C.c_int32), ("lcw3_val", C.c_uint32), ("da_ctr", C.c_int32), ("da_len", C.c_int32),
+                ("cont", C.c_int32), ("crc_ok", C.c_int32), ("stored_crc", C.c_uint32), ("computed_crc", C.c_uint32),
+                ("fixederrs", C.c_int32), ("payload_len", C.c_int32), ("bch_len", C.c_int32), ("direction", C.c_int32),
+                ("payload", C.c_uint8 * 32), ("bch_stream", C.c_uint8 * 256), ("lcw_header", C.c_char * 128),
+                ("id", C.c_uint64), ("timestamp", C.c_uint64), ("frequency", C.c_double), ("magnitude", C.c_float),
+                ("noise", C.c_float), ("level", C.c_float), ("confidence", C.c_int32), ("n_symbols", C.c_int32),
+                ("pad", C.c_int32)]
+
+
 _lib = None
 
 
@@ -101,6 +112,8 @@ def lib():
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
         L.irdm_poll_decoded.argtypes = [C.c_void_p, C.POINTER(Decoded), C.c_int]
+        L.irdm_poll_ida.argtypes = [C.c_void_p, C.POINTER(Ida), C.c_int]
+        L.irdm_ida_decode_batch.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int, C.c_int, C.POINTER(Ida)]
         L.irdm_frame_decode_batch.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int, C.c_int, C.POINTER(Decoded)]
         L.irdm_tagged_bursts.argtypes = [C.c_void_p]
         L.irdm_tagged_bursts.restype = C.c_uint64
@@ -217,6 +230,19 @@ class Pipeline:
     def poll_decoded(self):
         """irdm_poll_decoded: one Decoded per polled Demod (option "decode_frames" = 1)."""
         return self._poll(self.L.irdm_poll_decoded, Decoded)
+
+    def poll_ida(self):
+        """irdm_poll_ida: one Ida per polled Demod (option "decode_ida" = 1)."""
+        return self._poll(self.L.irdm_poll_ida, Ida)
+
+    def ida_decode_batch(self, demods, use_llr=True):
+        """irdm_ida_decode_batch: ida_decode() for a list of Demod records (direction field = demodulator's)."""
+        n = len(demods)
+        arr = (Demod * max(n, 1))(*demods)
+        out = (Ida * max(n, 1))()
+        if self.L.irdm_ida_decode_batch(self.h, arr, n, 1 if use_llr else 0, out) != 0:
+            raise RuntimeError("irdm_ida_decode_batch failed")
+        return [out[i] for i in range(n)]
 
     def frame_decode_batch(self, demods, use_llr=True):
         """irdm_frame_decode_batch: frame_decode() for a list of Demod records."""

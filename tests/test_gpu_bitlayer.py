@@ -124,3 +124,100 @@ def test_pipeline_decodes_ira_and_ibc_frames_like_the_oracle():
     # the strong bursts decode; an IRA frame may be claimed by the IBC branch first (frame_decode.c tries IBC before IRA and
     # the Chase decoder accepts many random blocks) -- whatever the reference's logic says is what must come out
     assert n_ok[1] >= 2 and n_ok[2] >= 3, n_ok
+
+
+# ------------------------------------------------------------------ IDA (ida_decode.c) ----
+from test_oracle_bitlayer import ida_decode_with, ida_tuple, make_ida_cases
+
+IDA_FIELDS = ("ok", "ft", "lcw_ft", "lcw_code", "ec_lcw", "lcw3_val", "da_ctr", "da_len", "cont", "crc_ok", "stored_crc",
+              "computed_crc", "fixederrs", "payload_len", "bch_len")
+
+
+def same_ida(g, o):
+    for f in IDA_FIELDS:
+        assert getattr(g, f) == getattr(o, f), (f, getattr(g, f), getattr(o, f))
+    assert bytes(g.payload) == bytes(o.payload) and bytes(g.bch_stream) == bytes(o.bch_stream)
+    assert g.lcw_header == o.lcw_header, (g.lcw_header, o.lcw_header)
+
+
+@pytest.mark.parametrize("seed", (0, 1))
+def test_ida_decode_batch_matches_oracle(seed):
+    L = orc.lib()
+    L.orc_ida_decode.restype = C.c_int
+    cases = make_ida_cases(seed, n=160)
+    p = irdm.Pipeline(2_000_000, max_chunk_samples=32768, max_bursts_per_chunk=256)
+    try:
+        n_ok = 0
+        for use_llr in (True, False):
+            sel = [(b, l, d) for b, l, d in cases if (l is not None) == use_llr]
+            dem = []
+            for k, (b, l, d) in enumerate(sel):
+                r = to_demod(b, l, k)
+                r.direction = d
+                dem.append(r)
+            got = p.ida_decode_batch(dem, use_llr=use_llr)
+            for k, ((b, l, d), g) in enumerate(zip(sel, got)):
+                r, o = ida_decode_with(L.orc_ida_decode, b, l, d)
+                same_ida(g, o)
+                assert g.id == 10 * k and (not g.ok or g.direction == d)
+                n_ok += g.ok
+        assert n_ok >= 40
+        # every LCW header form through the product's host formatter
+        rng = np.random.default_rng(3)
+        dem, want = [], []
+        for d5 in range(32):
+            for rep in range(3):
+                st = bl.ida_stream(1, 20, 0, [0] * 20, rng)
+                bits = bl.ida_frame(bl.lcw_bits(2, d5, int(rng.integers(0, 1 << 21))), st, rng)
+                r = to_demod(bits, None, len(dem))
+                r.direction = 1
+                dem.append(r)
+                want.append(ida_decode_with(L.orc_ida_decode, bits, None, 1)[1])
+        for g, o in zip(p.ida_decode_batch(dem, use_llr=False), want):
+            same_ida(g, o)
+    finally:
+        p.close()
+
+
+def test_pipeline_decodes_ida_bursts_like_the_oracle():
+    fs = 2_000_000
+    rng = np.random.default_rng(41)
+    n = int(2.0 * fs) // 32768 * 32768
+    first = 530 * 2048
+    bursts = []
+    for k in range(8):
+        st = bl.ida_stream(k % 8, 20 if k % 3 else 11, k & 1, [int(b) for b in rng.integers(0, 256, 20)], rng,
+                           good_crc=bool(k != 5))
+        bits = bl.ida_frame(bl.lcw_bits(2, int(rng.integers(0, 32)), int(rng.integers(0, 1 << 21))), st, rng)
+        amp = 0.05 if k < 6 else 0.0065
+        bursts.append(dict(start=first + 3000 + 200_000 * k, freq_hz=siggen.channel_freq(int(rng.integers(-20, 21)) or 4),
+                           quads=[0] * 16 + siggen.bits_to_quadrants("".join(str(b) for b in bits)), amp=amp))
+    iq = siggen.make_stream(fs, n, bursts, seed=41)[0]
+    ref = orc.run_stream(iq, fs)
+    L = orc.lib()
+    L.orc_ida_decode.restype = C.c_int
+    p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024, pipeline_depth=1)
+    p.set_option("decode_ida", 1)
+    p.set_option("decode_frames", 1)
+    try:
+        half = len(iq) // 2 // 32768 * 32768
+        p.feed_host(iq[:half])
+        p.feed_host(iq[half:])
+        p.flush()
+        demods, ida, dec = p.poll_demods(), p.poll_ida(), p.poll_decoded()
+    finally:
+        p.close()
+    assert len(ida) == len(dec) == len(demods) == len(ref.demods) >= 6
+    n_ok = n_crc = 0
+    for g, dm, rd in zip(ida, demods, ref.demods):
+        bits = np.ctypeslib.as_array(rd.bits)[:rd.n_bits]
+        llr = np.ctypeslib.as_array(rd.llr)[:rd.n_bits]
+        r, o = ida_decode_with(L.orc_ida_decode, bits, llr, rd.direction)
+        same_ida(g, o)
+        assert g.id == dm.id
+        if g.ok:
+            assert (g.timestamp, g.frequency, g.direction, g.confidence, g.n_symbols) == \
+                   (dm.timestamp, dm.center_frequency, dm.direction, dm.confidence, dm.n_payload_symbols)
+            n_ok += 1
+            n_crc += g.crc_ok
+    assert n_ok >= 6 and n_crc >= 5, (n_ok, n_crc)
