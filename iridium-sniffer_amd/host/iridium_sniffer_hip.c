@@ -13,6 +13,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <semaphore.h>
 
 #include "irdm_hip.h"
 
@@ -24,6 +26,35 @@ static const char *ext_of(const char *p)
 
 /* print every finished frame (frame_output_print, frame_output.c:160-199) and discard the other record queues */
 static const char *g_save_dir;
+
+/* file reader thread: fills the two pinned buffers alternately */
+typedef struct {
+    FILE *f;
+    size_t bps, chunk;
+    void *buf[2];
+    size_t n[2];
+    sem_t filled, empty;
+    volatile int stop;
+} reader_t;
+
+static void *reader_main(void *arg)
+{
+    reader_t *r = arg;
+    for (int k = 0;; k ^= 1) {
+        sem_wait(&r->empty);
+        if (r->stop) break;
+        r->n[k] = fread(r->buf[k], r->bps, r->chunk, r->f);
+        sem_post(&r->filled);
+        if (r->n[k] < r->chunk) {                   /* short read: after it an explicit end marker */
+            if (r->n[k] != 0) {
+                sem_wait(&r->empty);
+                if (!r->stop) { r->n[k ^ 1] = 0; sem_post(&r->filled); }
+            }
+            break;
+        }
+    }
+    return NULL;
+}
 
 static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, uint64_t *t0, char *line, size_t cap)
 {
@@ -110,25 +141,48 @@ int main(int argc, char **argv)
 
     FILE *f = strcmp(file, "-") ? fopen(file, "rb") : stdin;
     if (!f) { perror(file); return 1; }
-    /* pinned read buffer: the H2D copy of chunk k+1 is DMA that overlaps chunk k's detector scan */
-    void *buf = irdm_host_alloc(chunk * bps);
-    if (!buf) { fprintf(stderr, "irdm_host_alloc failed\n"); return 1; }
+    /* Two pinned read buffers and a reader thread (the reference's spewer thread, main.c:223-284): the file read of
+     * chunk k+1 overlaps the H2D copy and GPU work of chunk k; the H2D copy itself is DMA that overlaps chunk k-1's
+     * detector scan. */
+    reader_t rd;
+    memset(&rd, 0, sizeof(rd));
+    rd.f = f;
+    rd.bps = bps;
+    rd.chunk = chunk;
+    for (int i = 0; i < 2; i++) {
+        rd.buf[i] = irdm_host_alloc(chunk * bps);
+        if (!rd.buf[i]) { fprintf(stderr, "irdm_host_alloc failed\n"); return 1; }
+    }
+    sem_init(&rd.filled, 0, 0);
+    sem_init(&rd.empty, 0, 2);
+    pthread_t th;
+    if (pthread_create(&th, NULL, reader_main, &rd) != 0) { fprintf(stderr, "pthread_create failed\n"); return 1; }
     irdm_demod_t *d = malloc(sizeof(*d) * 256);
     static char line[256 * IRDM_RAW_LINE_MAX];
     uint64_t t0 = 0;
-    size_t r;
     int rc = 0;
-    while ((r = fread(buf, bps, chunk, f)) > 0) {
-        if (irdm_feed_host(p, buf, r) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; break; }
-        drain(p, d, file_info, &t0, line, sizeof line);
-        if (r < chunk) break;
+    for (int k = 0;; k ^= 1) {
+        sem_wait(&rd.filled);
+        const size_t r = rd.n[k];
+        if (r == 0) break;                          /* end of file */
+        if (rc == 0 && irdm_feed_host(p, rd.buf[k], r) < 0) {
+            fprintf(stderr, "burst_detect: GPU processing failed\n");
+            rc = 1;
+        }
+        sem_post(&rd.empty);                        /* irdm_feed_host has consumed the buffer when it returns */
+        if (rc == 0) drain(p, d, file_info, &t0, line, sizeof line);
+        if (r < chunk) { rd.stop = 1; sem_post(&rd.empty); break; }   /* ragged last chunk = end of stream */
     }
+    rd.stop = 1;
+    sem_post(&rd.empty);
+    pthread_join(th, NULL);
     if (rc == 0 && irdm_flush(p) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; }
     drain(p, d, file_info, &t0, line, sizeof line);
     fflush(stdout);
     fprintf(stderr, "burst_detect: tagged %lu bursts total\n", (unsigned long)irdm_tagged_bursts(p));
     irdm_destroy(p);
-    irdm_host_free(buf);
+    irdm_host_free(rd.buf[0]);
+    irdm_host_free(rd.buf[1]);
     free(d);
     if (f != stdin) fclose(f);
     return rc;
