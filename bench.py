@@ -44,6 +44,9 @@ def build_scene(torch, device, fs, n, density_per_msample, seed):
     first = 520 * fft
     nb = int(round(density_per_msample * n / 1e6))
     span = n - first - int(0.012 * fs)
+    if span <= 0:
+        raise SystemExit("--samples %d is too small: the detector primes on the first %d samples (512 frames of %d)"
+                         % (n, first, fft))
     starts = np.sort(rng.integers(0, span, size=nb)) + first
     half_ch = int((fs / 2 - 60e3) // (1e6 / 24.0))
     lens = 0
