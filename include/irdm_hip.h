@@ -276,6 +276,8 @@ int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, ui
 
 /* Options: "decode_frames" / "decode_ida" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded /
  * irdm_poll_ida),
+ * "detect_only" (0/1, default 0: 1 = stage A alone, burst_detector_feed's role: only burst records are produced --
+ * irdm_poll_bursts, irdm_burst_samples; no downmix / demodulation),
  * "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
  * "scan_mode" (0 = sparse detector scan with exact dense fallback, 1 = dense scan only).
  * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */

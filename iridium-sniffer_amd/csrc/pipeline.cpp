@@ -180,7 +180,7 @@ struct irdm_pipeline {
     DecodedOut *d_decoded;      // post-demod bit layer (bitlayer.hip)
     int2 *d_syn_ra, *d_syn_hdr; // BCH syndrome -> (error count, locator) tables (frame_decode.c:95-135)
     int *d_nbits;
-    int decode_frames, decode_ida;
+    int decode_frames, decode_ida, detect_only;
     IdaOut *d_ida;
     int2 *d_syn_da, *d_syn_l1, *d_syn_l2, *d_syn_l3;
     int *d_dirs;
@@ -732,6 +732,15 @@ static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneB
             }
             if (!w.drop_reason)
                 for (int o = 0; o < w.dec_len; o += kFirTileOut) p->h_tiles.push_back(FirTile{ i, o });
+        }
+        if (p->detect_only) {
+            // stage A alone (burst_detector_feed's callback payload minus the samples): burst records, no downmix / demod
+            for (int i = 0; i < nb; i++) {
+                p->q_bursts.push_back(recs[i]);
+                p->last_bursts.push_back(recs[i]);
+                p->tagged++;
+            }
+            continue;
         }
         if (p->h_tiles.size() > p->tiles_cap) {
             (void)hipFree(p->d_tiles);
@@ -1508,6 +1517,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
     if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
     if (!strcmp(key, "decode_ida")) { p->decode_ida = value; return 0; }
+    if (!strcmp(key, "detect_only")) { p->detect_only = value; return 0; }
     // kernel-variant hooks (process-wide; parity tests and A/B timing): generic runtime-M decimator, radix-2 FFT
     if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }

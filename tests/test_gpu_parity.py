@@ -148,6 +148,31 @@ def test_ci16_device_resident_and_pinned_host_feed():
     parity.compare(got, ref)
 
 
+def test_detect_only_mode_emits_the_same_bursts():
+    """option "detect_only" (stage A alone, BASELINE config 2): the burst records of the full pipeline, nothing else"""
+    fs, iq = _scene_2m(seed=23, n_bursts=6, secs=2.0)
+    ref = orc.run_stream(iq, fs)
+    p = irdm.Pipeline(fs, max_chunk_samples=32768 * 40, max_bursts_per_chunk=1024, pipeline_depth=1)
+    p.set_option("detect_only", 1)
+    try:
+        off = 0
+        while off < len(iq):
+            c = min(32768 * 40, len(iq) - off)
+            p.feed_host(iq[off:off + c])
+            off += c
+        p.flush()
+        bursts = p.poll_bursts()
+        assert p.poll_demods() == [] and p.poll_frames()[0] == []
+        assert p.tagged == ref.n_tagged and len(bursts) == len(ref.bursts) >= 6
+        for g, r in zip(bursts, ref.bursts):
+            for f in ("id", "start", "stop", "last_active", "center_bin", "num_samples", "avail_end"):
+                assert getattr(g, f) == getattr(r, f), f
+            assert parity.bits_of(g.magnitude) == parity.bits_of(r.magnitude)
+            assert parity.bits_of(g.noise) == parity.bits_of(r.noise)
+    finally:
+        p.close()
+
+
 def test_kernel_variants_agree():
     """The runtime-M decimator and the radix-2 FFT kernels (fallbacks for sizes without a specialised kernel) give the
     same records as the specialised ones and the oracle."""
