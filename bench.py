@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=4, help="oracle passes over that prefix (~3 s each)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="extra CPU baseline: this many oracle processes in parallel, one pass each over the same prefix "
+                         "(independent streams, the way the path shards); -1 = all host cores, capped at 32; 0 = skip")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="irdm_set_option before the run (kernel-variant A/B: fir_generic=1, fft_radix2=1, scan_mode=1)")
     ap.add_argument("--host-steps", type=int, default=6,
@@ -297,6 +300,37 @@ def main():
                          "(reference --no-simd --no-gpu algorithm, pinned FFT), %d bursts -> %d RAW frames per pass"
                          % (max(args.cpu_passes, 1), m, cdt, ref.n_tagged, len(ref.demods))}
 
+    # ---- the same oracle on every host core at once (independent streams; reported beside the 1-core figure) ----
+    cpu_all = None
+    if cpu is not None and args.cpu_procs != 0:
+        try:
+            import subprocess
+            import tempfile
+            procs = args.cpu_procs if args.cpu_procs > 0 else min(os.cpu_count() or 1, 64)
+            mm = min(m, 8 * 1024 * 1024)                               # 64 MB per process at cf32
+            passes = 8
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+            path = os.path.join(shm, "irdm_bench_prefix_%d.bin" % os.getpid())
+            host[:mm if args.format == "cf32" else 2 * mm].tofile(path)
+            child = ("import sys, time, numpy as np; sys.path.insert(0, %r); import orc; "
+                     "a = np.fromfile(%r, dtype=%r); orc.lib(); t = time.perf_counter();\n"
+                     "for _ in range(%d): r = orc.run_stream(a, %d, fmt=%d, cap_bursts=8192)\n"
+                     "print(time.perf_counter() - t)"
+                     % (os.path.join(ROOT, "tests"), path, str(host.dtype), passes, fs, int(fmt)))
+            ps = [subprocess.Popen([sys.executable, "-c", child], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                  for _ in range(procs)]
+            outs = [p_.communicate(timeout=300)[0] for p_ in ps]
+            ok = all(p_.returncode == 0 for p_ in ps)
+            os.remove(path)
+            if ok:
+                slowest = max(float(o.decode().strip().splitlines()[-1]) for o in outs)
+                cpu_all = {"value": round(procs * passes * mm / slowest / 1e6, 2), "unit": "Msamples/s", "cores": procs,
+                           "kind": "port",
+                           "sample": "%d oracle processes in parallel (independent streams), %d passes each over the first "
+                                     "%d samples; slowest process %.1f s" % (procs, passes, mm, slowest)}
+        except Exception as e:                                         # a reported extra, never a reason to fail the bench
+            cpu_all = {"error": str(e)[:200]}
+
     if rank == 0:
         out = {
             "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz %s" % (fs // 1_000_000, args.format),
@@ -313,6 +347,7 @@ def main():
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames")}},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "pcie_inclusive": pcie,
         }
         print(json.dumps(out), flush=True)
