@@ -5,6 +5,7 @@
  *   stage B  burst_downmix.c  (rotate -> 801-tap FIR /M -> LPF -> start -> CFO -> RRC -> sync)
  *   stage C  qpsk_demod.c     (Gardner -> PLL -> slicer -> UW -> DQPSK -> bits/LLR)
  *   surface  frame_output.c   (RAW line)
+ *   bit layer frame_decode.c / ida_decode.c (access code, de-interleave, BCH + Chase, IRA / IBC / IDA fields)
  * Citations are file:line into the reference tree.  Build with
  *   gcc -O2 -std=gnu99 -ffp-contract=off   (no FMA contraction: the reference's
  *   scalar path is built -O3 -msse4.1 without -mfma, CMakeLists.txt:6-18)
