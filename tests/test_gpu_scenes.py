@@ -82,3 +82,18 @@ def test_random_scenes_10mhz(seed):
     ref = orc.run_stream(iq, fs)
     parity.compare(parity.run_gpu(iq, fs), ref)
     parity.compare(parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1), ref)
+
+
+@pytest.mark.parametrize("thr_db,gardner", [(12.0, 1), (22.0, 1), (16.0, 0)])
+def test_threshold_and_no_gardner_options(thr_db, gardner):
+    """-d <dB> (burst_detect.c:213-226 threshold_lin) and --no-gardner (qpsk_demod.c:409-415 decimate_simple): other
+    operating points of the same state machine / demodulator, against the oracle"""
+    import siggen
+    fs = 2_000_000
+    iq, _ = siggen.standard_scene(fs, int(2.0 * fs) // 32768 * 32768, 8, seed=51, uplink_every=3, amp=0.03)
+    ref = orc.run_stream(iq, fs, threshold_db=thr_db, use_gardner=gardner)
+    got = parity.run_gpu(iq, fs, threshold_db=thr_db, use_gardner=gardner)
+    s = parity.compare(got, ref)
+    assert s["bursts"] >= 4
+    chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, threshold_db=thr_db, use_gardner=gardner)
+    parity.compare(chunked, ref)
