@@ -543,10 +543,13 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     float sps, float2 *__restrict__ rrc_ws, float2 *__restrict__ frames)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *rot = reinterpret_cast<float2 *>(smem_raw);          // kFrameNeed
-    float2 *fa = rot + kFrameNeed;                               // kCorrN
+    // the rotated frame (steps 5-6) and the three correlation buffers (step 7) are never live together: they share the
+    // same 48 KB, so three workgroups fit a CU and all bursts of a chunk are resident at once
+    float2 *rot = reinterpret_cast<float2 *>(smem_raw);          // kFrameNeed (<= 3 * kCorrN)
+    float2 *fa = rot;                                            // kCorrN
     float2 *fd = fa + kCorrN;                                    // kCorrN
     float2 *fu = fd + kCorrN;                                    // kCorrN
+    static_assert(kFrameNeed <= 3 * kCorrN, "the frame buffer aliases the correlation buffers");
     float *redf = reinterpret_cast<float *>(fu + kCorrN);
     int *redi = reinterpret_cast<int *>(redf + 4);
     const int tid = threadIdx.x;
@@ -658,7 +661,7 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int d
                          float sps, float2 *rrc_ws, float2 *frames, hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
-    const size_t lds = sizeof(float2) * (kFrameNeed + 3 * kCorrN) + 64;
+    const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
     (void)hipFuncSetAttribute((const void *)downmix_post2_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(downmix_post2_kernel, dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
