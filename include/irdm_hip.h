@@ -74,7 +74,8 @@ typedef struct {
     uint64_t start_time_ns;    /* replaces the wall clock read at burst_detect.c:849-853; 0 -> now */
     int device;                /* HIP device ordinal */
     size_t max_chunk_samples;  /* largest chunk passed to irdm_feed_*; 0 -> 64 Mi */
-    int max_bursts_per_chunk;  /* 0 -> 8192 */
+    int max_bursts_per_chunk;  /* sizing hint for the burst-record buffers, 0 -> 4096; a chunk with more finished bursts
+                                  is redone with larger buffers (costs one dense scan), never dropped */
     int pipeline_depth;        /* 0: irdm_feed_* returns with the chunk's results pollable.
                                   1: throughput mode.  irdm_feed_*(k) returns once chunk k is ingested (FFT done,
                                      samples in the history ring) and its detector scan is launched; the scan stays in

@@ -941,12 +941,13 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
     IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
     IRDM_HIP_CHECK(hipEventRecord(p->ev[9], p->stream));
     p->fl_sparse = p->scan_mode != 1;
+    // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts or the burst-record
+    // buffer turns out too small (scan_finish then redoes the chunk)
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
+                                  hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
     if (p->fl_sparse) {
-        // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
-                                      hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
         IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 64, p->stream));
         int done = 0;
         if (!p->host_primed) {
@@ -1017,10 +1018,36 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
     p->host_hist_idx = hdr[0];
     p->host_primed = hdr[1];
-    const int n_gone = (int)counters[0];
+    int n_gone = (int)counters[0];
     if (counters[1] || n_gone > p->gone_cap) {
-        fprintf(stderr, "irdm_hip: detector capacity exceeded (%d bursts in one chunk, cap %d)\n", n_gone, p->gone_cap);
-        return -1;
+        // more finished bursts in this chunk than the record buffer holds (the reference's lists grow without bound,
+        // burst_detect.c:148-154): grow it, restore the pre-chunk state and redo the chunk with the dense scan
+        const int want = std::max(n_gone, p->gone_cap) + 4096;
+        GoneBurst *bigger = dev_alloc<GoneBurst>((size_t)want);
+        if (!bigger) {
+            fprintf(stderr, "irdm_hip: %d bursts in one chunk and no memory for their records\n", n_gone);
+            return -1;
+        }
+        (void)hipFree(p->d_gone);
+        p->d_gone = bigger;
+        p->gone_cap = want;
+        p->h_gone.resize(want);
+        p->stat_fallbacks++;
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
+                                      hipMemcpyDeviceToDevice, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+        if (scan_dense(p, p->fl_mag, p->fl_frames, true) != 0) return -1;
+        IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        p->host_hist_idx = hdr[0];
+        p->host_primed = hdr[1];
+        n_gone = (int)counters[0];
+        if (counters[1] || n_gone > p->gone_cap) {
+            fprintf(stderr, "irdm_hip: detector capacity exceeded (%d bursts in one chunk, cap %d)\n", n_gone, p->gone_cap);
+            return -1;
+        }
     }
     if (n_gone > 0)
         IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));

@@ -97,3 +97,25 @@ def test_threshold_and_no_gardner_options(thr_db, gardner):
     assert s["bursts"] >= 4
     chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, threshold_db=thr_db, use_gardner=gardner)
     parity.compare(chunked, ref)
+
+
+def test_burst_record_buffer_grows_when_a_chunk_has_more_bursts_than_configured():
+    """max_bursts_per_chunk is a sizing hint, not a limit: 263 bursts (12 dB threshold: noise triggers) in one chunk with
+    room for 64 -> the chunk is redone with a larger record buffer, records equal the oracle's"""
+    import siggen
+    fs = 2_000_000
+    iq, _ = siggen.standard_scene(fs, int(2.0 * fs) // 32768 * 32768, 8, seed=51, uplink_every=3, amp=0.03)
+    ref = orc.run_stream(iq, fs, threshold_db=12.0)
+    assert len(ref.bursts) > 200
+    for depth in (0, 1):
+        p = irdm.Pipeline(fs, threshold_db=12.0, max_chunk_samples=len(iq), max_bursts_per_chunk=64, pipeline_depth=depth)
+        p.set_option("keep_frame_samples", 1)
+        try:
+            p.feed_host(iq)
+            p.flush()
+            infos, samples = p.poll_frames()
+            got = dict(bursts=p.poll_bursts(), infos=infos, samples=samples, demods=p.poll_demods(), tagged=p.tagged)
+            assert p.stat("scan_fallbacks") >= 1
+        finally:
+            p.close()
+        parity.compare(got, ref)
