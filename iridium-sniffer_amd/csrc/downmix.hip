@@ -32,6 +32,47 @@ __device__ __forceinline__ float2 burst_sample(const SampleSource &src, uint64_t
     return load_abs(src, a);
 }
 
+// 16 consecutive samples (one rotator segment, 16-sample aligned) with the widest loads the format allows, converted
+// exactly as load_iq does
+__device__ __forceinline__ void load_seg16(int fmt, const void *__restrict__ base, size_t idx, float2 (&x)[kRotSeg])
+{
+    if (fmt == 2) {
+        const float4 *g = reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(base) + idx);
+#pragma unroll
+        for (int u = 0; u < kRotSeg / 2; u++) {
+            const float4 v = g[u];
+            x[2 * u] = make_float2(v.x, v.y);
+            x[2 * u + 1] = make_float2(v.z, v.w);
+        }
+    } else if (fmt == 1) {
+        const int4 *g = reinterpret_cast<const int4 *>(reinterpret_cast<const short2 *>(base) + idx);   // 4 samples per 16 B
+#pragma unroll
+        for (int u = 0; u < kRotSeg / 4; u++) {
+            const int4 v = g[u];
+            const int w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const short re = (short)(w[k] & 0xffff), im = (short)(w[k] >> 16);
+                x[4 * u + k] = make_float2((float)(re >> 8) / 128.0f, (float)(im >> 8) / 128.0f);
+            }
+        }
+    } else {
+        const int4 *g = reinterpret_cast<const int4 *>(reinterpret_cast<const char2 *>(base) + idx);    // 8 samples per 16 B
+#pragma unroll
+        for (int u = 0; u < kRotSeg / 8; u++) {
+            const int4 v = g[u];
+            const int w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const signed char r0 = (signed char)(w[k] & 0xff), i0 = (signed char)((w[k] >> 8) & 0xff);
+                const signed char r1 = (signed char)((w[k] >> 16) & 0xff), i1 = (signed char)((w[k] >> 24) & 0xff);
+                x[8 * u + 2 * k] = make_float2((float)r0 / 128.0f, (float)i0 / 128.0f);
+                x[8 * u + 2 * k + 1] = make_float2((float)r1 / 128.0f, (float)i1 / 128.0f);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Rotator checkpoint table: phase_k of the float recurrence phase *= incr
 // (rotator.h:38-39) for k = 0, 16, 32, ...; one lane per FFT bin.  The sequence
@@ -223,25 +264,13 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
         int p = k0 % M, q = k0 / M;
         const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
         float2 x[kRotSeg];
-        if (src.fmt == 2 && a0 >= src.chunk_start && a0 + kRotSeg <= w.avail_end && k0 + kRotSeg <= span) {
-            const float4 *g = reinterpret_cast<const float4 *>(
-                reinterpret_cast<const float2 *>(src.chunk) + (a0 - src.chunk_start));
-#pragma unroll
-            for (int u = 0; u < kRotSeg / 2; u++) {
-                const float4 v = g[u];
-                x[2 * u] = make_float2(v.x, v.y);
-                x[2 * u + 1] = make_float2(v.z, v.w);
-            }
-        } else if (src.fmt == 2 && a0 + kRotSeg <= src.chunk_start && a0 + kRotSeg <= w.avail_end &&
-                   k0 + kRotSeg <= span) {
-            const float4 *g = reinterpret_cast<const float4 *>(
-                reinterpret_cast<const float2 *>(src.ring) + (a0 % src.ring_len));
-#pragma unroll
-            for (int u = 0; u < kRotSeg / 2; u++) {
-                const float4 v = g[u];
-                x[2 * u] = make_float2(v.x, v.y);
-                x[2 * u + 1] = make_float2(v.z, v.w);
-            }
+        const bool whole = a0 + kRotSeg <= w.avail_end && k0 + kRotSeg <= span;
+        if (whole && a0 >= src.chunk_start) {
+            // the whole segment lies in the chunk being fed: 16-byte loads, all in flight (cf32 8, ci16 4, ci8 2 of them)
+            load_seg16(src.fmt, src.chunk, (size_t)(a0 - src.chunk_start), x);
+        } else if (whole && a0 + kRotSeg <= src.chunk_start) {
+            // same from the history ring: ring_len is a multiple of 16 and a0 is too, so no wrap inside
+            load_seg16(src.fmt, src.ring, (size_t)(a0 % src.ring_len), x);
         } else {
 #pragma unroll
             for (int u = 0; u < kRotSeg; u++)
