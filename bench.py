@@ -254,7 +254,12 @@ def main():
                 "ms_per_launch": round(ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in ms.items()},
                 "host_ms": {k: round(v / K, 3) for k, v in host.items()},
-                "stage_GBps": {k: round(alg_bytes[k] / (ms[k] * 1e-3) / 1e9, 2) for k in alg_bytes if ms[k] > 0}}
+                "stage_GBps": {k: round(alg_bytes[k] / (ms[k] * 1e-3) / 1e9, 2) for k in alg_bytes if ms[k] > 0},
+                # SURVEY 8(d) B_full = B_det * N_samples + sum_bursts 8 * L_b (+ 8 * L_b / M): all algorithmic bytes of one
+                # step over the whole step time -- the path's HBM fraction as a whole (the sequential scan bounds it)
+                "pipeline": {"algorithmic_bytes": round(sum(alg_bytes.values())),
+                             "achieved_GBps": round(sum(alg_bytes.values()) / (dt / K) / 1e9, 2),
+                             "frac": round(sum(alg_bytes.values()) / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)}}
 
     # ---- PCIe-inclusive rate: the same chunk fed from pinned host memory (never `value`) ----
     pcie = None
