@@ -131,7 +131,14 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int idx = t + T * r;
-            const float2 x = load_iq<FMT>(iq, base + idx);
+            // streamed once: non-temporal load (and stores below), the chunk and its magnitudes are far larger than L2 / MALL
+            float2 x;
+            if (FMT == 2) {
+                const double raw = __builtin_nontemporal_load(reinterpret_cast<const double *>(iq) + base + idx);
+                x = *reinterpret_cast<const float2 *>(&raw);
+            } else {
+                x = load_iq<FMT>(iq, base + idx);
+            }
             const float w = window[idx];
             v[rev4c(r)] = make_float2(x.x * w, x.y * w);
         }
@@ -155,7 +162,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int p = q * 256 + lo3;
-                mag[base + ((p + N / 2) & (N - 1))] = mag2(v[q]);
+                __builtin_nontemporal_store(mag2(v[q]), &mag[base + ((p + N / 2) & (N - 1))]);
             }
             __syncthreads();
         } else {
@@ -176,7 +183,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
                 for (int q = 0; q < RQ; q++) {
                     const int k = pp + q * 4096;
-                    mag[base + ((k + N / 2) & (N - 1))] = mag2(d[q]);
+                    __builtin_nontemporal_store(mag2(d[q]), &mag[base + ((k + N / 2) & (N - 1))]);
                 }
             }
             __syncthreads();
