@@ -398,6 +398,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             } else {
                 if (s_scan) (void)hipStreamDestroy(s_scan);
                 if (s_rest) (void)hipStreamDestroy(s_rest);
+                if (s_fft) (void)hipStreamDestroy(s_fft);
                 fprintf(stderr, "irdm_hip: CU-masked streams unavailable, scan shares the chip\n");
             }
         }
