@@ -280,7 +280,10 @@ int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, ui
  * "detect_only" (0/1, default 0: 1 = stage A alone, burst_detector_feed's role: only burst records are produced --
  * irdm_poll_bursts, irdm_burst_samples; no downmix / demodulation),
  * "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
- * "scan_mode" (0 = sparse detector scan with exact dense fallback, 1 = dense scan only).
+ * "scan_mode" (0 = sparse detector scan with exact dense fallback -- multi-CU form (one leader workgroup + "scan_updaters"
+ *   baseline-update workgroups) on devices with >= 64 CUs, single-CU form otherwise; 1 = dense scan only; 2 = sparse,
+ *   single-CU form; 3 = sparse, multi-CU form),
+ * "scan_updaters" (1..32, default 7: updater workgroups of the multi-CU sparse scan).
  * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */
 int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);
 int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);

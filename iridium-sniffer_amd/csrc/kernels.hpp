@@ -19,7 +19,8 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
 int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
                             int n_frames, const unsigned *counts, const unsigned *goff,
                             const ListEntry *compact, const float *pre, GoneBurst *gone, int gone_cap,
-                            int *status, hipStream_t stream);
+                            int *status, unsigned long long *mc_ops, int mc_ops_cap, unsigned *mc_done,
+                            int mc_updaters, hipStream_t stream);
 
 // where a burst window's samples live: the chunk being fed, or the history ring
 struct SampleSource {

@@ -194,7 +194,11 @@ struct irdm_pipeline {
     float *d_pre, *d_sum_bak, *d_hist_bak;
     DetState *d_state_bak;
     int *d_status;
-    int scan_mode;              // 0 auto (sparse, dense fallback), 1 dense only
+    unsigned long long *d_mc_ops;   // multi-CU sparse scan: operation words leader -> updaters, completion counters back
+    unsigned *d_mc_done;
+    int mc_ops_cap, mc_updaters, mc_auto;
+    int scan_mode;              // 0 auto (sparse multi-CU where the device has the CUs, dense fallback), 1 dense only,
+                                // 2 sparse on one CU, 3 sparse multi-CU
     uint64_t stat_fast_chunks, stat_fallbacks, stat_dense_frames;
     int host_primed, host_hist_idx;
 
@@ -249,7 +253,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
                      p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
                      p->d_fir_off, p->d_mag2, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
-                     p->d_status };
+                     p->d_status, p->d_mc_ops, p->d_mc_done };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
@@ -499,6 +503,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_hist_bak, float, (size_t)kHistory * P.n);
         AL(p->d_state_bak, DetState, 1);
         AL(p->d_status, int, 64);
+        p->mc_ops_cap = (int)(4 * max_frames + 64);
+        AL(p->d_mc_ops, unsigned long long, (size_t)p->mc_ops_cap);
+        AL(p->d_mc_done, unsigned, 32 * 16);
     }
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
 #undef UP
@@ -527,6 +534,11 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->last_chunk = nullptr;
     p->keep_frame_samples = 0;
     p->scan_mode = 0;
+    p->mc_updaters = 7;         // + the leader = 8 workgroups: the scan stream's 8 reserved CUs (pipeline_depth 1)
+    {
+        hipDeviceProp_t prop;
+        p->mc_auto = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 64;
+    }
     p->stat_fast_chunks = p->stat_fallbacks = p->stat_dense_frames = 0;
     p->host_primed = 0;
     p->host_hist_idx = 0;
@@ -961,11 +973,18 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
             if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
                                  p->d_goff, p->d_compact, n_frames - done, p->stream) != 0)
                 return -1;
+            const int upd = (p->scan_mode == 3 || (p->scan_mode == 0 && p->mc_auto)) ? p->mc_updaters : 0;
+            const int mc_words = (int)std::min<size_t>((size_t)p->mc_ops_cap, 3 * (size_t)(n_frames - done) + 64);
+            if (upd > 0) {
+                // at most 3 operations per frame + the exit word
+                IRDM_HIP_CHECK(hipMemsetAsync(p->d_mc_ops, 0, sizeof(unsigned long long) * (size_t)mc_words, p->stream));
+                IRDM_HIP_CHECK(hipMemsetAsync(p->d_mc_done, 0, sizeof(unsigned) * 32 * 16, p->stream));
+            }
             if (scan_hop_in(p) != 0) return -1;
             IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->sstream));
             if (launch_detect_scan_fast(P, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done,
                                         p->d_counts, p->d_goff, p->d_compact, p->d_pre, p->d_gone,
-                                        p->gone_cap, p->d_status, p->sstream) != 0)
+                                        p->gone_cap, p->d_status, p->d_mc_ops, mc_words, p->d_mc_done, upd, p->sstream) != 0)
                 return -1;
             IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->sstream));
             if (scan_hop_out(p) != 0) return -1;
@@ -1543,6 +1562,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
+    if (!strcmp(key, "scan_updaters")) { if (value < 1 || value > 32) return -1; p->mc_updaters = value; return 0; }
     if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
     if (!strcmp(key, "decode_ida")) { p->decode_ida = value; return 0; }
     if (!strcmp(key, "detect_only")) { p->detect_only = value; return 0; }

@@ -244,6 +244,66 @@ __device__ __forceinline__ void bulk_group(const float *__restrict__ mag, float 
     }
 }
 
+// ---- multi-CU form (MC): the baseline updates leave the leader's workgroup ----
+// The leader (workgroup 0) publishes every baseline operation -- a run of quiet frames, a forced update, a reset, a
+// list-validity check -- as ONE 64-bit word in device memory and keeps going; W updater workgroups (bins partitioned
+// between them, sums resident in their LDS) execute the operations in order, write the new sums of their bins to
+// sum_g and count the operation in done[w].  The leader needs sums only for the few listed bins of the next
+// crossing test: it waits for done[*] == published and reads exactly those bins with agent-scope loads.
+// Everything that crosses workgroups -- operation words, sums, counters -- moves through agent-scope (sc1) atomic
+// loads / stores, which complete at the device's coherence point; "sums acknowledged (vmcnt 0), then the counter" is
+// the only ordering needed, so there is no release / acquire fence (L2 write-back / invalidate) on either side.
+// Every spin is bounded: a timeout aborts the chunk (dense fallback).
+enum { MCF_PRIMED = 1, MCF_DETECT = 2, MCF_ZERO = 4, MCF_EXIT = 8, MCF_VALIDATE = 16 };
+constexpr unsigned long long kMcValid = 1ull << 63;
+constexpr int kMcDoneStride = 16;        // one cache line (64 B) per updater's counter
+constexpr int kMcMaxUpdaters = 32;
+constexpr int kMcSpinLimit = 4000000;    // bounded spins: >= 1 s, far beyond any chunk's scan
+__host__ __device__ inline unsigned long long mc_pack(int f0, int run, int hist_idx, int flags)
+{
+    return kMcValid | ((unsigned long long)(unsigned)f0 << 32) | ((unsigned long long)(unsigned)run << 20) |
+           ((unsigned long long)(unsigned)hist_idx << 8) | (unsigned long long)(unsigned)flags;
+}
+
+// G consecutive baseline updates of ONE float4 group of bins (the same arithmetic, in the same order, as bulk_group)
+template <int G>
+__device__ __forceinline__ void mc_group(const float *__restrict__ mag, float *__restrict__ hist, int N, int f0,
+                                         int &hidx, int &prm, float4 &s4, int g4, int detect, float thr,
+                                         int half_bw, int dc, bool &bad)
+{
+    float4 m[G], old[G];
+    int row[G], prm_g[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        row[g] = hidx;
+        prm_g[g] = prm;
+        m[g] = reinterpret_cast<const float4 *>(mag + (size_t)(f0 + g) * N)[g4];
+        old[g] = reinterpret_cast<const float4 *>(hist + (size_t)hidx * N)[g4];
+        if (++hidx == kHistory) { prm = 1; hidx = 0; }
+    }
+    float s[4] = { s4.x, s4.y, s4.z, s4.w };
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const float4 o = prm_g[g] ? old[g] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float mv[4] = { m[g].x, m[g].y, m[g].z, m[g].w };
+        const float ov[4] = { o.x, o.y, o.z, o.w };
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (detect) {
+                if (mv[u] > 0.99f * thr * s[u]) {
+                    const float rel = s[u] > 0 ? mv[u] / s[u] : 0.0f;
+                    const int b = 4 * g4 + u;
+                    if (rel > thr && b >= half_bw && b < N - half_bw && !(b >= dc - 3 && b <= dc + 3)) bad = true;
+                }
+            }
+            const float d = s[u] - ov[u];
+            s[u] = d + mv[u];
+        }
+        reinterpret_cast<float4 *>(hist + (size_t)row[g] * N)[g4] = m[g];
+    }
+    s4 = make_float4(s[0], s[1], s[2], s[3]);
+}
+
 struct FastShared {
     int cmd, f0, run, detect, hist_idx, primed;
     int abort;
@@ -269,16 +329,102 @@ enum { S_TOP = 0, S_CPLX_A = 1, S_CPLX_B = 2, S_FRAME_END = 3 };
 // Dense per-bin work (baseline updates while no burst is active, :438-454) is a command executed by
 // all eight wavefronts.  Q = float4 groups per thread; thread t owns bins (q*512 + t)*4 .. +3.
 // ---------------------------------------------------------------------------
-template <int Q>
+template <int Q, bool MC>
 __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     DetParams P, DetState *__restrict__ st, float *__restrict__ sum_g, float *__restrict__ hist,
     const float *__restrict__ mag, int n_frames, const unsigned *__restrict__ counts,
     const unsigned *__restrict__ goff, const ListEntry *__restrict__ compact,
-    const float *__restrict__ pre, GoneBurst *__restrict__ gone, int gone_cap, int *__restrict__ status)
+    const float *__restrict__ pre, GoneBurst *__restrict__ gone, int gone_cap, int *__restrict__ status,
+    unsigned long long *__restrict__ mc_ops, int mc_ops_cap, unsigned *__restrict__ mc_done)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int J = 4 * Q;
     const int N = P.n;
+    if constexpr (MC) {
+        if (blockIdx.x > 0) {
+            // ================= updater workgroup w of W: float4 groups [g_lo, g_hi) of every row =================
+            const int w = blockIdx.x - 1, W = gridDim.x - 1;
+            const int tid_ = threadIdx.x;
+            const int per = (N / 4 + W - 1) / W;
+            const int g_lo = w * per, g_hi = g_lo + per < N / 4 ? g_lo + per : N / 4;
+            const int cnt = g_hi > g_lo ? g_hi - g_lo : 0;
+            float4 *s_loc = reinterpret_cast<float4 *>(smem_raw);          // cnt sums
+            float4 *p_loc = s_loc + per;                                   // cnt prefilter references
+            __shared__ unsigned long long s_op;
+            for (int i = tid_; i < cnt; i += kFastThreads) {
+                s_loc[i] = reinterpret_cast<const float4 *>(sum_g)[g_lo + i];
+                p_loc[i] = reinterpret_cast<const float4 *>(pre)[g_lo + i];
+            }
+            __syncthreads();
+            const float thr_ = P.threshold;
+            const int half_bw_ = P.width / 2, dc_ = N / 2;
+            for (unsigned seen = 0;; seen++) {
+                if (tid_ == 0) {
+                    unsigned long long op = 0ull;
+                    if ((int)seen < mc_ops_cap) {
+                        int spins = 0;
+                        while ((op = __hip_atomic_load(&mc_ops[seen], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0ull) {
+                            if (++spins > kMcSpinLimit) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                    if (op == 0ull) {                                      // the leader went away: give up
+                        atomicOr(&status[0], 256);
+                        op = mc_pack(0, 0, 0, MCF_EXIT);
+                    }
+                    s_op = op;
+                }
+                __syncthreads();
+                const unsigned long long op = s_op;
+                const int flags = (int)(op & 0xffu);
+                if (flags & MCF_EXIT) break;
+                const int f0 = (int)((op >> 32) & 0x7fffffffu), run = (int)((op >> 20) & 0xfffu);
+                const int hidx0 = (int)((op >> 8) & 0xfffu);
+                bool bad = false, stale = false;
+                for (int i = tid_; i < cnt; i += kFastThreads) {
+                    float4 s4 = s_loc[i];
+                    if (flags & MCF_ZERO) {
+                        s4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    } else {
+                        int hidx = hidx0, prm = flags & MCF_PRIMED ? 1 : 0, k0 = 0;
+                        const int det = flags & MCF_DETECT ? 1 : 0;
+                        for (; run - k0 >= 8; k0 += 8)
+                            mc_group<8>(mag, hist, N, f0 + k0, hidx, prm, s4, g_lo + i, det, thr_, half_bw_, dc_, bad);
+                        for (; run - k0 >= 2; k0 += 2)
+                            mc_group<2>(mag, hist, N, f0 + k0, hidx, prm, s4, g_lo + i, det, thr_, half_bw_, dc_, bad);
+                        for (; k0 < run; k0++)
+                            mc_group<1>(mag, hist, N, f0 + k0, hidx, prm, s4, g_lo + i, det, thr_, half_bw_, dc_, bad);
+                    }
+                    if (flags & MCF_VALIDATE) {
+                        // the prefilter lists are complete only while pre[b] <= 0.9*thr*sum[b]
+                        const float4 pq = p_loc[i];
+                        stale |= (s4.x > 0) & (pq.x > 0.9f * thr_ * s4.x);
+                        stale |= (s4.y > 0) & (pq.y > 0.9f * thr_ * s4.y);
+                        stale |= (s4.z > 0) & (pq.z > 0.9f * thr_ * s4.z);
+                        stale |= (s4.w > 0) & (pq.w > 0.9f * thr_ * s4.w);
+                    }
+                    if (run > 0 || (flags & MCF_ZERO)) {
+                        s_loc[i] = s4;
+                        // agent-scope (write-through) stores: complete at the device's coherence point when acknowledged
+                        unsigned *dst = reinterpret_cast<unsigned *>(sum_g) + 4 * (size_t)(g_lo + i);
+                        __hip_atomic_store(dst + 0, __float_as_uint(s4.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, __float_as_uint(s4.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 2, __float_as_uint(s4.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 3, __float_as_uint(s4.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (bad) atomicOr(&status[0], 1);
+                if (stale) atomicOr(&status[0], 2);
+                // __syncthreads() waits for vmcnt(0) in every wavefront: all sums of this workgroup are acknowledged
+                // before the counter moves, so the counter needs no release fence (no L2 write-back of the XCD's
+                // unrelated dirty lines on the leader's critical path)
+                __syncthreads();
+                if (tid_ == 0)
+                    __hip_atomic_store(&mc_done[w * kMcDoneStride], seen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
     float *s_sum = reinterpret_cast<float *>(smem_raw);                                   // N
     unsigned *s_crossT = reinterpret_cast<unsigned *>(s_sum + N);                         // N frame masks
     unsigned *s_mbits = s_crossT + N;                                                     // N/32: 1 = not masked
@@ -352,10 +498,48 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         gone_base = n_gone;                                                                        \
     } while (0)
 
+    // MC: publish one baseline operation (single 64-bit word, no fence, no wait)
+#define MC_PUBLISH(F0, RUN, FLAGS)                                                                     \
+    do {                                                                                               \
+        if (RARE((int)n_pub >= mc_ops_cap - 1)) { abort_code |= 128; }                                 \
+        else {                                                                                         \
+            if (lane == 0)                                                                             \
+                __hip_atomic_store(&mc_ops[n_pub], mc_pack((F0), (RUN), hist_idx, (FLAGS) | (primed ? MCF_PRIMED : 0)), \
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                        \
+            n_pub++;                                                                                   \
+        }                                                                                              \
+    } while (0)
+    // MC: RUN baseline updates starting at frame F0 -- what CMD_BULK and the bookkeeping after it do
+#define MC_BULK(F0, RUN, DET)                                                                          \
+    do {                                                                                               \
+        MC_PUBLISH(F0, RUN, (DET) ? MCF_DETECT : 0);                                                   \
+        const int tot_ = hist_idx + (RUN);                                                             \
+        if (tot_ >= kHistory) primed = 1;                                                              \
+        hist_idx = tot_ % kHistory;                                                                    \
+        cross_valid = false;                                                                           \
+    } while (0)
+    // MC: every published operation has been executed by every updater (their sums are in sum_g)
+#define MC_WAIT()                                                                                      \
+    do {                                                                                               \
+        if (n_ack != n_pub) {                                                                          \
+            const int W_ = (int)gridDim.x - 1;                                                         \
+            int spins_ = 0;                                                                            \
+            for (;;) {                                                                                 \
+                unsigned d_ = n_pub;                                                                   \
+                if (lane < W_) d_ = __hip_atomic_load(&mc_done[lane * kMcDoneStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                if (__all((int)(d_ - n_pub) >= 0)) break;                                              \
+                if (++spins_ > kMcSpinLimit) { abort_code |= 128; break; }                             \
+                __builtin_amdgcn_s_sleep(1);                                                           \
+            }                                                                                          \
+            n_ack = n_pub;                                                                             \
+        }                                                                                              \
+    } while (0)
+#define MC_SUM(bin) __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(sum_g) + (bin), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+
     // ---- load carried state ----
 #pragma unroll
     for (int j = 0; j < J; j++) {
-        s_sum[BIN_OF(j)] = sum_g[BIN_OF(j)];
+        if constexpr (!MC) s_sum[BIN_OF(j)] = sum_g[BIN_OF(j)];     // MC: s_sum only caches the bins read from sum_g
         s_crossT[BIN_OF(j)] = 0u;
     }
     for (int i = tid; i < N / 32; i += kFastThreads) s_mbits[i] = ~0u;
@@ -409,6 +593,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
     unsigned H = 0;                        // lane s: frames of the batch in which slot s sees a crossing near its centre
     unsigned C = 0;                        // frames of the batch that hold a peak candidate under the current mask
     int f = 0, state = S_TOP;
+    unsigned n_pub = 0, n_ack = 0;         // MC: operations published / known to be completed by every updater
     int e0 = 0, e1 = 0, n_cand = 0, hist_before = 0;
     bool any_cand = false, was_quiet = false;
     unsigned long long ev_del = 0;
@@ -433,6 +618,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         // update_filters_pre returns 0 (:427-428): updates only, up to the priming frame
                         int run = kHistory - hist_idx;
                         if (run > n_frames - f) run = n_frames - f;
+                        if constexpr (MC) { MC_BULK(f, run, 0); f += run; continue; }
                         cmd = CMD_BULK; c_f0 = f; c_run = run; c_detect = 0;
                         f += run;
                         break;
@@ -479,8 +665,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         const unsigned long long nz = __ballot(nonempty) >> k0;
                         const int run = nz ? __builtin_ctzll(nz) : snf - k0;
                         if (run > 0) {
-                            cmd = CMD_BULK; c_f0 = f; c_run = run; c_detect = 1;
                             squelch = squelch > run ? squelch - run : 0;
+                            if constexpr (MC) { MC_BULK(f, run, 1); f += run; continue; }
+                            cmd = CMD_BULK; c_f0 = f; c_run = run; c_detect = 1;
                             f += run;
                             break;
                         }
@@ -489,6 +676,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         e0 = __builtin_amdgcn_readlane((int)r_off, k0);
                         e1 = __builtin_amdgcn_readlane((int)r_off, k0 + 1);
                         n_cand = 0;
+                        if constexpr (MC) MC_WAIT();
                         for (int base = e0; base < e1; base += 64) {
                             const int i = base + lane;
                             bool cand = false;
@@ -497,7 +685,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (i < e1) {
                                 const ListEntry e = s_ent[i];
                                 const int bin = e.bin & 0x3FFF;
-                                const float sv = s_sum[bin];
+                                float sv;
+                                if constexpr (MC) { sv = MC_SUM(bin); s_sum[bin] = sv; } else { sv = s_sum[bin]; }
                                 c.rel = sv > 0 ? e.mag / sv : 0.0f;
                                 c.bin = bin;
                                 cand = c.rel > thr && VALID_BIN(bin);
@@ -527,6 +716,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         // batch's staged entries: a dense command when there are enough of them to pay for
                         // the two barriers, the leader alone otherwise.
                         const int ef = __builtin_amdgcn_readlane((int)r_off, k0);
+                        if constexpr (MC) { if (!cross_cmd_done) MC_WAIT(); }
                         if (!cross_cmd_done && total - ef + n_bins > 192) {
                             cmd = CMD_CROSS; c_f0 = ef; c_run = total; c_detect = sb;
                             break;
@@ -543,7 +733,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                                 const ListEntry e = s_ent[i];
                                 bin = e.bin & 0x3FFF;
                                 const int k = (e.bin >> 14) - sb;
-                                const float sv = s_sum[bin];
+                                float sv;
+                                if constexpr (MC) { sv = MC_SUM(bin); s_sum[bin] = sv; } else { sv = s_sum[bin]; }
                                 const float rel = sv > 0 ? e.mag / sv : 0.0f;
                                 if (rel > thr) first = atomicOr(&s_crossT[bin], 1u << k) == 0u;
                             }
@@ -687,6 +878,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         if (squelch > 0) squelch--;                               // create_new_bursts' else branch (:629-630)
                         state = S_FRAME_END;
                         TK(12, t4_);
+                        if constexpr (MC) { if (RARE(force)) MC_BULK(f, 1, 0); continue; }
                         if (RARE(force)) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; break; }
                         continue;
                     }
@@ -799,6 +991,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     state = S_CPLX_B;
                     TK(4, t4_);
                     if (RARE(force)) {                                            // update_filters_post(d, 1)
+                        if constexpr (MC) { MC_BULK(f, 1, 0); continue; }
                         cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0;
                         break;
                     }
@@ -827,10 +1020,16 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                         const int bb = (int)~(unsigned)key;
                         if (RARE(occ == ~0ull)) { abort_code |= 4; break; }
                         const int sl = __builtin_ctzll(~occ);
+                        float base_v = s_sum[bb];
+                        if constexpr (MC) {
+                            // a forced update earlier in this frame (delete_gone_bursts, :508-512) moved the sums after
+                            // the cache was filled: burst_detect.c:583 reads the updated one
+                            if (RARE(hist_idx != hist_before)) { MC_WAIT(); base_v = MC_SUM(bb); }
+                        }
                         if (lane == sl) {
                             r_cb = bb;
                             r_peak = br;
-                            r_base = s_sum[bb];
+                            r_base = base_v;
                             r_start = index - (uint64_t)P.pre_len;
                             r_la = r_start;
                             r_id = burst_id;
@@ -877,14 +1076,23 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     WAVE_SYNC();
                     state = S_FRAME_END;
                     TK(5, t5_);
-                    if (RARE(reset)) { cmd = CMD_ZERO; break; }
+                    if (RARE(reset)) {
+                        if constexpr (MC) { MC_PUBLISH(0, 0, MCF_ZERO); cross_valid = false; continue; }
+                        cmd = CMD_ZERO;
+                        break;
+                    }
                     continue;
                 }
                 // S_FRAME_END: update_filters_post(d, 0) (:698)
                 const long long tE_ = IRDM_TICK();
                 state = S_TOP;
-                if (RARE(occ == 0 || !primed)) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
-                else if (RARE(was_quiet || hist_idx != hist_before)) { cmd = CMD_VALIDATE; }
+                if constexpr (MC) {
+                    if (RARE(occ == 0 || !primed)) { MC_BULK(f, 1, 0); }
+                    else if (RARE(was_quiet || hist_idx != hist_before)) { MC_PUBLISH(0, 0, MCF_VALIDATE); }
+                } else {
+                    if (RARE(occ == 0 || !primed)) { cmd = CMD_BULK; c_f0 = f; c_run = 1; c_detect = 0; }
+                    else if (RARE(was_quiet || hist_idx != hist_before)) { cmd = CMD_VALIDATE; }
+                }
                 if (RARE(n_gone - gone_base > (unsigned)(kGoneLds - 40))) { WAVE_SYNC(); FLUSH_GONE(); }
                 f++;
                 TK(8, tE_);
@@ -912,7 +1120,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         if (cmd == CMD_EXIT) break;
 
         // ================= dense command, all threads =================
-        if (cmd == CMD_BULK) {
+        if (!MC && cmd == CMD_BULK) {
             // consecutive baseline updates (simd_baseline_update + memcpy, burst_detect.c:441-452)
             const int f0 = uni(sh.f0), run = uni(sh.run), detect = uni(sh.detect);
             int hidx = uni(sh.hist_idx), prm = uni(sh.primed);
@@ -936,7 +1144,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
 #pragma unroll
             for (int j = 0; j < J; j++) s_sum[BIN_OF(j)] = s[j];
             if (bad) atomicOr(&sh.abort, 1);
-        } else if (cmd == CMD_VALIDATE) {
+        } else if (!MC && cmd == CMD_VALIDATE) {
             // the prefilter lists are complete only while pre[b] <= 0.9*thr*sum[b]
             bool bad = false;
             float4 pv[Q];
@@ -952,7 +1160,7 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 }
             }
             if (bad) atomicOr(&sh.abort, 2);
-        } else if (cmd == CMD_ZERO) {
+        } else if (!MC && cmd == CMD_ZERO) {
 #pragma unroll
             for (int j = 0; j < J; j++) s_sum[BIN_OF(j)] = 0.0f;
         } else if (cmd == CMD_CROSS) {
@@ -968,7 +1176,8 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                     const ListEntry e = s_ent[i];
                     bin = e.bin & 0x3FFF;
                     const int k = (e.bin >> 14) - sb_;
-                    const float sv = s_sum[bin];
+                    float sv;
+                    if constexpr (MC) { sv = MC_SUM(bin); s_sum[bin] = sv; } else { sv = s_sum[bin]; }
                     const float rel = sv > 0 ? e.mag / sv : 0.0f;
                     if (rel > thr) first = atomicOr(&s_crossT[bin], 1u << k) == 0u;
                 }
@@ -1016,7 +1225,14 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
             for (int i = 0; i < 12; i++) { dbg[1 + i] = tk[i]; dbg[13 + i] = nk[i]; }
             dbg[29] = bulk_frames; dbg[25] = tk[12]; dbg[26] = nk[12]; dbg[27] = tk[13]; dbg[28] = nk[13];
 #endif
-            status[0] = abort_code | sh.abort;
+            if constexpr (MC) {
+                // the updaters leave; their verdicts (safety net, stale lists, timeout) are OR-ed into status[0] as well
+                if ((int)n_pub < mc_ops_cap)
+                    __hip_atomic_store(&mc_ops[n_pub], mc_pack(0, 0, 0, MCF_EXIT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (abort_code | sh.abort) atomicOr(&status[0], abort_code | sh.abort);
+            } else {
+                status[0] = abort_code | sh.abort;
+            }
             if (n_gone > (unsigned)gone_cap) st->overflow = 1;
             st->index = index0 + (uint64_t)n_frames * N;
             st->burst_id = burst_id;
@@ -1028,8 +1244,14 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
         }
     }
     __syncthreads();
+    if constexpr (!MC) {
 #pragma unroll
-    for (int j = 0; j < J; j++) sum_g[BIN_OF(j)] = s_sum[BIN_OF(j)];
+        for (int j = 0; j < J; j++) sum_g[BIN_OF(j)] = s_sum[BIN_OF(j)];
+    }
+#undef MC_PUBLISH
+#undef MC_BULK
+#undef MC_WAIT
+#undef MC_SUM
 #undef TK
 #undef WAVE_SYNC
 #undef RARE
@@ -1055,18 +1277,32 @@ size_t scan_fast_lds_bytes(int n)
 int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
                             int n_frames, const unsigned *counts, const unsigned *goff,
                             const ListEntry *compact, const float *pre, GoneBurst *gone, int gone_cap,
-                            int *status, hipStream_t stream)
+                            int *status, unsigned long long *mc_ops, int mc_ops_cap, unsigned *mc_done,
+                            int mc_updaters, hipStream_t stream)
 {
     const int Q = P.n / (4 * kFastThreads);
     if (Q < 1) return -1;
     const size_t lds = scan_fast_lds_bytes(P.n);
+    // mc_updaters > 0: multi-CU form, 1 leader + mc_updaters workgroups (mc_ops / mc_done zeroed by the caller)
+    const bool mc = mc_updaters > 0 && mc_ops && mc_done;
+    if (mc && mc_updaters > kMcMaxUpdaters) return -1;
 #define IRDM_LAUNCH_FAST(JJ)                                                                     \
     do {                                                                                         \
-        (void)hipFuncSetAttribute((const void *)detect_scan_fast_kernel<JJ>,                     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        hipLaunchKernelGGL((detect_scan_fast_kernel<JJ>), dim3(1), dim3(kFastThreads), lds,       \
-                           stream, P, st, sum, hist, mag, n_frames, counts, goff, compact, pre,  \
-                           gone, gone_cap, status);                                              \
+        if (mc) {                                                                                \
+            (void)hipFuncSetAttribute((const void *)detect_scan_fast_kernel<JJ, true>,           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            hipLaunchKernelGGL((detect_scan_fast_kernel<JJ, true>), dim3(1 + mc_updaters),       \
+                               dim3(kFastThreads), lds, stream, P, st, sum, hist, mag, n_frames, \
+                               counts, goff, compact, pre, gone, gone_cap, status, mc_ops,       \
+                               mc_ops_cap, mc_done);                                             \
+        } else {                                                                                 \
+            (void)hipFuncSetAttribute((const void *)detect_scan_fast_kernel<JJ, false>,          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            hipLaunchKernelGGL((detect_scan_fast_kernel<JJ, false>), dim3(1), dim3(kFastThreads),\
+                               lds, stream, P, st, sum, hist, mag, n_frames, counts, goff,       \
+                               compact, pre, gone, gone_cap, status,                             \
+                               (unsigned long long *)nullptr, 0, (unsigned *)nullptr);           \
+        }                                                                                        \
     } while (0)
     switch (Q) {
     case 1: IRDM_LAUNCH_FAST(1); break;

@@ -52,6 +52,53 @@ def test_scene_parity_sparse_dense_and_chunked(case):
     assert s["bursts"] == len(ref.bursts)
 
 
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_scene_parity_single_cu_scan(case):
+    """scan_mode 2: the sparse scan confined to one workgroup (the default, scan_mode 0, spreads the baseline updates over
+    updater workgroups on MI355X -- scan_fast.hip, MC form) -- same scenes, one chunk and chunked in throughput mode;
+    every record must equal the oracle's"""
+    name = case.replace("_simplex", "")
+    skw, ckw = CASES[case]
+    fs, iq = scenes.ALL[name](**skw)
+    ref = orc.run_stream(iq, fs, **ckw)
+    got = parity.run_gpu(iq, fs, scan_mode=2, **ckw)
+    parity.compare(got, ref)
+    chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 5), depth=1, scan_mode=2, **ckw)
+    parity.compare(chunked, ref)
+    if name in ("many_active_10m", "squelch"):
+        assert got["stats"]["scan_fallbacks"] >= 1, got["stats"]
+    else:
+        assert got["stats"]["scan_fallbacks"] == 0 and got["stats"]["scan_fast_chunks"] >= 1, got["stats"]
+
+
+@pytest.mark.parametrize("seed", (3, 7, 100))
+def test_scan_forms_random_scenes_and_final_baseline(seed):
+    """randomised emitters through the single-CU (2) and multi-CU (3) sparse scans against the oracle, and the carried
+    noise-floor sums after the stream bit-identical to the dense scan's (in the multi-CU form the updaters own them)"""
+    fs, iq = scenes.random_scene(seed, fs=10_000_000, secs=0.8) if seed >= 100 else scenes.random_scene(seed)
+    ref = orc.run_stream(iq, fs)
+    parity.compare(parity.run_gpu(iq, fs, scan_mode=3), ref)
+    parity.compare(parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 7), depth=1, scan_mode=2), ref)
+    sums = []
+    for mode in (1, 2, 3):
+        cs = _chunks(len(iq), 3)
+        p = irdm.Pipeline(fs, max_chunk_samples=max(cs), pipeline_depth=1)
+        p.set_option("scan_mode", mode)
+        try:
+            off = 0
+            for c in cs:
+                p.feed_host(iq[off:off + c])
+                off += c
+            p.flush()
+            sums.append(p.baseline_sum().copy())
+            if mode != 1:
+                assert p.stat("scan_fallbacks") == 0, "the sparse scan fell back to the dense scan"
+        finally:
+            p.close()
+    assert np.array_equal(sums[0].view(np.uint32), sums[1].view(np.uint32))
+    assert np.array_equal(sums[0].view(np.uint32), sums[2].view(np.uint32))
+
+
 def test_squelch_scene_ci8():
     """the same squelch / reset sequence through the ci8 ingest path"""
     import siggen
