@@ -197,6 +197,7 @@ struct irdm_pipeline {
     unsigned long long *d_mc_ops;   // multi-CU sparse scan: operation words leader -> updaters, completion counters back
     unsigned *d_mc_done;
     int mc_ops_cap, mc_updaters, mc_auto;
+    int scan_cus;               // CUs the scan stream may use (its CU mask, or the whole device)
     int scan_mode;              // 0 auto (sparse multi-CU where the device has the CUs, dense fallback), 1 dense only,
                                 // 2 sparse on one CU, 3 sparse multi-CU
     uint64_t stat_fast_chunks, stat_fallbacks, stat_dense_frames;
@@ -393,6 +394,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
                 hipExtStreamCreateWithCUMask(&s_rest, words, rest.data()) == hipSuccess &&
                 hipExtStreamCreateWithCUMask(&s_fft, words, rest.data()) == hipSuccess) {
                 p->sstream = s_scan;
+                p->scan_cus = xcds;
                 p->fstream = s_fft;
                 (void)hipStreamDestroy(p->stream2);
                 p->stream2 = s_rest;
@@ -537,7 +539,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->mc_updaters = 7;         // + the leader = 8 workgroups: the scan stream's 8 reserved CUs (pipeline_depth 1)
     {
         hipDeviceProp_t prop;
-        p->mc_auto = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 64;
+        const bool have = hipGetDeviceProperties(&prop, cfg->device) == hipSuccess;
+        p->mc_auto = have && prop.multiProcessorCount >= 64;
+        if (p->scan_cus == 0) p->scan_cus = have ? prop.multiProcessorCount : 1;
     }
     p->stat_fast_chunks = p->stat_fallbacks = p->stat_dense_frames = 0;
     p->host_primed = 0;
@@ -973,7 +977,10 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
             if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
                                  p->d_goff, p->d_compact, n_frames - done, p->stream) != 0)
                 return -1;
-            const int upd = (p->scan_mode == 3 || (p->scan_mode == 0 && p->mc_auto)) ? p->mc_updaters : 0;
+            // the leader and every updater need a CU of their own (one workgroup's LDS fills more than half a CU): more
+            // workgroups than the scan stream has CUs would wait for each other until the bounded spins give up
+            const int upd = (p->scan_mode == 3 || (p->scan_mode == 0 && p->mc_auto))
+                                ? std::min(p->mc_updaters, p->scan_cus - 1) : 0;
             const int mc_words = (int)std::min<size_t>((size_t)p->mc_ops_cap, 3 * (size_t)(n_frames - done) + 64);
             if (upd > 0) {
                 // at most 3 operations per frame + the exit word
