@@ -415,9 +415,12 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 }
                 if (bad) atomicOr(&status[0], 1);
                 if (stale) atomicOr(&status[0], 2);
-                // __syncthreads() waits for vmcnt(0) in every wavefront: all sums of this workgroup are acknowledged
+                // every wavefront waits for the acknowledgement of its own stores (vmcnt 0: an sc1 store is acknowledged
+                // when it is visible at agent scope), then the workgroup meets: all sums of this workgroup are visible
                 // before the counter moves, so the counter needs no release fence (no L2 write-back of the XCD's
-                // unrelated dirty lines on the leader's critical path)
+                // unrelated dirty lines on the leader's critical path).  The wait must be explicit: __syncthreads()
+                // alone compiles to `s_waitcnt lgkmcnt(0); s_barrier` here -- the stores could still be in flight.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 if (tid_ == 0)
                     __hip_atomic_store(&mc_done[w * kMcDoneStride], seen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
