@@ -8,10 +8,14 @@
 //     re-evaluates exactly those with the live baseline (mag / sum > thr,
 //     correctly rounded division) -- one wavefront ("leader"), no barriers.
 //   * while no burst is active every bin's running sum is updated each frame
-//     (simd_baseline_update) -- dense, all 1024 threads, in runs of frames with
+//     (simd_baseline_update) -- dense and bin-parallel, in runs of frames with
 //     an empty prefilter list, each thread also re-checking its own bins
 //     exactly (safety net: a crossing the list did not announce aborts the
 //     kernel, the host restores the pre-chunk state and runs the dense scan).
+//     Two forms of the same kernel: MC = false, the updates are commands that
+//     all wavefronts of the leader's workgroup execute; MC = true (default on
+//     MI355X), the leader publishes them as 64-bit operation words and
+//     updater workgroups on CUs of their own execute them, owning the sums.
 //
 // Exactness: the lists are only hints.  Every decision uses the same float
 // operations as the reference on the live state; a stale or overflowing list
