@@ -153,10 +153,40 @@ def e2e():
     json.dump(out, open(os.path.join(HERE, "e2e_scenes.json"), "w"), indent=1)
 
 
+def ref_bitlayer(R):
+    """Post-demod bit layer: seeded encoded / corrupted / truncated frames (tests/test_oracle_bitlayer.py's generators)
+    and what the REFERENCE's frame_decode.c / ida_decode.c return for them.  Stored: the input bits, the LLRs (or their
+    absence), the direction, and every output field as integers (doubles as their bit patterns, texts as bytes)."""
+    import test_oracle_bitlayer as T
+    R.ref_frame_decode.restype = C.c_int
+    R.ref_ida_decode.restype = C.c_int
+    fd, ida = [], []
+    for bits, llr in T.make_cases(4242, n=90):
+        r, d = T.decode_with(R.ref_frame_decode, bits, llr)
+        fd.append(dict(bits=bytes(bytearray(bits)).hex(), llr=None if llr is None else np.asarray(llr, np.float32).tobytes().hex(),
+                       ret=int(r), out=[int(v) if not isinstance(v, tuple) else [int(x) for x in v] for v in T.as_tuple(d)]))
+    for bits, llr, direction in T.make_ida_cases(4343, n=90):
+        r, d = T.ida_decode_with(R.ref_ida_decode, bits, llr, direction)
+        t = T.ida_tuple(d)
+        ida.append(dict(bits=bytes(bytearray(bits)).hex(), llr=None if llr is None else np.asarray(llr, np.float32).tobytes().hex(),
+                        direction=int(direction), ret=int(r),
+                        out=[v.hex() if isinstance(v, (bytes, bytearray)) else
+                             ([int(x) for x in v] if isinstance(v, (tuple, list)) else int(v)) for v in t]))
+    import gzip
+    with gzip.GzipFile(os.path.join(HERE, "ref_bitlayer.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(dict(frame_decode=fd, ida_decode=ida)).encode())
+    print("ref_bitlayer:", len(fd), "frame_decode cases,", len(ida), "ida_decode cases;",
+          sum(c["ret"] for c in fd), "+", sum(c["ret"] for c in ida), "decoded")
+
+
 if __name__ == "__main__":
     R = orc.ref()
     if R is None:
         raise SystemExit("needs oracle/_ref (the reference tree)")
+    if len(sys.argv) > 1 and sys.argv[1] == "bitlayer":      # only the newer fixture; the others stay byte-identical
+        ref_bitlayer(R)
+        raise SystemExit(0)
     ref_stage_c(R)
     ref_designs(R)
     e2e()
+    ref_bitlayer(R)
