@@ -349,7 +349,8 @@ def main():
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
                        "pipeline_depth": args.depth,
-                       "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames")}},
+                       "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
+                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags")}},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,

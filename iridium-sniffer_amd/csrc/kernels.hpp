@@ -22,6 +22,44 @@ int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float 
                             int *status, unsigned long long *mc_ops, int mc_ops_cap, unsigned *mc_done,
                             int mc_updaters, hipStream_t stream);
 
+// scan_band.hip (band-parallel speculative scan; band_core.hpp holds the per-band state machine)
+constexpr int kBandRounds = 6;           // speculation rounds before giving up (2-3 on the benchmark scenes)
+struct BandRec;
+struct BandParams;
+struct BandCtl {                         // control block on the device, copied to the host after the scan
+    int32_t status;                      // 0 running, 1 accepted (and committed), 2 aborted (carried state untouched)
+    int32_t rounds;
+    uint32_t flags;                      // BAND_F_* abort reasons
+    int32_t n_upd, n_snap, agree_fail, mismatch, first_mismatch;
+    int32_t n_gone, n_total, committed, h0;
+    int32_t pad[4];
+};
+struct BandWork {                        // device workspace, carved out of one allocation (band_work_carve)
+    BandCtl *ctl;
+    uint8_t *uq, *uf;                    // speculated per-frame updates: frame ends quiet / forces an update
+    int32_t *cnt_before, *tmp, *upd_frame, *old_row, *snap_after, *need, *snap_slot, *slot_pre, *slot_post;
+    uint64_t *cross;
+    float *relq, *snap;
+    int snap_cap;
+    uint64_t *occ, *busy, *forced;
+    uint32_t *conc;
+    BandRec *recs;
+    uint32_t *rec_count;
+    float *sum_new;
+    uint32_t *tot;
+    uint64_t *ids;
+    uint32_t *flags;
+};
+int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0);
+size_t band_work_bytes(int n, size_t max_chunk);
+int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
+int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
+                     int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
+                     float *smin, GoneBurst *gone, int gone_cap, hipStream_t stream);
+// smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
+int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
+                           unsigned *counts, ListEntry *entries, int n_frames, hipStream_t stream);
+
 // where a burst window's samples live: the chunk being fed, or the history ring
 struct SampleSource {
     const void *chunk;        // device pointer, configured format

@@ -29,6 +29,7 @@
 #include "common.hpp"
 #include "host_design.hpp"
 #include "kernels.hpp"
+#include "band_core.hpp"
 #include "types.hpp"
 
 using namespace irdm;
@@ -202,6 +203,15 @@ struct irdm_pipeline {
                                 // 2 sparse on one CU, 3 sparse multi-CU
     uint64_t stat_fast_chunks, stat_fallbacks, stat_dense_frames;
     int host_primed, host_hist_idx;
+    // band-parallel speculative scan (scan_band.hip): the default where band_scan_supported()
+    void *d_band;               // one allocation, carved into `band`
+    BandWork band;
+    float *d_smin;              // smallest sum every bin went through in the last band scan (stale-list retry)
+    bool band_ok;
+    int fl_mode;                // scan in flight: 0 dense, 1 sparse (leader/updaters), 2 band
+    int fl_done;                // frames the dense scan primed before the in-flight scan proper
+    uint64_t stat_band_chunks, stat_band_rounds, stat_band_retries, stat_band_aborts;
+    uint32_t last_band_flags;
 
     std::vector<GoneBurst> h_gone;
     // pipeline_depth 1: bursts of the last fed chunk, processed during the next feed / irdm_flush
@@ -254,7 +264,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
                      p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
                      p->d_fir_off, p->d_mag2, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
-                     p->d_status, p->d_mc_ops, p->d_mc_done };
+                     p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
@@ -509,6 +519,12 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_mc_ops, unsigned long long, (size_t)p->mc_ops_cap);
         AL(p->d_mc_done, unsigned, 32 * 16);
     }
+    p->band_ok = band_scan_supported(P, nullptr, 1, 0) != 0;
+    if (p->band_ok) {
+        AL(p->d_smin, float, (size_t)P.n);
+        if (ok) ok = hipMalloc(&p->d_band, band_work_bytes(P.n, p->max_chunk)) == hipSuccess;
+        if (ok) band_work_carve(&p->band, p->d_band, P.n, p->max_chunk);
+    }
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
 #undef UP
 #undef AL
@@ -544,6 +560,10 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         if (p->scan_cus == 0) p->scan_cus = have ? prop.multiProcessorCount : 1;
     }
     p->stat_fast_chunks = p->stat_fallbacks = p->stat_dense_frames = 0;
+    p->stat_band_chunks = p->stat_band_rounds = p->stat_band_retries = p->stat_band_aborts = 0;
+    p->last_band_flags = 0;
+    p->fl_mode = 0;
+    p->fl_done = 0;
     p->host_primed = 0;
     p->host_hist_idx = 0;
     return p;
@@ -952,26 +972,62 @@ static int scan_dense(irdm_pipeline *p, const float *mag, int n_frames, bool tim
     return 0;
 }
 
-static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_t c1)
+// which scan a chunk gets: scan_mode 0 = the band scan where the geometry allows it (else the sparse leader scan,
+// else dense), 1 dense, 2 / 3 the sparse leader scan on one CU / with updater workgroups, 4 band
+static int scan_pick(const irdm_pipeline *p)
+{
+    if (p->scan_mode == 1) return 0;
+    if ((p->scan_mode == 0 || p->scan_mode == 4) && p->band_ok) return 2;
+    return p->P.n >= 2048 ? 1 : 0;          // the sparse kernel's lanes own 2048-bin quarters (scan_fast.hip)
+}
+
+static int scan_snapshot(irdm_pipeline *p)
 {
     const DetParams &P = p->P;
-    IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[9], p->stream));
-    p->fl_sparse = p->scan_mode != 1;
     // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts or the burst-record
     // buffer turns out too small (scan_finish then redoes the chunk)
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
                                   hipMemcpyDeviceToDevice, p->stream));
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state_bak, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
-    if (p->fl_sparse) {
+    return 0;
+}
+
+static int scan_restore(irdm_pipeline *p)
+{
+    const DetParams &P = p->P;
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
+                                  hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+    return 0;
+}
+
+// the band scan proper over the primed frames [done, n_frames) of the chunk; retry = 1: the lists went stale, rebuild
+// them against the lowered reference first
+static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry)
+{
+    const DetParams &P = p->P;
+    const float *mag_rest = mag + (size_t)done * P.n;
+    const uint64_t idx0 = p->fl_c1 - (uint64_t)(n_frames - done) * (uint64_t)P.n;
+    if (launch_prefilter_lists(p->d_sum, P.threshold, p->d_pre, retry ? p->d_smin : nullptr, mag_rest, P.n, p->d_counts,
+                               p->d_entries, n_frames - done, p->stream) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->stream));
+    if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, p->d_counts,
+                         p->d_entries, p->d_pre, p->d_smin, p->d_gone, p->gone_cap, p->stream) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->stream));
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->h_pin + 96, p->band.ctl, sizeof(BandCtl), hipMemcpyDeviceToHost, p->stream));
+    return 0;
+}
+
+// the sequential forms: the sparse leader scan with the dense kernel as its exact fallback, or the dense kernel alone
+static int scan_legacy_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, bool sparse)
+{
+    const DetParams &P = p->P;
+    if (sparse) {
         IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 64, p->stream));
-        int done = 0;
-        if (!p->host_primed) {
-            // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428)
-            done = std::min(n_frames, kHistory - p->host_hist_idx);
-            if (scan_dense(p, mag, done, done == n_frames) != 0) return -1;
-        }
         if (done < n_frames) {
             const float *mag_rest = mag + (size_t)done * P.n;
             if (launch_prefilter(p->d_sum, P.threshold, p->d_pre, mag_rest, P.n, p->d_counts, p->d_entries,
@@ -979,7 +1035,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
                 return -1;
             // the leader and every updater need a CU of their own (one workgroup's LDS fills more than half a CU): more
             // workgroups than the scan stream has CUs would wait for each other until the bounded spins give up
-            const int upd = (p->scan_mode == 3 || (p->scan_mode == 0 && p->mc_auto))
+            const int upd = (p->scan_mode == 3 || (p->scan_mode != 2 && p->mc_auto))
                                 ? std::min(p->mc_updaters, p->scan_cus - 1) : 0;
             const int mc_words = (int)std::min<size_t>((size_t)p->mc_ops_cap, 3 * (size_t)(n_frames - done) + 64);
             if (upd > 0) {
@@ -997,25 +1053,87 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
             if (scan_hop_out(p) != 0) return -1;
         }
         IRDM_HIP_CHECK(hipMemcpyAsync(p->h_pin, p->d_status, sizeof(int) * 64, hipMemcpyDeviceToHost, p->stream));
-    } else {
-        if (scan_dense(p, mag, n_frames, true) != 0) return -1;
+    } else if (done < n_frames) {
+        if (scan_dense(p, mag + (size_t)done * P.n, n_frames - done, true) != 0) return -1;
     }
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
-    p->fl_active = true;
+    return 0;
+}
+
+static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_t c1)
+{
+    IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[9], p->stream));
+    p->fl_mode = scan_pick(p);
+    p->fl_sparse = p->fl_mode == 1;
     p->fl_mag = mag;
     p->fl_frames = n_frames;
     p->fl_c1 = c1;
+    // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428) -- dense kernel, no bursts
+    int done = 0;
+    if (!p->host_primed && p->fl_mode != 0) {
+        done = std::min(n_frames, kHistory - p->host_hist_idx);
+        if (scan_dense(p, mag, done, done == n_frames) != 0) return -1;
+    }
+    p->fl_done = done;
+    // (a snapshot, where one is taken, is the state AFTER the priming frames: a redo restarts at frame `done`)
+    if (p->fl_mode == 2) {
+        // nothing of the carried state is written before the band scan's commit: no snapshot
+        memset(p->h_pin + 96, 0, sizeof(BandCtl));
+        if (done < n_frames) {
+            if (scan_band_enqueue(p, mag, n_frames, done, 0) != 0) return -1;
+        } else {
+            reinterpret_cast<BandCtl *>(p->h_pin + 96)->status = 1;       // the chunk was all priming
+        }
+    } else {
+        if (scan_snapshot(p) != 0) return -1;
+        if (scan_legacy_enqueue(p, mag, n_frames, done, p->fl_mode == 1) != 0) return -1;
+    }
+    IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
+    p->fl_active = true;
     return 0;
 }
 
 static int scan_finish(irdm_pipeline *p, int *n_gone_out)
 {
-    const DetParams &P = p->P;
     *n_gone_out = 0;
     if (!p->fl_active) return 0;
     p->fl_active = false;
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-    if (p->fl_sparse) {
+    int redo_from = p->fl_done;       // where a dense redo restarts (the priming frames are never redone)
+    if (p->fl_mode == 2) {
+        const BandCtl *ctl = reinterpret_cast<const BandCtl *>(p->h_pin + 96);
+        int tries = 0;
+        while (ctl->status != 1 && ctl->flags == BAND_F_STALE && tries < 2) {
+            // a bin's running sum fell below what the prefilter lists assumed (the noise floor dropped by more than
+            // 1.8x inside the chunk): rebuild the lists against the lowest sums seen and scan again
+            tries++;
+            p->stat_band_retries++;
+            if (scan_band_enqueue(p, p->fl_mag, p->fl_frames, p->fl_done, 1) != 0) return -1;
+            IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        }
+        p->stat_band_rounds += (uint64_t)ctl->rounds;
+        if (ctl->status == 1) {
+            p->stat_band_chunks++;
+            p->stat_fast_chunks++;
+        } else {
+            // declined (possible squelch, capacities, no fixed point, ...): the carried state is untouched, the
+            // sequential kernels take the chunk
+            p->stat_band_aborts++;
+            p->stat_fallbacks++;
+            p->last_band_flags = ctl->flags;
+            if (getenv("IRDM_SCAN_DEBUG"))
+                fprintf(stderr, "irdm_hip: band scan declined the chunk (flags 0x%x, %d rounds, %d mismatches from frame %d) -> sequential scan\n",
+                        ctl->flags, ctl->rounds, ctl->mismatch, ctl->first_mismatch);
+            p->fl_mode = p->P.n >= 2048 && p->scan_mode != 4 ? 1 : 0;
+            p->fl_sparse = p->fl_mode == 1;
+            IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
+            if (scan_snapshot(p) != 0) return -1;
+            if (scan_legacy_enqueue(p, p->fl_mag, p->fl_frames, p->fl_done, p->fl_mode == 1) != 0) return -1;
+            IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
+            IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        }
+    }
+    if (p->fl_mode == 1) {
         const int status = p->h_pin[0];
         if (getenv("IRDM_SCAN_DEBUG")) {
             const long long *d = reinterpret_cast<const long long *>(p->h_pin + 4);
@@ -1028,11 +1146,8 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
             p->stat_fallbacks++;
             if (getenv("IRDM_SCAN_DEBUG")) fprintf(stderr, "irdm_hip: sparse scan aborted with status 0x%x -> dense scan\n", status);
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
-                                          hipMemcpyDeviceToDevice, p->stream));
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
-            if (scan_dense(p, p->fl_mag, p->fl_frames, true) != 0) return -1;
+            if (scan_restore(p) != 0) return -1;
+            if (scan_dense(p, p->fl_mag + (size_t)redo_from * p->P.n, p->fl_frames - redo_from, true) != 0) return -1;
             IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
         } else {
             p->stat_fast_chunks++;
@@ -1060,11 +1175,8 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         p->gone_cap = want;
         p->h_gone.resize(want);
         p->stat_fallbacks++;
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
-                                      hipMemcpyDeviceToDevice, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, p->d_state_bak, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
-        if (scan_dense(p, p->fl_mag, p->fl_frames, true) != 0) return -1;
+        if (scan_restore(p) != 0) return -1;
+        if (scan_dense(p, p->fl_mag + (size_t)redo_from * p->P.n, p->fl_frames - redo_from, true) != 0) return -1;
         IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, p->stream));
         IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, p->stream));
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -1079,7 +1191,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     if (n_gone > 0)
         IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));
     float ms = 0;
-    // the scan kernel proper (the sparse kernel, or the dense one when it ran instead)
+    // the scan proper (band passes, the sparse kernel, or the dense one when it ran instead)
     p->last_ms[1] = hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
     p->last_frames = p->fl_frames;
     p->d_mag_last = p->fl_mag;
@@ -1584,6 +1696,11 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!p || !key) return -1;
     if (!strcmp(key, "scan_fast_chunks")) return (int64_t)p->stat_fast_chunks;
     if (!strcmp(key, "scan_fallbacks")) return (int64_t)p->stat_fallbacks;
+    if (!strcmp(key, "band_chunks")) return (int64_t)p->stat_band_chunks;
+    if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
+    if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;
+    if (!strcmp(key, "band_aborts")) return (int64_t)p->stat_band_aborts;
+    if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
     return -1;
 }

@@ -132,6 +132,27 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the per-frame lists alone (scan_band.hip reads them in place, no compaction).  smin != nullptr: a retry after the
+// band scan found the lists stale -- the threshold only goes down, to 0.45 * thr * (smallest sum the bin went through)
+__global__ void prefilter_lower_kernel(const float *__restrict__ smin, float thr, float *__restrict__ pre, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pre[i] = fminf(pre[i], 0.45f * thr * smin[i]);
+}
+
+int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
+                           unsigned *counts, ListEntry *entries, int n_frames, hipStream_t stream)
+{
+    if (n_frames <= 0) return 0;
+    if (smin)
+        hipLaunchKernelGGL(prefilter_lower_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, smin, thr, pre, n);
+    else
+        hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
+    const int grid = n_frames < 8192 ? n_frames : 8192;
+    hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---- wavefront reductions on the DPP network (no LDS round trips: __shfl_xor compiles to
 // ds_bpermute, ~100+ cycles each for a lone wavefront) ----
 template <int CTRL>
