@@ -38,7 +38,7 @@ constexpr int kBandMaxTotal = 8192;   // owned burst records per chunk that the 
 enum : uint32_t {
     BAND_F_SLOTS = 1,        // more simultaneous bursts in a band than kBandSlots
     BAND_F_RECS = 2,         // more records in a band than kBandRecCap
-    BAND_F_LIST = 4,         // a prefilter list overflowed (kListCap)
+    BAND_F_LIST = 4,         // a prefilter list overflowed (kBandListCap)
     BAND_F_STALE = 8,        // the running sum fell below what the prefilter threshold assumed
     BAND_F_SQUELCH = 16,     // the bound on simultaneously active bursts reaches max_bursts (:594)
     BAND_F_AGREE = 32,       // neighbouring bands disagree on a burst near their boundary
@@ -55,6 +55,7 @@ struct BandParams {
     int32_t pre_len, post_len, max_len, max_bursts;
     int32_t band_w, n_bands;     // owned bins per band; extended range = band_w / 2 bins on either side
     int32_t gap;                 // ceil(post_len / n): frames after the last crossing at which a burst is gone
+    int32_t list_cap;            // entries per frame in the prefilter lists
     float thr;
     uint64_t idx0;               // absolute sample index of frame 0
 };

@@ -50,6 +50,7 @@ struct BandWork {                        // device workspace, carved out of one 
     uint64_t *ids;
     uint32_t *flags;
 };
+int band_list_cap(int n);                // entries per frame the band scan's lists hold
 int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0);
 size_t band_work_bytes(int n, size_t max_chunk);
 int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
@@ -58,7 +59,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                      float *smin, GoneBurst *gone, int gone_cap, hipStream_t stream);
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
-                           unsigned *counts, ListEntry *entries, int n_frames, hipStream_t stream);
+                           unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream);
 
 // where a burst window's samples live: the chunk being fed, or the history ring
 struct SampleSource {

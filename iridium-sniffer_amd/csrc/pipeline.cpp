@@ -228,7 +228,7 @@ struct irdm_pipeline {
     bool fl_active, fl_sparse;
     const float *fl_mag, *d_mag_last;
     int fl_frames;
-    uint64_t fl_c1;
+    uint64_t fl_c1, fl_c0;
     hipStream_t fstream;     // K1 (== stream unless pipeline_depth 1)
     float *d_mag2;           // pipeline_depth 1: second magnitude buffer
     int mag_parity;
@@ -507,7 +507,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     {
         const size_t max_frames = p->max_chunk / P.n;
         AL(p->d_counts, unsigned, max_frames);
-        AL(p->d_entries, ListEntry, max_frames * kListCap);
+        AL(p->d_entries, ListEntry, max_frames * (size_t)std::max(kListCap, band_list_cap(P.n)));
         AL(p->d_goff, unsigned, max_frames + 1);
         AL(p->d_compact, ListEntry, max_frames * kListCap);
         AL(p->d_pre, float, (size_t)P.n);
@@ -1009,9 +1009,9 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
 {
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
-    const uint64_t idx0 = p->fl_c1 - (uint64_t)(n_frames - done) * (uint64_t)P.n;
+    const uint64_t idx0 = p->fl_c0 + (uint64_t)done * (uint64_t)P.n;     // chunks start on frame boundaries
     if (launch_prefilter_lists(p->d_sum, P.threshold, p->d_pre, retry ? p->d_smin : nullptr, mag_rest, P.n, p->d_counts,
-                               p->d_entries, n_frames - done, p->stream) != 0)
+                               p->d_entries, n_frames - done, band_list_cap(P.n), p->stream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->stream));
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, p->d_counts,
@@ -1068,6 +1068,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
     p->fl_mag = mag;
     p->fl_frames = n_frames;
     p->fl_c1 = c1;
+    p->fl_c0 = p->total_samples;
     // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428) -- dense kernel, no bursts
     int done = 0;
     if (!p->host_primed && p->fl_mode != 0) {

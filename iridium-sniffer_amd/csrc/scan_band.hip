@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
         for (int f = tid; f < F; f += kPlanThreads) {
             W.uq[f] = 0;
             W.uf[f] = 0;
-            if (counts[f] > (unsigned)kListCap) atomicOr(&s_flags, BAND_F_LIST);
+            if (counts[f] > (unsigned)P.list_cap) atomicOr(&s_flags, BAND_F_LIST);
         }
         if (tid == 0) ctl->h0 = st->hist_idx;
     } else {
@@ -260,11 +260,11 @@ __global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork 
     if (W.ctl->status != 0) return;
     const int f = blockIdx.x, tid = threadIdx.x, N = P.n;
     const unsigned c = counts[f];
-    if (c == 0 || c > (unsigned)kListCap) return;
+    if (c == 0 || c > (unsigned)P.list_cap) return;
     for (int w = tid; w < N / 32; w += 256) s_bits[w] = 0;
     __syncthreads();
     const float *__restrict__ srow = W.snap + (size_t)W.slot_pre[f] * N;
-    const ListEntry *__restrict__ e = entries + (size_t)f * kListCap;
+    const ListEntry *__restrict__ e = entries + (size_t)f * P.list_cap;
     float *__restrict__ rq = W.relq + (size_t)f * N;
     for (unsigned i = tid; i < c; i += 256) {
         const int bin = e[i].bin;
@@ -471,6 +471,8 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
 
 }  // namespace
 
+int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
+
 int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0)
 {
     BandParams P;
@@ -488,6 +490,7 @@ int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint6
     P.gap = (D.post_len + D.n - 1) / D.n;
     P.thr = D.threshold;
     P.idx0 = idx0;
+    P.list_cap = band_list_cap(D.n);
     if (out) *out = P;
     // what the kernels assume: at most 64 bands (one wavefront), the halo wider than two masks, a segment cut within
     // one 64-frame word, at least one whole band

@@ -46,7 +46,7 @@ __global__ void prefilter_threshold_kernel(const float *__restrict__ sum, float 
 __global__ __launch_bounds__(256) void prefilter_kernel(const float *__restrict__ mag,
                                                         const float *__restrict__ pre, int n,
                                                         unsigned *__restrict__ counts,
-                                                        ListEntry *__restrict__ entries, int n_frames)
+                                                        ListEntry *__restrict__ entries, int n_frames, int cap)
 {
     __shared__ int cnt;
     const int tid = threadIdx.x;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const float *__restrict_
         __syncthreads();
         const float4 *m4 = reinterpret_cast<const float4 *>(mag + (size_t)frame * n);
         const float4 *p4 = reinterpret_cast<const float4 *>(pre);
-        ListEntry *out = entries + (size_t)frame * kListCap;
+        ListEntry *out = entries + (size_t)frame * cap;
         for (int q = tid; q < n / 4; q += 256) {
             const float4 m = m4[q], p = p4[q];
             const float mv[4] = { m.x, m.y, m.z, m.w }, pv[4] = { p.x, p.y, p.z, p.w };
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const float *__restrict_
             for (int u = 0; u < 4; u++) {
                 if (mv[u] > pv[u]) {
                     const int slot = atomicAdd(&cnt, 1);
-                    if (slot < kListCap) {
+                    if (slot < cap) {
                         out[slot].bin = 4 * q + u;
                         out[slot].mag = mv[u];
                     }
@@ -126,7 +126,7 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
     if (n_frames <= 0) return 0;
     hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
     const int grid = n_frames < 8192 ? n_frames : 8192;
-    hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames);
+    hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames, kListCap);
     hipLaunchKernelGGL(list_offsets_kernel, dim3(1), dim3(1024), 0, stream, counts, goff, n_frames);
     hipLaunchKernelGGL(list_compact_kernel, dim3(grid), dim3(256), 0, stream, counts, goff, entries, compact, n_frames);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -141,7 +141,7 @@ __global__ void prefilter_lower_kernel(const float *__restrict__ smin, float thr
 }
 
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
-                           unsigned *counts, ListEntry *entries, int n_frames, hipStream_t stream)
+                           unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream)
 {
     if (n_frames <= 0) return 0;
     if (smin)
@@ -149,7 +149,7 @@ int launch_prefilter_lists(const float *sum, float thr, float *pre, const float 
     else
         hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
     const int grid = n_frames < 8192 ? n_frames : 8192;
-    hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames);
+    hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames, cap);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

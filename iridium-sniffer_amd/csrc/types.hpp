@@ -59,7 +59,8 @@ struct ListEntry {
     int32_t bin;
     float mag;
 };
-constexpr int kListCap = 1024;           // entries per frame; more -> dense scan fallback
+constexpr int kListCap = 1024;           // entries per frame of the sparse leader scan; more -> dense scan fallback
+constexpr int kBandListCap = 4096;       // entries per frame of the band scan (at most fft_size); more -> sequential scan
 
 // one decimator tile = kFirTileOut outputs of one burst
 struct FirTile {

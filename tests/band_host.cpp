@@ -59,7 +59,7 @@ int band_chunk(Host &H, const float *mag, int n_frames, std::vector<GoneBurst> &
     P.n = N; P.nw64 = N / 64; P.n_frames = F; P.occ_words = (F + 63) / 64; P.hw = D.width / 2;
     P.pre_len = D.pre_len; P.post_len = D.post_len; P.max_len = D.max_len; P.max_bursts = D.max_bursts;
     P.band_w = band_w_override ? band_w_override : (P.hw <= 20 ? 128 : 256);
-    P.n_bands = N / P.band_w; P.gap = (D.post_len + N - 1) / N; P.thr = D.threshold; P.idx0 = H.st.index;
+    P.list_cap = std::min(kBandListCap, N); P.n_bands = N / P.band_w; P.gap = (D.post_len + N - 1) / N; P.thr = D.threshold; P.idx0 = H.st.index;
     const int OW = P.occ_words;
 
     // prefilter lists (scan_fast.hip prefilter_kernel); pre_io: the caller lowers it and retries after BAND_F_STALE
@@ -120,7 +120,7 @@ int band_chunk(Host &H, const float *mag, int n_frames, std::vector<GoneBurst> &
             }
         } else {
             for (int f = 0; f < F; f++)
-                if (lists[f].size() > (size_t)kListCap) { H.last_flags = BAND_F_LIST; return 2; }
+                if (lists[f].size() > (size_t)std::min(kBandListCap, N)) { H.last_flags = BAND_F_LIST; return 2; }
         }
         std::fill(occ.begin(), occ.end(), 0); std::fill(busy.begin(), busy.end(), 0);
         std::fill(forced.begin(), forced.end(), 0); std::fill(conc.begin(), conc.end(), 0);
