@@ -39,9 +39,15 @@ __device__ float2 cubic_interp(const float2 *in, int n, float pos)
     return cadd(cadd(cadd(cscale(mu3, a), cscale(mu2, b)), cscale(mu, c)), s1);
 }
 
-// One wavefront per frame.  The frame (<= 4440 samples) and the per-symbol work arrays live in LDS;
-// lane 0 runs the sequential recurrences (Gardner loop, PLL, end-of-frame rule, the float sums whose
-// order matters), the other lanes stage the frame and write the per-symbol outputs.
+// One wavefront per frame.  The frame (<= 4440 samples) and the per-symbol work arrays live in LDS.
+// What is a true recurrence stays sequential, everything else is spread over the 64 lanes:
+//   * Gardner loop (qpsk_demod.c:85-130): position n+1 depends on the timing error of position n -> sequential,
+//     but the on-time and the mid-point interpolation of one step are independent: lanes 0 and 1 run the same
+//     Catmull-Rom instruction stream on the two positions and exchange the results over the DPP network;
+//   * PLL (:145-195): phi_{i+1} depends on phi_i through cabsf / atan2f / cosf / sinf -> sequential on lane 0;
+//   * slicer, per-symbol magnitudes, confidence flags, unique-word angles, |.| for the LLR scale: one symbol per
+//     lane; only the float sums whose order matters (level :247, LLR scale :489-497) and the end-of-frame rule
+//     (:210-225, a running maximum) are walked in order by lane 0, over values already computed.
 __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__ work, int n_bursts,
                                                    const float2 *__restrict__ frames, int use_gardner, float sps,
                                                    float2 *__restrict__ ws, DemodOut *__restrict__ out)
@@ -49,9 +55,12 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
     __shared__ float2 s_fr[kMaxFrameSamples];
     __shared__ float2 s_dec[kMaxSymbols];
     __shared__ float2 s_po[kMaxSymbols];
-    __shared__ int s_sym[kMaxSymbols];
+    __shared__ float s_mag[kMaxSymbols];      // sqrtf(re^2 + im^2) of the PLL output (:205, :231)
+    __shared__ float s_abs[kMaxSymbols];      // cabsf of the PLL output (:493)
+    __shared__ int s_sym[kMaxSymbols];        // quadrant | confidence flag << 2
     __shared__ int s_res[4];          // ok, direction, ns, confidence
     __shared__ float s_resf[3];       // level, total_phase, llr scale
+    __shared__ int s_n;
     (void)ws;
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
@@ -67,49 +76,55 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
     for (int i = lane; i < n_samples; i += 64) s_fr[i] = gin[i];
     __syncthreads();
 
-    if (lane == 0) {
-        const float2 *in = s_fr;
-        float2 *dec = s_dec, *po = s_po;
-        int *sym = s_sym;
-        // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
-        int n = 0;
-        if (use_gardner) {
+    // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
+    if (use_gardner) {
+        if (lane < 2) {
+            int n = 0;
             float pos = 0.0f, toff = 0.0f;
             float2 prev = make_float2(0.0f, 0.0f);
             while (pos < (float)(n_samples - 3) && n < kMaxSymbols) {
-                const float2 on = cubic_interp(in, n_samples, pos);
-                dec[n] = on;
-                if (n > 0) {
-                    const float mid_pos = pos - sps * 0.5f;
-                    if (mid_pos >= 1.0f) {
-                        const float2 mid = cubic_interp(in, n_samples, mid_pos);
-                        const float2 diff = csub(prev, on);
-                        // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
-                        const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
-                        float err = p0 - p1;
-                        if (err > 1.0f) err = 1.0f;
-                        if (err < -1.0f) err = -1.0f;
-                        toff += 0.0002f * err;
-                        float adj = 0.02f * err + toff;
-                        if (adj > 0.5f) adj = 0.5f;
-                        if (adj < -0.5f) adj = -0.5f;
-                        pos += adj;
-                    }
+                const float mid_pos = pos - sps * 0.5f;
+                // lane 0: the on-time sample; lane 1: the mid-point sample (used only where the reference computes it)
+                const float2 mine = cubic_interp(s_fr, n_samples, lane == 0 ? pos : (mid_pos >= 1.0f ? mid_pos : 1.0f));
+                const float2 on = make_float2(__shfl(mine.x, 0), __shfl(mine.y, 0));
+                const float2 mid = make_float2(__shfl(mine.x, 1), __shfl(mine.y, 1));
+                if (lane == 0) s_dec[n] = on;
+                if (n > 0 && mid_pos >= 1.0f) {
+                    const float2 diff = csub(prev, on);
+                    // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
+                    const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
+                    float err = p0 - p1;
+                    if (err > 1.0f) err = 1.0f;
+                    if (err < -1.0f) err = -1.0f;
+                    toff += 0.0002f * err;
+                    float adj = 0.02f * err + toff;
+                    if (adj > 0.5f) adj = 0.5f;
+                    if (adj < -0.5f) adj = -0.5f;
+                    pos += adj;
                 }
                 prev = on;
                 n++;
                 pos += sps;
             }
-        } else {
-            for (int i = 0; i < n_samples && n < kMaxSymbols; i += (int)sps) dec[n++] = in[i];
+            if (lane == 0) s_n = n;
         }
+    } else {
+        const int step = (int)sps;
+        int n = (n_samples + step - 1) / step;
+        if (n > kMaxSymbols) n = kMaxSymbols;
+        for (int i = lane; i < n; i += 64) s_dec[i] = s_fr[i * step];
+        if (lane == 0) s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
 
-        // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
+    // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
+    if (lane == 0) {
         float2 phi = make_float2(1.0f, 0.0f);
         float total_phase = 0.0f;
         for (int i = 0; i < n; i++) {
-            const float2 v = cmul(dec[i], phi);
-            po[i] = v;
+            const float2 v = cmul(s_dec[i], phi);
+            s_po[i] = v;
             float2 xh;
             if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
             else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
@@ -121,21 +136,41 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
             const float2 unit = make_float2(er.x / em, er.y / em);
             const float ang = atan2f(unit.y, unit.x);
             const float sa = 0.2f * ang;
-            const float2 corr = make_float2(cosf(sa), sinf(sa));
+            float sn, cs;
+            sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
+            const float2 corr = make_float2(cs, sn);
             total_phase += sa;
             phi = cmul(make_float2(corr.x, -corr.y), phi);
             const float pm = cabs_f(phi);
             if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
         }
+        s_resf[1] = total_phase;
+    }
+    __syncthreads();
 
-        // step 3: demod_qpsk (qpsk_demod.c:199-260): the end-of-frame rule fixes ns, then level and
-        // confidence are accumulated over [0, ns) in order
+    // step 3a: per-symbol values of demod_qpsk (qpsk_demod.c:199-260), one symbol per lane
+    for (int i = lane; i < n; i += 64) {
+        const float re = s_po[i].x, im = s_po[i].y;
+        const float a = re * re, bq = im * im;
+        s_mag[i] = sqrtf(a + bq);
+        s_abs[i] = cabs_f(s_po[i]);
+        int sq;
+        if (re >= 0 && im >= 0) sq = 0;
+        else if (re < 0 && im >= 0) sq = 1;
+        else if (re < 0) sq = 2;
+        else sq = 3;
+        const float phase = (atan2f(im, re) + IRDM_PI_F) * 180.0f / IRDM_PI_F;
+        const float offs = 45.0f - fmodf(phase, 90.0f);
+        s_sym[i] = sq | ((fabsf(offs) <= 22.0f) ? 4 : 0);
+    }
+    __syncthreads();
+
+    if (lane == 0) {
+        // step 3b: the end-of-frame rule fixes ns, then level and confidence are accumulated over [0, ns) in order
         float max_mag = 0.0f, sum = 0.0f;
         int low = 0, ns = 0, n_ok = 0;
         for (int i = 0; i < n; i++) {
-            const float re = po[i].x, im = po[i].y;
-            const float a = re * re, bq = im * im;
-            const float mag = sqrtf(a + bq);
+            const float mag = s_mag[i];
             if (mag > max_mag) max_mag = mag;
             ns++;
             if (mag < max_mag / 8.0f) {
@@ -145,18 +180,8 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
             }
         }
         for (int i = 0; i < ns; i++) {
-            const float re = po[i].x, im = po[i].y;
-            const float a = re * re, bq = im * im;
-            sum += sqrtf(a + bq);
-            int sq;
-            if (re >= 0 && im >= 0) sq = 0;
-            else if (re < 0 && im >= 0) sq = 1;
-            else if (re < 0) sq = 2;
-            else sq = 3;
-            sym[i] = sq;
-            const float phase = (atan2f(im, re) + IRDM_PI_F) * 180.0f / IRDM_PI_F;
-            const float offs = 45.0f - fmodf(phase, 90.0f);
-            if (fabsf(offs) <= 22.0f) n_ok++;
+            sum += s_mag[i];
+            n_ok += s_sym[i] >> 2;
         }
         const float level = ns > 0 ? sum / (float)ns : 0.0f;
         const int confidence = ns > 0 ? (100 * n_ok) / ns : 0;
@@ -170,8 +195,9 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
         if (ns >= 12) {
             int dd = 0, du = 0;
             for (int i = 0; i < 12; i++) {
-                int a = abs(sym[i] - UW_DL[i]); if (a == 3) a = 1; dd += a;
-                int c = abs(sym[i] - UW_UL[i]); if (c == 3) c = 1; du += c;
+                const int sq = s_sym[i] & 3;
+                int a = abs(sq - UW_DL[i]); if (a == 3) a = 1; dd += a;
+                int c = abs(sq - UW_UL[i]); if (c == 3) c = 1; du += c;
             }
             dl_ok = dd <= 2;
             ul_ok = du <= 2;
@@ -181,7 +207,7 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
             if (ns >= 12) {
                 de = 0.0f; ue = 0.0f;
                 for (int i = 0; i < 12; i++) {
-                    float actual = atan2f(po[i].y, po[i].x);
+                    float actual = atan2f(s_po[i].y, s_po[i].x);
                     if (actual < 0) actual += 2.0f * IRDM_PI_F;
                     {
                         const float expect = IRDM_PI_F * 0.25f + (float)UW_DL[i] * IRDM_PI_F * 0.5f;
@@ -209,9 +235,9 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
         // LLR normalisation (:489-497): sum of |.| in symbol order
         float sm = 0.0f;
         if (ok)
-            for (int i = 0; i < ns; i++) sm += cabs_f(po[i]);
+            for (int i = 0; i < ns; i++) sm += s_abs[i];
         s_res[0] = ok; s_res[1] = direction; s_res[2] = ns; s_res[3] = confidence;
-        s_resf[0] = level; s_resf[1] = total_phase;
+        s_resf[0] = level;
         s_resf[2] = (ns > 0 && sm > 0) ? (kSqrt1_2 / (sm / (float)ns)) : 1.0f;
     }
     __syncthreads();
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
     const float scale = s_resf[2];
     for (int i = lane; i < ns; i += 64) {
         const int dq[4] = { 0, 2, 3, 1 };
-        const int sq = s_sym[i], old = i > 0 ? s_sym[i - 1] : 0;
+        const int sq = s_sym[i] & 3, old = i > 0 ? (s_sym[i - 1] & 3) : 0;
         const int v = dq[(sq - old + 4) % 4];
         o.bits[2 * i] = (uint8_t)((v >> 1) & 1);
         o.bits[2 * i + 1] = (uint8_t)(v & 1);

@@ -23,7 +23,7 @@ int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float 
                             int mc_updaters, hipStream_t stream);
 
 // scan_band.hip (band-parallel speculative scan; band_core.hpp holds the per-band state machine)
-constexpr int kBandRounds = 6;           // speculation rounds before giving up (2-3 on the benchmark scenes)
+constexpr int kBandRounds = 5;           // speculation rounds before giving up (2-3 on the benchmark scenes)
 struct BandRec;
 struct BandParams;
 struct BandCtl {                         // control block on the device, copied to the host after the scan

@@ -13,7 +13,8 @@
 //   cross   (1 WG / frame) relative magnitude = mag / sum > threshold (simd_relative_mag, exact division) for the
 //                          bins the prefilter listed -> crossing bits, relative magnitudes, band occupancy
 //   walk    (1 lane / band x 64-frame block) the state machine per band and activity segment (band_core.hpp)
-//   verify  (1 WG / band boundary) neighbouring bands agree on every burst within burst_width/2 of the boundary
+//   (verify: the next round's plan checks that neighbouring bands agree on every burst within burst_width/2 of
+//            their common boundary, one wavefront per boundary)
 //
 // A round is accepted when the update vector the bands produce equals the speculated one (then, by induction over
 // the frames, every sum, crossing and burst equals the sequential result: the state at frame f depends only on
@@ -41,23 +42,28 @@ namespace {
 constexpr int kPlanThreads = 1024;
 
 // exclusive scan of in[0..len) into out[0..len), total returned to every thread; one workgroup, kPlanThreads threads
+// (each thread a contiguous run; wave scans on the shuffle network, the 16 wave totals through LDS)
 __device__ int block_scan(const int32_t *in, int32_t *out, int len, int32_t *s_part)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (len + kPlanThreads - 1) / kPlanThreads;
     const int lo = tid * per, hi = min(lo + per, len);
     int s = 0;
     for (int i = lo; i < hi; i++) s += in[i];
-    s_part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < kPlanThreads; d <<= 1) {
-        const int v = tid >= d ? s_part[tid - d] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    int incl = s;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
     }
-    const int total = s_part[kPlanThreads - 1];
-    int run = tid ? s_part[tid - 1] : 0;
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int wave_base = 0, total = 0;
+    for (int w = 0; w < kPlanThreads / 64; w++) {
+        const int v = s_part[w];
+        if (w < wave) wave_base += v;
+        total += v;
+    }
+    int run = wave_base + incl - s;
     for (int i = lo; i < hi; i++) {
         const int v = in[i];
         out[i] = run;
@@ -67,11 +73,35 @@ __device__ int block_scan(const int32_t *in, int32_t *out, int len, int32_t *s_p
     return total;
 }
 
+// bands i and i+1 must agree on every burst within burst_width/2 of their common boundary (one wavefront per boundary)
+__device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, int lane)
+{
+    const int X = (i + 1) * P.band_w;
+    const BandRec *A = W.recs + (size_t)i * kBandRecCap, *B = W.recs + (size_t)(i + 1) * kBandRecCap;
+    const int na = min((int)W.rec_count[i], kBandRecCap), nb = min((int)W.rec_count[i + 1], kBandRecCap);
+    int bad = 0, ca = 0, cb = 0;
+    for (int a = lane; a < na; a += 64) {
+        if (A[a].cb < X - P.hw || A[a].cb >= X + P.hw) continue;
+        ca++;
+        bool found = false;
+        for (int b = 0; b < nb && !found; b++) found = band_rec_same(A[a], B[b]);
+        if (!found) bad = 1;
+    }
+    for (int b = lane; b < nb; b += 64)
+        if (B[b].cb >= X - P.hw && B[b].cb < X + P.hw) cb++;
+    for (int d = 32; d; d >>= 1) {
+        ca += __shfl_xor(ca, d);
+        cb += __shfl_xor(cb, d);
+        bad |= __shfl_xor(bad, d);
+    }
+    return !(bad || ca != cb);
+}
+
 __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                                  const DetState *__restrict__ st, int round)
 {
     __shared__ int32_t s_part[kPlanThreads];
-    __shared__ int s_mismatch, s_first, s_status;
+    __shared__ int s_mismatch, s_first, s_status, s_agree_fail;
     __shared__ unsigned s_flags;
     const int tid = threadIdx.x;
     BandCtl *ctl = W.ctl;
@@ -83,6 +113,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
         s_first = 0x7fffffff;
         s_flags = 0;
         s_status = 0;
+        s_agree_fail = 0;
     }
     __syncthreads();
     if (round == 0) {
@@ -104,6 +135,8 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
         }
         for (int b = tid; b < P.occ_words; b += kPlanThreads)
             if (W.conc[b] >= (unsigned)P.max_bursts) atomicOr(&s_flags, BAND_F_SQUELCH);
+        for (int i = tid >> 6; i + 1 < P.n_bands; i += kPlanThreads / 64)
+            if (!boundary_agrees(P, W, i, tid & 63) && (tid & 63) == 0) atomicOr(&s_agree_fail, 1);
         __syncthreads();
         if (tid == 0) {
             unsigned fl = s_flags | *W.flags;
@@ -111,7 +144,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
             if (fl) {
                 status = 2;
             } else if (s_mismatch == 0) {
-                if (ctl->agree_fail) {
+                if (s_agree_fail) {
                     fl |= BAND_F_AGREE;
                     status = 2;
                 } else {
@@ -152,7 +185,6 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
         W.conc[i] = 0;
     }
     for (int i = tid; i < P.n_bands; i += kPlanThreads) W.rec_count[i] = 0;
-    if (tid == 0) ctl->agree_fail = 0;
 
     // ---- update steps ----
     for (int f = tid; f < F; f += kPlanThreads) W.tmp[f] = W.uq[f] + W.uf[f];
@@ -325,32 +357,6 @@ __global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W,
     }
 }
 
-// ---- verify: bands i and i+1 on the bursts within burst_width/2 of their boundary ----
-__global__ __launch_bounds__(64) void band_verify_kernel(BandParams P, BandWork W)
-{
-    if (W.ctl->status != 0) return;
-    const int i = blockIdx.x, lane = threadIdx.x;
-    const int X = (i + 1) * P.band_w;
-    const BandRec *A = W.recs + (size_t)i * kBandRecCap, *B = W.recs + (size_t)(i + 1) * kBandRecCap;
-    const int na = min((int)W.rec_count[i], kBandRecCap), nb = min((int)W.rec_count[i + 1], kBandRecCap);
-    int bad = 0, ca = 0, cb = 0;
-    for (int a = lane; a < na; a += 64) {
-        if (A[a].cb < X - P.hw || A[a].cb >= X + P.hw) continue;
-        ca++;
-        bool found = false;
-        for (int b = 0; b < nb && !found; b++) found = band_rec_same(A[a], B[b]);
-        if (!found) bad = 1;
-    }
-    for (int b = lane; b < nb; b += 64)
-        if (B[b].cb >= X - P.hw && B[b].cb < X + P.hw) cb++;
-    for (int d = 32; d; d >>= 1) {
-        ca += __shfl_xor(ca, d);
-        cb += __shfl_xor(cb, d);
-        bad |= __shfl_xor(bad, d);
-    }
-    if (lane == 0 && (bad || ca != cb)) W.ctl->agree_fail = 1;
-}
-
 // ---- commit ----
 __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P, BandWork W, DetState *__restrict__ st,
                                                                    float *__restrict__ sum, GoneBurst *__restrict__ gone,
@@ -369,16 +375,21 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
         s_gone = 0;
     }
     __syncthreads();
-    // the bands' own bursts
-    for (int i = tid; i < P.n_bands * kBandRecCap; i += kPlanThreads) {
-        const int band = i / kBandRecCap, j = i % kBandRecCap;
-        if (j >= (int)W.rec_count[band]) continue;
-        const BandRec &r = W.recs[i];
-        if (!(r.flags & 1)) continue;
-        const unsigned at = atomicAdd(&s_n, 1u);
-        if (at < (unsigned)kBandMaxTotal) W.tot[at] = i;
-        if (r.cf < 0) atomicAdd(&s_carried, 1u);
-        if (r.stop >= 0) atomicAdd(&s_gone, 1u);
+    // the bands' own bursts (16 threads per band, only over the records that exist)
+    {
+        const int band = tid >> 4;
+        if (band < P.n_bands) {
+            const int cnt = min((int)W.rec_count[band], kBandRecCap);
+            for (int j = tid & 15; j < cnt; j += 16) {
+                const int i = band * kBandRecCap + j;
+                const BandRec &r = W.recs[i];
+                if (!(r.flags & 1)) continue;
+                const unsigned at = atomicAdd(&s_n, 1u);
+                if (at < (unsigned)kBandMaxTotal) W.tot[at] = i;
+                if (r.cf < 0) atomicAdd(&s_carried, 1u);
+                if (r.stop >= 0) atomicAdd(&s_gone, 1u);
+            }
+        }
     }
     __syncthreads();
     const int n = (int)s_n, n_carried = (int)s_carried, n_gone = (int)s_gone;
@@ -598,8 +609,6 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             hipLaunchKernelGGL((band_walk_kernel<4>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
         else
             hipLaunchKernelGGL((band_walk_kernel<8>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
-        if (P.n_bands > 1)
-            hipLaunchKernelGGL(band_verify_kernel, dim3(P.n_bands - 1), dim3(64), 0, stream, P, W);
     }
     hipLaunchKernelGGL(band_commit_kernel, dim3(1), dim3(kPlanThreads), commit_lds, stream, P, W, st, sum, gone, gone_cap);
     hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist);
