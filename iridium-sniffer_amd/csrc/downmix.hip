@@ -5,6 +5,7 @@
 //   downmix_post1_kernel       step 2b noise LPF, step 3 find_burst_start, step 4 fine CFO (FFT 4096)
 //   downmix_post2_kernel       step 5 fine rotate, step 6 RRC, step 7 sync correlation
 //                              (FFT 2048 + 2 x IFFT 2048), step 8 phase align, step 9 frame cut
+#include <algorithm>
 #include "common.hpp"
 #include "types.hpp"
 #include "kernels.hpp"
@@ -361,6 +362,49 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const Fi
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
                        tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Word copy executed BY THE GPU when the stream reaches it, with system-scope loads and stores.  Used around the host
+// step of the per-burst chain, between device memory and a mapped pinned buffer the host writes in between:
+//   * a small hipMemcpyAsync may read its (pinned) source when it is enqueued, i.e. before the host step has run;
+//   * a kernel that follows other kernels is dispatched with an agent-scope acquire, so plain loads of host memory
+//     can be served from L2 lines an earlier kernel left there (measured: the second pipeline of a process, and
+//     every step after the first, read the work records WITHOUT the host's update).  sc0 sc1 accesses go to memory.
+__global__ void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        __hip_atomic_store(dst + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+}
+
+int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return 0;
+    const size_t n = bytes / 4;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 256);
+    hipLaunchKernelGGL(copy_words_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint32_t *>(dst),
+                       static_cast<const uint32_t *>(src), n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// The stream waits here until the host has published `seq` in a mapped pinned word (the per-burst chain's host step:
+// hipLaunchHostFunc did not hold later work back on this ROCm, measured -- so the hand-shake is explicit).  One lane,
+// system-scope loads, bounded: ~2 s without an answer sets *err and lets the stream go (the results are then wrong and
+// bursts_finish reports the error).
+__global__ void wait_host_flag_kernel(const uint32_t *flag, uint32_t seq, uint32_t *err)
+{
+    for (long long n = 0; n < 20000000ll; n++) {
+        if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) return;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    *err = 1;
+}
+
+int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wait_host_flag_kernel, dim3(1), dim3(1), 0, stream, flag, seq, err);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -24,6 +24,9 @@
 #include <deque>
 #include <new>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 
 #include "../../include/irdm_hip.h"
 #include "common.hpp"
@@ -141,6 +144,35 @@ extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, flo
 // ===========================================================================
 // 2. batched pipeline
 // ===========================================================================
+struct irdm_pipeline;
+
+// One batch of finished bursts on its way through the per-burst stages K4..K7.  pipeline_depth 0 uses one context on the
+// detector's stream; pipeline_depth >= 1 alternates between two, each on a stream of its own, so that the FIR of one
+// chunk's bursts overlaps the latency-bound tail (sync correlation, demodulator, result copies) of the previous one's.
+struct BatchCtx {
+    irdm_pipeline *owner;
+    hipStream_t stream;
+    hipEvent_t ev[4];            // FIR begin / FIR end / post end / demod end
+    hipEvent_t ev_cfo;           // work records are in the mapped buffer: the helper thread may do the host step
+    BurstWork *d_work;
+    FirTile *d_tiles;
+    size_t tiles_cap;
+    float2 *d_dec, *d_lpf, *d_rrc_ws, *d_frames, *d_demod_ws;
+    DemodOut *d_demod;
+    DecodedOut *d_decoded;
+    IdaOut *d_ida;
+    BurstWork *hp_work, *hp_work_dev;   // host / device view of the same mapped pinned buffer
+    FirTile *hp_tiles;
+    DemodOut *hp_demod;
+    uint32_t *hp_flag, *hp_flag_dev;    // [0] sequence number the helper publishes, [1] time-out flag of the waiting kernel
+    uint32_t cfo_seq;
+    std::vector<double> h_cfreq;
+    std::vector<irdm_burst_t> recs;
+    int n;                       // bursts in flight (0: idle)
+    bool owns_buffers;           // context 1 allocates its own device scratch; context 0 aliases the pipeline's
+    float ms[3];                 // fir, post, demod of the last finished batch
+};
+
 struct irdm_pipeline {
     irdm_config_t cfg;
     DetParams P;
@@ -159,6 +191,7 @@ struct irdm_pipeline {
     hipStream_t stream;      // detector (K1, prefilter, K2)
     hipStream_t bstream;     // per-burst stages + history ring (== stream unless pipeline_depth 1)
     hipStream_t stream2;
+    std::vector<uint32_t> bstream_mask;   // CU mask of the per-burst streams (empty: whole device)
     hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream with CUs of its own (CU mask), so that the
                              // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
     hipEvent_t ev_scan_in, ev_scan_out;
@@ -217,7 +250,7 @@ struct irdm_pipeline {
     // pipeline_depth 1: bursts of the last fed chunk, processed during the next feed / irdm_flush
     std::vector<GoneBurst> pend_gone;
     bool has_pending;
-    uint64_t pend_c1;
+    uint64_t pend_c1, pend_no, fl_no;
     int depth;
     int *h_pin;              // pinned host words: [0..63] scan status, [64..65] n_gone/overflow, [66..67] hist_idx/primed.
                              // (a D2H copy into pageable memory blocks the host until the stream drains -- that would
@@ -233,6 +266,19 @@ struct irdm_pipeline {
     float *d_mag2;           // pipeline_depth 1: second magnitude buffer
     int mag_parity;
     std::vector<BurstWork> h_work;
+    // the per-burst chains (bursts_enqueue / bursts_finish) and the helper thread that does their host step
+    BatchCtx bc[2];
+    int n_bc;
+    std::thread cfo_thread;
+    std::mutex cfo_mu;
+    std::condition_variable cfo_cv;
+    std::deque<BatchCtx *> cfo_jobs;
+    bool cfo_quit;
+    GoneBurst *hp_gone;         // pinned copy of the finished-burst records of a scan
+    int hp_gone_cap;
+    hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
+    uint64_t chunk_no;          // chunks fed so far
+    std::deque<std::pair<uint64_t, int>> emitted_q;
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
     std::vector<float> h_frames;
@@ -268,6 +314,33 @@ static void pipeline_free(irdm_pipeline *p)
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (p->h_pin) (void)hipHostFree(p->h_pin);
+    if (p->cfo_thread.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(p->cfo_mu);
+            p->cfo_quit = true;
+        }
+        p->cfo_cv.notify_one();
+        p->cfo_thread.join();
+    }
+    for (int i = 0; i < 2; i++) {
+        BatchCtx &b = p->bc[i];
+        if (b.ev_cfo) (void)hipEventDestroy(b.ev_cfo);
+        for (auto &e : b.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (b.hp_flag) (void)hipHostFree(b.hp_flag);
+        if (b.hp_work) (void)hipHostFree(b.hp_work);
+        if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
+        if (b.hp_demod) (void)hipHostFree(b.hp_demod);
+        if (b.owns_buffers) {
+            void *own[] = { b.d_work, b.d_tiles, b.d_dec, b.d_lpf, b.d_rrc_ws, b.d_frames, b.d_demod_ws, b.d_demod,
+                            b.d_decoded, b.d_ida };
+            for (void *q : own)
+                if (q) (void)hipFree(q);
+            if (b.stream) (void)hipStreamDestroy(b.stream);
+        }
+    }
+    if (p->hp_gone) (void)hipHostFree(p->hp_gone);
+    if (p->ev_ring) (void)hipEventDestroy(p->ev_ring);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
@@ -282,6 +355,8 @@ static void pipeline_free(irdm_pipeline *p)
 }
 
 extern "C" void irdm_destroy(irdm_pipeline_t *p) { pipeline_free(p); }
+
+static void cfo_helper_main(irdm_pipeline *p);
 
 extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
 {
@@ -341,7 +416,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
     p->depth = cfg->pipeline_depth > 0 ? 1 : 0;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
-    if (p->depth) p->ring_len += p->max_chunk;      // the whole previous chunk must still be readable
+    if (p->depth) p->ring_len += 3 * p->max_chunk;  // two per-burst chains in flight read the two previous chunks while this one is copied in
     p->ring_len = (p->ring_len + 15) / 16 * 16;     // 16-sample segments never straddle the wrap
     p->n_ckpt = (int)(p->l_cap / kRotSeg) + 2;
 
@@ -409,6 +484,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
                 (void)hipStreamDestroy(p->stream2);
                 p->stream2 = s_rest;
                 p->bstream = s_rest;
+                p->bstream_mask = rest;
                 ok = hipEventCreateWithFlags(&p->ev_scan_in, hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&p->ev_scan_out, hipEventDisableTiming) == hipSuccess;
             } else {
@@ -459,6 +535,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_work, BurstWork, (size_t)p->burst_cap);
     p->tiles_cap = (size_t)p->burst_cap * 64;
     AL(p->d_tiles, FirTile, p->tiles_cap);
+    p->cfo_quit = false;
     AL(p->d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
     AL(p->d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
     AL(p->d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
@@ -526,6 +603,52 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         if (ok) band_work_carve(&p->band, p->d_band, P.n, p->max_chunk);
     }
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
+    // batch contexts: [0] aliases the pipeline's per-burst scratch and runs on bstream; [1] (pipeline_depth >= 1) has
+    // scratch and a stream of its own
+    p->n_bc = p->depth ? 2 : 1;
+    for (int i = 0; i < p->n_bc && ok; i++) {
+        BatchCtx &b = p->bc[i];
+        b.owner = p;
+        b.n = 0;
+        b.cfo_seq = 0;
+        b.owns_buffers = i > 0;
+        b.tiles_cap = p->tiles_cap;
+        if (i == 0) {
+            b.stream = p->bstream;
+            b.d_work = p->d_work; b.d_tiles = p->d_tiles; b.d_dec = p->d_dec; b.d_lpf = p->d_lpf;
+            b.d_rrc_ws = p->d_rrc_ws; b.d_frames = p->d_frames; b.d_demod_ws = p->d_demod_ws; b.d_demod = p->d_demod;
+            b.d_decoded = p->d_decoded; b.d_ida = p->d_ida;
+        } else {
+            ok = ok && (p->bstream_mask.empty()
+                            ? hipStreamCreate(&b.stream) == hipSuccess
+                            : hipExtStreamCreateWithCUMask(&b.stream, (uint32_t)p->bstream_mask.size(), p->bstream_mask.data()) == hipSuccess);
+            AL(b.d_work, BurstWork, (size_t)p->burst_cap);
+            AL(b.d_tiles, FirTile, b.tiles_cap);
+            AL(b.d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
+            AL(b.d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
+            AL(b.d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
+            AL(b.d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
+            AL(b.d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
+            AL(b.d_demod, DemodOut, (size_t)p->burst_cap);
+            AL(b.d_decoded, DecodedOut, (size_t)p->burst_cap);
+            AL(b.d_ida, IdaOut, (size_t)p->burst_cap);
+        }
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_work), sizeof(BurstWork) * (size_t)p->burst_cap,
+                                 hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+             hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_work_dev), b.hp_work, 0) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_demod), sizeof(DemodOut) * (size_t)p->burst_cap, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_flag), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+             hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_flag_dev), b.hp_flag, 0) == hipSuccess;
+        if (ok) memset(b.hp_flag, 0, 64);
+        ok = ok && hipEventCreateWithFlags(&b.ev_cfo, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : b.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        b.h_cfreq.assign((size_t)p->burst_cap, 0.0);
+    }
+    p->hp_gone_cap = p->gone_cap;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->ev_ring, hipEventDisableTiming) == hipSuccess;
+    p->chunk_no = 0;
 #undef UP
 #undef AL
     if (!ok) {
@@ -566,6 +689,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->fl_done = 0;
     p->host_primed = 0;
     p->host_hist_idx = 0;
+    p->cfo_thread = std::thread(cfo_helper_main, p);
     return p;
 }
 
@@ -588,7 +712,7 @@ static SampleSource make_source(const irdm_pipeline *p, const void *chunk, uint6
 }
 
 // copy the chunk's tail into the history ring (absolute index % ring_len)
-static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1)
+static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1, hipStream_t st)
 {
     uint64_t a0 = c1 > p->ring_len ? std::max(c0, c1 - p->ring_len) : c0;
     while (a0 < c1) {
@@ -596,7 +720,7 @@ static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t
         const uint64_t run = std::min<uint64_t>(c1 - a0, p->ring_len - pos);
         IRDM_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(p->d_ring) + pos * p->bps,
                                       static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
-                                      run * p->bps, hipMemcpyDeviceToDevice, p->bstream));
+                                      run * p->bps, hipMemcpyDeviceToDevice, st));
         a0 += run;
     }
     return 0;
@@ -723,216 +847,287 @@ static irdm_ida_t finish_ida(const IdaOut &d, const irdm_demod_t &f)
     return o;
 }
 
-static int process_bursts(irdm_pipeline *p, const SampleSource &src, const GoneBurst *gone_list, int n_gone)
+// ---- per-burst stages (K4..K7) of one batch of finished bursts ----
+// bursts_enqueue() only enqueues on the context's stream; bursts_finish() waits for the batch and turns it into result
+// records.  Nothing in between blocks the host: the one step that needs the host libm -- cexpf of the fine CFO
+// (burst_downmix.c:716-717) and the centre frequency that decides the frame-length rules (:719, :763-767) -- is done by
+// a helper thread over a mapped pinned copy of the work records: the stream records an event, the helper waits for it,
+// does the arithmetic and publishes a sequence number that a one-lane kernel on the stream is waiting for.
+static void fine_cfo_host(BatchCtx &b)
+{
+    irdm_pipeline *p = b.owner;
+    const DetParams &P = p->P;
+    const int fs = p->cfg.sample_rate;
+    for (int i = 0; i < b.n; i++) {
+        BurstWork &w = b.hp_work[i];
+        const float rel = (w.center_bin - P.n / 2) / (float)P.n;
+        double cf = p->cfg.center_frequency;
+        cf += rel * fs;                                                   // burst_downmix.c:663-671
+        if (!w.drop_reason) {
+            const cfloat inc = fine_rotator_incr(w.center_offset);
+            w.incr_re = inc.real();
+            w.incr_im = inc.imag();
+            cf += w.center_offset * p->out_rate;
+        }
+        b.h_cfreq[i] = cf;
+        w.simplex = cf > 1626000000 ? 1 : 0;                              // iridium.h:18
+    }
+}
+
+static void cfo_helper_main(irdm_pipeline *p)
+{
+    (void)hipSetDevice(p->cfg.device);
+    for (;;) {
+        BatchCtx *b;
+        {
+            std::unique_lock<std::mutex> lk(p->cfo_mu);
+            p->cfo_cv.wait(lk, [&] { return p->cfo_quit || !p->cfo_jobs.empty(); });
+            if (p->cfo_quit) return;
+            b = p->cfo_jobs.front();
+            p->cfo_jobs.pop_front();
+        }
+        (void)hipEventSynchronize(b->ev_cfo);
+        fine_cfo_host(*b);
+        __atomic_store_n(b->hp_flag, b->cfo_seq, __ATOMIC_RELEASE);
+    }
+}
+
+static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src, const GoneBurst *gone_list, int nb)
 {
     const DetParams &P = p->P;
     const int fs = p->cfg.sample_rate;
+    b.n = nb;
+    b.recs.assign(nb, irdm_burst_t());
+    size_t n_tiles = 0;
+    for (int i = 0; i < nb; i++) {
+        const GoneBurst &g = gone_list[i];
+        irdm_burst_t &r = b.recs[i];
+        r.id = g.id; r.start = g.start; r.stop = g.stop; r.last_active = g.last_active;
+        r.center_bin = g.center_bin;
+        r.peak_rel = g.peak_rel; r.base_sum = g.base_sum;
+        // burst_detect.c:572, :583-586 with the host libm
+        r.magnitude = 10.0f * log10f(g.peak_rel * kHistory * 1.72f);
+        r.noise = 10.0f * log10f(g.base_sum / kHistory / ((float)P.n * P.n) / 1.72f /
+                                 ((float)fs / P.n));
+        r.num_samples = g.stop + (uint64_t)P.pre_len - g.start;          // burst_detect.c:708-712
+        // the frame [stop, stop+N) was processed by the feed call that delivered its last sample
+        uint64_t e = (g.stop + (uint64_t)P.n + p->feed_block - 1) / p->feed_block * p->feed_block;
+        r.avail_end = std::min<uint64_t>(e, src.chunk_end);
+
+        BurstWork &w = b.hp_work[i];
+        memset(&w, 0, sizeof(w));
+        w.start = g.start;
+        w.avail_end = r.avail_end;
+        w.center_bin = g.center_bin;
+        int n = r.num_samples > (uint64_t)(2 * 1024 * 1024) ? 2 * 1024 * 1024 : (int)r.num_samples;
+        if ((size_t)n > p->l_cap) {
+            fprintf(stderr, "irdm_hip: burst window %d exceeds l_cap %zu\n", n, p->l_cap);
+            return -1;
+        }
+        w.n = n;
+        w.dec_len = 0;
+        w.drop_reason = 0;
+        if (r.num_samples < 100) {
+            w.drop_reason = 1;                                           // burst_downmix.c:645
+        } else {
+            int n_out = (n - p->in_ntaps + 1) / p->decim;                // burst_downmix.c:423
+            if (n_out < 0) n_out = 0;
+            w.dec_len = n_out;
+            if (n_out < 100) w.drop_reason = 2;                          // burst_downmix.c:677
+        }
+        if (!w.drop_reason) n_tiles += (size_t)(w.dec_len + kFirTileOut - 1) / kFirTileOut;
+    }
+    if (p->detect_only || nb == 0) return 0;      // stage A alone: burst records, no downmix / demod
+    if (n_tiles > b.tiles_cap) {
+        (void)hipFree(b.d_tiles);
+        if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
+        b.hp_tiles = nullptr;
+        b.tiles_cap = n_tiles * 2;
+        b.d_tiles = dev_alloc<FirTile>(b.tiles_cap);
+        if (!b.owns_buffers) p->d_tiles = b.d_tiles;
+        if (!b.d_tiles ||
+            hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) != hipSuccess)
+            return -1;
+    }
+    n_tiles = 0;
+    for (int i = 0; i < nb; i++) {
+        const BurstWork &w = b.hp_work[i];
+        if (!w.drop_reason)
+            for (int o = 0; o < w.dec_len; o += kFirTileOut) b.hp_tiles[n_tiles++] = FirTile{ i, o };
+    }
+    hipStream_t st = b.stream;
+    IRDM_HIP_CHECK(hipMemcpyAsync(b.d_work, b.hp_work, sizeof(BurstWork) * nb, hipMemcpyHostToDevice, st));
+    if (n_tiles)
+        IRDM_HIP_CHECK(hipMemcpyAsync(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, hipMemcpyHostToDevice, st));
+    IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
+    if (launch_fir_decimate(src, b.d_work, b.d_tiles, (int)n_tiles, p->decim, p->d_in_taps,
+                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
+    if (launch_downmix_post1(b.d_work, nb, b.d_dec, p->dec_stride, b.d_lpf, p->d_noise_taps,
+                             p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
+                             p->pre_start, p->d_cfo_window, p->d_tw4096, st) != 0)
+        return -1;
+    // host libm step, ordered on the stream: work records down (mapped pinned buffer), helper thread, records up.
+    // (Copies by kernel: they move the data when the stream gets there, not when they are enqueued, and with
+    // system-scope accesses.)
+    if (launch_copy_words(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, st) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(b.ev_cfo, st));
+    b.cfo_seq++;
+    {
+        std::lock_guard<std::mutex> lk(p->cfo_mu);
+        p->cfo_jobs.push_back(&b);
+    }
+    p->cfo_cv.notify_one();
+    if (launch_wait_host_flag(b.hp_flag_dev, b.cfo_seq, b.hp_flag_dev + 1, st) != 0) return -1;
+    if (launch_copy_words(b.d_work, b.hp_work_dev, sizeof(BurstWork) * nb, st) != 0) return -1;
+    if (launch_downmix_post2(b.d_work, nb, b.d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
+                             p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
+                             b.d_rrc_ws, b.d_frames, st) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(b.ev[2], st));
+    if (launch_demod(b.d_work, nb, b.d_frames, p->cfg.use_gardner, p->sps, b.d_demod_ws, b.d_demod, st) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(b.ev[3], st));
+    IRDM_HIP_CHECK(hipMemcpyAsync(b.hp_work, b.d_work, sizeof(BurstWork) * nb, hipMemcpyDeviceToHost, st));
+    if (p->decode_frames) {
+        // post-demod bit layer on the demodulator's device-resident output (frames that failed the unique word
+        // have ok = 0 and decode to FRAME_UNKNOWN)
+        if (launch_frame_decode(b.d_demod, nb, p->d_syn_ra, p->d_syn_hdr, 1, nullptr, b.d_decoded, st) != 0)
+            return -1;
+    }
+    if (p->decode_ida) {
+        if (launch_ida_decode(b.d_demod, nb, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, 1, nullptr, nullptr,
+                              b.d_ida, st) != 0)
+            return -1;
+    }
+    IRDM_HIP_CHECK(hipMemcpyAsync(b.hp_demod, b.d_demod, sizeof(DemodOut) * nb, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// returns the number of bursts whose records were emitted, -1 on error
+static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
+{
+    const int nb = b.n;
+    const int fs = p->cfg.sample_rate;
+    if (nb == 0) return 0;
+    if (p->detect_only) {
+        b.n = 0;
+        for (int i = 0; i < nb; i++) {
+            p->q_bursts.push_back(b.recs[i]);
+            p->last_bursts.push_back(b.recs[i]);
+            p->tagged++;
+        }
+        return nb;
+    }
+    IRDM_HIP_CHECK(hipStreamSynchronize(b.stream));
+    b.n = 0;                     // only now: the helper thread reads it while the chain is in flight
+    if (b.hp_flag[1]) {
+        fprintf(stderr, "irdm_hip: the host step of the per-burst chain did not answer\n");
+        return -1;
+    }
+    float ms = 0;
+    b.ms[0] = hipEventElapsedTime(&ms, b.ev[0], b.ev[1]) == hipSuccess ? ms : -1.0f;
+    b.ms[1] = hipEventElapsedTime(&ms, b.ev[1], b.ev[2]) == hipSuccess ? ms : -1.0f;
+    b.ms[2] = hipEventElapsedTime(&ms, b.ev[2], b.ev[3]) == hipSuccess ? ms : -1.0f;
+    for (int i = 0; i < 3; i++) p->last_ms[2 + i] = b.ms[i];
+    if (p->decode_frames) {
+        p->h_decoded.resize(nb);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_decoded.data(), b.d_decoded, sizeof(DecodedOut) * nb, hipMemcpyDeviceToHost, b.stream));
+    }
+    if (p->decode_ida) {
+        p->h_ida.resize(nb);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_ida.data(), b.d_ida, sizeof(IdaOut) * nb, hipMemcpyDeviceToHost, b.stream));
+    }
+    if (p->keep_frame_samples) {
+        p->h_frames.resize((size_t)nb * kMaxFrameSamples * 2);
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_frames.data(), b.d_frames, sizeof(float2) * (size_t)nb * kMaxFrameSamples,
+                                      hipMemcpyDeviceToHost, b.stream));
+    }
+    if (p->decode_frames || p->decode_ida || p->keep_frame_samples) IRDM_HIP_CHECK(hipStreamSynchronize(b.stream));
+    for (int i = 0; i < nb; i++) {
+        const BurstWork &w = b.hp_work[i];
+        irdm_burst_t &r = b.recs[i];
+        p->q_bursts.push_back(r);
+        p->last_bursts.push_back(r);
+        p->tagged++;
+
+        irdm_frame_info_t f;
+        memset(&f, 0, sizeof(f));
+        f.id = r.id;
+        f.drop_reason = w.drop_reason;
+        f.dec_len = w.dec_len;
+        uint64_t timestamp = p->start_time_ns + (uint64_t)((double)r.start / fs * 1e9);   // :659-660
+        if (w.dec_len > 0) timestamp += (uint64_t)((p->in_ntaps / 2) * 1000000000ULL / fs); // :431-433
+        if (w.drop_reason == 0 || w.drop_reason >= 3) f.start = w.start_idx;
+        if (w.drop_reason == 0 || w.drop_reason >= 4) {
+            f.center_offset = w.center_offset;
+            f.uw_start_idx = w.uw_start;
+            f.corr_re = w.corr_re;
+            f.corr_im = w.corr_im;
+            f.direction = w.direction;
+        }
+        if (w.drop_reason == 0) {
+            f.timestamp = timestamp + (uint64_t)((double)w.start_idx / p->out_rate * 1e9);  // :783
+            f.center_frequency = b.h_cfreq[i];
+            f.sample_rate = (float)p->out_rate;
+            f.samples_per_symbol = p->sps;
+            f.magnitude = r.magnitude;
+            f.noise = r.noise;
+            f.uw_start = w.uw_corr;
+            f.num_samples = w.num_samples;
+        }
+        if (w.drop_reason == 0) {
+            f.demod_ok = b.hp_demod[i].ok ? 1 : 0;
+            f.demod_direction = b.hp_demod[i].ok ? b.hp_demod[i].direction : 0;      // DIR_UNDEF, qpsk_demod.c:444
+        }
+        p->q_frames.push_back(f);
+        {
+            // always one entry per frame record, so that the two queues stay paired whatever keep_frame_samples does
+            std::vector<float> sv;
+            if (p->keep_frame_samples && w.drop_reason == 0)
+                sv.assign(p->h_frames.begin() + (size_t)i * kMaxFrameSamples * 2,
+                          p->h_frames.begin() + (size_t)i * kMaxFrameSamples * 2 + 2 * (size_t)w.num_samples);
+            p->q_frame_samples.push_back(std::move(sv));
+        }
+        if (w.drop_reason == 0 && b.hp_demod[i].ok) {
+            const DemodOut &d = b.hp_demod[i];
+            irdm_demod_t o;
+            memset(&o, 0, sizeof(o));
+            o.id = r.id;
+            o.timestamp = f.timestamp;
+            o.direction = d.direction;
+            o.magnitude = r.magnitude;
+            o.noise = r.noise;
+            o.confidence = d.confidence;
+            o.level = d.level;
+            o.n_symbols = d.n_symbols;
+            o.n_payload_symbols = d.n_symbols - 12;
+            o.n_bits = 2 * d.n_symbols;
+            o.ok = 1;
+            o.total_phase = d.total_phase;
+            memcpy(o.bits, d.bits, sizeof(o.bits));
+            memcpy(o.llr, d.llr, sizeof(o.llr));
+            if (d.n_symbols > 0) {                                       // qpsk_demod.c:521-527
+                const double duration = (double)d.n_symbols / 25000;
+                o.center_frequency = f.center_frequency + d.total_phase / duration / M_PI / 2.0;
+            } else {
+                o.center_frequency = f.center_frequency;
+            }
+            p->q_demods.push_back(o);
+            if (p->decode_frames) p->q_decoded.push_back(finish_decoded(p->h_decoded[i], o.id, o.timestamp, o.center_frequency));
+            if (p->decode_ida) p->q_ida.push_back(finish_ida(p->h_ida[i], o));
+        }
+    }
+    return nb;
+}
+
+// all finished bursts of a chunk, synchronously, through context `b` (batches of at most burst_cap)
+static int process_bursts(irdm_pipeline *p, BatchCtx &b, const SampleSource &src, const GoneBurst *gone_list, int n_gone)
+{
     for (int base = 0; base < n_gone; base += p->burst_cap) {
         const int nb = std::min(p->burst_cap, n_gone - base);
-        p->h_work.assign(nb, BurstWork());
-        p->h_tiles.clear();
-        std::vector<irdm_burst_t> recs(nb);
-        for (int i = 0; i < nb; i++) {
-            const GoneBurst &g = gone_list[base + i];
-            irdm_burst_t &r = recs[i];
-            r.id = g.id; r.start = g.start; r.stop = g.stop; r.last_active = g.last_active;
-            r.center_bin = g.center_bin;
-            r.peak_rel = g.peak_rel; r.base_sum = g.base_sum;
-            // burst_detect.c:572, :583-586 with the host libm
-            r.magnitude = 10.0f * log10f(g.peak_rel * kHistory * 1.72f);
-            r.noise = 10.0f * log10f(g.base_sum / kHistory / ((float)P.n * P.n) / 1.72f /
-                                     ((float)fs / P.n));
-            r.num_samples = g.stop + (uint64_t)P.pre_len - g.start;          // burst_detect.c:708-712
-            // the frame [stop, stop+N) was processed by the feed call that delivered its last sample
-            uint64_t e = (g.stop + (uint64_t)P.n + p->feed_block - 1) / p->feed_block * p->feed_block;
-            r.avail_end = std::min<uint64_t>(e, src.chunk_end);
-
-            BurstWork &w = p->h_work[i];
-            w.start = g.start;
-            w.avail_end = r.avail_end;
-            w.center_bin = g.center_bin;
-            int n = r.num_samples > (uint64_t)(2 * 1024 * 1024) ? 2 * 1024 * 1024 : (int)r.num_samples;
-            if ((size_t)n > p->l_cap) {
-                fprintf(stderr, "irdm_hip: burst window %d exceeds l_cap %zu\n", n, p->l_cap);
-                return -1;
-            }
-            w.n = n;
-            w.dec_len = 0;
-            w.drop_reason = 0;
-            if (r.num_samples < 100) {
-                w.drop_reason = 1;                                           // burst_downmix.c:645
-            } else {
-                int n_out = (n - p->in_ntaps + 1) / p->decim;                // burst_downmix.c:423
-                if (n_out < 0) n_out = 0;
-                w.dec_len = n_out;
-                if (n_out < 100) w.drop_reason = 2;                          // burst_downmix.c:677
-            }
-            if (!w.drop_reason)
-                for (int o = 0; o < w.dec_len; o += kFirTileOut) p->h_tiles.push_back(FirTile{ i, o });
-        }
-        if (p->detect_only) {
-            // stage A alone (burst_detector_feed's callback payload minus the samples): burst records, no downmix / demod
-            for (int i = 0; i < nb; i++) {
-                p->q_bursts.push_back(recs[i]);
-                p->last_bursts.push_back(recs[i]);
-                p->tagged++;
-            }
-            continue;
-        }
-        if (p->h_tiles.size() > p->tiles_cap) {
-            (void)hipFree(p->d_tiles);
-            p->tiles_cap = p->h_tiles.size() * 2;
-            p->d_tiles = dev_alloc<FirTile>(p->tiles_cap);
-            if (!p->d_tiles) return -1;
-        }
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb,
-                                      hipMemcpyHostToDevice, p->bstream));
-        if (!p->h_tiles.empty())
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->d_tiles, p->h_tiles.data(), sizeof(FirTile) * p->h_tiles.size(),
-                                          hipMemcpyHostToDevice, p->bstream));
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[3], p->bstream));
-        if (launch_fir_decimate(src, p->d_work, p->d_tiles, (int)p->h_tiles.size(), p->decim, p->d_in_taps,
-                                p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, p->d_dec, p->dec_stride,
-                                p->bstream) != 0)
-            return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[4], p->bstream));
-        if (launch_downmix_post1(p->d_work, nb, p->d_dec, p->dec_stride, p->d_lpf, p->d_noise_taps,
-                                 p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
-                                 p->pre_start, p->d_cfo_window, p->d_tw4096, p->bstream) != 0)
-            return -1;
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
-                                      hipMemcpyDeviceToHost, p->bstream));
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
-
-        // host: fine-CFO increment with the host libm; centre frequency (burst_downmix.c:663-671, :716-719)
-        std::vector<double> cfreq(nb);
-        for (int i = 0; i < nb; i++) {
-            BurstWork &w = p->h_work[i];
-            const float rel = (w.center_bin - P.n / 2) / (float)P.n;
-            double cf = p->cfg.center_frequency;
-            cf += rel * fs;
-            if (!w.drop_reason) {
-                const cfloat inc = fine_rotator_incr(w.center_offset);
-                w.incr_re = inc.real();
-                w.incr_im = inc.imag();
-                cf += w.center_offset * p->out_rate;
-            }
-            cfreq[i] = cf;
-            w.simplex = cf > 1626000000 ? 1 : 0;                             // iridium.h:18
-        }
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->d_work, p->h_work.data(), sizeof(BurstWork) * nb,
-                                      hipMemcpyHostToDevice, p->bstream));
-        if (launch_downmix_post2(p->d_work, nb, p->d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
-                                 p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
-                                 p->d_rrc_ws, p->d_frames, p->bstream) != 0)
-            return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[5], p->bstream));
-        if (launch_demod(p->d_work, nb, p->d_frames, p->cfg.use_gardner, p->sps, p->d_demod_ws,
-                         p->d_demod, p->bstream) != 0)
-            return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[6], p->bstream));
-        p->h_demod.resize(nb);
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_work.data(), p->d_work, sizeof(BurstWork) * nb,
-                                      hipMemcpyDeviceToHost, p->bstream));
-        if (p->decode_frames) {
-            // post-demod bit layer on the demodulator's device-resident output (frames that failed the unique word
-            // have ok = 0 and decode to FRAME_UNKNOWN)
-            if (launch_frame_decode(p->d_demod, nb, p->d_syn_ra, p->d_syn_hdr, 1, nullptr, p->d_decoded, p->bstream) != 0)
-                return -1;
-            p->h_decoded.resize(nb);
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->h_decoded.data(), p->d_decoded, sizeof(DecodedOut) * nb,
-                                          hipMemcpyDeviceToHost, p->bstream));
-        }
-        if (p->decode_ida) {
-            if (launch_ida_decode(p->d_demod, nb, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, 1, nullptr, nullptr,
-                                  p->d_ida, p->bstream) != 0)
-                return -1;
-            p->h_ida.resize(nb);
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->h_ida.data(), p->d_ida, sizeof(IdaOut) * nb, hipMemcpyDeviceToHost, p->bstream));
-        }
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->h_demod.data(), p->d_demod, sizeof(DemodOut) * nb,
-                                      hipMemcpyDeviceToHost, p->bstream));
-        if (p->keep_frame_samples) {
-            p->h_frames.resize((size_t)nb * kMaxFrameSamples * 2);
-            IRDM_HIP_CHECK(hipMemcpyAsync(p->h_frames.data(), p->d_frames,
-                                          sizeof(float2) * (size_t)nb * kMaxFrameSamples,
-                                          hipMemcpyDeviceToHost, p->bstream));
-        }
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
-
-        for (int i = 0; i < nb; i++) {
-            const BurstWork &w = p->h_work[i];
-            const irdm_burst_t &r = recs[i];
-            p->q_bursts.push_back(r);
-            p->last_bursts.push_back(r);
-            p->tagged++;
-
-            irdm_frame_info_t f;
-            memset(&f, 0, sizeof(f));
-            f.id = r.id;
-            f.drop_reason = w.drop_reason;
-            f.dec_len = w.dec_len;
-            uint64_t timestamp = p->start_time_ns + (uint64_t)((double)r.start / fs * 1e9);   // :659-660
-            if (w.dec_len > 0) timestamp += (uint64_t)((p->in_ntaps / 2) * 1000000000ULL / fs); // :431-433
-            if (w.drop_reason == 0 || w.drop_reason >= 3) f.start = w.start_idx;
-            if (w.drop_reason == 0 || w.drop_reason >= 4) {
-                f.center_offset = w.center_offset;
-                f.uw_start_idx = w.uw_start;
-                f.corr_re = w.corr_re;
-                f.corr_im = w.corr_im;
-                f.direction = w.direction;
-            }
-            if (w.drop_reason == 0) {
-                f.timestamp = timestamp + (uint64_t)((double)w.start_idx / p->out_rate * 1e9);  // :783
-                f.center_frequency = cfreq[i];
-                f.sample_rate = (float)p->out_rate;
-                f.samples_per_symbol = p->sps;
-                f.magnitude = r.magnitude;
-                f.noise = r.noise;
-                f.uw_start = w.uw_corr;
-                f.num_samples = w.num_samples;
-            }
-            if (w.drop_reason == 0) {
-                f.demod_ok = p->h_demod[i].ok ? 1 : 0;
-                f.demod_direction = p->h_demod[i].ok ? p->h_demod[i].direction : 0;      // DIR_UNDEF, qpsk_demod.c:444
-            }
-            p->q_frames.push_back(f);
-            if (p->keep_frame_samples) {
-                std::vector<float> s;
-                if (w.drop_reason == 0)
-                    s.assign(p->h_frames.begin() + (size_t)i * kMaxFrameSamples * 2,
-                             p->h_frames.begin() + (size_t)i * kMaxFrameSamples * 2 + 2 * (size_t)w.num_samples);
-                p->q_frame_samples.push_back(std::move(s));
-            }
-            if (w.drop_reason == 0 && p->h_demod[i].ok) {
-                const DemodOut &d = p->h_demod[i];
-                irdm_demod_t o;
-                memset(&o, 0, sizeof(o));
-                o.id = r.id;
-                o.timestamp = f.timestamp;
-                o.direction = d.direction;
-                o.magnitude = r.magnitude;
-                o.noise = r.noise;
-                o.confidence = d.confidence;
-                o.level = d.level;
-                o.n_symbols = d.n_symbols;
-                o.n_payload_symbols = d.n_symbols - 12;
-                o.n_bits = 2 * d.n_symbols;
-                o.ok = 1;
-                o.total_phase = d.total_phase;
-                memcpy(o.bits, d.bits, sizeof(o.bits));
-                memcpy(o.llr, d.llr, sizeof(o.llr));
-                if (d.n_symbols > 0) {                                       // qpsk_demod.c:521-527
-                    const double duration = (double)d.n_symbols / 25000;
-                    o.center_frequency = f.center_frequency + d.total_phase / duration / M_PI / 2.0;
-                } else {
-                    o.center_frequency = f.center_frequency;
-                }
-                p->q_demods.push_back(o);
-                if (p->decode_frames) p->q_decoded.push_back(finish_decoded(p->h_decoded[i], o.id, o.timestamp, o.center_frequency));
-                if (p->decode_ida) p->q_ida.push_back(finish_ida(p->h_ida[i], o));
-            }
-        }
+        if (bursts_enqueue(p, b, src, gone_list + base, nb) != 0 || bursts_finish(p, b) < 0) return -1;
     }
     return 0;
 }
@@ -1069,6 +1264,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
     p->fl_frames = n_frames;
     p->fl_c1 = c1;
     p->fl_c0 = p->total_samples;
+    p->fl_no = p->chunk_no;
     // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428) -- dense kernel, no bursts
     int done = 0;
     if (!p->host_primed && p->fl_mode != 0) {
@@ -1189,8 +1385,19 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             return -1;
         }
     }
-    if (n_gone > 0)
-        IRDM_HIP_CHECK(hipMemcpy(p->h_gone.data(), p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost));
+    if (n_gone > 0) {
+        // (no null-stream hipMemcpy here: it would wait for every other stream, K1 of this chunk included)
+        if (n_gone > p->hp_gone_cap) {
+            (void)hipHostFree(p->hp_gone);
+            p->hp_gone = nullptr;
+            p->hp_gone_cap = p->gone_cap;
+            if (hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) != hipSuccess)
+                return -1;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(p->hp_gone, p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost, p->stream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+        memcpy(p->h_gone.data(), p->hp_gone, sizeof(GoneBurst) * n_gone);
+    }
     float ms = 0;
     // the scan proper (band passes, the sparse kernel, or the dense one when it ran instead)
     p->last_ms[1] = hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
@@ -1211,29 +1418,35 @@ static int settle(irdm_pipeline *p)
     p->pend_gone.assign(p->h_gone.begin(), p->h_gone.begin() + n_gone);
     p->has_pending = true;
     p->pend_c1 = c1;
+    p->pend_no = p->fl_no;
     return 0;
 }
 
-// pipeline_depth 1: per-burst stages of the previously fed chunk (reading the history ring only), then
-// the copy of the chunk being fed into the ring -- all on bstream, concurrent with the detector.
-static int run_deferred(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1)
+// pipeline_depth >= 1: the finished bursts of the previously scanned chunk (pend_gone) go through the per-burst
+// stages on the next batch context, reading the history ring only; nothing waits here.  A chunk with more bursts than
+// burst_cap is worked off synchronously, batch by batch, except for its last batch.
+static int deferred_enqueue(irdm_pipeline *p)
 {
-    p->deferred_emitted = 0;
-    p->last_bursts.clear();
-    for (int i = 3; i <= 6; i++) IRDM_HIP_CHECK(hipEventRecord(p->ev[i], p->bstream));
-    if (p->has_pending) {
-        const SampleSource src = make_source(p, nullptr, 0, p->pend_c1);
-        const int n = (int)p->pend_gone.size();
-        if (process_bursts(p, src, p->pend_gone.data(), n) != 0) return -1;
-        p->deferred_emitted = n;
-        p->has_pending = false;
+    if (!p->has_pending) return 0;
+    BatchCtx &b = p->bc[p->pend_no % p->n_bc];
+    const SampleSource src = make_source(p, nullptr, 0, p->pend_c1);
+    const int n = (int)p->pend_gone.size();
+    int base = 0;
+    // the chain reads the ring: it must hold the chunk these bursts come from
+    IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, p->ev_ring, 0));
+    while (n - base > p->burst_cap) {
+        if (process_bursts(p, b, src, p->pend_gone.data() + base, p->burst_cap) != 0) return -1;
+        base += p->burst_cap;
     }
-    if (d_iq) {
-        // the ring copy reads the caller's buffer: order it after the caller's producer
-        if (p->caller_ordered) IRDM_HIP_CHECK(hipStreamWaitEvent(p->bstream, p->ev[8], 0));
-        if (ring_update(p, d_iq, c0, c1) != 0) return -1;
-    }
+    if (bursts_enqueue(p, b, src, p->pend_gone.data() + base, n - base) != 0) return -1;
+    p->has_pending = false;
     return 0;
+}
+
+// wait for the context's batch (if any) and emit its records; returns the number of bursts emitted, -1 on error
+static int deferred_finish(irdm_pipeline *p, BatchCtx &b)
+{
+    return bursts_finish(p, b);
 }
 
 extern "C" int irdm_flush(irdm_pipeline_t *p)
@@ -1242,10 +1455,25 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
     if (!p->depth) return 0;
     (void)hipSetDevice(p->cfg.device);
     if (settle(p) != 0) return -1;
-    if (!p->has_pending) return 0;
-    if (run_deferred(p, nullptr, 0, 0) != 0) return -1;
-    IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
-    return p->deferred_emitted;
+    int emitted = 0;
+    // records leave in chunk order: the context that is not about to be used holds the older batch
+    const int next = p->has_pending ? (int)(p->pend_no % p->n_bc) : -1;
+    for (int i = 0; i < p->n_bc; i++) {
+        if (i == next) continue;
+        const int e = deferred_finish(p, p->bc[i]);
+        if (e < 0) return -1;
+        emitted += e;
+    }
+    if (next >= 0) {
+        int e = deferred_finish(p, p->bc[next]);          // (idle unless n_bc == 1)
+        if (e < 0) return -1;
+        emitted += e;
+        if (deferred_enqueue(p) != 0) return -1;
+        e = deferred_finish(p, p->bc[next]);
+        if (e < 0) return -1;
+        emitted += e;
+    }
+    return emitted;
 }
 
 extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
@@ -1298,33 +1526,40 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         p->last_chunk_start = c0;
         p->last_chunk_end = c1;
         const SampleSource src = make_source(p, d_iq, c0, c1);
-        // events 3..6 are re-recorded per sub-batch; record them once so an empty chunk has valid timings
-        for (int i = 3; i <= 6; i++) IRDM_HIP_CHECK(hipEventRecord(p->ev[i], p->bstream));
-        if (process_bursts(p, src, p->h_gone.data(), n_gone) != 0) return -1;
-        if (ring_update(p, d_iq, c0, c1) != 0) return -1;
+        // record the stage events once so an empty chunk has valid timings
+        for (int i = 0; i < 4; i++) IRDM_HIP_CHECK(hipEventRecord(p->bc[0].ev[i], p->bc[0].stream));
+        if (process_bursts(p, p->bc[0], src, p->h_gone.data(), n_gone) != 0) return -1;
+        if (ring_update(p, d_iq, c0, c1, p->stream) != 0) return -1;
         IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->stream));
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
         emitted = n_gone;
     } else {
+        // 0. this chunk into the history ring, behind K1 on its stream (the ring keeps three chunks: the copy never
+        //    overwrites what the per-burst chains in flight still read)
+        if (ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
         // 1. the previous chunk's detector must be done before this chunk's can start: collect its bursts
         if (settle(p) != 0) return -1;
-        // 2. this chunk's detector (needs K1's output)
+        // 2. their per-burst stages: enqueued on the idle batch context, nothing waits.  (The context of the chunk
+        //    before that is still at work: its tail overlaps this one's FIR.)
+        p->last_bursts.clear();
+        if (deferred_enqueue(p) != 0) return -1;
+        // 3. this chunk's detector (needs K1's output), enqueued while the GPU works on 2.
         IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[1], 0));
         if (scan_launch(p, mag, n_frames, c1) != 0) return -1;
-        // 3. while it runs on its CU: the previous chunk's per-burst stages and this chunk's ring copy (bstream)
-        if (run_deferred(p, d_iq, c0, c1) != 0) return -1;
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->bstream));
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->bstream));
-        IRDM_HIP_CHECK(hipEventSynchronize(p->ev[1]));     // the caller may overwrite d_iq once we return
-        emitted = p->deferred_emitted;
+        // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
+        emitted = deferred_finish(p, p->bc[p->chunk_no % p->n_bc]);
+        if (emitted < 0) return -1;
+        // 5. the caller may overwrite d_iq once we return: K1 and the ring copy are done with it
+        IRDM_HIP_CHECK(hipEventRecord(p->ev_ring, p->fstream));
+        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->fstream));
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
     }
+    p->chunk_no++;
     p->total_samples = c1;
 
-    const int pairs[6][2] = { { 0, 1 }, { 9, 2 }, { 3, 4 }, { 4, 5 }, { 5, 6 }, { 0, 7 } };
-    for (int i = 0; i < 6; i++) {
-        if (i == 1) continue;           // set by scan_finish (pipeline_depth 1: the previous chunk's scan)
-        p->last_ms[i] = hipEventElapsedTime(&ms, p->ev[pairs[i][0]], p->ev[pairs[i][1]]) == hipSuccess ? ms : -1.0f;
-    }
+    // [0] K1, [5] the whole call on the detector side; [1] is set by scan_finish, [2..4] by bursts_finish
+    p->last_ms[0] = hipEventElapsedTime(&ms, p->ev[0], p->ev[1]) == hipSuccess ? ms : -1.0f;
+    p->last_ms[5] = hipEventElapsedTime(&ms, p->ev[0], p->ev[7]) == hipSuccess ? ms : -1.0f;
     return emitted;
 }
 
@@ -1528,13 +1763,14 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     std::deque<irdm_burst_t> qb; std::deque<irdm_frame_info_t> qf; std::deque<std::vector<float>> qs;
     std::deque<irdm_demod_t> qd;
     qb.swap(p->q_bursts); qf.swap(p->q_frames); qs.swap(p->q_frame_samples); qd.swap(p->q_demods);
-    const int keep = p->keep_frame_samples, dec = p->decode_frames, dec_ida = p->decode_ida;
+    const int keep = p->keep_frame_samples, dec = p->decode_frames, dec_ida = p->decode_ida, det = p->detect_only;
     p->decode_frames = 0;
     p->decode_ida = 0;
+    p->detect_only = 0;          // a stage-B call on a detect-only context still runs stage B
     const uint64_t tagged = p->tagged;
     std::vector<irdm_burst_t> last; last.swap(p->last_bursts);
     p->keep_frame_samples = 1;
-    const int rc = process_bursts(p, src, &g, 1);
+    const int rc = process_bursts(p, p->bc[0], src, &g, 1);
     int ret = -1;
     if (rc == 0 && !p->q_frames.empty()) {
         *frame = p->q_frames.front();
@@ -1546,6 +1782,7 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     }
     p->q_bursts.swap(qb); p->q_frames.swap(qf); p->q_frame_samples.swap(qs); p->q_demods.swap(qd);
     p->keep_frame_samples = keep;
+    p->detect_only = det;
     p->decode_frames = dec;
     p->decode_ida = dec_ida;
     p->tagged = tagged;
