@@ -11,10 +11,19 @@ frame records are gathered to rank 0 over RCCL.  `value` = samples all ranks pro
 / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      dominant kernel (largest mean HIP-event time per step): achieved =
-                algorithmic bytes per launch / mean launch duration, vs the 8 TB/s HBM peak.
-  cpu_baseline  the CPU oracle (scalar C port of the reference, 1 core) timed on a bounded
-                prefix of the same stream, N=1 / rank 0 only.
+  roofline       dominant kernel (largest mean HIP-event time per step, measured inside the timed
+                 region, i.e. with the other stages of neighbouring chunks running beside it):
+                 achieved = algorithmic bytes per launch / mean launch duration, vs the 8 TB/s HBM peak.
+                 stage_ms_alone = the same stages from a few extra steps at pipeline_depth 0 (one
+                 kernel on the chip at a time).
+  cpu_baseline   the CPU oracle (scalar C port of the reference) in the reference's thread layout
+                 (1 detector + 4 downmix + 1 demod thread, main.c:175) on a bounded prefix of the
+                 same stream, N=1 / rank 0 only; cpu_baseline_1core: the same oracle on one core.
+  parity_checked the records of one chunk through the HIP path compared field by field with the
+                 oracle's for the same samples (burst indices and hard bits exact, soft 1e-4).
+  detect_only    BASELINE config 2 on the same chunk (K1 + scan, burst records only).
+  file_to_raw    the C99 binary (iridium-sniffer-hip -f) on the chunk written to a file: wall clock
+                 of the whole process, file in the page cache.
 """
 import argparse
 import ctypes as C
@@ -62,6 +71,84 @@ def build_scene(torch, device, fs, n, density_per_msample, seed):
     return x, nb
 
 
+def cpu_reference_layout(orc, host, fs, fmt, workers=4):
+    """The oracle's stage functions in the reference's thread layout (main.c:175, :667-694): one detector thread feeding
+    32768-sample blocks, `workers` downmix threads, one demod thread, bounded queues in between.  ctypes releases the
+    GIL inside the C calls, so the stages really run in parallel.  Returns wall seconds and counts."""
+    import ctypes as C
+    import queue
+    import threading
+    L = orc.lib()
+    det = L.orc_detector_create(1622000000.0, int(fs), 0.0, 0)
+    n_fft = L.orc_detector_fft_size(det)
+    q_burst, q_frame = queue.Queue(2048), queue.Queue(512)
+    counts = {"bursts": 0, "demods": 0}
+
+    def cb(rec, samples, user):
+        r = orc.BurstRec()
+        C.memmove(C.byref(r), rec, C.sizeof(orc.BurstRec))
+        buf = np.ctypeslib.as_array(samples, shape=(2 * r.num_samples,)).copy()
+        counts["bursts"] += 1
+        q_burst.put((r, buf))
+
+    cbf = orc.BURST_CB(cb)
+
+    def detector():
+        per = 1 if fmt == 2 else 2
+        flat = host.view(np.float32) if fmt == 2 else host
+        step = 32768
+        nn = len(host) if fmt == 2 else len(host) // 2
+        for o in range(0, nn, step):
+            cnt = min(step, nn - o)
+            if fmt == 2:
+                blk = flat[2 * o:2 * (o + cnt)]
+                L.orc_detector_feed_cf32(det, orc.fptr(blk), cnt, cbf, None)
+            else:
+                blk = flat[per * o:per * (o + cnt)]
+                i8 = (blk >> 8).astype(np.int8) if fmt == 1 else blk
+                L.orc_detector_feed_i8(det, i8.ctypes.data_as(C.c_void_p), cnt, cbf, None)
+        for _ in range(workers):
+            q_burst.put(None)
+
+    def worker():
+        dm = L.orc_downmix_create()
+        while True:
+            it = q_burst.get()
+            if it is None:
+                break
+            r, buf = it
+            fr = orc.Frame()
+            if L.orc_downmix_process(dm, C.byref(r), orc.fptr(buf), 1622000000.0, int(fs), n_fft, 1700000000 * 10**9, C.byref(fr)) > 0:
+                q_frame.put(fr)
+        L.orc_downmix_destroy(dm)
+        q_frame.put(None)
+
+    def demod():
+        done = 0
+        buf = C.create_string_buffer(4096)
+        t0 = C.c_uint64(0)
+        while done < workers:
+            fr = q_frame.get()
+            if fr is None:
+                done += 1
+                continue
+            d = orc.Demod()
+            if L.orc_qpsk_demod(C.byref(fr), 1, C.byref(d)) > 0:
+                L.orc_format_raw(C.byref(d), b"bench", C.byref(t0), buf, 4096)
+                counts["demods"] += 1
+
+    ths = [threading.Thread(target=detector)] + [threading.Thread(target=worker) for _ in range(workers)] + \
+          [threading.Thread(target=demod)]
+    t = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t
+    L.orc_detector_destroy(det)
+    return dict(seconds=dt, bursts=counts["bursts"], demods=counts["demods"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,10 +166,12 @@ def main():
                          "feed returns its own chunk's results")
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
-    ap.add_argument("--cpu-passes", type=int, default=4, help="oracle passes over that prefix (~3 s each)")
-    ap.add_argument("--cpu-procs", type=int, default=-1,
-                    help="extra CPU baseline: this many oracle processes in parallel, one pass each over the same prefix "
-                         "(independent streams, the way the path shards); -1 = all host cores, capped at 32; 0 = skip")
+    ap.add_argument("--cpu-passes", type=int, default=3, help="one-core oracle passes over that prefix (~3 s each)")
+    ap.add_argument("--alone-steps", type=int, default=4,
+                    help="extra steps at pipeline_depth 0 (stage times with one kernel on the chip at a time, and the records "
+                         "for the parity check; 0 = skip)")
+    ap.add_argument("--detect-steps", type=int, default=10, help="extra detect-only steps (BASELINE config 2; 0 = skip)")
+    ap.add_argument("--file-run", type=int, default=1, help="1: also time the C99 binary on the chunk written to a file")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="irdm_set_option before the run (kernel-variant A/B: fir_generic=1, fft_radix2=1, scan_mode=1)")
     ap.add_argument("--host-steps", type=int, default=6,
@@ -229,10 +318,10 @@ def main():
     lb = totals["burst_samples"] / K
     alg_bytes = {
         "fft_mag": float(bps) * n,                # one read of every sample (B_det's b_in: 8 / 4 / 2 bytes)
-        "scan": 8.0 * n,                          # history row read + write per bin-frame (B_det = 16 B/sample with K1)
+        "scan": 8.0 * n,                          # SURVEY 8(d): history row read + write per bin-frame (B_det = 16 B/sample with K1)
         "fir": float(bps) * lb + 8.0 * lb / decim,   # burst-window re-read + decimated (cf32) write
     }
-    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "detect_scan_fast_kernel", "fir": "fir_decimate_kernel"}
+    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "band_* (scan_band.hip passes)", "fir": "fir_decimate_kernel_m"}
     dom = max(alg_bytes, key=lambda k: ms[k])
     ach = alg_bytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs and
@@ -253,6 +342,7 @@ def main():
                 "algorithmic_bytes": round(alg_bytes[dom]),
                 "ms_per_launch": round(ms[dom], 4),
                 "stage_ms": {k: round(v, 4) for k, v in ms.items()},
+                "stage_ms_alone": None,
                 "host_ms": {k: round(v / K, 3) for k, v in host.items()},
                 "stage_GBps": {k: round(alg_bytes[k] / (ms[k] * 1e-3) / 1e9, 2) for k in alg_bytes if ms[k] > 0},
                 # SURVEY 8(d) B_full = B_det * N_samples + sum_bursts 8 * L_b (+ 8 * L_b / M): all algorithmic bytes of one
@@ -286,8 +376,84 @@ def main():
                         "overlaps the detector scan of chunk k"}
         irdm.host_free(hptr)
 
-    # ---- CPU baseline: oracle on a bounded prefix of the same stream (rank 0, N=1) ----
+    # ---- the same stages with one kernel on the chip at a time (pipeline_depth 0), and the chunk's records for the
+    #      parity check below ----
+    alone = None
+    gpu_recs = None
+    if rank == 0 and world == 1 and args.alone_steps > 0:
+        p0 = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192, device=local, pipeline_depth=0)
+        for kv in args.opt:
+            key, val = kv.split("=")
+            p0.set_option(key, int(val))
+        acc = {k: 0.0 for k in stage}
+        for i in range(args.alone_steps):
+            p0.feed_device(x.data_ptr(), n, None)
+            if i == 0:
+                gpu_recs = (p0.poll_bursts(), p0.poll_demods())
+            else:
+                p0.poll_bursts_raw(); p0.poll_demods_raw()
+            p0.drop_frames()
+            if i > 0 or args.alone_steps == 1:
+                t = p0.timings()
+                for kk in acc:
+                    acc[kk] += t[kk]
+        d = max(args.alone_steps - 1, 1)
+        alone = {k: round(v / d, 4) for k, v in acc.items()}
+        p0.close()
+
+    # ---- BASELINE config 2: detect-only (K1 + scan, burst records) on the same chunk ----
+    detect_only = None
+    if rank == 0 and world == 1 and args.detect_steps > 0:
+        pd = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192, device=local, pipeline_depth=args.depth)
+        pd.set_option("detect_only", 1)
+        for _ in range(2):
+            pd.feed_device(x.data_ptr(), n, None); pd.poll_bursts_raw()
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        nbd = 0
+        for _ in range(args.detect_steps):
+            pd.feed_device(x.data_ptr(), n, None)
+            nbd += len(pd.poll_bursts_raw())
+        if args.depth:
+            pd.flush()
+            nbd += len(pd.poll_bursts_raw())
+        torch.cuda.synchronize()
+        ddt = time.perf_counter() - td
+        detect_only = {"value": round(n * args.detect_steps / ddt / 1e6, 2), "unit": "Msamples/s",
+                       "ms_per_step": round(ddt / args.detect_steps * 1e3, 3), "steps": args.detect_steps,
+                       "bursts_per_step": nbd / args.detect_steps,
+                       "algorithmic_GBps": round((bps + 8.0) * n * args.detect_steps / ddt / 1e9, 1),
+                       "note": "cfg2: K1 + prefilter + band scan, burst records only; B_det = %d B/sample" % (bps + 8)}
+        pd.close()
+
+    # ---- file -> RAW lines with the C99 binary (wall clock of the whole process, file in the page cache) ----
+    file_to_raw = None
+    if rank == 0 and world == 1 and args.file_run:
+        try:
+            import subprocess
+            import tempfile
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+            ext = {"cf32": "cf32", "ci16": "ci16", "ci8": "ci8"}[args.format]
+            path = os.path.join(shm, "irdm_bench_%d.%s" % (os.getpid(), ext))
+            x.cpu().numpy().tofile(path)
+            exe = os.path.join(ROOT, "iridium-sniffer_amd", "iridium-sniffer-hip")
+            tf = time.perf_counter()
+            r = subprocess.run([exe, "-f", path, "-r", str(fs), "--format", args.format, "--file-info", "bench"],
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            fdt = time.perf_counter() - tf
+            os.remove(path)
+            lines = r.stdout.count(b"\nRAW:") + (1 if r.stdout.startswith(b"RAW:") else 0)
+            file_to_raw = {"value": round(n / fdt / 1e6, 2), "unit": "Msamples/s", "wall_s": round(fdt, 3),
+                           "raw_lines": lines, "rc": r.returncode,
+                           "note": "iridium-sniffer-hip -f <%d samples %s>, process start to exit (HIP init, "
+                                   "context creation, fread from the page cache, H2D, GPU, RAW lines to a pipe)" % (n, args.format)}
+        except Exception as e:
+            file_to_raw = {"error": str(e)[:200]}
+
+    # ---- CPU baseline: the oracle on a bounded prefix of the same stream (rank 0, N=1) ----
     cpu = None
+    cpu1 = None
+    parity_checked = None
     if rank == 0 and world == 1 and args.cpu_samples > 0:
         import orc
         m = min(n, args.cpu_samples) // 32768 * 32768
@@ -295,48 +461,56 @@ def main():
             host = x[:m].cpu().numpy().view(np.complex64).reshape(-1)
         else:
             host = x[:m].cpu().numpy().reshape(-1)
+        # (a) one core, the whole path in one thread
         t1 = time.perf_counter()
         for _ in range(max(args.cpu_passes, 1)):
             ref = orc.run_stream(host, fs, fmt=int(fmt), cap_bursts=8192)
         cdt = time.perf_counter() - t1
-        cpu = {"value": round(max(args.cpu_passes, 1) * m / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-               "kind": "port",
-               "sample": "%d passes over the first %d samples of the rank-0 stream (%.1f s of CPU), scalar C oracle "
-                         "(reference --no-simd --no-gpu algorithm, pinned FFT), %d bursts -> %d RAW frames per pass"
-                         % (max(args.cpu_passes, 1), m, cdt, ref.n_tagged, len(ref.demods))}
-
-    # ---- the same oracle on every host core at once (independent streams; reported beside the 1-core figure) ----
-    cpu_all = None
-    if cpu is not None and args.cpu_procs != 0:
+        cpu1 = {"value": round(max(args.cpu_passes, 1) * m / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                "kind": "port",
+                "sample": "%d passes over the first %d samples of the rank-0 stream (%.1f s of CPU), scalar C oracle "
+                          "(reference --no-simd --no-gpu algorithm, pinned FFT), %d bursts -> %d RAW frames per pass"
+                          % (max(args.cpu_passes, 1), m, cdt, ref.n_tagged, len(ref.demods))}
+        # (b) the reference's thread layout: 1 detector thread -> 4 downmix workers -> 1 demod / output thread
+        #     (main.c:175, :667-694); the oracle's stage functions release the GIL while they run
         try:
-            import subprocess
-            import tempfile
-            procs = args.cpu_procs if args.cpu_procs > 0 else min(os.cpu_count() or 1, 64)
-            mm = min(m, 8 * 1024 * 1024)                               # 64 MB per process at cf32
-            passes = 8
-            shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-            path = os.path.join(shm, "irdm_bench_prefix_%d.bin" % os.getpid())
-            host[:mm if args.format == "cf32" else 2 * mm].tofile(path)
-            child = ("import sys, time, numpy as np; sys.path.insert(0, %r); import orc; "
-                     "a = np.fromfile(%r, dtype=%r); orc.lib(); t = time.perf_counter();\n"
-                     "for _ in range(%d): r = orc.run_stream(a, %d, fmt=%d, cap_bursts=8192)\n"
-                     "print(time.perf_counter() - t)"
-                     % (os.path.join(ROOT, "tests"), path, str(host.dtype), passes, fs, int(fmt)))
-            ps = [subprocess.Popen([sys.executable, "-c", child], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-                  for _ in range(procs)]
-            outs = [p_.communicate(timeout=300)[0] for p_ in ps]
-            ok = all(p_.returncode == 0 for p_ in ps)
-            os.remove(path)
+            lay = cpu_reference_layout(orc, host, fs, int(fmt), workers=4)
+            cpu = {"value": round(m / lay["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": 6, "kind": "port",
+                   "sample": "one pass over the first %d samples in the reference's thread layout (1 detector + 4 downmix + "
+                             "1 demod thread around the oracle's stage functions), %.1f s wall, %d bursts -> %d frames"
+                             % (m, lay["seconds"], lay["bursts"], lay["demods"])}
+        except Exception as e:
+            cpu = dict(cpu1)
+            cpu["sample"] += " [thread-layout run failed: %s]" % str(e)[:80]
+        # (c) parity of the benchmark scene itself: the chunk's records through the HIP path vs the oracle's
+        if gpu_recs is not None and m == n:
+            gb, gd = gpu_recs
+            ok = len(gb) == len(ref.bursts) and len(gd) == len(ref.demods)
+            max_soft = 0.0
             if ok:
-                slowest = max(float(o.decode().strip().splitlines()[-1]) for o in outs)
-                cpu_all = {"value": round(procs * passes * mm / slowest / 1e6, 2), "unit": "Msamples/s", "cores": procs,
-                           "kind": "port",
-                           "sample": "%d oracle processes in parallel (independent streams), %d passes each over the first "
-                                     "%d samples; slowest process %.1f s" % (procs, passes, mm, slowest)}
-        except Exception as e:                                         # a reported extra, never a reason to fail the bench
-            cpu_all = {"error": str(e)[:200]}
+                for g, r_ in zip(gb, ref.bursts):
+                    ok = ok and (g.id, g.start, g.stop, g.last_active, g.center_bin, g.num_samples) == \
+                        (r_.id, r_.start, r_.stop, r_.last_active, r_.center_bin, r_.num_samples)
+                    ok = ok and np.float32(g.magnitude).view(np.uint32) == np.float32(r_.magnitude).view(np.uint32)
+                    ok = ok and np.float32(g.noise).view(np.uint32) == np.float32(r_.noise).view(np.uint32)
+                for g, r_ in zip(gd, ref.demods):
+                    ok = ok and (g.id, g.timestamp, g.n_symbols, g.n_bits, g.confidence, g.direction) == \
+                        (r_.id, r_.timestamp, r_.n_symbols, r_.n_bits, r_.confidence, r_.direction)
+                    ok = ok and bytes(g.bits[:g.n_bits]) == bytes(r_.bits[:r_.n_bits])
+                    soft = max(abs(g.level - r_.level),
+                               float(np.max(np.abs(np.array(g.llr[:g.n_bits], np.float32) - np.array(r_.llr[:r_.n_bits], np.float32))))
+                               if g.n_bits else 0.0)
+                    max_soft = max(max_soft, soft)
+                ok = ok and max_soft <= 1e-4
+            parity_checked = {"ok": bool(ok), "bursts": len(gb), "frames": len(gd), "oracle_bursts": len(ref.bursts),
+                              "oracle_frames": len(ref.demods), "max_soft": max_soft,
+                              "what": "ids / indices / centre bins / dB fields / hard bits / confidence exact, level and LLR within 1e-4"}
 
     if rank == 0:
+        roofline["stage_ms_alone"] = alone
+        if alone and alone.get(dom, 0) > 0:
+            roofline["achieved_alone"] = round(alg_bytes[dom] / (alone[dom] * 1e-3) / 1e9, 2)
+            roofline["frac_alone"] = round(roofline["achieved_alone"] / HBM_PEAK_GBS, 5)
         out = {
             "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz %s" % (fs // 1_000_000, args.format),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -350,10 +524,15 @@ def main():
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
                        "pipeline_depth": args.depth,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
-                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags")}},
+                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags")},
+                       "host_us_total": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(
+                           ("k1_ring_enqueue", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync"))}},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "cpu_baseline_all_cores": cpu_all,
+            "cpu_baseline_1core": cpu1,
+            "parity_checked": parity_checked,
+            "detect_only": detect_only,
+            "file_to_raw": file_to_raw,
             "pcie_inclusive": pcie,
         }
         print(json.dumps(out), flush=True)

@@ -210,6 +210,14 @@ int irdm_flush(irdm_pipeline_t *p);
 void *irdm_host_alloc(size_t bytes);
 void irdm_host_free(void *ptr);
 
+/*
+ * Device buffers for hosts without HIP headers (the C99 binary, tests): an IQ chunk that lives in HBM before it is
+ * fed with irdm_feed_device (the case the headline metric is quoted on).  irdm_device_upload is synchronous.
+ */
+void *irdm_device_alloc(int device, size_t bytes);
+void irdm_device_free(void *dptr);
+int irdm_device_upload(void *dptr, const void *host, size_t bytes);
+
 /* Results of all chunks fed so far, in burst-emission order; each call drains up to max
  * entries.  bursts: one per emitted burst (burst_callback_t payload minus samples).
  * frames: one per emitted burst (drop_reason says whether a frame was produced).

@@ -49,8 +49,8 @@ __host__ __device__ __forceinline__ float mag2(float2 v)
 
 // glibc 2.35 cabsf/hypotf for finite inputs: sqrt in double of the exactly
 // representable double sum of squares, rounded once to float
-// (sysdeps/ieee754/flt-32/e_hypotf.c).  Checked against the host libm in
-// tests/test_host_math.py via irdm_test_cabsf.
+// (sysdeps/ieee754/flt-32/e_hypotf.c).  Exercised against the oracle (host libm cabsf) through every
+// stage-B / stage-C parity test: start detection maxima, correlation peaks and the PLL would differ otherwise.
 __host__ __device__ __forceinline__ float cabs_f(float2 v)
 {
     double x = (double)v.x, y = (double)v.y;

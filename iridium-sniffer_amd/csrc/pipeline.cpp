@@ -191,7 +191,7 @@ struct irdm_pipeline {
     hipStream_t stream;      // detector (K1, prefilter, K2)
     hipStream_t bstream;     // per-burst stages + history ring (== stream unless pipeline_depth 1)
     hipStream_t stream2;
-    std::vector<uint32_t> bstream_mask;   // CU mask of the per-burst streams (empty: whole device)
+    int bstream_prio;        // priority of the per-burst streams
     hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream with CUs of its own (CU mask), so that the
                              // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
     hipEvent_t ev_scan_in, ev_scan_out;
@@ -278,7 +278,7 @@ struct irdm_pipeline {
     int hp_gone_cap;
     hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
     uint64_t chunk_no;          // chunks fed so far
-    std::deque<std::pair<uint64_t, int>> emitted_q;
+    double host_us[6];          // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
     std::vector<float> h_frames;
@@ -454,47 +454,29 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
                         tw2048 = design_twiddles(kCorrN);
     std::vector<cfloat> rot_incr = design_rotator_incr(P.n);
 
-    bool ok = hipStreamCreate(&p->stream) == hipSuccess && hipStreamCreate(&p->stream2) == hipSuccess;
-    p->bstream = p->depth ? p->stream2 : p->stream;
-    p->sstream = p->stream;
-    p->fstream = p->stream;
-    p->ev_scan_in = p->ev_scan_out = nullptr;
-    if (ok && p->depth) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount >= 8) {
-            const int words = (prop.multiProcessorCount + 31) / 32;
-            std::vector<uint32_t> one(words, 0u), rest(words, 0xffffffffu);
-            // CU-mask bits are dealt round-robin to the XCDs, and a workgroup is placed on whichever XCD the dispatcher
-            // picks: a one-bit mask does not confine it (measured: with only bit 0 reserved the scan still shared its CU
-            // with the per-burst kernels, 7.7 ms; with one bit per XCD reserved, 6.9 ms; alone 6.45 ms).  So the scan
-            // stream gets the first `xcds` bits -- one CU in every XCD -- and every other stream the remaining CUs.
-            if (prop.multiProcessorCount % 32) rest[words - 1] = (1u << (prop.multiProcessorCount % 32)) - 1u;
-            const int xcds = prop.multiProcessorCount >= 64 ? 8 : 1;
-            for (int b = 0; b < xcds; b++) {
-                one[b / 32] |= 1u << (b % 32);
-                rest[b / 32] &= ~(1u << (b % 32));
-            }
-            hipStream_t s_scan = nullptr, s_rest = nullptr, s_fft = nullptr;
-            if (hipExtStreamCreateWithCUMask(&s_scan, words, one.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&s_rest, words, rest.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&s_fft, words, rest.data()) == hipSuccess) {
-                p->sstream = s_scan;
-                p->scan_cus = xcds;
-                p->fstream = s_fft;
-                (void)hipStreamDestroy(p->stream2);
-                p->stream2 = s_rest;
-                p->bstream = s_rest;
-                p->bstream_mask = rest;
-                ok = hipEventCreateWithFlags(&p->ev_scan_in, hipEventDisableTiming) == hipSuccess &&
-                     hipEventCreateWithFlags(&p->ev_scan_out, hipEventDisableTiming) == hipSuccess;
-            } else {
-                if (s_scan) (void)hipStreamDestroy(s_scan);
-                if (s_rest) (void)hipStreamDestroy(s_rest);
-                if (s_fft) (void)hipStreamDestroy(s_fft);
-                fprintf(stderr, "irdm_hip: CU-masked streams unavailable, scan shares the chip\n");
-            }
-        }
+    // Streams.  pipeline_depth 0: everything on one stream.  pipeline_depth >= 1: the detector (prefilter + scan) and K1
+    // get streams of the highest priority, the per-burst chains (two batch contexts) streams of the lowest: the scan of
+    // chunk k gates the per-burst work of chunk k, whereas a chain's result is not needed for two more feeds -- without
+    // priorities the scan's small kernels queue up behind the FIR workgroups of two chains (measured: the host waited
+    // 1.3 ms per feed for a 0.6 ms scan).  (Round 1 confined a sequential leader scan to CUs of its own with CU masks;
+    // the band scan is wide and short, masks would only take CUs away from it.)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
+    bool ok = true;
+    p->stream2 = nullptr;
+    if (p->depth) {
+        ok = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+             hipStreamCreateWithPriority(&p->fstream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+             hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) == hipSuccess;
+        p->bstream = p->stream2;
+    } else {
+        ok = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess;
+        p->bstream = p->stream;
+        p->fstream = p->stream;
     }
+    p->sstream = p->stream;
+    p->bstream_prio = prio_lo;
+    p->ev_scan_in = p->ev_scan_out = nullptr;
     p->has_pending = false;
     p->pend_c1 = 0;
     for (auto &e : p->ev_sk) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -619,9 +601,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             b.d_rrc_ws = p->d_rrc_ws; b.d_frames = p->d_frames; b.d_demod_ws = p->d_demod_ws; b.d_demod = p->d_demod;
             b.d_decoded = p->d_decoded; b.d_ida = p->d_ida;
         } else {
-            ok = ok && (p->bstream_mask.empty()
-                            ? hipStreamCreate(&b.stream) == hipSuccess
-                            : hipExtStreamCreateWithCUMask(&b.stream, (uint32_t)p->bstream_mask.size(), p->bstream_mask.data()) == hipSuccess);
+            ok = ok && hipStreamCreateWithPriority(&b.stream, hipStreamNonBlocking, p->bstream_prio) == hipSuccess;
             AL(b.d_work, BurstWork, (size_t)p->burst_cap);
             AL(b.d_tiles, FirTile, b.tiles_cap);
             AL(b.d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
@@ -661,7 +641,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
          hipMemset(p->d_state, 0, sizeof(DetState)) == hipSuccess &&
          hipMemset(p->d_ring, 0, p->ring_len * p->bps) == hipSuccess;
     ok = ok && launch_rotator_table(p->d_rot_incr, p->d_rot_table, P.n, p->n_ckpt, p->stream) == 0;
-    ok = ok && hipStreamSynchronize(p->stream) == hipSuccess;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
     if (!ok) {
         fprintf(stderr, "irdm_hip: device initialisation failed\n");
         pipeline_free(p);
@@ -1422,6 +1402,16 @@ static int settle(irdm_pipeline *p)
     return 0;
 }
 
+// control-plane calls (state export / import, probes, stage-level entry points): the detector settled and every stream
+// idle -- the pipeline's streams are non-blocking, a null-stream copy orders against none of them
+static int quiesce(irdm_pipeline *p)
+{
+    (void)hipSetDevice(p->cfg.device);
+    if (settle(p) != 0) return -1;
+    IRDM_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 // pipeline_depth >= 1: the finished bursts of the previously scanned chunk (pend_gone) go through the per-burst
 // stages on the next batch context, reading the history ring only; nothing waits here.  A chunk with more bursts than
 // burst_cap is worked off synchronously, batch by batch, except for its last batch.
@@ -1534,25 +1524,39 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
         emitted = n_gone;
     } else {
+        auto now_us = [] {
+            struct timespec ts;
+            clock_gettime(CLOCK_MONOTONIC, &ts);
+            return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+        };
+        double t0 = now_us(), t1;
+#define IRDM_HOST_PHASE(i) do { t1 = now_us(); p->host_us[i] += t1 - t0; t0 = t1; } while (0)
         // 0. this chunk into the history ring, behind K1 on its stream (the ring keeps three chunks: the copy never
         //    overwrites what the per-burst chains in flight still read)
         if (ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
+        IRDM_HOST_PHASE(0);
         // 1. the previous chunk's detector must be done before this chunk's can start: collect its bursts
         if (settle(p) != 0) return -1;
+        IRDM_HOST_PHASE(1);
         // 2. their per-burst stages: enqueued on the idle batch context, nothing waits.  (The context of the chunk
         //    before that is still at work: its tail overlaps this one's FIR.)
         p->last_bursts.clear();
         if (deferred_enqueue(p) != 0) return -1;
+        IRDM_HOST_PHASE(2);
         // 3. this chunk's detector (needs K1's output), enqueued while the GPU works on 2.
         IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[1], 0));
         if (scan_launch(p, mag, n_frames, c1) != 0) return -1;
+        IRDM_HOST_PHASE(3);
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
         emitted = deferred_finish(p, p->bc[p->chunk_no % p->n_bc]);
         if (emitted < 0) return -1;
+        IRDM_HOST_PHASE(4);
         // 5. the caller may overwrite d_iq once we return: K1 and the ring copy are done with it
         IRDM_HIP_CHECK(hipEventRecord(p->ev_ring, p->fstream));
         IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->fstream));
         IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
+        IRDM_HOST_PHASE(5);
+#undef IRDM_HOST_PHASE
     }
     p->chunk_no++;
     p->total_samples = c1;
@@ -1575,6 +1579,25 @@ extern "C" void *irdm_host_alloc(size_t bytes)
 extern "C" void irdm_host_free(void *q)
 {
     if (q) (void)hipHostFree(q);
+}
+
+extern "C" void *irdm_device_alloc(int device, size_t bytes)
+{
+    void *q = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+    return q;
+}
+
+extern "C" void irdm_device_free(void *q)
+{
+    if (q) (void)hipFree(q);
+}
+
+extern "C" int irdm_device_upload(void *dptr, const void *host, size_t bytes)
+{
+    if (!dptr || (!host && bytes)) return -1;
+    IRDM_HIP_CHECK(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    return 0;
 }
 
 extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples)
@@ -1638,7 +1661,7 @@ extern "C" int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max)
 extern "C" int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_frames)
 {
     if (!p || !out) return -1;
-    if (settle(p) != 0) return -1;
+    if (quiesce(p) != 0) return -1;
     const size_t nf = std::min<size_t>(max_frames, (size_t)p->last_frames);
     if (!nf) return 0;
     IRDM_HIP_CHECK(hipMemcpy(out, p->d_mag_last, nf * p->P.n * sizeof(float), hipMemcpyDeviceToHost));
@@ -1647,7 +1670,7 @@ extern "C" int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_f
 
 extern "C" int irdm_baseline_sum(irdm_pipeline_t *p, float *out)
 {
-    if (!p || !out || settle(p) != 0) return -1;
+    if (!p || !out || quiesce(p) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpy(out, p->d_sum, p->P.n * sizeof(float), hipMemcpyDeviceToHost));
     return p->P.n;
 }
@@ -1682,7 +1705,7 @@ extern "C" size_t irdm_state_bytes(const irdm_pipeline_t *p)
 
 extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap)
 {
-    if (!p || !buf || cap < irdm_state_bytes(p) || settle(p) != 0) return -1;
+    if (!p || !buf || cap < irdm_state_bytes(p) || quiesce(p) != 0) return -1;
     (void)hipSetDevice(p->cfg.device);
     char *o = static_cast<char *>(buf);
     StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
@@ -1699,7 +1722,7 @@ extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap
 
 extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
 {
-    if (!p || !buf || n < irdm_state_bytes(p) || settle(p) != 0) return -1;
+    if (!p || !buf || n < irdm_state_bytes(p) || quiesce(p) != 0) return -1;
     (void)hipSetDevice(p->cfg.device);
     const char *i = static_cast<const char *>(buf);
     StateHeader h;
@@ -1722,7 +1745,7 @@ extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
 extern "C" int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start)
 {
     if (!p || (!h_iq && n_samples) || n_samples > abs_start) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    if (quiesce(p) != 0) return -1;
     if (n_samples > p->ring_len) {       // only the most recent ring_len samples can matter
         h_iq = static_cast<const char *>(h_iq) + (n_samples - p->ring_len) * p->bps;
         n_samples = p->ring_len;
@@ -1746,7 +1769,7 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
 {
     if (!p || !info || !samples || !frame || p->dev_fmt != 2) return -1;
     if (num_samples > p->l_cap) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    if (quiesce(p) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpy(p->d_probe, samples, num_samples * sizeof(float2), hipMemcpyHostToDevice));
     // the burst window is presented as a "chunk" that starts at info->start
     SampleSource src = make_source(p, p->d_probe, info->start, info->start + num_samples);
@@ -1934,6 +1957,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!p || !key) return -1;
     if (!strcmp(key, "scan_fast_chunks")) return (int64_t)p->stat_fast_chunks;
     if (!strcmp(key, "scan_fallbacks")) return (int64_t)p->stat_fallbacks;
+    if (!strncmp(key, "host_us_", 8) && key[8] >= '0' && key[8] <= '5') return (int64_t)p->host_us[key[8] - '0'];
     if (!strcmp(key, "band_chunks")) return (int64_t)p->stat_band_chunks;
     if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
     if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;

@@ -108,6 +108,11 @@ def lib():
         L.irdm_host_alloc.restype = C.c_void_p
         L.irdm_host_free.argtypes = [C.c_void_p]
         L.irdm_host_free.restype = None
+        L.irdm_device_alloc.argtypes = [C.c_int, C.c_size_t]
+        L.irdm_device_alloc.restype = C.c_void_p
+        L.irdm_device_free.argtypes = [C.c_void_p]
+        L.irdm_device_free.restype = None
+        L.irdm_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
@@ -155,6 +160,24 @@ def host_alloc(nbytes):
         raise MemoryError("irdm_host_alloc(%d) failed" % nbytes)
     view = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
     return ptr, view
+
+
+def device_buffer(array, device=0):
+    """Copy a numpy array into a device buffer allocated by the library (irdm_device_alloc + irdm_device_upload);
+    returns the device pointer, release with device_free(pointer)."""
+    L = lib()
+    a = np.ascontiguousarray(array)
+    ptr = L.irdm_device_alloc(device, a.nbytes)
+    if not ptr:
+        raise MemoryError("irdm_device_alloc(%d) failed" % a.nbytes)
+    if L.irdm_device_upload(ptr, a.ctypes.data_as(C.c_void_p), a.nbytes) != 0:
+        L.irdm_device_free(ptr)
+        raise RuntimeError("irdm_device_upload failed")
+    return ptr
+
+
+def device_free(ptr):
+    lib().irdm_device_free(ptr)
 
 
 def host_free(ptr):

@@ -109,33 +109,29 @@ def test_ci16_device_resident_and_pinned_host_feed():
     """Raw int16 pairs are narrowed in the kernels' load stage (main.c:245-246): a device-resident ci16 chunk
     (irdm_feed_device) and a pinned host buffer (irdm_host_alloc + irdm_feed_host), both chunked at pipeline_depth 1,
     give the records the oracle gives for the whole stream."""
-    import ctypes as C
-    import torch
     fs, iq = _scene_2m(seed=17, n_bursts=5, secs=2.0)
     i16 = siggen.to_ci16(iq)
     n = len(i16) // 2
     ref = orc.run_stream(i16, fs, fmt=1)
     chunks = [32768 * 30, 32768 * 17, n - 32768 * 47]
-    # device-resident (the buffer comes from torch, which carries a HIP runtime of its own: INTEGRATION.md section 3; if
-    # that runtime cannot come up this late in the process, only the pinned-host half below runs)
+    # device-resident: the buffer is allocated and filled through the library itself (irdm_device_alloc / _upload), so
+    # this half never depends on another HIP runtime in the process
+    dptr = irdm.device_buffer(i16)
     try:
-        d = torch.from_numpy(i16.copy()).cuda()
-    except RuntimeError as e:
-        d = None
-        print("torch.cuda unavailable in this process (%s): device-resident half skipped" % e)
-    if d is not None:
         p = irdm.Pipeline(fs, fmt=irdm.FMT_CI16, max_chunk_samples=max(chunks), max_bursts_per_chunk=1024, pipeline_depth=1)
         p.set_option("keep_frame_samples", 1)
         off = 0
         for c in chunks:
-            p.feed_device(d.data_ptr() + off * 4, c, torch.cuda.current_stream().cuda_stream)
+            p.feed_device(dptr + off * 4, c, None)
             off += c
         p.flush()
         infos, samples = p.poll_frames()
         got = dict(bursts=p.poll_bursts(), infos=infos, samples=samples, demods=p.poll_demods(), tagged=p.tagged)
         p.close()
-        s1 = parity.compare(got, ref)
-        assert s1["demods"] >= 3, s1
+    finally:
+        irdm.device_free(dptr)
+    s1 = parity.compare(got, ref)
+    assert s1["demods"] >= 3, s1
     # pinned host buffer
     ptr, view = irdm.host_alloc(max(chunks) * 4)
     p = irdm.Pipeline(fs, fmt=irdm.FMT_CI16, max_chunk_samples=max(chunks), max_bursts_per_chunk=1024, pipeline_depth=1)
