@@ -149,6 +149,113 @@ def cpu_reference_layout(orc, host, fs, fmt, workers=4):
     return dict(seconds=dt, bursts=counts["bursts"], demods=counts["demods"])
 
 
+def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, backend):
+    """BASELINE config 4: ONE 12 MHz cf32 stream, 16384-point detect, consecutive time-chunks on consecutive ranks.
+    Rank 0 holds one period of the stream (world chunks) in HBM and scatters [overlap | chunk] slices every super-step;
+    the detector state travels rank to rank (sharding.TimeShard); demodulated-frame records are gathered to rank 0.
+    value = world * chunk * steps / max-over-ranks time."""
+    import sharding
+    fs = 12_000_000 if args.sample_rate == 10_000_000 else args.sample_rate
+    nfft = 1 << int(round(np.log2(fs / 1000.0)))
+    chunk = args.samples // 32768 * 32768
+    ov = (sharding.required_overlap(fs, nfft) + 15) // 16 * 16
+    if ov >= chunk:
+        raise SystemExit("--samples %d is smaller than the chunk overlap %d" % (chunk, ov))
+    bps = 8
+    nccl = backend == "nccl"
+    parts = None
+    nb = 0
+    if rank == 0:
+        x, nb = build_scene(torch, device, fs, world * chunk, args.density, seed=4)
+        flat = x.view(torch.uint8).reshape(-1)
+        parts = []
+        for k in range(world):
+            lo = (k * chunk - ov) * bps
+            hi = (k + 1) * chunk * bps
+            piece = torch.cat([flat[lo:], flat[:hi]]) if lo < 0 else flat[lo:hi].clone()
+            parts.append(piece if nccl else piece.cpu())
+        del x, flat
+    buf = torch.empty((ov + chunk) * bps, dtype=torch.uint8, device=device)
+    stage = None if nccl else torch.empty((ov + chunk) * bps, dtype=torch.uint8)
+    pipe = irdm.Pipeline(fs, fmt=irdm.FMT_CF32, max_chunk_samples=chunk, max_bursts_per_chunk=8192, device=local,
+                         pipeline_depth=args.depth)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        pipe.set_option(key, int(val))
+    ts = sharding.TimeShard(dist, pipe, torch, device, chunk, bps, ov) if world > 1 else None
+    REC = C.sizeof(irdm.Demod)
+    cap = 4096
+    gbuf = torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) if world > 1 else None
+    glist = [torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    counts = torch.zeros((2,), dtype=torch.int64, device=cdev)
+    step_no = [0]
+
+    def super_step(record):
+        if world > 1:
+            dist.scatter(buf if nccl else stage, parts if rank == 0 else None, src=0)
+            if not nccl:
+                buf.copy_(stage)
+            torch.cuda.synchronize()
+            ts.step(buf, first_of_stream=True)
+        else:
+            pipe.feed_device(parts[0].data_ptr() + ov * bps, chunk, None)
+            pipe.flush()
+        step_no[0] += 1
+        nbst = len(pipe.poll_bursts_raw())
+        pipe.drop_frames()
+        demods = pipe.poll_demods_raw()
+        if world > 1:
+            k = min(len(demods), cap)
+            if k:
+                gbuf[:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(cdev)
+            dist.gather(gbuf, glist, dst=0)
+        if record:
+            counts[0] += nbst
+            counts[1] += len(demods)
+
+    for _ in range(args.warmup):
+        super_step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        super_step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        ts.drain()
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    K = max(args.steps, 1)
+    t = pipe.timings()
+    if rank == 0:
+        state_mb = pipe.state_bytes() / 1e6
+        out = {
+            "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz cf32" % (fs // 1_000_000),
+            "value": round(world * chunk * K / dt / 1e6, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg4: ONE %d MHz cf32 stream, %d-pt detect, full pipeline; a step = %d consecutive time-chunks of "
+                                   "%d samples, one per GPU, scattered from rank 0 with a %d-sample overlap, detector state "
+                                   "(%.1f MB) handed rank to rank, %.0f bursts/Msample"
+                                   % (fs // 1_000_000, nfft, world, chunk, ov, state_mb, args.density),
+                       "samples_per_step_per_gpu": chunk, "parallelism": "time-chunks x%d" % world,
+                       "job_bursts_per_step": int(counts[0].item()) / K, "raw_frames_per_step": int(counts[1].item()) / K,
+                       "pipeline_depth": args.depth, "backend": backend,
+                       "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
+            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_m", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    pipe.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +274,10 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="one-core oracle passes over that prefix (~3 s each)")
+    ap.add_argument("--shard", choices=("streams", "time"), default="streams",
+                    help="streams (default): one independent stream per GPU (BASELINE config 5 / the headline metric at N=1); "
+                         "time: ONE 12 MHz stream, consecutive time-chunks on consecutive ranks with the detector state handed "
+                         "rank to rank over RCCL (BASELINE config 4)")
     ap.add_argument("--alone-steps", type=int, default=4,
                     help="extra steps at pipeline_depth 0 (stage times with one kernel on the chip at a time, and the records "
                          "for the parity check; 0 = skip)")
@@ -205,6 +316,11 @@ def main():
     fs = args.sample_rate
     n = args.samples // 32768 * 32768
     irdm.build()
+    if args.shard == "time":
+        bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, backend)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     x, nb = build_scene(torch, device, fs, n, args.density, seed=2 + rank)
     torch.cuda.synchronize()
 

@@ -202,6 +202,11 @@ void irdm_destroy(irdm_pipeline_t *p);
  * (irdm_host_alloc, hipHostMalloc, hipHostRegister) and overlaps the previous chunk's detector scan.
  * Returns the number of bursts whose records became pollable, or -1 on error. */
 int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
+/* irdm_feed_device in two halves: _begin = what does not depend on the detector state (K1 of the chunk, its copy into
+ * the history ring), _end = detector scan + per-burst work.  A time-sharded rank calls _begin, receives the previous
+ * rank's state (irdm_import_state_device), then calls _end. */
+int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
+int irdm_feed_end(irdm_pipeline_t *p);
 int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples);
 /* pipeline_depth 1: finish the detector scan in flight and run the per-burst stages of the last fed chunk now.
  * Returns bursts processed or -1. */
@@ -282,6 +287,11 @@ size_t irdm_state_bytes(const irdm_pipeline_t *p);
 long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap);
 int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n);
 int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start);
+/* the same three with DEVICE buffers (a blob RCCL moves GPU to GPU; a chunk overlap received from the previous rank):
+ * no host bounce, and only the detector is waited for -- K1 of the next chunk and per-burst work in flight go on */
+long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, size_t cap);
+int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, size_t n);
+int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, uint64_t abs_start);
 
 /* Options: "decode_frames" / "decode_ida" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded /
  * irdm_poll_ida),

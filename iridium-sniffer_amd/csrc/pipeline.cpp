@@ -278,6 +278,11 @@ struct irdm_pipeline {
     int hp_gone_cap;
     hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
     uint64_t chunk_no;          // chunks fed so far
+    bool fb_active;             // irdm_feed_begin done, irdm_feed_end pending
+    const void *fb_iq;
+    uint64_t fb_c0, fb_c1;
+    float *fb_mag;
+    int fb_frames;
     double host_us[6];          // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
@@ -1466,9 +1471,13 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
     return emitted;
 }
 
-extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
+// A feed in two halves.  irdm_feed_begin: everything that does not depend on the detector state -- K1 of the chunk and
+// (pipeline_depth >= 1) its copy into the history ring.  irdm_feed_end: the detector scan and the per-burst work.  A
+// time-sharded rank calls them around the arrival of the previous rank's state (sharding.py); irdm_feed_device is the
+// two back to back.
+extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
 {
-    if (!p || (!d_iq && n_samples)) return -1;
+    if (!p || (!d_iq && n_samples) || p->fb_active) return -1;
     if (p->stream_closed) {
         fprintf(stderr, "irdm_hip: stream already ended by a chunk that was not a multiple of feed_block\n");
         return -1;
@@ -1493,7 +1502,6 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     const DetParams &P = p->P;
     const uint64_t c0 = p->total_samples, c1 = c0 + n_samples;
     const int n_frames = (int)(n_samples / (size_t)P.n);
-    float ms = 0;
 
     // K1 of this chunk.  pipeline_depth 1: on its own stream and into the other magnitude buffer, while the detector
     // scan of the previous chunk may still be running
@@ -1506,6 +1514,28 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->fstream));
+    // this chunk into the history ring, behind K1 on its stream (the ring keeps three chunks: the copy never
+    // overwrites what the per-burst chains in flight still read)
+    if (p->depth && ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
+    p->fb_active = true;
+    p->fb_iq = d_iq;
+    p->fb_c0 = c0;
+    p->fb_c1 = c1;
+    p->fb_mag = mag;
+    p->fb_frames = n_frames;
+    return 0;
+}
+
+extern "C" int irdm_feed_end(irdm_pipeline_t *p)
+{
+    if (!p || !p->fb_active) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    p->fb_active = false;
+    const void *d_iq = p->fb_iq;
+    const uint64_t c0 = p->fb_c0, c1 = p->fb_c1;
+    float *mag = p->fb_mag;
+    const int n_frames = p->fb_frames;
+    float ms = 0;
 
     int emitted = 0;
     if (!p->depth) {
@@ -1531,9 +1561,6 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
         };
         double t0 = now_us(), t1;
 #define IRDM_HOST_PHASE(i) do { t1 = now_us(); p->host_us[i] += t1 - t0; t0 = t1; } while (0)
-        // 0. this chunk into the history ring, behind K1 on its stream (the ring keeps three chunks: the copy never
-        //    overwrites what the per-burst chains in flight still read)
-        if (ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
         IRDM_HOST_PHASE(0);
         // 1. the previous chunk's detector must be done before this chunk's can start: collect its bursts
         if (settle(p) != 0) return -1;
@@ -1565,6 +1592,12 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
     p->last_ms[0] = hipEventElapsedTime(&ms, p->ev[0], p->ev[1]) == hipSuccess ? ms : -1.0f;
     p->last_ms[5] = hipEventElapsedTime(&ms, p->ev[0], p->ev[7]) == hipSuccess ? ms : -1.0f;
     return emitted;
+}
+
+extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
+{
+    if (irdm_feed_begin(p, d_iq, n_samples, stream_v) != 0) return -1;
+    return irdm_feed_end(p);
 }
 
 // Pinned host memory for irdm_feed_host callers that have no HIP headers (the C99 host): H2D copies from pinned
@@ -1739,6 +1772,70 @@ extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
     p->start_time_ns = h.start_time_ns;
     p->host_primed = h.host_primed;
     p->host_hist_idx = h.host_hist_idx;
+    return 0;
+}
+
+// The same blob in DEVICE memory (e.g. a torch tensor that RCCL sends to the next rank): no host bounce of the 16-32 MiB
+// history, and no device-wide synchronisation -- only the detector has to have settled; K1 / the ring copy of the next
+// chunk and the per-burst chains in flight do not touch the detector state.
+extern "C" long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, size_t cap)
+{
+    if (!p || !d_buf || cap < irdm_state_bytes(p)) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (settle(p) != 0) return -1;
+    char *o = static_cast<char *>(d_buf);
+    const StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
+                            p->start_time_ns, p->host_primed, p->host_hist_idx };
+    IRDM_HIP_CHECK(hipMemcpyAsync(o, &h, sizeof(h), hipMemcpyHostToDevice, p->stream));
+    o += sizeof(h);
+    IRDM_HIP_CHECK(hipMemcpyAsync(o, p->d_state, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+    o += sizeof(DetState);
+    IRDM_HIP_CHECK(hipMemcpyAsync(o, p->d_sum, sizeof(float) * p->P.n, hipMemcpyDeviceToDevice, p->stream));
+    o += sizeof(float) * p->P.n;
+    IRDM_HIP_CHECK(hipMemcpyAsync(o, p->d_hist, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    return (long long)irdm_state_bytes(p);
+}
+
+extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, size_t n)
+{
+    if (!p || !d_buf || n < irdm_state_bytes(p)) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (settle(p) != 0) return -1;
+    const char *i = static_cast<const char *>(d_buf);
+    StateHeader h;
+    IRDM_HIP_CHECK(hipMemcpyAsync(&h, i, sizeof(h), hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (h.magic != 0x4952444d53544154ull || h.n != (uint64_t)p->P.n || h.hist != (uint64_t)kHistory) return -1;
+    i += sizeof(h);
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, i, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+    i += sizeof(DetState);
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, i, sizeof(float) * p->P.n, hipMemcpyDeviceToDevice, p->stream));
+    i += sizeof(float) * p->P.n;
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, i, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (!p->fb_active) p->total_samples = h.total_samples;     // (a feed already begun has fixed its own position)
+    p->tagged = h.tagged;
+    p->start_time_ns = h.start_time_ns;
+    p->host_primed = h.host_primed;
+    p->host_hist_idx = h.host_hist_idx;
+    return 0;
+}
+
+// the preceding samples from DEVICE memory (a chunk overlap received from the previous rank)
+extern "C" int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, uint64_t abs_start)
+{
+    if (!p || (!d_iq && n_samples) || n_samples > abs_start || p->fb_active) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (n_samples > p->ring_len) {
+        d_iq = static_cast<const char *>(d_iq) + (n_samples - p->ring_len) * p->bps;
+        n_samples = p->ring_len;
+    }
+    // behind whatever the ring stream still has to do; the per-burst chains wait for ev_ring before they read the ring
+    if (ring_update(p, d_iq, abs_start - n_samples, abs_start, p->fstream) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_ring, p->fstream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
+    p->total_samples = abs_start;
     return 0;
 }
 

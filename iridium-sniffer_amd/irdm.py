@@ -108,6 +108,12 @@ def lib():
         L.irdm_host_alloc.restype = C.c_void_p
         L.irdm_host_free.argtypes = [C.c_void_p]
         L.irdm_host_free.restype = None
+        L.irdm_feed_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.irdm_feed_end.argtypes = [C.c_void_p]
+        L.irdm_export_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_export_state_device.restype = C.c_longlong
+        L.irdm_import_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_seed_history_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
         L.irdm_device_alloc.argtypes = [C.c_int, C.c_size_t]
         L.irdm_device_alloc.restype = C.c_void_p
         L.irdm_device_free.argtypes = [C.c_void_p]
@@ -288,6 +294,32 @@ class Pipeline:
         if rc < 0:
             raise RuntimeError("irdm_feed_device failed")
         return rc
+
+    def feed_begin(self, ptr, n_samples, stream=None):
+        """K1 + history-ring copy of a device-resident chunk (what does not depend on the detector state)."""
+        if self.L.irdm_feed_begin(self.h, C.c_void_p(ptr), n_samples, C.c_void_p(stream or 0)) != 0:
+            raise RuntimeError("irdm_feed_begin failed")
+
+    def feed_end(self):
+        rc = self.L.irdm_feed_end(self.h)
+        if rc < 0:
+            raise RuntimeError("irdm_feed_end failed")
+        return rc
+
+    def state_bytes(self):
+        return int(self.L.irdm_state_bytes(self.h))
+
+    def export_state_device(self, dptr, cap):
+        if self.L.irdm_export_state_device(self.h, C.c_void_p(dptr), cap) < 0:
+            raise RuntimeError("irdm_export_state_device failed")
+
+    def import_state_device(self, dptr, n):
+        if self.L.irdm_import_state_device(self.h, C.c_void_p(dptr), n) != 0:
+            raise RuntimeError("irdm_import_state_device failed")
+
+    def seed_history_device(self, dptr, n_samples, abs_start):
+        if self.L.irdm_seed_history_device(self.h, C.c_void_p(dptr), n_samples, abs_start) != 0:
+            raise RuntimeError("irdm_seed_history_device failed")
 
     def flush(self):
         rc = self.L.irdm_flush(self.h)

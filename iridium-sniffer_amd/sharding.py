@@ -115,5 +115,87 @@ def run_time_sharded(dist, make_pipeline, iq, fmt_is_cf32, sample_rate, fft_size
         handoff_send(dist, pipe.export_state(), device)
     else:
         pipe.feed_host(iq[start * per:stop * per])
+    if hasattr(pipe, "flush"):
+        pipe.flush()                     # pipeline_depth >= 1: the chunk's per-burst work is still in flight
     recs = pipe.poll_demods_raw()
     return gather_records(dist, recs, recs.shape[1] if recs.size else 4544, 4096, device)
+
+
+class TimeShard:
+    """ONE stream, processed in super-steps of `world` consecutive chunks, chunk k of a super-step on rank k
+    (BASELINE config 4).  Per rank and super-step:
+
+        seed_history_device   the `overlap` samples in front of the chunk (arrive with the chunk)
+        feed_begin            K1 + history-ring copy: no detector state needed, runs while the state is on its way
+        recv + import         the detector state of the previous chunk (rank k-1; rank 0: rank world-1's of the
+                              previous super-step) -- DetState + sums + 512-frame history, 16-32 MiB, GPU to GPU
+        feed_end              prefilter + scan (+ per-burst chain enqueued)
+        export + send         the state moves on as soon as the scan has settled; only this recv -> scan -> send
+                              stretch is sequential across the ranks (burst_detect.c:438-454, :594-631)
+        flush                 the chunk's per-burst stages, overlapping the next ranks' scans
+
+    With "nccl" the blob is a device tensor (RCCL send/recv over xGMI); with "gloo" (CPU tests, or several ranks
+    sharing one GPU) it bounces through a host tensor.  Expected throughput: world * chunk / max(world * t_hop,
+    t_rank), t_hop = recv + import + scan + export + send, t_rank = t_hop + K1 + per-burst chain -- the state chain
+    caps the speed-up at t_rank / t_hop however many GPUs there are."""
+
+    def __init__(self, dist, pipe, torch, device, chunk_samples, bps, overlap):
+        self.dist, self.pipe, self.torch, self.device = dist, pipe, torch, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.chunk, self.bps, self.overlap = chunk_samples, bps, overlap
+        self.nccl = dist.get_backend() == "nccl"
+        self.nbytes = pipe.state_bytes()
+        self.state = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
+        self.host_state = None if self.nccl else torch.empty(self.nbytes, dtype=torch.uint8)
+        self.step_no = 0
+
+    def _recv_state(self, src):
+        if self.nccl:
+            self.dist.recv(self.state, src=src)
+        else:
+            self.dist.recv(self.host_state, src=src)
+            self.state.copy_(self.host_state)
+        self.torch.cuda.synchronize(self.device)
+
+    def _send_state(self, dst):
+        if self.nccl:
+            self.dist.send(self.state, dst=dst)
+        else:
+            self.host_state.copy_(self.state)
+            self.dist.send(self.host_state, dst=dst)
+
+    def step(self, buf, first_of_stream):
+        """buf: device uint8 tensor holding [overlap samples | chunk samples] for this rank's chunk of the current
+        super-step (the overlap part is ignored for the very first chunk of the stream).  Returns after the chunk's
+        records are in the pipeline's queues.  Every rank's point-to-point traffic of a super-step is complete when
+        step() returns on all ranks (rank 0 takes the last rank's state at the END of its step and keeps it for the
+        next one), so collectives may follow."""
+        pipe, rank, world = self.pipe, self.rank, self.world
+        abs_start = (self.step_no * world + rank) * self.chunk
+        base = buf.data_ptr()
+        if world == 1:                   # nothing to hand over: the context carries its own state
+            pipe.feed_begin(base + self.overlap * self.bps, self.chunk, None)
+            pipe.feed_end()
+            pipe.flush()
+            self.step_no += 1
+            return
+        first = first_of_stream and self.step_no == 0 and rank == 0
+        if not first:
+            pipe.seed_history_device(base, self.overlap, abs_start)
+        pipe.feed_begin(base + self.overlap * self.bps, self.chunk, None)
+        if not first:
+            if rank != 0:
+                self._recv_state(rank - 1)
+            # (rank 0 already holds the state: received at the end of its previous step)
+            pipe.import_state_device(self.state.data_ptr(), self.nbytes)
+        pipe.feed_end()
+        pipe.export_state_device(self.state.data_ptr(), self.nbytes)
+        self._send_state((rank + 1) % world)
+        pipe.flush()
+        if rank == 0:
+            self._recv_state(world - 1)
+        self.step_no += 1
+
+    def drain(self):
+        """Nothing left in flight (kept for callers of the earlier protocol)."""
+        return

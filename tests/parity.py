@@ -91,3 +91,28 @@ def raw_fields(line):
     """RAW line -> (file_info, ts, freq, N-field, id, conf, level, payload, bits)"""
     p = line.split()
     return p[1], float(p[2]), int(p[3]), p[4], p[5], p[6], float(p[7]), int(p[8]), p[9]
+
+
+def compare_records(bursts, demods, ref):
+    """Burst and demodulated-frame records only (no per-frame samples): what a sharded run gathers.  ids, indices, centre
+    bins, dB fields, hard bits and confidence exact; level / LLR within SOFT_TOL."""
+    assert len(bursts) == len(ref.bursts), (len(bursts), len(ref.bursts))
+    for g, r in zip(bursts, ref.bursts):
+        for f in ("id", "start", "stop", "last_active", "center_bin", "num_samples", "avail_end"):
+            assert getattr(g, f) == getattr(r, f), (f, g.id, getattr(g, f), getattr(r, f))
+        for f in ("magnitude", "noise", "peak_rel", "base_sum"):
+            assert bits_of(getattr(g, f)) == bits_of(getattr(r, f)), (f, g.id)
+    assert len(demods) == len(ref.demods), (len(demods), len(ref.demods))
+    max_soft = 0.0
+    for g, r in zip(demods, ref.demods):
+        assert g.id == r.id and g.timestamp == r.timestamp
+        assert (g.direction, g.n_symbols, g.n_payload_symbols, g.n_bits) == \
+               (r.direction, r.n_symbols, r.n_payload_symbols, r.n_bits), g.id
+        assert bytes(g.bits[:g.n_bits]) == bytes(r.bits[:r.n_bits]), g.id
+        assert g.confidence == r.confidence
+        gl = np.array(g.llr[:g.n_bits], np.float32)
+        rl = np.array(r.llr[:r.n_bits], np.float32)
+        max_soft = max(max_soft, abs(g.level - r.level), float(np.max(np.abs(gl - rl))) if g.n_bits else 0.0)
+        assert bits_of(g.magnitude) == bits_of(r.magnitude) and bits_of(g.noise) == bits_of(r.noise)
+    assert max_soft <= SOFT_TOL
+    return dict(bursts=len(bursts), demods=len(demods), max_soft=max_soft)

@@ -1,0 +1,111 @@
+"""-m gpu: time-chunk sharding of ONE stream with the real pipeline (BASELINE config 4), world size 2.
+
+Two processes (gloo for the control plane, both on GPU 0 -- a one-GPU box is enough for the functional check) run
+sharding.TimeShard: chunk j of the stream goes to rank j % 2, the detector state (DetState + sums + 512-frame history)
+travels rank to rank between the scans, each rank seeds the samples in front of its chunk, K1 of a chunk runs before
+its state arrives (irdm_feed_begin / irdm_feed_end).  The merged records must equal the oracle's for the whole stream:
+the sequential dependency that has to survive is burst_detect.c:438-454 (noise floor) and :594-631 (bursts, ids)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "iridium-sniffer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+FS = 2_000_000
+NFFT = 2048
+STEPS = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _stream():
+    import sharding
+    import siggen
+    ov = (sharding.required_overlap(FS, NFFT) + 15) // 16 * 16
+    chunk = (ov + 32768 * 4) // 32768 * 32768
+    n = chunk * 2 * STEPS
+    rng = np.random.default_rng(77)
+    first = 520 * NFFT
+    starts = np.sort(rng.integers(first, n - int(0.05 * FS), 40))
+    bursts = [dict(start=int(s), freq_hz=siggen.channel_freq(int(rng.integers(-22, 23)) or 1),
+                   payload=rng.integers(0, 4, int(rng.integers(119, 180))).tolist()) for s in starts]
+    # one burst right across every chunk boundary
+    for j in range(1, 2 * STEPS):
+        bursts.append(dict(start=j * chunk - 9000, freq_hz=siggen.channel_freq(3 * j), payload=rng.integers(0, 4, 170).tolist()))
+    iq, _ = siggen.make_stream(FS, n, bursts, seed=77)
+    return iq, chunk, ov
+
+
+def _worker(rank, world, port, depth, q):
+    import torch
+    import torch.distributed as dist
+    import irdm
+    import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        iq, chunk, ov = _stream()
+        dev = torch.device("cuda", 0)
+        pipe = irdm.Pipeline(FS, max_chunk_samples=chunk, max_bursts_per_chunk=1024, pipeline_depth=depth)
+        ts = sharding.TimeShard(dist, pipe, torch, dev, chunk, 8, ov)
+        out = []
+        for s in range(STEPS):
+            j = s * world + rank
+            lo = j * chunk - ov
+            piece = np.concatenate([np.zeros(-lo, np.complex64), iq[:(j + 1) * chunk]]) if lo < 0 else iq[lo:(j + 1) * chunk]
+            buf = torch.from_numpy(np.ascontiguousarray(piece).view(np.uint8).copy()).to(dev)
+            ts.step(buf, first_of_stream=True)
+            out.append((j, pipe.poll_bursts_raw().copy(), pipe.poll_demods_raw().copy()))
+            pipe.drop_frames()
+        ts.drain()
+        stats = {k: pipe.stat(k) for k in ("band_chunks", "scan_fallbacks")}
+        pipe.close()
+        q.put((rank, out, stats))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth", [0, 1])
+def test_two_rank_time_shard_equals_the_oracle(depth):
+    import irdm
+    import orc
+    import parity
+    iq, chunk, ov = _stream()
+    ref = orc.run_stream(iq, FS)
+    assert len(ref.bursts) >= 40
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, depth, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get() for _ in range(world)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    pieces = sorted((j, b, d) for _, out, _ in res for j, b, d in out)
+    bursts = [irdm.Burst.from_buffer_copy(bytes(row)) for _, b, _ in pieces for row in b]
+    demods = [irdm.Demod.from_buffer_copy(bytes(row)) for _, _, d in pieces for row in d]
+    s = parity.compare_records(bursts, demods, ref)
+    assert s["bursts"] >= 40
+    # bursts straddle every chunk boundary: their windows were cut on one rank from samples the other rank fed
+    for j in range(1, 2 * STEPS):
+        assert any(b.start < j * chunk < b.start + b.num_samples for b in bursts)
+    for _, _, stats in res:
+        assert stats["scan_fallbacks"] == 0, stats
