@@ -235,6 +235,7 @@ int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max);
 uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p);
 uint64_t irdm_sample_count(const irdm_pipeline_t *p);
 int irdm_fft_size(const irdm_pipeline_t *p);
+uint64_t irdm_start_time_ns(const irdm_pipeline_t *p);   /* burst_data_t.start_time_ns (burst_detect.c:849-853) */
 
 /* Stage probes (parity tests): magnitudes of the last chunk (frames x fft_size floats,
  * device -> host copy), current baseline sum. */

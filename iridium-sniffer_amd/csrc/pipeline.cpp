@@ -681,6 +681,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
 extern "C" uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p) { return p ? p->tagged : 0; }
 extern "C" uint64_t irdm_sample_count(const irdm_pipeline_t *p) { return p ? p->total_samples : 0; }
 extern "C" int irdm_fft_size(const irdm_pipeline_t *p) { return p ? p->P.n : -1; }
+extern "C" uint64_t irdm_start_time_ns(const irdm_pipeline_t *p) { return p ? p->start_time_ns : 0; }
 
 static SampleSource make_source(const irdm_pipeline *p, const void *chunk, uint64_t c0, uint64_t c1)
 {

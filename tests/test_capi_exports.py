@@ -25,6 +25,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), n
 
 
+def test_reference_stage_level_names_present():
+    # include/irdm_compat.h: the reference's stage API (burst_detect.h:67-94, burst_downmix.h:64-73, qpsk_demod.h:42)
+    src = open(os.path.join(ROOT, "include", "irdm_compat.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b((?:burst_detector|burst_downmix|qpsk_demod|irdm_compat)[a-z0-9_]*)\s*\(", src)))
+    assert "burst_detector_feed_cf32" in names and "burst_downmix_process" in names and "qpsk_demod" in names
+    L = C.CDLL(irdm.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+
+
 def test_reference_plug_point_names_present():
     # opencl/burst_fft.h:35-47 -- the three symbols burst_detect.c links against
     L = irdm.lib()
