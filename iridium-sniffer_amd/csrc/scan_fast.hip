@@ -392,6 +392,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                             if (++spins > kMcSpinLimit) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        // the operation word has been seen (the loop exit waited for its load): nothing that follows may
+                        // be moved in front of it by the compiler -- the loads of the operation's rows and sums are relaxed
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                     if (op == 0ull) {                                      // the leader went away: give up
                         atomicOr(&status[0], 256);
@@ -559,6 +562,9 @@ __global__ __launch_bounds__(kFastThreads) void detect_scan_fast_kernel(
                 if (++spins_ > kMcSpinLimit) { abort_code |= 128; break; }                             \
                 __builtin_amdgcn_s_sleep(1);                                                           \
             }                                                                                          \
+            /* the counters have been seen: the MC_SUM loads that follow are relaxed atomics to other  \
+               addresses, which the compiler could otherwise hoist above the spin exit */              \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
             n_ack = n_pub;                                                                             \
         }                                                                                              \
     } while (0)

@@ -475,3 +475,21 @@ def test_cli_save_bursts_dumps_every_downmixed_frame(tmp_path):
         got = np.fromfile(m[:-5] + ".cf32", np.float32)
         assert np.array_equal(got.view(np.uint32), np.ctypeslib.as_array(f.samples)[:2 * f.num_samples].view(np.uint32))
     assert any(f.id not in ok_ids for f in frames)            # the scene really has rejected frames
+
+
+def test_pipeline_1mhz_fft_1024():
+    """1 MHz -> 1024-point frames, /4 decimation: below the band scan's and the sparse scan's geometry (both need
+    >= 2048 bins), so the dense scan and the runtime-M decimator serve it -- every feed must work and match the oracle
+    (round-1 review: the sparse path returned -1 after priming at this size)."""
+    fs = 1_000_000
+    n = int(3.0 * fs) // 32768 * 32768
+    rng = np.random.default_rng(31)
+    first = 520 * 1024
+    bursts = [dict(start=first + 3000 + 260_000 * i, freq_hz=siggen.channel_freq(int(rng.integers(-10, 11)) or 1),
+                   payload=rng.integers(0, 4, 150).tolist()) for i in range(8)]
+    iq, _ = siggen.make_stream(fs, n, bursts, seed=31)
+    ref = orc.run_stream(iq, fs)
+    assert len(ref.bursts) >= 8 and len(ref.demods) >= 6
+    got = parity.run_gpu(iq, fs, chunks=[32768 * 30, n - 32768 * 30])
+    parity.compare(got, ref)
+    assert got["stats"]["band_chunks"] == 0 and got["stats"]["scan_fast_chunks"] == 0
