@@ -38,6 +38,7 @@ struct BandWork {                        // device workspace, carved out of one 
     BandCtl *ctl;
     uint8_t *uq, *uf;                    // speculated per-frame updates: frame ends quiet / forces an update
     int32_t *cnt_before, *tmp, *upd_frame, *old_row, *snap_after, *need, *snap_slot, *slot_pre, *slot_post;
+    int4 *steps;                         // packed (frame, old row, snapshot slot) per update step, padded
     uint64_t *cross;
     float *relq, *snap;
     int snap_cap;

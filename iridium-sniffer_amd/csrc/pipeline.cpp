@@ -169,6 +169,7 @@ struct BatchCtx {
     std::vector<double> h_cfreq;
     std::vector<irdm_burst_t> recs;
     int n;                       // bursts in flight (0: idle)
+    uint64_t chunk_no;           // the chunk they come from
     bool owns_buffers;           // context 1 allocates its own device scratch; context 0 aliases the pipeline's
     float ms[3];                 // fir, post, demod of the last finished batch
 };
@@ -267,7 +268,7 @@ struct irdm_pipeline {
     int mag_parity;
     std::vector<BurstWork> h_work;
     // the per-burst chains (bursts_enqueue / bursts_finish) and the helper thread that does their host step
-    BatchCtx bc[2];
+    BatchCtx bc[3];
     int n_bc;
     std::thread cfo_thread;
     std::mutex cfo_mu;
@@ -276,6 +277,7 @@ struct irdm_pipeline {
     bool cfo_quit;
     GoneBurst *hp_gone;         // pinned copy of the finished-burst records of a scan
     int hp_gone_cap;
+    hipEvent_t ev_rot;          // the rotator checkpoint table is complete
     hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
     uint64_t chunk_no;          // chunks fed so far
     bool fb_active;             // irdm_feed_begin done, irdm_feed_end pending
@@ -327,7 +329,7 @@ static void pipeline_free(irdm_pipeline *p)
         p->cfo_cv.notify_one();
         p->cfo_thread.join();
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         BatchCtx &b = p->bc[i];
         if (b.ev_cfo) (void)hipEventDestroy(b.ev_cfo);
         for (auto &e : b.ev)
@@ -346,6 +348,7 @@ static void pipeline_free(irdm_pipeline *p)
     }
     if (p->hp_gone) (void)hipHostFree(p->hp_gone);
     if (p->ev_ring) (void)hipEventDestroy(p->ev_ring);
+    if (p->ev_rot) (void)hipEventDestroy(p->ev_rot);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
@@ -419,9 +422,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     if (p->ref_ring < (uint64_t)2 * fs) p->ref_ring = (uint64_t)2 * fs;
     // longest possible burst window: stop - start < max_len + post_len + N, plus pre_len
     p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
-    p->depth = cfg->pipeline_depth > 0 ? 1 : 0;
+    p->depth = cfg->pipeline_depth > 0 ? std::min(cfg->pipeline_depth, 2) : 0;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
-    if (p->depth) p->ring_len += 3 * p->max_chunk;  // two per-burst chains in flight read the two previous chunks while this one is copied in
+    if (p->depth) p->ring_len += (size_t)(p->depth + 2) * p->max_chunk;  // the per-burst chains in flight read the previous depth+1 chunks while this one is copied in
     p->ring_len = (p->ring_len + 15) / 16 * 16;     // 16-sample segments never straddle the wrap
     p->n_ckpt = (int)(p->l_cap / kRotSeg) + 2;
 
@@ -592,7 +595,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
     // batch contexts: [0] aliases the pipeline's per-burst scratch and runs on bstream; [1] (pipeline_depth >= 1) has
     // scratch and a stream of its own
-    p->n_bc = p->depth ? 2 : 1;
+    p->n_bc = p->depth ? std::min(p->depth + 1, 3) : 1;
     for (int i = 0; i < p->n_bc && ok; i++) {
         BatchCtx &b = p->bc[i];
         b.owner = p;
@@ -645,8 +648,13 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
          hipMemset(p->d_sum, 0, sizeof(float) * P.n) == hipSuccess &&
          hipMemset(p->d_state, 0, sizeof(DetState)) == hipSuccess &&
          hipMemset(p->d_ring, 0, p->ring_len * p->bps) == hipSuccess;
-    ok = ok && launch_rotator_table(p->d_rot_incr, p->d_rot_table, P.n, p->n_ckpt, p->stream) == 0;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
+    // The rotator checkpoint table (one sequential float recurrence per FFT bin, 12.5 ms of one-lane-per-bin work at
+    // 10 MHz) is not needed before the first burst reaches the decimator -- at the earliest 512 priming frames into
+    // the stream -- so irdm_create does not wait for it: it runs on a per-burst stream, the chains wait for ev_rot.
+    ok = ok && hipEventCreateWithFlags(&p->ev_rot, hipEventDisableTiming) == hipSuccess;
+    ok = ok && launch_rotator_table(p->d_rot_incr, p->d_rot_table, P.n, p->n_ckpt, p->bc[0].stream) == 0;
+    ok = ok && hipEventRecord(p->ev_rot, p->bc[0].stream) == hipSuccess;
     if (!ok) {
         fprintf(stderr, "irdm_hip: device initialisation failed\n");
         pipeline_free(p);
@@ -942,6 +950,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             for (int o = 0; o < w.dec_len; o += kFirTileOut) b.hp_tiles[n_tiles++] = FirTile{ i, o };
     }
     hipStream_t st = b.stream;
+    IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));
     IRDM_HIP_CHECK(hipMemcpyAsync(b.d_work, b.hp_work, sizeof(BurstWork) * nb, hipMemcpyHostToDevice, st));
     if (n_tiles)
         IRDM_HIP_CHECK(hipMemcpyAsync(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, hipMemcpyHostToDevice, st));
@@ -1425,6 +1434,7 @@ static int deferred_enqueue(irdm_pipeline *p)
 {
     if (!p->has_pending) return 0;
     BatchCtx &b = p->bc[p->pend_no % p->n_bc];
+    b.chunk_no = p->pend_no;
     const SampleSource src = make_source(p, nullptr, 0, p->pend_c1);
     const int n = (int)p->pend_gone.size();
     int base = 0;
@@ -1452,20 +1462,20 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
     (void)hipSetDevice(p->cfg.device);
     if (settle(p) != 0) return -1;
     int emitted = 0;
-    // records leave in chunk order: the context that is not about to be used holds the older batch
-    const int next = p->has_pending ? (int)(p->pend_no % p->n_bc) : -1;
-    for (int i = 0; i < p->n_bc; i++) {
-        if (i == next) continue;
-        const int e = deferred_finish(p, p->bc[i]);
+    // records leave in chunk order: the batches in flight, oldest first, then the pending bursts of the last scan
+    for (;;) {
+        BatchCtx *oldest = nullptr;
+        for (int i = 0; i < p->n_bc; i++)
+            if (p->bc[i].n > 0 && (!oldest || p->bc[i].chunk_no < oldest->chunk_no)) oldest = &p->bc[i];
+        if (!oldest) break;
+        const int e = deferred_finish(p, *oldest);
         if (e < 0) return -1;
         emitted += e;
     }
-    if (next >= 0) {
-        int e = deferred_finish(p, p->bc[next]);          // (idle unless n_bc == 1)
-        if (e < 0) return -1;
-        emitted += e;
+    if (p->has_pending) {
+        BatchCtx &b = p->bc[p->pend_no % p->n_bc];
         if (deferred_enqueue(p) != 0) return -1;
-        e = deferred_finish(p, p->bc[next]);
+        const int e = deferred_finish(p, b);
         if (e < 0) return -1;
         emitted += e;
     }

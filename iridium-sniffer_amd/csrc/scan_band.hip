@@ -40,6 +40,7 @@ namespace irdm {
 namespace {
 
 constexpr int kPlanThreads = 1024;
+constexpr int kSumDepth = 16;             // update steps per batch of the sums pass (two batches of loads in flight)
 
 // exclusive scan of in[0..len) into out[0..len), total returned to every thread; one workgroup, kPlanThreads threads
 // (each thread a contiguous run; wave scans on the shuffle network, the 16 wave totals through LDS)
@@ -206,11 +207,14 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
     for (int k = tid; k <= n_upd; k += kPlanThreads) W.snap_slot[k] = W.need[k] ? W.tmp[k] : -1;
     __syncthreads();
     const int h0 = ctl->h0;
+    // (the sums pass reads whole batches of step descriptors: pad them with no-ops that touch valid memory)
+    for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = make_int4(0, 0, -1, 0);
     for (int k = tid; k < n_upd; k += kPlanThreads) {
         W.snap_after[k] = W.snap_slot[k + 1];
         // the row an update replaces: one of the carried history for the first 512 steps, after that the magnitude
         // row written 512 steps earlier (the ring is only materialised by the commit)
         W.old_row[k] = k < kHistory ? -(((h0 + k) % kHistory) + 1) : W.upd_frame[k - kHistory];
+        W.steps[k] = make_int4(W.upd_frame[k], W.old_row[k], W.snap_after[k], 0);
     }
     for (int f = tid; f < F; f += kPlanThreads) {
         const int k = W.cnt_before[f];
@@ -230,50 +234,51 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
 }
 
 // ---- sums: one lane per bin along the planned update steps ----
-constexpr int kSumDepth = 16;
 
 __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
                                                       const float *__restrict__ hist, const float *__restrict__ sum,
-                                                      const float *__restrict__ pre, float *__restrict__ smin_out)
+                                                      const float *__restrict__ pre, float *__restrict__ smin_out,
+                                                      const int4 *__restrict__ steps, float *__restrict__ snap)
 {
     const BandCtl *ctl = W.ctl;
     if (ctl->status != 0) return;
     const int b = blockIdx.x * 64 + threadIdx.x;
     const int N = P.n;
     const int n = ctl->n_upd;
-    const int32_t *__restrict__ uf = W.upd_frame;
-    const int32_t *__restrict__ orow = W.old_row;
-    const int32_t *__restrict__ sa = W.snap_after;
+    // steps: (frame, old row, snapshot slot after the step, -) per update step, padded with no-ops; a kernel argument of
+    // its own (like snap) so that the compiler knows nothing here writes it and fetches it with scalar loads
     float s = sum[b], smin = s;
     const int slot0 = W.snap_slot[0];
-    if (slot0 >= 0) W.snap[(size_t)slot0 * N + b] = s;
+    if (slot0 >= 0) snap[(size_t)slot0 * N + b] = s;
 
+    // Two batches of kSumDepth steps are in flight: the loads of batch i+1 are issued before batch i is consumed.  The
+    // step descriptors are wave-uniform and read a batch at a time (scalar loads of 16 bytes per step, unguarded: the
+    // plan pads the list), so that the per-step work is two vector loads and two float operations.
     float nwA[kSumDepth], olA[kSumDepth], nwB[kSumDepth], olB[kSumDepth];
-#define IRDM_SUM_LOAD(nw, ol, k0)                                                                       \
+    int slA[kSumDepth], slB[kSumDepth];
+#define IRDM_SUM_LOAD(nw, ol, sl, k0)                                                                   \
     _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) {                                             \
-        if ((k0) + j < n) {                                                                             \
-            const int fr = uf[(k0) + j], o = orow[(k0) + j];                                            \
-            const float *po = o < 0 ? hist + (size_t)(-o - 1) * N : mag + (size_t)o * N;                \
-            nw[j] = mag[(size_t)fr * N + b];                                                            \
-            ol[j] = po[b];                                                                              \
-        }                                                                                               \
+        const int4 st = steps[(k0) + j];                                                                \
+        const float *po = st.y < 0 ? hist + (size_t)(-st.y - 1) * N : mag + (size_t)st.y * N;           \
+        nw[j] = mag[(size_t)st.x * N + b];                                                              \
+        ol[j] = po[b];                                                                                  \
+        sl[j] = st.z;                                                                                   \
     }
-#define IRDM_SUM_CONSUME(nw, ol, k0)                                                                    \
+#define IRDM_SUM_CONSUME(nw, ol, sl, k0)                                                                \
     _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) {                                             \
         if ((k0) + j < n) {                                                                             \
             const float d = s - ol[j]; /* simd_baseline_update: two separately rounded operations */    \
             s = d + nw[j];                                                                              \
             smin = fminf(smin, s);                                                                      \
-            const int slot = sa[(k0) + j];                                                              \
-            if (slot >= 0) W.snap[(size_t)slot * N + b] = s;                                            \
+            if (sl[j] >= 0) snap[(size_t)sl[j] * N + b] = s;                                            \
         }                                                                                               \
     }
-    IRDM_SUM_LOAD(nwA, olA, 0)
+    IRDM_SUM_LOAD(nwA, olA, slA, 0)
     for (int k0 = 0; k0 < n; k0 += 2 * kSumDepth) {
-        IRDM_SUM_LOAD(nwB, olB, k0 + kSumDepth)
-        IRDM_SUM_CONSUME(nwA, olA, k0)
-        IRDM_SUM_LOAD(nwA, olA, k0 + 2 * kSumDepth)
-        IRDM_SUM_CONSUME(nwB, olB, k0 + kSumDepth)
+        IRDM_SUM_LOAD(nwB, olB, slB, k0 + kSumDepth)
+        IRDM_SUM_CONSUME(nwA, olA, slA, k0)
+        if (k0 + 2 * kSumDepth < n) { IRDM_SUM_LOAD(nwA, olA, slA, k0 + 2 * kSumDepth) }
+        IRDM_SUM_CONSUME(nwB, olB, slB, k0 + kSumDepth)
     }
 #undef IRDM_SUM_LOAD
 #undef IRDM_SUM_CONSUME
@@ -521,6 +526,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(F); add(F);                                  // uq, uf
     add(4 * (F + 2)); add(4 * (2 * F + 4));          // cnt_before, tmp
     add(4 * (2 * F + 4)); add(4 * (2 * F + 4)); add(4 * (2 * F + 4));   // upd_frame, old_row, snap_after
+    add(16 * (2 * F + 4 + 3 * kSumDepth));                              // steps
     add(4 * (2 * F + 4)); add(4 * (2 * F + 4));      // need, snap_slot
     add(4 * F); add(4 * F);                          // slot_pre, slot_post
     add(F * (size_t)n / 8);                          // cross
@@ -546,6 +552,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->upd_frame = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->old_row = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->snap_after = static_cast<int32_t *>(take(4 * (2 * F + 4)));
+    W->steps = static_cast<int4 *>(take(16 * (2 * F + 4 + 3 * kSumDepth)));
     W->need = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->snap_slot = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->slot_pre = static_cast<int32_t *>(take(4 * F));
@@ -603,7 +610,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     for (int round = 0; round <= kBandRounds; round++) {
         hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, P, W, counts, st, round);
         if (round == kBandRounds) break;
-        hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin);
+        hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
         if (P.band_w == 128)
             hipLaunchKernelGGL((band_walk_kernel<4>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
