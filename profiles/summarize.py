@@ -11,11 +11,20 @@ src, tag = sys.argv[1], sys.argv[2]
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:70]
 
 
 rows = list(csv.DictReader(open(f"{src}/r1_kernel_stats.csv")))
+import os
+if os.path.exists(f"{src}/r1d0_kernel_stats.csv"):
+    with open(f"profiles/{tag}_kernel_stats_depth0.csv", "w") as f:
+        f.write("kernel,calls,total_ms,avg_us,pct\n")
+        for r in csv.DictReader(open(f"{src}/r1d0_kernel_stats.csv")):
+            if "irdm::" not in r["Name"] and "rocclr" not in r["Name"]:
+                continue
+            f.write("%s,%s,%.3f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                             float(r["AverageNs"]) / 1e3, r["Percentage"]))
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
     f.write("kernel,calls,total_ms,avg_us,pct\n")
     for r in rows:
