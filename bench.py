@@ -248,7 +248,7 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                        "job_bursts_per_step": int(counts[0].item()) / K, "raw_frames_per_step": int(counts[1].item()) / K,
                        "pipeline_depth": args.depth, "backend": backend,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
-            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_m", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_w", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
             "cpu_baseline": None,
         }
@@ -437,7 +437,7 @@ def main():
         "scan": 8.0 * n,                          # history row read + write per bin-frame (B_det = 16 B/sample with K1)
         "fir": float(bps) * lb + 8.0 * lb / decim,   # burst-window re-read + decimated (cf32) write
     }
-    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "band_* (scan_band.hip passes)", "fir": "fir_decimate_kernel_m"}
+    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "band_* (scan_band.hip passes)", "fir": "fir_geom_kernel + fir_decimate_kernel_w"}
     dom = max(alg_bytes, key=lambda k: ms[k])
     ach = alg_bytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs and

@@ -6,6 +6,7 @@
 //   downmix_post2_kernel       step 5 fine rotate, step 6 RRC, step 7 sync correlation
 //                              (FFT 2048 + 2 x IFFT 2048), step 8 phase align, step 9 frame cut
 #include <algorithm>
+#include <cstdio>
 #include "common.hpp"
 #include "types.hpp"
 #include "kernels.hpp"
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
         int p = k0 % M, q = k0 / M;
         const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
         float2 x[kRotSeg];
-        const bool whole = a0 + kRotSeg <= w.avail_end && k0 + kRotSeg <= span;
+        // (a segment that runs past the tile's span is loaded whole as long as its samples exist: the slots past the
+        // span are never read by a tap, and the tile has room for them)
+        const bool whole = a0 + kRotSeg <= w.avail_end;
         if (whole && a0 >= src.chunk_start) {
             // the whole segment lies in the chunk being fed: 16-byte loads, all in flight (cf32 8, ci16 4, ci8 2 of them)
             load_seg16(src.fmt, src.chunk, (size_t)(a0 - src.chunk_start), x);
@@ -321,7 +324,376 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same decimator with the tile stored COLUMN-MAJOR: the M rotated samples that output column q needs for one row of
+// taps (k = r*M .. r*M+M-1 -> samples (q+r)*M .. (q+r)*M+M-1) are contiguous, CS = M*8 + 16 bytes per column.
+//   * tap loop: one ds_read_b128 brings the samples of TWO taps (M/2 reads per row instead of M ds_read_b64): per tap
+//     and wavefront 0.5 + 0.25 LDS instructions + 2 VALU = 2.75 instead of 3.25 -- the loop is bound by instruction
+//     issue (DESIGN.md "The decimator");
+//   * the 16-byte pad makes the lane stride CS/4 = 2M+4 dwords: the lanes of a 16-lane ds_read_b128 group start in
+//     different banks for every M used here (8, 16, 40, 48);
+//   * staging: a lane's 16 consecutive rotated samples are contiguous in a column (or split once, at a multiple of 8
+//     samples, between two columns): eight ds_write_b128 instead of sixteen ds_write_b64 with per-sample addressing.
+// Accumulation order is unchanged (k ascending, two independent chains).
+// ---------------------------------------------------------------------------
+template <int M>
+struct FirCol {
+    static constexpr int NR = kFirTaps / M;                  // full rows of M taps
+    static constexpr int REM = kFirTaps - NR * M;            // taps of the last, partial row
+    static constexpr int COLS = kFirTileOut + NR + 1;        // columns a full tile touches
+    static constexpr int CS = M * 8 + 16;                    // column stride, bytes
+    static constexpr size_t LDS = (size_t)COLS * CS + sizeof(float) * (kFirTaps + 3);
+    static_assert(M % 8 == 0, "a 16-sample segment splits between columns only at a multiple of 8 samples");
+};
+
+template <int M>
+__global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
+    SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
+    const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride)
+{
+    using C = FirCol<M>;
+    constexpr int NR = C::NR, REM = C::REM, CS = C::CS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char *s = smem_raw;
+    float *s_taps = reinterpret_cast<float *>(s + (size_t)C::COLS * CS);     // 16-byte aligned: CS is a multiple of 16
+    const int tid = threadIdx.x;
+    const FirTile tile = tiles[blockIdx.x];
+    const BurstWork w = work[tile.burst];
+    const int o0 = tile.first_out;
+    int n_out = w.dec_len - o0;
+    if (n_out > kFirTileOut) n_out = kFirTileOut;
+    const int span = (n_out - 1) * M + kFirTaps;
+    const int s0 = o0 * M;                           // multiple of kRotSeg
+    const float2 inc = rot_incr[w.center_bin];
+    const float2 *ck = rot_table + (size_t)w.center_bin * n_ckpt + s0 / kRotSeg;
+    const int n_seg = (span + kRotSeg - 1) / kRotSeg;
+
+    for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
+    for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
+        float2 ph = ck[seg];
+        const int k0 = seg * kRotSeg;
+        const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
+        float2 x[kRotSeg];
+        // (a segment that runs past the tile's span is loaded whole as long as its samples exist: the slots past the
+        // span are never read by a tap, and the tile has room for them)
+        const bool whole = a0 + kRotSeg <= w.avail_end;
+        if (whole && a0 >= src.chunk_start) {
+            load_seg16(src.fmt, src.chunk, (size_t)(a0 - src.chunk_start), x);
+        } else if (whole && a0 + kRotSeg <= src.chunk_start) {
+            load_seg16(src.fmt, src.ring, (size_t)(a0 % src.ring_len), x);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kRotSeg; u++)
+                x[u] = (k0 + u < span) ? burst_sample(src, w.start, w.avail_end, s0 + k0 + u)
+                                       : make_float2(0.0f, 0.0f);
+        }
+        // rotate (rotator.h:38-39); samples past the tile's span are never read by a tap, their slots may hold anything
+        float2 y[kRotSeg];
+#pragma unroll
+        for (int u = 0; u < kRotSeg; u++) {
+            y[u] = cmul(x[u], ph);
+            ph = cmul(ph, inc);
+        }
+        // samples k0 .. k0+7 and k0+8 .. k0+15: each half lies inside one column (k0 and M are multiples of 8)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = k0 + 8 * h;
+            float4 *dst = reinterpret_cast<float4 *>(s + (size_t)(k / M) * CS + (size_t)(k % M) * 8);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                dst[u] = make_float4(y[8 * h + 2 * u].x, y[8 * h + 2 * u].y, y[8 * h + 2 * u + 1].x, y[8 * h + 2 * u + 1].y);
+        }
+    }
+    __syncthreads();
+
+    if (tid < n_out) {
+        float ar = 0.0f, ai = 0.0f;
+        const unsigned char *col = s + (size_t)tid * CS;
+#pragma unroll 1
+        for (int r = 0; r < NR; r++) {
+            const float4 *c4 = reinterpret_cast<const float4 *>(col + (size_t)r * CS);
+            const float4 *t4 = reinterpret_cast<const float4 *>(s_taps + r * M);
+            float4 v[M / 2];
+            float4 t[M / 4];
+#pragma unroll
+            for (int j = 0; j < M / 2; j++) v[j] = c4[j];
+#pragma unroll
+            for (int j = 0; j < M / 4; j++) t[j] = t4[j];
+#pragma unroll
+            for (int j = 0; j < M / 4; j++) {
+                ar += t[j].x * v[2 * j].x;     ai += t[j].x * v[2 * j].y;
+                ar += t[j].y * v[2 * j].z;     ai += t[j].y * v[2 * j].w;
+                ar += t[j].z * v[2 * j + 1].x; ai += t[j].z * v[2 * j + 1].y;
+                ar += t[j].w * v[2 * j + 1].z; ai += t[j].w * v[2 * j + 1].w;
+            }
+        }
+        {
+            const float2 *c2 = reinterpret_cast<const float2 *>(col + (size_t)NR * CS);
+#pragma unroll
+            for (int p = 0; p < REM; p++) {
+                const float2 v = c2[p];
+                const float t = s_taps[NR * M + p];
+                ar += t * v.x;
+                ai += t * v.y;
+            }
+        }
+        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(ar, ai);
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// The column-major decimator as a PERSISTENT kernel: the workgroups that fit the chip's LDS walk tiles blockIdx.x,
+// blockIdx.x + gridDim.x, ... of TO outputs each.  What that buys over one tile per workgroup (measured there at the
+// bench's 667 bursts: staging alone 0.43 ms, tap loop alone 0.51 ms, together 0.80 ms):
+//   * the raw samples of the NEXT tile are requested before the tap loop of the current one and wait in registers
+//     (3 segments of 16 samples per lane at M = 40: 96 VGPRs), so the HBM latency of staging is covered by the tap loop;
+//   * the tap loop is software-pipelined by hand: the LDS reads of step s+1 are issued before the multiplies of step s;
+//   * the taps come through the scalar cache into SGPRs instead of as LDS broadcast reads -- a broadcast ds_read_b128
+//     still costs its 4 LDS cycles, a third of the loop's LDS time (MI355X_MICROARCH.md, LDS table);
+//   * one FirGeom record per tile (fir_geom_kernel) replaces the tile -> burst -> rotator-table pointer chase;
+//   * larger tiles shrink the share of the 801-tap halo that is staged twice (21 of TO + 21 columns at M = 40).
+// The loop is bound by the multiply-add chain, not by memory: v_pk_mul_f32 / v_pk_add_f32 issue once per ~7.4 cycles per
+// SIMD (tools/ubench/valu_chain.hip: no faster with two wavefronts per SIMD, and plain v_mul/v_add at 4 cycles each
+// cost the same per complex tap), a dependent v_pk_add_f32 can issue ~23 cycles after its producer, and the reference
+// rounds the product before the add (no FMA): 16 SIMD-cycles per complex tap and wavefront = 0.36 ms for the bench's
+// 4.4 M outputs, before staging.  Two wavefronts per SIMD (or two outputs per lane) are needed to cover the chain, and
+// the tile's LDS footprint allows six per CU.  Forming the product of tap q + 4 ahead of the add of tap q halved the
+// tap loop's cycle count (s_memtime) but cost 8 % wall time (register copies at the loop edge, SGPR spills); tiles of
+// 256 / 448 outputs measured 0.84 / 0.70 ms against 0.66 ms.
+// Values and accumulation order are those of fir_decimate_kernel_c.
+// ---------------------------------------------------------------------------
+template <int M, int TO>
+struct FirW {
+    static constexpr int NR = kFirTaps / M;
+    static constexpr int REM = kFirTaps - NR * M;
+    static constexpr int COLS = TO + NR + 1;
+    static constexpr int CS = M * 8 + 16;
+    static constexpr size_t LDS = (size_t)COLS * CS + 16;     // + the word the claimed tile index is broadcast through
+    static constexpr int SPAN_MAX = (TO - 1) * M + kFirTaps;
+    static constexpr int SEG_MAX = (SPAN_MAX + kRotSeg - 1) / kRotSeg;
+    static constexpr int SLOTS = (SEG_MAX + TO - 1) / TO;
+    // taps per pipeline step: a divisor of M, multiple of 4, at most 24
+    static constexpr int T = (M % 24 == 0) ? 24 : (M % 20 == 0) ? 20 : (M % 16 == 0) ? 16 : 8;
+    static constexpr int SPR = M / T;                 // steps per row
+    static constexpr int NS = NR * SPR;               // pipeline steps
+    static_assert(M % 8 == 0 && M % T == 0 && T % 4 == 0 && NS % 2 == 0, "step size");
+    static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
+};
+
+// one lane per tile: everything the decimator's workgroups need, in one record
+__global__ void fir_geom_kernel(const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles, int n_tiles, int M,
+                                int tile_out, uint64_t ring_len, const float2 *__restrict__ rot_incr, int n_ckpt,
+                                int dec_stride, FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *next_tile = 0;
+    if (t >= n_tiles) return;
+    const FirTile tile = tiles[t];
+    const BurstWork *w = work + tile.burst;
+    const int o0 = tile.first_out;
+    int n_out = w->dec_len - o0;
+    if (n_out > tile_out) n_out = tile_out;
+    FirGeom g;
+    g.n_out = n_out;
+    g.span = (n_out - 1) * M + kFirTaps;
+    g.s0 = o0 * M;
+    g.n_seg = (g.span + kRotSeg - 1) / kRotSeg;
+    g.burst_start = w->start;
+    g.a_tile = w->start + (uint64_t)g.s0;
+    g.avail_end = w->avail_end;
+    g.ring_pos = g.a_tile % ring_len;
+    const int cb = w->center_bin;
+    const float2 inc = rot_incr[cb];
+    g.inc_re = inc.x;
+    g.inc_im = inc.y;
+    g.ck_index = (uint64_t)cb * (uint64_t)n_ckpt + (uint64_t)(g.s0 / kRotSeg);
+    g.out_base = (int64_t)tile.burst * dec_stride + o0;
+    for (int i = 0; i < 6; i++) g.pad[i] = 0;
+    geom[t] = g;
+}
+
+__device__ unsigned long long g_fir_prof_dev[8];
+#define FIR_PROF_MARK(i)                                                         \
+    do {                                                                         \
+        if (PROF) {                                                              \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+            prof[i] += now_ - tlast;                                             \
+            tlast = now_;                                                        \
+        }                                                                        \
+    } while (0)
+
+template <int M, int FMT, int TO, bool PROF = false>
+__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_w(
+    SampleSource src, const FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile, int n_tiles, int budget,
+    const float *__restrict__ taps, const float2 *__restrict__ rot_table, float2 *__restrict__ dec)
+{
+    using W = FirW<M, TO>;
+    constexpr int NR = W::NR, REM = W::REM, CS = W::CS, SLOTS = W::SLOTS, T = W::T, SPR = W::SPR, NS = W::NS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char *s = smem_raw;
+    const int tid = threadIdx.x;
+
+    float2 x[SLOTS][kRotSeg];
+    float2 ph0[SLOTS];
+    // request the raw samples of tile `g`: whole segments inside the chunk or the ring; the others are read in consume()
+    auto prefetch = [&](const FirGeom &g) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            const int seg = tid + TO * j;
+            const int k0 = seg * kRotSeg;
+            const uint64_t a0 = g.a_tile + (uint64_t)k0;
+            const bool whole = seg < g.n_seg && a0 + kRotSeg <= g.avail_end;      // (may run past the span: never read)
+            const bool in_chunk = whole && a0 >= src.chunk_start;
+            const bool in_ring = whole && a0 + kRotSeg <= src.chunk_start;
+            uint64_t rp = g.ring_pos + (uint64_t)k0;
+            if (rp >= src.ring_len) rp -= src.ring_len;
+            // (segments that are not loaded here read the start of the ring: always mapped, never used)
+            const void *base = in_chunk ? src.chunk : src.ring;
+            const size_t idx = in_chunk ? (size_t)(a0 - src.chunk_start) : in_ring ? (size_t)rp : 0;
+            load_seg16(FMT, base, idx, x[j]);
+            ph0[j] = rot_table[g.ck_index + (uint64_t)(seg < g.n_seg ? seg : 0)];
+        }
+    };
+    // rotate the samples of tile `g` (rotator.h:38-39) and store them in the tile
+    auto consume = [&](const FirGeom &g) {
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            const int seg = tid + TO * j;
+            if (seg >= g.n_seg) continue;
+            const int k0 = seg * kRotSeg;
+            const uint64_t a0 = g.a_tile + (uint64_t)k0;
+            const bool whole = a0 + kRotSeg <= g.avail_end;
+            const bool fast = whole && (a0 >= src.chunk_start || a0 + kRotSeg <= src.chunk_start);
+            float2 ph = ph0[j];
+            const float2 inc = make_float2(g.inc_re, g.inc_im);
+            if (!fast) {
+                // a segment across the chunk / ring / availability boundary: sample by sample
+#pragma unroll 1
+                for (int u = 0; u < kRotSeg; u++) {
+                    const int k = k0 + u;
+                    const float2 xs = (k < g.span) ? burst_sample(src, g.burst_start, g.avail_end, g.s0 + k)
+                                                   : make_float2(0.0f, 0.0f);
+                    *reinterpret_cast<float2 *>(s + (size_t)(k / M) * CS + (size_t)(k % M) * 8) = cmul(xs, ph);
+                    ph = cmul(ph, inc);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = k0 + 8 * h;
+                float4 *dst = reinterpret_cast<float4 *>(s + (size_t)(k / M) * CS + (size_t)(k % M) * 8);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float2 y0 = cmul(x[j][8 * h + 2 * u], ph);
+                    ph = cmul(ph, inc);
+                    const float2 y1 = cmul(x[j][8 * h + 2 * u + 1], ph);
+                    ph = cmul(ph, inc);
+                    dst[u] = make_float4(y0.x, y0.y, y1.x, y1.y);
+                }
+            }
+        }
+    };
+
+    unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    // Tiles are claimed dynamically (the workgroups do not run at the same speed: a wavefront alone on its SIMD is
+    // faster than two that share one, and the last tile of a burst is short): the first two tiles of a workgroup are
+    // blockIdx.x and blockIdx.x + gridDim.x, every further one comes from the counter fir_geom_kernel zeroed.  A
+    // workgroup retires after `budget` tiles: its LDS and registers go back to the dispatcher, which hands them to the
+    // high-priority detector stream first -- a grid that stayed resident for the whole launch kept the other streams'
+    // kernels out of every CU (measured: the band scan of the next chunk took 1.15 ms instead of 0.86 ms).
+    unsigned *s_claim = reinterpret_cast<unsigned *>(s + (size_t)W::COLS * CS);
+    int t = blockIdx.x;
+    int t1 = t + (int)gridDim.x;
+    int n_claimed = 2;
+    FirGeom g = geom[t];
+    prefetch(g);
+    FIR_PROF_MARK(0);
+    for (;;) {
+        const bool more = t1 < n_tiles;
+        // the last round requests its own tile again (no branch around the loads: a join would wait for them)
+        const FirGeom gn = geom[more ? t1 : t];
+        unsigned claimed = 0x7fffffffu;
+        if (tid == 0 && n_claimed < budget) claimed = atomicAdd(next_tile, 1u) + 2u * gridDim.x;
+        n_claimed++;
+        consume(g);
+        if (tid == 0) *s_claim = claimed;
+        FIR_PROF_MARK(1);
+        __syncthreads();
+        FIR_PROF_MARK(2);
+        prefetch(gn);
+        const int t2 = (int)*s_claim;
+        FIR_PROF_MARK(3);
+
+        if (tid < g.n_out) {
+            float ar = 0.0f, ai = 0.0f;
+            const unsigned char *col = s + (size_t)tid * CS;
+            float4 va[T / 2], vb[T / 2];
+            float ta[T], tb[T];
+            auto issue = [&](int st, float4 (&v)[T / 2], float (&tt)[T]) {
+                const float4 *c4 = reinterpret_cast<const float4 *>(col + (size_t)(st / SPR) * CS + (size_t)(st % SPR) * (T * 8));
+#pragma unroll
+                for (int q = 0; q < T / 2; q++) v[q] = c4[q];
+#pragma unroll
+                for (int q = 0; q < T; q++) tt[q] = taps[st * T + q];
+            };
+            // taps [q0, q1) of a step
+            auto mac = [&](const float4 (&v)[T / 2], const float (&tt)[T], int q0, int q1) {
+#pragma unroll
+                for (int q = q0; q < q1; q += 2) {
+                    ar += tt[q] * v[q / 2].x;     ai += tt[q] * v[q / 2].y;
+                    ar += tt[q + 1] * v[q / 2].z; ai += tt[q + 1] * v[q / 2].w;
+                }
+            };
+            issue(0, va, ta);
+#pragma unroll 1
+            for (int st = 0; st < NS; st += 2) {
+                // the first multiply of a step comes before the next step's requests: whatever the step waits for
+                // was requested a whole step ago (scalar loads return out of order, so the wait is for everything)
+                mac(va, ta, 0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(st + 1, vb, tb);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(va, ta, 2, T);
+                mac(vb, tb, 0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(st + 2 < NS ? st + 2 : 0, va, ta);       // (the last round's request is not used)
+                __builtin_amdgcn_sched_barrier(0);
+                mac(vb, tb, 2, T);
+            }
+            {
+                const float2 *c2 = reinterpret_cast<const float2 *>(col + (size_t)NR * CS);
+#pragma unroll
+                for (int q = 0; q < REM; q++) {
+                    const float2 v = c2[q];
+                    const float tq = taps[NR * M + q];
+                    ar += tq * v.x;
+                    ai += tq * v.y;
+                }
+            }
+            dec[g.out_base + tid] = make_float2(ar, ai);
+        }
+        FIR_PROF_MARK(4);
+        __syncthreads();
+        FIR_PROF_MARK(5);
+        if (PROF) prof[6] += 1;
+        if (!more) break;
+        t = t1;
+        t1 = t2;
+        g = gn;
+    }
+    if (PROF && (tid & 63) == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&g_fir_prof_dev[i], prof[i]);
+        atomicAdd(&g_fir_prof_dev[7], 1ull);
+    }
+}
+
 int g_fir_force_generic = 0;   // test hook: 1 = always use the runtime-M kernel
+int g_fir_layout = 2;          // 2: persistent column-major kernel (fir_decimate_kernel_w), 1: column-major, one tile per
+                               // workgroup (fir_decimate_kernel_c), 0: polyphase rows (fir_decimate_kernel_m)
+int g_fir_prof = 0;
 
 int fir_tile_row(int decim)
 {
@@ -330,7 +702,76 @@ int fir_tile_row(int decim)
     return r;
 }
 
-int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
+int g_fir_reserve_cus = 0;     // persistent kernel: CUs left to the other streams' kernels
+int g_fir_budget = 4;          // persistent kernel: tiles per workgroup before it retires (0: one resident grid)
+
+static bool fir_wide_ok(int decim)
+{
+    return !g_fir_force_generic && g_fir_layout == 2 && (decim == 8 || decim == 16 || decim == 40 || decim == 48);
+}
+
+static int fir_wide_tile(int)
+{
+    // 256 outputs (one workgroup per CU, a wavefront per SIMD) and 448 (seven wavefronts, the whole LDS) measured
+    // 0.84 and 0.70 ms against 0.66 ms for three workgroups of 128 per CU
+    return 128;
+}
+
+// outputs per FirTile for the kernel launch_fir_decimate() will pick
+int fir_tile_out(int decim)
+{
+    return fir_wide_ok(decim) ? fir_wide_tile(decim) : kFirTileOut;
+}
+
+template <int M, int FMT, int TO>
+static int launch_fir_w(const SampleSource &src, const FirGeom *geom, unsigned *next_tile, int n_tiles, const float *taps,
+                         const float2 *rot_table, float2 *dec, int n_cu, hipStream_t stream)
+{
+    using W = FirW<M, TO>;
+    int slots = (n_cu - g_fir_reserve_cus) * (int)((160 * 1024) / W::LDS);
+    if (slots < 1) slots = 1;
+    // budget tiles per workgroup (at least 2: the two static ones); a budget of 0 keeps one resident grid
+    int budget = g_fir_budget >= 2 ? g_fir_budget : 0x3fffffff;
+    int grid = n_tiles < slots ? n_tiles : slots;
+    if (g_fir_budget >= 2 && (n_tiles + budget - 1) / budget > grid) grid = (n_tiles + budget - 1) / budget;
+    if constexpr (M == 40 && FMT == 2) if (g_fir_prof) {
+        unsigned long long z[8] = { 0 };
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fir_prof_dev), z, sizeof(z));
+        (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_w<M, FMT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipStreamSynchronize(stream);
+        (void)hipEventRecord(e0, stream);
+        hipLaunchKernelGGL((fir_decimate_kernel_w<M, FMT, TO, true>), dim3(grid), dim3(TO), W::LDS, stream, src, geom, next_tile, n_tiles, budget, taps, rot_table, dec);
+        (void)hipEventRecord(e1, stream);
+        (void)hipStreamSynchronize(stream);
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        fprintf(stderr, "fir prof kernel %.4f ms; ", ms);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fir_prof_dev), sizeof(z));
+        const double w = z[7] ? (double)z[7] : 1.0;
+        fprintf(stderr, "fir prof TO=%d (cycles per wave, %llu waves, %.1f tiles/wave): prologue %.0f consume %.0f barrierA %.0f prefetch %.0f taps %.0f barrierB %.0f\n",
+                TO, z[7], z[6] / w, z[0] / w, z[1] / w, z[2] / w, z[3] / w, z[4] / w, z[5] / w);
+        return 0;
+    }
+    (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_w<M, FMT, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
+    hipLaunchKernelGGL((fir_decimate_kernel_w<M, FMT, TO>), dim3(grid), dim3(TO), W::LDS, stream, src, geom, next_tile, n_tiles, budget, taps, rot_table, dec);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int M, int TO>
+static int launch_fir_w_fmt(const SampleSource &src, const FirGeom *geom, unsigned *next_tile, int n_tiles, const float *taps,
+                            const float2 *rot_table, float2 *dec, int n_cu, hipStream_t stream)
+{
+    if (src.fmt == 2) return launch_fir_w<M, 2, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+    if (src.fmt == 1) return launch_fir_w<M, 1, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+    return launch_fir_w<M, 0, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+}
+
+int launch_fir_decimate(const SampleSource &src, const BurstWork *work, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream)
@@ -345,6 +786,45 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const Fi
                            work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
+#define IRDM_LAUNCH_FIR_C(MM)                                                                                  \
+    do {                                                                                                       \
+        (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_c<MM>,                                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)FirCol<MM>::LDS);           \
+        hipLaunchKernelGGL(fir_decimate_kernel_c<MM>, dim3(n_tiles), dim3(kFirTileOut), FirCol<MM>::LDS, stream, src, \
+                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);                   \
+        return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
+    } while (0)
+    if (fir_wide_ok(decim) && tiles_cap >= (size_t)n_tiles) {
+        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
+        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);      // (one spare record behind the last)
+        const int to = fir_wide_tile(decim);
+        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, tiles, n_tiles, decim,
+                           to, src.ring_len, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        switch (decim) {
+        case 8: return launch_fir_w_fmt<8, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+        case 16: return launch_fir_w_fmt<16, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+        case 48: return launch_fir_w_fmt<48, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+        case 40: return launch_fir_w_fmt<40, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+        default: break;
+        }
+    }
+    if (!g_fir_force_generic && g_fir_layout == 1) {
+        switch (decim) {
+        case 8: IRDM_LAUNCH_FIR_C(8);
+        case 16: IRDM_LAUNCH_FIR_C(16);
+        case 40: IRDM_LAUNCH_FIR_C(40);
+        case 48: IRDM_LAUNCH_FIR_C(48);
+        default: break;
+        }
+    }
+#undef IRDM_LAUNCH_FIR_C
     if (!g_fir_force_generic) {
         switch (decim) {
         case 8: IRDM_LAUNCH_FIR_M(8);

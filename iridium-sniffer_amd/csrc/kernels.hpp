@@ -77,8 +77,13 @@ struct SampleSource {
 int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream);
 int fir_tile_row(int decim);
 extern int g_fir_force_generic;   // 1: always the runtime-M decimator kernel
+extern int g_fir_layout;          // 2 (default): persistent column-major kernel, 1: column-major tile, 0: polyphase rows
+extern int g_fir_prof;            // 1: time the persistent decimator's phases (debug)
+extern int g_fir_budget;          // persistent kernel: tiles per workgroup before it retires
+extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the other streams
+int fir_tile_out(int decim);      // outputs per FirTile of the kernel launch_fir_decimate() picks
 extern int g_fft_force_radix2;    // 1: always the radix-2 LDS FFT kernel
-int launch_fir_decimate(const SampleSource &src, const BurstWork *work, const FirTile *tiles,
+int launch_fir_decimate(const SampleSource &src, const BurstWork *work, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream);

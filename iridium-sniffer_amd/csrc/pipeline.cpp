@@ -524,7 +524,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_rot_table, float2, (size_t)P.n * p->n_ckpt);
     AL(p->d_work, BurstWork, (size_t)p->burst_cap);
     p->tiles_cap = (size_t)p->burst_cap * 64;
-    AL(p->d_tiles, FirTile, p->tiles_cap);
+    AL(p->d_tiles, FirTile, (p->tiles_cap + 1) * kFirTileUnits);
     p->cfo_quit = false;
     AL(p->d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
     AL(p->d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
@@ -611,7 +611,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         } else {
             ok = ok && hipStreamCreateWithPriority(&b.stream, hipStreamNonBlocking, p->bstream_prio) == hipSuccess;
             AL(b.d_work, BurstWork, (size_t)p->burst_cap);
-            AL(b.d_tiles, FirTile, b.tiles_cap);
+            AL(b.d_tiles, FirTile, (b.tiles_cap + 1) * kFirTileUnits);
             AL(b.d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
             AL(b.d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
             AL(b.d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
@@ -893,6 +893,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     b.n = nb;
     b.recs.assign(nb, irdm_burst_t());
     size_t n_tiles = 0;
+    const int tile_out = fir_tile_out(p->decim);
     for (int i = 0; i < nb; i++) {
         const GoneBurst &g = gone_list[i];
         irdm_burst_t &r = b.recs[i];
@@ -929,7 +930,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             w.dec_len = n_out;
             if (n_out < 100) w.drop_reason = 2;                          // burst_downmix.c:677
         }
-        if (!w.drop_reason) n_tiles += (size_t)(w.dec_len + kFirTileOut - 1) / kFirTileOut;
+        if (!w.drop_reason) n_tiles += (size_t)(w.dec_len + tile_out - 1) / tile_out;
     }
     if (p->detect_only || nb == 0) return 0;      // stage A alone: burst records, no downmix / demod
     if (n_tiles > b.tiles_cap) {
@@ -937,7 +938,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
         b.hp_tiles = nullptr;
         b.tiles_cap = n_tiles * 2;
-        b.d_tiles = dev_alloc<FirTile>(b.tiles_cap);
+        b.d_tiles = dev_alloc<FirTile>((b.tiles_cap + 1) * kFirTileUnits);
         if (!b.owns_buffers) p->d_tiles = b.d_tiles;
         if (!b.d_tiles ||
             hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) != hipSuccess)
@@ -947,7 +948,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     for (int i = 0; i < nb; i++) {
         const BurstWork &w = b.hp_work[i];
         if (!w.drop_reason)
-            for (int o = 0; o < w.dec_len; o += kFirTileOut) b.hp_tiles[n_tiles++] = FirTile{ i, o };
+            for (int o = 0; o < w.dec_len; o += tile_out) b.hp_tiles[n_tiles++] = FirTile{ i, o };
     }
     hipStream_t st = b.stream;
     IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));
@@ -955,7 +956,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     if (n_tiles)
         IRDM_HIP_CHECK(hipMemcpyAsync(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, hipMemcpyHostToDevice, st));
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
-    if (launch_fir_decimate(src, b.d_work, b.d_tiles, (int)n_tiles, p->decim, p->d_in_taps,
+    if (launch_fir_decimate(src, b.d_work, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
                             p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
@@ -2056,6 +2057,10 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "detect_only")) { p->detect_only = value; return 0; }
     // kernel-variant hooks (process-wide; parity tests and A/B timing): generic runtime-M decimator, radix-2 FFT
     if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
+    if (!strcmp(key, "fir_layout")) { irdm::g_fir_layout = value; return 0; }
+    if (!strcmp(key, "fir_prof")) { irdm::g_fir_prof = value; return 0; }
+    if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
+    if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
     return -1;
 }

@@ -68,6 +68,23 @@ struct FirTile {
     int32_t first_out;       // first output index of the tile
 };
 
+// what the persistent decimator needs to know about one tile, written by fir_geom_kernel (downmix.hip) so that the
+// decimator's workgroups read ONE record per tile instead of chasing tile -> burst -> rotator-table pointers
+struct FirGeom {
+    uint64_t a_tile;         // absolute index of the tile's first sample
+    uint64_t avail_end;
+    uint64_t ring_pos;       // a_tile % ring_len
+    uint64_t burst_start;
+    uint64_t ck_index;       // index of the rotator checkpoint of the tile's first segment
+    float inc_re, inc_im;    // rotator increment of the burst's centre bin
+    int32_t s0, span, n_seg, n_out;
+    int64_t out_base;        // index of the tile's first output in dec[]
+    int32_t pad[6];
+};
+static_assert(sizeof(FirGeom) == 96, "FirGeom is read with scalar loads");
+// device tile lists are allocated with room for the FirGeom records behind the FirTile array
+constexpr size_t kFirTileUnits = 1 + sizeof(FirGeom) / sizeof(FirTile);
+
 struct BurstWork {
     uint64_t start;          // absolute index of sample 0 of the burst window
     uint64_t avail_end;      // samples at/after this index read the stale ring slot (burst_detect.c:401-422)

@@ -176,11 +176,13 @@ def test_detect_only_mode_emits_the_same_bursts():
 
 
 def test_kernel_variants_agree():
-    """The runtime-M decimator and the radix-2 FFT kernels (fallbacks for sizes without a specialised kernel) give the
-    same records as the specialised ones and the oracle."""
+    """The runtime-M decimator and the radix-2 FFT kernels (fallbacks for sizes without a specialised kernel), the
+    one-tile-per-workgroup decimators (row-major and column-major tile) and the persistent decimator with one resident
+    grid / the smallest tile budget give the same records as the default kernels and the oracle."""
     fs, iq = _scene_2m(seed=19, n_bursts=6, secs=2.0)
     ref = orc.run_stream(iq, fs)
-    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}):
+    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 2, "fir_budget": 4}
+    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"fir_layout": 0}, {"fir_layout": 1}, {"fir_budget": 0}, {"fir_budget": 2}):
         p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)
         p.set_option("keep_frame_samples", 1)
         try:
@@ -191,7 +193,7 @@ def test_kernel_variants_agree():
             got = dict(bursts=p.poll_bursts(), infos=infos, samples=samples, demods=p.poll_demods(), tagged=p.tagged)
         finally:
             for k in opts:
-                p.set_option(k, 0)
+                p.set_option(k, defaults[k])
             p.close()
         parity.compare(got, ref)
 
