@@ -285,6 +285,11 @@ def main():
     ap.add_argument("--file-run", type=int, default=1, help="1: also time the C99 binary on the chunk written to a file")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="irdm_set_option before the run (kernel-variant A/B: fir_generic=1, fft_radix2=1, scan_mode=1)")
+    ap.add_argument("--ingest", type=int, default=1,
+                    help="pipeline_depth >= 1: 1 = the chunk lives in its slot of the history ring (irdm_ingest_ptr; the ring is "
+                         "filled with the synthetic chunk before the timed region), 0 = fed from a separate buffer and copied")
+    ap.add_argument("--lookahead", type=int, default=1,
+                    help="pipeline_depth >= 1: 1 = irdm_feed_begin(k+1) before irdm_feed_end(k)")
     ap.add_argument("--host-steps", type=int, default=6,
                     help="extra, separately timed steps fed from pinned HOST memory (PCIe-inclusive rate; 0 = skip)")
     args = ap.parse_args()
@@ -354,9 +359,43 @@ def main():
 
     host = {"feed_call": 0.0, "poll": 0.0}
 
+    ingest = bool(args.depth and args.ingest)
+    look = bool(args.depth and args.lookahead)
+    if ingest:
+        # inputs resident in HBM before the timed region: every chunk-sized slot of the history ring holds the chunk
+        # (what a producer that writes in place -- an H2D copy, a conversion kernel -- leaves behind)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        ring_ptr, ring_len = pipe.ring()
+        assert ring_len % n == 0, (ring_len, n)
+        for k in range(ring_len // n):
+            rc = hip.hipMemcpy(C.c_void_p(ring_ptr + k * n * bps), C.c_void_p(x.data_ptr()), n * bps, 3)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+    pending = [0]
+
+    def feed_one():
+        ptr = pipe.ingest_ptr(n) if ingest else x.data_ptr()
+        assert ptr
+        if not look:
+            return pipe.feed_device(ptr, n, stream)
+        pipe.feed_begin(ptr, n, stream)
+        pending[0] += 1
+        if pending[0] > 1:
+            pending[0] -= 1
+            return pipe.feed_end()
+        return 0
+
+    def drain_feed():
+        nb = 0
+        while pending[0]:
+            pending[0] -= 1
+            nb += pipe.feed_end()
+        return nb
+
     def step(record):
         ta = time.perf_counter()
-        nb_step = pipe.feed_device(x.data_ptr(), n, stream)
+        nb_step = feed_one()
         tb = time.perf_counter()
         bursts = pipe.poll_bursts_raw()          # [n, 72] bytes
         pipe.drop_frames()
@@ -390,6 +429,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     if args.depth:
+        drain_feed()
         pipe.flush()
         pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
     if world > 1:
@@ -399,7 +439,8 @@ def main():
     for _ in range(args.steps):
         step(True)
     if args.depth:
-        # drain: the last chunk's per-burst stages belong to the timed work
+        # drain: the last chunk's detector scan and per-burst stages belong to the timed work
+        nb_tail = drain_feed()
         pipe.flush()
         tb_ = pipe.poll_bursts_raw()
         pipe.drop_frames()
@@ -638,7 +679,7 @@ def main():
                        "samples_per_step_per_gpu": n, "bursts_per_step": totals["bursts"] / K,
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
-                       "pipeline_depth": args.depth,
+                       "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": look,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
                                                           "band_rounds", "band_retries", "band_aborts", "band_last_flags")},
                        "host_us_total": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(

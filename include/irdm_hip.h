@@ -77,11 +77,14 @@ typedef struct {
     int max_bursts_per_chunk;  /* sizing hint for the burst-record buffers, 0 -> 4096; a chunk with more finished bursts
                                   is redone with larger buffers (costs one dense scan), never dropped */
     int pipeline_depth;        /* 0: irdm_feed_* returns with the chunk's results pollable.
-                                  1: throughput mode.  irdm_feed_*(k) returns once chunk k is ingested (FFT done,
+                                  1, 2: throughput mode.  irdm_feed_*(k) returns once chunk k is ingested (FFT done,
                                      samples in the history ring) and its detector scan is launched; the scan stays in
-                                     flight while the caller produces chunk k+1.  The bursts of chunk k are demodulated
-                                     during irdm_feed_*(k+1) (or irdm_flush), so results arrive one chunk later --
-                                     identical records, same order. */
+                                     flight while the caller produces chunk k+1.  The bursts of chunk k enter their
+                                     per-burst chain (decimator .. demodulator, on a stream of its own) during
+                                     irdm_feed_*(k+1); pipeline_depth + 1 chains are in flight and their records
+                                     become pollable when their context is needed again, i.e. during
+                                     irdm_feed_*(k+1+pipeline_depth), or at irdm_flush -- identical records, same order.
+                                     Values above 2 are treated as 2. */
 } irdm_config_t;
 
 /* burst_info_t (burst_detect.h:29-37) + what emit_gone_bursts adds (burst_detect.c:703-742) */
@@ -204,12 +207,26 @@ void irdm_destroy(irdm_pipeline_t *p);
 int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
 /* irdm_feed_device in two halves: _begin = what does not depend on the detector state (K1 of the chunk, its copy into
  * the history ring), _end = detector scan + per-burst work.  A time-sharded rank calls _begin, receives the previous
- * rank's state (irdm_import_state_device), then calls _end. */
+ * rank's state (irdm_import_state_device), then calls _end.
+ * pipeline_depth >= 1: one chunk of look-ahead -- irdm_feed_begin(k+1) may be called before irdm_feed_end(k) (the
+ * calls still alternate after that), which puts K1 of chunk k+1 on the GPU before the host waits for the detector
+ * scan of chunk k-1.  The buffer handed to _begin may be reused when the matching _end has returned. */
 int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
 int irdm_feed_end(irdm_pipeline_t *p);
+/* pipeline_depth >= 1: where the producer of the next chunk (an H2D copy, a conversion kernel) may write it so that the
+ * context does not have to copy it into its history ring (8 B/sample read + written for cf32): the ring slot of the
+ * stream position the next irdm_feed_begin starts at.  Pass the pointer to irdm_feed_begin / irdm_feed_device as
+ * d_iq; nothing waits for the chunk to be "released" then.  NULL at pipeline_depth 0 or if the chunk would straddle the
+ * end of the ring -- it never does when every chunk but the last has max_chunk_samples.  The slot belongs to the
+ * producer until it is fed; it is reused one ring length (irdm_ring_ptr) later. */
+void *irdm_ingest_ptr(irdm_pipeline_t *p, size_t n_samples);
+/* the history ring (device memory, configured sample format) and its length in samples: sample i of the stream lives
+ * at index i % length */
+void *irdm_ring_ptr(irdm_pipeline_t *p, uint64_t *len_samples);
 int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples);
-/* pipeline_depth 1: finish the detector scan in flight and run the per-burst stages of the last fed chunk now.
- * Returns bursts processed or -1. */
+/* pipeline_depth >= 1: finish the detector scan in flight and every per-burst chain, oldest first; all records of the
+ * chunks fed so far are pollable afterwards.  Returns bursts processed or -1 (also when a chunk handed over with
+ * irdm_feed_begin still waits for its irdm_feed_end). */
 int irdm_flush(irdm_pipeline_t *p);
 /* Pinned (page-locked) host memory for feed buffers, for hosts without HIP headers.  NULL on failure. */
 void *irdm_host_alloc(size_t bytes);

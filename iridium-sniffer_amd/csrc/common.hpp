@@ -10,6 +10,11 @@
 #include <stdint.h>
 #include <stdio.h>
 
+// The detector's kernels (prefilter, band scan) are chains of small, latency-bound launches that decide when the next
+// chunk may be scanned; their wavefronts share SIMDs with the per-burst chains' long-running ones (decimator, demod),
+// and the issue arbiter serves the oldest wavefront first.  s_setprio raises the wavefront's issue priority (0..3).
+#define IRDM_DETECTOR_PRIO() __builtin_amdgcn_s_setprio(3)
+
 #define IRDM_HIP_CHECK(expr)                                                        \
     do {                                                                            \
         hipError_t _e = (expr);                                                     \

@@ -113,6 +113,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
                                                                        float *__restrict__ mag, int n_frames)
 {
     constexpr int N = 1 << LOGN, T = N / 16, LB = LOGN - 8, NB = 1 << LB, ROW = NB + 1, RD = LOGN - 12;
+    __builtin_amdgcn_s_setprio(2);      // the scan of this chunk waits for K1; it shares SIMDs with the per-burst chains
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *X = reinterpret_cast<float2 *>(smem_raw);
     const int t = threadIdx.x;

@@ -258,6 +258,7 @@ struct irdm_pipeline {
                              // serialise pipeline_depth 1's deferred work behind the detector scan)
     int deferred_emitted;
     bool caller_ordered;     // the current chunk was handed over on a stream (ev[8] recorded)
+    int k1_first;            // per-burst chains start behind K1 (1) / K1 + ring copy (2) of the chunk just fed
     // detector scan in flight (scan_launch .. scan_finish)
     bool fl_active, fl_sparse;
     const float *fl_mag, *d_mag_last;
@@ -265,7 +266,6 @@ struct irdm_pipeline {
     uint64_t fl_c1, fl_c0;
     hipStream_t fstream;     // K1 (== stream unless pipeline_depth 1)
     float *d_mag2;           // pipeline_depth 1: second magnitude buffer
-    int mag_parity;
     std::vector<BurstWork> h_work;
     // the per-burst chains (bursts_enqueue / bursts_finish) and the helper thread that does their host step
     BatchCtx bc[3];
@@ -280,11 +280,19 @@ struct irdm_pipeline {
     hipEvent_t ev_rot;          // the rotator checkpoint table is complete
     hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
     uint64_t chunk_no;          // chunks fed so far
-    bool fb_active;             // irdm_feed_begin done, irdm_feed_end pending
-    const void *fb_iq;
-    uint64_t fb_c0, fb_c1;
-    float *fb_mag;
-    int fb_frames;
+    // chunks between irdm_feed_begin and irdm_feed_end: at most one at pipeline_depth 0, two (one chunk of look-ahead:
+    // K1 of chunk N+1 is on the GPU before the host waits for the scan of chunk N-1) otherwise
+    struct FeedSlot {
+        const void *iq;
+        uint64_t c0, c1;
+        float *mag;
+        int frames;
+        bool in_ring;           // the caller wrote the chunk where irdm_ingest_ptr() said: no copy into the ring
+        hipEvent_t ev_start, ev_k1, ev_copy;
+    } fs[3];
+    uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % 3
+    uint64_t begun_samples;     // absolute index the next irdm_feed_begin starts at
+    float *d_mag3;
     double host_us[6];          // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
@@ -316,7 +324,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
                      p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
-                     p->d_fir_off, p->d_mag2, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
+                     p->d_fir_off, p->d_mag2, p->d_mag3, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -348,6 +356,11 @@ static void pipeline_free(irdm_pipeline *p)
     }
     if (p->hp_gone) (void)hipHostFree(p->hp_gone);
     if (p->ev_ring) (void)hipEventDestroy(p->ev_ring);
+    for (auto &f : p->fs) {
+        if (f.ev_start) (void)hipEventDestroy(f.ev_start);
+        if (f.ev_k1) (void)hipEventDestroy(f.ev_k1);
+        if (f.ev_copy) (void)hipEventDestroy(f.ev_copy);
+    }
     if (p->ev_rot) (void)hipEventDestroy(p->ev_rot);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
@@ -423,9 +436,13 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     // longest possible burst window: stop - start < max_len + post_len + N, plus pre_len
     p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
     p->depth = cfg->pipeline_depth > 0 ? std::min(cfg->pipeline_depth, 2) : 0;
+    p->k1_first = 1;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
-    if (p->depth) p->ring_len += (size_t)(p->depth + 2) * p->max_chunk;  // the per-burst chains in flight read the previous depth+1 chunks while this one is copied in
+    // the per-burst chains in flight read the previous depth+1 chunks while this one and the next (look-ahead) arrive
+    if (p->depth) p->ring_len += (size_t)(p->depth + 3) * p->max_chunk;
     p->ring_len = (p->ring_len + 15) / 16 * 16;     // 16-sample segments never straddle the wrap
+    // whole chunks: a chunk written in place (irdm_ingest_ptr) is contiguous (max_chunk is a multiple of feed_block)
+    if (p->depth) p->ring_len = (p->ring_len + p->max_chunk - 1) / p->max_chunk * p->max_chunk;
     p->n_ckpt = (int)(p->l_cap / kRotSeg) + 2;
 
     // ---- downmix constants (burst_downmix.c:223-373) ----
@@ -517,6 +534,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_sum, float, (size_t)P.n);
     AL(p->d_mag, float, p->max_chunk);
     if (p->depth) AL(p->d_mag2, float, p->max_chunk);
+    if (p->depth) AL(p->d_mag3, float, p->max_chunk);
     AL(p->d_state, DetState, 1);
     AL(p->d_gone, GoneBurst, (size_t)p->gone_cap);
     AL(p->d_cand_a, PeakCand, (size_t)P.n);
@@ -636,6 +654,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->hp_gone_cap = p->gone_cap;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&p->ev_ring, hipEventDisableTiming) == hipSuccess;
+    for (auto &f : p->fs)
+        ok = ok && hipEventCreate(&f.ev_start) == hipSuccess && hipEventCreate(&f.ev_k1) == hipSuccess &&
+             hipEventCreateWithFlags(&f.ev_copy, hipEventDisableTiming) == hipSuccess;
     p->chunk_no = 0;
 #undef UP
 #undef AL
@@ -661,7 +682,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         return nullptr;
     }
     p->h_gone.resize(p->gone_cap);
-    p->total_samples = 0;
+    p->total_samples = p->begun_samples = 0;
+    p->begin_no = p->end_no = 0;
     p->tagged = 0;
     p->stream_closed = false;
     p->last_frames = 0;
@@ -1439,8 +1461,16 @@ static int deferred_enqueue(irdm_pipeline *p)
     const SampleSource src = make_source(p, nullptr, 0, p->pend_c1);
     const int n = (int)p->pend_gone.size();
     int base = 0;
-    // the chain reads the ring: it must hold the chunk these bursts come from
+    // the chain reads the ring: it must hold the chunk these bursts come from (ev_ring: a seeded history)
     IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, p->ev_ring, 0));
+    IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, p->fs[p->pend_no % 3].ev_copy, 0));
+    // ... and K1 of the newest chunk goes first (k1_first 1), or K1 and its ring copy (2): a detector scan waits for
+    // it, and K1 next to the decimator took 1.0-1.6 ms instead of 0.24 ms
+    if (p->begin_no > 0) {
+        const irdm_pipeline::FeedSlot &newest = p->fs[(p->begin_no - 1) % 3];
+        if (p->k1_first >= 2) IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, newest.ev_copy, 0));
+        else if (p->k1_first == 1) IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, newest.ev_k1, 0));
+    }
     while (n - base > p->burst_cap) {
         if (process_bursts(p, b, src, p->pend_gone.data() + base, p->burst_cap) != 0) return -1;
         base += p->burst_cap;
@@ -1460,6 +1490,7 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
 {
     if (!p) return -1;
     if (!p->depth) return 0;
+    if (p->begin_no != p->end_no) return -1;        // a chunk handed over with irdm_feed_begin is still pending
     (void)hipSetDevice(p->cfg.device);
     if (settle(p) != 0) return -1;
     int emitted = 0;
@@ -1489,7 +1520,8 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
 // two back to back.
 extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
 {
-    if (!p || (!d_iq && n_samples) || p->fb_active) return -1;
+    if (!p || (!d_iq && n_samples)) return -1;
+    if (p->begin_no - p->end_no > (p->depth ? 1u : 0u)) return -1;      // one chunk of look-ahead, pipeline_depth >= 1 only
     if (p->stream_closed) {
         fprintf(stderr, "irdm_hip: stream already ended by a chunk that was not a multiple of feed_block\n");
         return -1;
@@ -1512,41 +1544,46 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
         if (caller != p->fstream) IRDM_HIP_CHECK(hipStreamWaitEvent(p->fstream, p->ev[8], 0));
     }
     const DetParams &P = p->P;
-    const uint64_t c0 = p->total_samples, c1 = c0 + n_samples;
+    const uint64_t c0 = p->begun_samples, c1 = c0 + n_samples;
     const int n_frames = (int)(n_samples / (size_t)P.n);
 
     // K1 of this chunk.  pipeline_depth 1: on its own stream and into the other magnitude buffer, while the detector
     // scan of the previous chunk may still be running
-    float *mag = p->d_mag;
-    if (p->depth) {
-        p->mag_parity ^= 1;
-        mag = p->mag_parity ? p->d_mag2 : p->d_mag;
-    }
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[0], p->fstream));
+    irdm_pipeline::FeedSlot &f = p->fs[p->begin_no % 3];
+    float *const mags[3] = { p->d_mag, p->d_mag2, p->d_mag3 };
+    float *mag = p->depth ? mags[p->begin_no % 3] : p->d_mag;
+    // written in place (irdm_ingest_ptr)?  Then the ring already holds the chunk.
+    const uint64_t pos = c0 % p->ring_len;
+    const bool in_ring = p->depth && n_samples > 0 && pos + n_samples <= p->ring_len &&
+                         d_iq == static_cast<const char *>(p->d_ring) + pos * p->bps;
+    IRDM_HIP_CHECK(hipEventRecord(f.ev_start, p->fstream));
     if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream) != 0)
         return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[1], p->fstream));
-    // this chunk into the history ring, behind K1 on its stream (the ring keeps three chunks: the copy never
-    // overwrites what the per-burst chains in flight still read)
-    if (p->depth && ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
-    p->fb_active = true;
-    p->fb_iq = d_iq;
-    p->fb_c0 = c0;
-    p->fb_c1 = c1;
-    p->fb_mag = mag;
-    p->fb_frames = n_frames;
+    IRDM_HIP_CHECK(hipEventRecord(f.ev_k1, p->fstream));
+    // this chunk into the history ring, behind K1 on its stream (the ring keeps the chunks the per-burst chains in
+    // flight still read: the copy never overwrites them)
+    if (p->depth && !in_ring && ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(f.ev_copy, p->fstream));
+    f.iq = d_iq;
+    f.c0 = c0;
+    f.c1 = c1;
+    f.mag = mag;
+    f.frames = n_frames;
+    f.in_ring = in_ring;
+    p->begun_samples = c1;
+    p->begin_no++;
     return 0;
 }
 
 extern "C" int irdm_feed_end(irdm_pipeline_t *p)
 {
-    if (!p || !p->fb_active) return -1;
+    if (!p || p->begin_no == p->end_no) return -1;
     (void)hipSetDevice(p->cfg.device);
-    p->fb_active = false;
-    const void *d_iq = p->fb_iq;
-    const uint64_t c0 = p->fb_c0, c1 = p->fb_c1;
-    float *mag = p->fb_mag;
-    const int n_frames = p->fb_frames;
+    irdm_pipeline::FeedSlot &f = p->fs[p->end_no % 3];
+    const void *d_iq = f.iq;
+    const uint64_t c0 = f.c0, c1 = f.c1;
+    float *mag = f.mag;
+    const int n_frames = f.frames;
     float ms = 0;
 
     int emitted = 0;
@@ -1583,26 +1620,26 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         if (deferred_enqueue(p) != 0) return -1;
         IRDM_HOST_PHASE(2);
         // 3. this chunk's detector (needs K1's output), enqueued while the GPU works on 2.
-        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev[1], 0));
+        IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, f.ev_k1, 0));
         if (scan_launch(p, mag, n_frames, c1) != 0) return -1;
         IRDM_HOST_PHASE(3);
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
         emitted = deferred_finish(p, p->bc[p->chunk_no % p->n_bc]);
         if (emitted < 0) return -1;
         IRDM_HOST_PHASE(4);
-        // 5. the caller may overwrite d_iq once we return: K1 and the ring copy are done with it
-        IRDM_HIP_CHECK(hipEventRecord(p->ev_ring, p->fstream));
-        IRDM_HIP_CHECK(hipEventRecord(p->ev[7], p->fstream));
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
+        // 5. the caller may overwrite d_iq once we return: K1 and the ring copy are done with it.  (A chunk written in
+        //    place stays where it is; K1 is waited for only so that its time can be read.)
+        IRDM_HIP_CHECK(hipEventSynchronize(f.in_ring ? f.ev_k1 : f.ev_copy));
         IRDM_HOST_PHASE(5);
 #undef IRDM_HOST_PHASE
     }
     p->chunk_no++;
+    p->end_no++;
     p->total_samples = c1;
 
     // [0] K1, [5] the whole call on the detector side; [1] is set by scan_finish, [2..4] by bursts_finish
-    p->last_ms[0] = hipEventElapsedTime(&ms, p->ev[0], p->ev[1]) == hipSuccess ? ms : -1.0f;
-    p->last_ms[5] = hipEventElapsedTime(&ms, p->ev[0], p->ev[7]) == hipSuccess ? ms : -1.0f;
+    p->last_ms[0] = hipEventElapsedTime(&ms, f.ev_start, f.ev_k1) == hipSuccess ? ms : -1.0f;
+    p->last_ms[5] = !p->depth && hipEventElapsedTime(&ms, f.ev_start, p->ev[7]) == hipSuccess ? ms : -1.0f;
     return emitted;
 }
 
@@ -1610,6 +1647,26 @@ extern "C" int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_s
 {
     if (irdm_feed_begin(p, d_iq, n_samples, stream_v) != 0) return -1;
     return irdm_feed_end(p);
+}
+
+// Where the producer of the next chunk (an H2D copy, a conversion kernel) may write it so that it needs no copy into
+// the history ring: the ring slot of the absolute sample index the next irdm_feed_begin starts at.  NULL when the
+// context keeps no ring copy (pipeline_depth 0) or the chunk would straddle the end of the ring (it cannot when every
+// chunk but the last has max_chunk_samples: the ring is a whole number of them).  The slot is the producer's until it
+// hands it over with irdm_feed_begin(p, ptr, n, stream); it is overwritten ring_len samples later.
+extern "C" void *irdm_ingest_ptr(irdm_pipeline_t *p, size_t n_samples)
+{
+    if (!p || !p->depth || n_samples == 0 || n_samples > p->max_chunk) return nullptr;
+    const uint64_t pos = p->begun_samples % p->ring_len;
+    if (pos + n_samples > p->ring_len) return nullptr;
+    return static_cast<char *>(p->d_ring) + pos * p->bps;
+}
+
+extern "C" void *irdm_ring_ptr(irdm_pipeline_t *p, uint64_t *len_samples)
+{
+    if (!p) return nullptr;
+    if (len_samples) *len_samples = p->ring_len;
+    return p->d_ring;
 }
 
 // Pinned host memory for irdm_feed_host callers that have no HIP headers (the C99 host): H2D copies from pinned
@@ -1779,7 +1836,7 @@ extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
     IRDM_HIP_CHECK(hipMemcpy(p->d_sum, i, sizeof(float) * p->P.n, hipMemcpyHostToDevice));
     i += sizeof(float) * p->P.n;
     IRDM_HIP_CHECK(hipMemcpy(p->d_hist, i, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyHostToDevice));
-    p->total_samples = h.total_samples;
+    p->total_samples = p->begun_samples = h.total_samples;
     p->tagged = h.tagged;
     p->start_time_ns = h.start_time_ns;
     p->host_primed = h.host_primed;
@@ -1826,7 +1883,7 @@ extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, s
     i += sizeof(float) * p->P.n;
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, i, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyDeviceToDevice, p->stream));
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-    if (!p->fb_active) p->total_samples = h.total_samples;     // (a feed already begun has fixed its own position)
+    if (p->begin_no == p->end_no) p->total_samples = p->begun_samples = h.total_samples;     // (a feed already begun has fixed its own position)
     p->tagged = h.tagged;
     p->start_time_ns = h.start_time_ns;
     p->host_primed = h.host_primed;
@@ -1837,7 +1894,7 @@ extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, s
 // the preceding samples from DEVICE memory (a chunk overlap received from the previous rank)
 extern "C" int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, uint64_t abs_start)
 {
-    if (!p || (!d_iq && n_samples) || n_samples > abs_start || p->fb_active) return -1;
+    if (!p || (!d_iq && n_samples) || n_samples > abs_start || p->begin_no != p->end_no) return -1;
     (void)hipSetDevice(p->cfg.device);
     if (n_samples > p->ring_len) {
         d_iq = static_cast<const char *>(d_iq) + (n_samples - p->ring_len) * p->bps;
@@ -1847,7 +1904,7 @@ extern "C" int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, si
     if (ring_update(p, d_iq, abs_start - n_samples, abs_start, p->fstream) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_ring, p->fstream));
     IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
-    p->total_samples = abs_start;
+    p->total_samples = p->begun_samples = abs_start;
     return 0;
 }
 
@@ -1869,7 +1926,7 @@ extern "C" int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_
                                  hipMemcpyHostToDevice));
         done += run;
     }
-    p->total_samples = abs_start;
+    p->total_samples = p->begun_samples = abs_start;
     return 0;
 }
 
@@ -2059,6 +2116,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
     if (!strcmp(key, "fir_layout")) { irdm::g_fir_layout = value; return 0; }
     if (!strcmp(key, "fir_prof")) { irdm::g_fir_prof = value; return 0; }
+    if (!strcmp(key, "k1_first")) { p->k1_first = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }

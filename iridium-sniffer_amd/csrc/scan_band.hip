@@ -101,6 +101,7 @@ __device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, i
 __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                                  const DetState *__restrict__ st, int round)
 {
+    IRDM_DETECTOR_PRIO();
     __shared__ int32_t s_part[kPlanThreads];
     __shared__ int s_mismatch, s_first, s_status, s_agree_fail;
     __shared__ unsigned s_flags;
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, 
                                                       const float *__restrict__ pre, float *__restrict__ smin_out,
                                                       const int4 *__restrict__ steps, float *__restrict__ snap)
 {
+    IRDM_DETECTOR_PRIO();
     const BandCtl *ctl = W.ctl;
     if (ctl->status != 0) return;
     const int b = blockIdx.x * 64 + threadIdx.x;
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, 
 __global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                          const ListEntry *__restrict__ entries)
 {
+    IRDM_DETECTOR_PRIO();
     __shared__ uint32_t s_bits[16384 / 32];
     if (W.ctl->status != 0) return;
     const int f = blockIdx.x, tid = threadIdx.x, N = P.n;
@@ -330,6 +333,7 @@ __global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork 
 template <int NW>
 __global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W, BandIO io, const DetState *__restrict__ st)
 {
+    IRDM_DETECTOR_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (W.ctl->status != 0) return;
     io.act_in = st->act;
@@ -367,6 +371,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
                                                                    float *__restrict__ sum, GoneBurst *__restrict__ gone,
                                                                    int gone_cap)
 {
+    IRDM_DETECTOR_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *s_key = reinterpret_cast<uint64_t *>(smem_raw);                    // kBandMaxTotal
     uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_key + kBandMaxTotal);      // kBandMaxTotal
@@ -476,6 +481,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
 __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
                                                            float *__restrict__ hist)
 {
+    IRDM_DETECTOR_PRIO();
     const BandCtl *ctl = W.ctl;
     if (ctl->status != 1 || !ctl->committed) return;
     const int k = ctl->n_upd - 1 - (int)blockIdx.x;

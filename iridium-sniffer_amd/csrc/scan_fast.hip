@@ -35,6 +35,7 @@ namespace irdm {
 __global__ void prefilter_threshold_kernel(const float *__restrict__ sum, float thr,
                                            float *__restrict__ pre, int n)
 {
+    IRDM_DETECTOR_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // 0.5: the list stays complete while the live sum is >= 0.556 of this reference (CMD_VALIDATE checks
     // pre <= 0.9*thr*sum).  Measured on the bench scene: per-bin sums move by +-20 % within a chunk (burst
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const float *__restrict_
                                                         unsigned *__restrict__ counts,
                                                         ListEntry *__restrict__ entries, int n_frames, int cap)
 {
+    IRDM_DETECTOR_PRIO();
     __shared__ int cnt;
     const int tid = threadIdx.x;
     for (int frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
@@ -136,6 +138,7 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
 // band scan found the lists stale -- the threshold only goes down, to 0.45 * thr * (smallest sum the bin went through)
 __global__ void prefilter_lower_kernel(const float *__restrict__ smin, float thr, float *__restrict__ pre, int n)
 {
+    IRDM_DETECTOR_PRIO();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) pre[i] = fminf(pre[i], 0.45f * thr * smin[i]);
 }

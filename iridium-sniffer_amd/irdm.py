@@ -110,6 +110,10 @@ def lib():
         L.irdm_host_free.restype = None
         L.irdm_feed_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.irdm_feed_end.argtypes = [C.c_void_p]
+        L.irdm_ingest_ptr.argtypes = [C.c_void_p, C.c_size_t]
+        L.irdm_ingest_ptr.restype = C.c_void_p
+        L.irdm_ring_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.irdm_ring_ptr.restype = C.c_void_p
         L.irdm_export_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_export_state_device.restype = C.c_longlong
         L.irdm_import_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -305,6 +309,16 @@ class Pipeline:
         if rc < 0:
             raise RuntimeError("irdm_feed_end failed")
         return rc
+
+    def ingest_ptr(self, n_samples):
+        """Device address the next chunk may be written to in place (its slot of the history ring), or None."""
+        return self.L.irdm_ingest_ptr(self.h, n_samples)
+
+    def ring(self):
+        """(device address, length in samples) of the history ring."""
+        n = C.c_uint64(0)
+        ptr = self.L.irdm_ring_ptr(self.h, C.byref(n))
+        return ptr, int(n.value)
 
     def state_bytes(self):
         return int(self.L.irdm_state_bytes(self.h))

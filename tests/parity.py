@@ -11,8 +11,11 @@ def bits_of(x):
     return np.float32(x).view(np.uint32)
 
 
-def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, **kw):
-    """Feed `iq` through the HIP pipeline in the given chunk sizes (samples)."""
+def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="host", **kw):
+    """Feed `iq` through the HIP pipeline in the given chunk sizes (samples).
+
+    feed: "host" irdm_feed_host per chunk; "ingest" every chunk written in place (irdm_ingest_ptr) and fed from there;
+    "lookahead" device buffers, irdm_feed_begin(k+1) before irdm_feed_end(k); "ingest_lookahead" both."""
     n = len(iq) if fmt == irdm.FMT_CF32 else len(iq) // 2
     max_chunk = max(chunks) if chunks else n
     p = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=max_chunk, max_bursts_per_chunk=1024,
@@ -21,9 +24,48 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, **kw):
     p.set_option("scan_mode", scan_mode)
     per = 1 if fmt == irdm.FMT_CF32 else 2
     off = 0
-    for c in (chunks or [n]):
-        p.feed_host(iq[off * per:(off + c) * per])
-        off += c
+    sizes = list(chunks or [n])
+    L = irdm.lib()
+    if feed == "host":
+        for c in sizes:
+            p.feed_host(iq[off * per:(off + c) * per])
+            off += c
+    else:
+        import ctypes as C
+        assert depth >= 1
+        ingest = feed.startswith("ingest")
+        look = feed.endswith("lookahead")
+        held = []                # device buffers of chunks begun (not "ingest"): released after their feed_end
+
+        def begin(c, off):
+            part = np.ascontiguousarray(iq[off * per:(off + c) * per])
+            if ingest:
+                ptr = p.ingest_ptr(c)
+                assert ptr, "irdm_ingest_ptr refused a chunk of %d samples" % c
+                assert L.irdm_device_upload(C.c_void_p(ptr), part.ctypes.data_as(C.c_void_p), part.nbytes) == 0
+                held.append(None)
+            else:
+                ptr = irdm.device_buffer(part)
+                held.append(ptr)
+            p.feed_begin(ptr, c)
+
+        def end():
+            p.feed_end()
+            ptr = held.pop(0)
+            if ptr:
+                irdm.device_free(ptr)
+
+        pending = 0
+        for c in sizes:
+            begin(c, off)
+            off += c
+            pending += 1
+            if pending > (1 if look else 0):
+                end()
+                pending -= 1
+        while pending:
+            end()
+            pending -= 1
     assert off == n
     if depth:
         p.flush()

@@ -1,0 +1,86 @@
+"""-m gpu: the throughput-mode feeding variants (include/irdm_hip.h, irdm_ingest_ptr / look-ahead) give the oracle's
+records:
+  ingest      every chunk written in place into its slot of the history ring and fed from there (no ring copy)
+  lookahead   irdm_feed_begin(k+1) before irdm_feed_end(k) on device buffers (K1 of the next chunk ahead of the host's
+              wait for the previous scan)
+  both together, at pipeline_depth 1 and 2, over a stream long enough for the ring to wrap (2 MHz: the ring is about
+  5.6 M samples, the stream 10 M), and on the scenes that end the stream with a ragged chunk / exceed max_bursts."""
+import numpy as np
+import pytest
+
+import irdm
+import orc
+import parity
+import scenes
+import siggen
+
+pytestmark = pytest.mark.gpu
+
+
+def _equal_chunks(n, blocks_per_chunk):
+    c = blocks_per_chunk * 32768
+    out = [c] * (n // c)
+    if n % c:
+        out.append(n % c)
+    return out
+
+
+@pytest.fixture(scope="module")
+def long_scene():
+    fs = 2_000_000
+    iq = siggen.standard_scene(fs, 5 * fs, 14, seed=23, uplink_every=4)[0]
+    return fs, iq, orc.run_stream(iq, fs)
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("feed", ["ingest", "lookahead", "ingest_lookahead"])
+def test_feed_variants_long_stream(long_scene, feed, depth):
+    fs, iq, ref = long_scene
+    got = parity.run_gpu(iq, fs, chunks=_equal_chunks(len(iq), 8), depth=depth, feed=feed)
+    s = parity.compare(got, ref)
+    assert s["bursts"] >= 14 and got["n_samples"] == len(iq)
+
+
+@pytest.mark.parametrize("name", ["squelch", "many_active_10m", "too_long"])
+def test_feed_variants_scenes(name):
+    if name not in scenes.ALL:
+        pytest.skip("no such scene")
+    fs, iq = scenes.ALL[name]()
+    ref = orc.run_stream(iq, fs)
+    blocks = max(1, (len(iq) // 32768) // 5)
+    for feed in ("ingest_lookahead", "lookahead"):
+        got = parity.run_gpu(iq, fs, chunks=_equal_chunks(len(iq), blocks), depth=1, feed=feed)
+        parity.compare(got, ref)
+
+
+def test_ingest_ptr_contract():
+    fs = 2_000_000
+    chunk = 8 * 32768
+    p = irdm.Pipeline(fs, max_chunk_samples=chunk, pipeline_depth=1)
+    p0 = irdm.Pipeline(fs, max_chunk_samples=chunk, pipeline_depth=0)
+    try:
+        assert not p0.ingest_ptr(chunk)                 # no ring copy to save at pipeline_depth 0
+        base, n = p.ring()
+        assert base and n % chunk == 0
+        assert p.ingest_ptr(chunk) == base              # the stream starts at ring index 0
+        assert not p.ingest_ptr(chunk + 32768)          # larger than max_chunk_samples
+        z = np.zeros(chunk, np.complex64)
+        p.feed_host(z)                                  # an ordinary feed moves the position as well
+        assert p.ingest_ptr(chunk) == base + chunk * 8
+        # two begins may be pending, not three; flush refuses while one is
+        a, b = irdm.device_buffer(z), irdm.device_buffer(z)
+        p.feed_begin(a, chunk)
+        p.feed_begin(b, chunk)
+        with pytest.raises(RuntimeError):
+            p.feed_begin(a, chunk)
+        assert p.L.irdm_flush(p.h) == -1
+        p.feed_end()
+        p.feed_end()
+        with pytest.raises(RuntimeError):
+            p.feed_end()
+        p.flush()
+        irdm.device_free(a)
+        irdm.device_free(b)
+    finally:
+        p.close()
+        p0.close()
