@@ -1,6 +1,5 @@
-// demod.hip -- stage C on gfx950 (qpsk_demod.c:393-535): Gardner-timed DQPSK
-// demodulation, one wavefront per frame (the loops of this stage are sequential per-symbol
-// recurrences of <= 445 steps run by lane 0 out of LDS; frames are independent).
+// demod.hip -- stage C on gfx950 (qpsk_demod.c:393-535): Gardner-timed DQPSK demodulation.  The sequential
+// per-symbol recurrences (<= 448 steps) run one frame per lane, the per-symbol independent work one symbol per lane.
 //
 // Numerics: float32 in the reference's operation order.  cabsf is reproduced
 // exactly (double sqrt); cargf/atan2f, cosf, sinf come from the device libm and
@@ -39,29 +38,106 @@ __device__ float2 cubic_interp(const float2 *in, int n, float pos)
     return cadd(cadd(cadd(cscale(mu3, a), cscale(mu2, b)), cscale(mu, c)), s1);
 }
 
-// One wavefront per frame.  The frame (<= 4440 samples) and the per-symbol work arrays live in LDS.
-// What is a true recurrence stays sequential, everything else is spread over the 64 lanes:
-//   * Gardner loop (qpsk_demod.c:85-130): position n+1 depends on the timing error of position n -> sequential,
-//     but the on-time and the mid-point interpolation of one step are independent: lanes 0 and 1 run the same
-//     Catmull-Rom instruction stream on the two positions and exchange the results over the DPP network;
-//   * PLL (:145-195): phi_{i+1} depends on phi_i through cabsf / atan2f / cosf / sinf -> sequential on lane 0;
-//   * slicer, per-symbol magnitudes, confidence flags, unique-word angles, |.| for the LLR scale: one symbol per
-//     lane; only the float sums whose order matters (level :247, LLR scale :489-497) and the end-of-frame rule
-//     (:210-225, a running maximum) are walked in order by lane 0, over values already computed.
-__global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__ work, int n_bursts,
-                                                   const float2 *__restrict__ frames, int use_gardner, float sps,
-                                                   float2 *__restrict__ ws, DemodOut *__restrict__ out)
+// Two kernels.
+//
+// demod_seq_kernel -- the true recurrences, ONE LANE PER FRAME (64 frames per wavefront):
+//   * Gardner loop (qpsk_demod.c:85-130): position n+1 depends on the timing error of position n;
+//   * PLL (:145-195): phi_{i+1} depends on phi_i through cabsf / atan2f / cosf / sinf.
+//   Both are chains of a few hundred dependent instructions per symbol (a dependent VALU instruction issues ~20 cycles
+//   after its producer, tools/ubench/valu_chain.hip), <= 448 symbols: ~0.5 ms however they are laid out.  One
+//   wavefront per frame (the earlier layout: lane 0 ran the chains out of 48 KB of LDS) kept 667 wavefronts and 125 KB
+//   of every CU's LDS busy for that long -- the decimator (50 KB per workgroup) and K1 (66 KB) of the other chunks in
+//   flight could not be placed until they retired.  A lane per frame needs 11 wavefronts and no LDS; the samples come
+//   from HBM/L2 (4 neighbours per interpolation, 32 contiguous bytes per lane).
+// demod_par_kernel -- everything that is per-symbol independent, one wavefront per frame, short:
+//   slicer, per-symbol magnitudes, confidence flags, unique-word angles, |.| for the LLR scale: one symbol per lane;
+//   only the float sums whose order matters (level :247, LLR scale :489-497) and the end-of-frame rule (:210-225, a
+//   running maximum) are walked in order by lane 0, over values already computed.
+__global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restrict__ work, int n_bursts,
+                                                       const float2 *__restrict__ frames, int use_gardner, float sps,
+                                                       float2 *__restrict__ ws, DemodOut *__restrict__ out)
 {
-    __shared__ float2 s_fr[kMaxFrameSamples];
-    __shared__ float2 s_dec[kMaxSymbols];
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_bursts) return;
+    if (work[b].drop_reason != 0) return;
+    const int n_samples = work[b].num_samples;
+    const float2 *fr = frames + (size_t)b * kMaxFrameSamples;
+    float2 *dec = ws + (size_t)b * 2 * kMaxSymbols;
+    float2 *po = dec + kMaxSymbols;
+
+    // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
+    int n = 0;
+    if (use_gardner) {
+        float pos = 0.0f, toff = 0.0f;
+        float2 prev = make_float2(0.0f, 0.0f);
+        while (pos < (float)(n_samples - 3) && n < kMaxSymbols) {
+            const float mid_pos = pos - sps * 0.5f;
+            // the on-time sample and the mid-point sample (used only where the reference computes it) are independent
+            const float2 on = cubic_interp(fr, n_samples, pos);
+            const float2 mid = cubic_interp(fr, n_samples, mid_pos >= 1.0f ? mid_pos : 1.0f);
+            dec[n] = on;
+            if (n > 0 && mid_pos >= 1.0f) {
+                const float2 diff = csub(prev, on);
+                // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
+                const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
+                float err = p0 - p1;
+                if (err > 1.0f) err = 1.0f;
+                if (err < -1.0f) err = -1.0f;
+                toff += 0.0002f * err;
+                float adj = 0.02f * err + toff;
+                if (adj > 0.5f) adj = 0.5f;
+                if (adj < -0.5f) adj = -0.5f;
+                pos += adj;
+            }
+            prev = on;
+            n++;
+            pos += sps;
+        }
+    } else {
+        const int step = (int)sps;
+        n = (n_samples + step - 1) / step;
+        if (n > kMaxSymbols) n = kMaxSymbols;
+        for (int i = 0; i < n; i++) dec[i] = fr[i * step];
+    }
+
+    // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
+    float2 phi = make_float2(1.0f, 0.0f);
+    float total_phase = 0.0f;
+    for (int i = 0; i < n; i++) {
+        const float2 v = cmul(dec[i], phi);
+        po[i] = v;
+        float2 xh;
+        if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
+        else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
+        else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
+        else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
+        const float2 er = cmul(make_float2(xh.x, -xh.y), v);
+        const float em = cabs_f(er);
+        if (em < 1e-10f) continue;
+        const float2 unit = make_float2(er.x / em, er.y / em);
+        const float ang = atan2f(unit.y, unit.x);
+        const float sa = 0.2f * ang;
+        float sn, cs;
+        sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
+        const float2 corr = make_float2(cs, sn);
+        total_phase += sa;
+        phi = cmul(make_float2(corr.x, -corr.y), phi);
+        const float pm = cabs_f(phi);
+        if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
+    }
+    out[b].n_symbols = n;               // (demod_par_kernel replaces it by the frame's symbol count)
+    out[b].total_phase = total_phase;
+}
+
+__global__ __launch_bounds__(64) void demod_par_kernel(const BurstWork *__restrict__ work, int n_bursts,
+                                                       const float2 *__restrict__ ws, DemodOut *__restrict__ out)
+{
     __shared__ float2 s_po[kMaxSymbols];
     __shared__ float s_mag[kMaxSymbols];      // sqrtf(re^2 + im^2) of the PLL output (:205, :231)
     __shared__ float s_abs[kMaxSymbols];      // cabsf of the PLL output (:493)
     __shared__ int s_sym[kMaxSymbols];        // quadrant | confidence flag << 2
     __shared__ int s_res[4];          // ok, direction, ns, confidence
     __shared__ float s_resf[3];       // level, total_phase, llr scale
-    __shared__ int s_n;
-    (void)ws;
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (b >= n_bursts) return;
@@ -71,81 +147,10 @@ __global__ __launch_bounds__(64) void demod_kernel(const BurstWork *__restrict__
         if (lane == 0) o.ok = 0;
         return;
     }
-    const int n_samples = w.num_samples;
-    const float2 *gin = frames + (size_t)b * kMaxFrameSamples;
-    for (int i = lane; i < n_samples; i += 64) s_fr[i] = gin[i];
-    __syncthreads();
-
-    // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
-    if (use_gardner) {
-        if (lane < 2) {
-            int n = 0;
-            float pos = 0.0f, toff = 0.0f;
-            float2 prev = make_float2(0.0f, 0.0f);
-            while (pos < (float)(n_samples - 3) && n < kMaxSymbols) {
-                const float mid_pos = pos - sps * 0.5f;
-                // lane 0: the on-time sample; lane 1: the mid-point sample (used only where the reference computes it)
-                const float2 mine = cubic_interp(s_fr, n_samples, lane == 0 ? pos : (mid_pos >= 1.0f ? mid_pos : 1.0f));
-                const float2 on = make_float2(__shfl(mine.x, 0), __shfl(mine.y, 0));
-                const float2 mid = make_float2(__shfl(mine.x, 1), __shfl(mine.y, 1));
-                if (lane == 0) s_dec[n] = on;
-                if (n > 0 && mid_pos >= 1.0f) {
-                    const float2 diff = csub(prev, on);
-                    // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
-                    const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
-                    float err = p0 - p1;
-                    if (err > 1.0f) err = 1.0f;
-                    if (err < -1.0f) err = -1.0f;
-                    toff += 0.0002f * err;
-                    float adj = 0.02f * err + toff;
-                    if (adj > 0.5f) adj = 0.5f;
-                    if (adj < -0.5f) adj = -0.5f;
-                    pos += adj;
-                }
-                prev = on;
-                n++;
-                pos += sps;
-            }
-            if (lane == 0) s_n = n;
-        }
-    } else {
-        const int step = (int)sps;
-        int n = (n_samples + step - 1) / step;
-        if (n > kMaxSymbols) n = kMaxSymbols;
-        for (int i = lane; i < n; i += 64) s_dec[i] = s_fr[i * step];
-        if (lane == 0) s_n = n;
-    }
-    __syncthreads();
-    const int n = s_n;
-
-    // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
-    if (lane == 0) {
-        float2 phi = make_float2(1.0f, 0.0f);
-        float total_phase = 0.0f;
-        for (int i = 0; i < n; i++) {
-            const float2 v = cmul(s_dec[i], phi);
-            s_po[i] = v;
-            float2 xh;
-            if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
-            else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
-            else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
-            else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
-            const float2 er = cmul(make_float2(xh.x, -xh.y), v);
-            const float em = cabs_f(er);
-            if (em < 1e-10f) continue;
-            const float2 unit = make_float2(er.x / em, er.y / em);
-            const float ang = atan2f(unit.y, unit.x);
-            const float sa = 0.2f * ang;
-            float sn, cs;
-            sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
-            const float2 corr = make_float2(cs, sn);
-            total_phase += sa;
-            phi = cmul(make_float2(corr.x, -corr.y), phi);
-            const float pm = cabs_f(phi);
-            if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
-        }
-        s_resf[1] = total_phase;
-    }
+    const int n = o.n_symbols;
+    if (lane == 0) s_resf[1] = o.total_phase;
+    const float2 *po = ws + (size_t)b * 2 * kMaxSymbols + kMaxSymbols;
+    for (int i = lane; i < n; i += 64) s_po[i] = po[i];
     __syncthreads();
 
     // step 3a: per-symbol values of demod_qpsk (qpsk_demod.c:199-260), one symbol per lane
@@ -268,8 +273,9 @@ int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int 
                  float sps, float2 *ws, DemodOut *out, hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
-    hipLaunchKernelGGL(demod_kernel, dim3(n_bursts), dim3(64), 0, stream, work, n_bursts,
+    hipLaunchKernelGGL(demod_seq_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts,
                        frames, use_gardner, sps, ws, out);
+    hipLaunchKernelGGL(demod_par_kernel, dim3(n_bursts), dim3(64), 0, stream, work, n_bursts, ws, out);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -87,6 +87,9 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, FirTile 
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream);
+int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneBurst *hp_gone, uint32_t *hp_hdr,
+                       const void *ctl, void *hp_ctl, int ctl_bytes, hipStream_t stream);
+int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t stream);
 int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream);   // bytes % 4 == 0
 int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hipStream_t stream);
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,

@@ -261,6 +261,7 @@ struct irdm_pipeline {
     int k1_first;            // per-burst chains start behind K1 (1) / K1 + ring copy (2) of the chunk just fed
     // detector scan in flight (scan_launch .. scan_finish)
     bool fl_active, fl_sparse;
+    bool fl_band_ran;        // the band scan's control block on the device belongs to the scan in flight
     const float *fl_mag, *d_mag_last;
     int fl_frames;
     uint64_t fl_c1, fl_c0;
@@ -293,7 +294,7 @@ struct irdm_pipeline {
     uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % 3
     uint64_t begun_samples;     // absolute index the next irdm_feed_begin starts at
     float *d_mag3;
-    double host_us[6];          // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
+    double host_us[10];         // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
     std::vector<float> h_frames;
@@ -974,9 +975,10 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     }
     hipStream_t st = b.stream;
     IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));
-    IRDM_HIP_CHECK(hipMemcpyAsync(b.d_work, b.hp_work, sizeof(BurstWork) * nb, hipMemcpyHostToDevice, st));
-    if (n_tiles)
-        IRDM_HIP_CHECK(hipMemcpyAsync(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, hipMemcpyHostToDevice, st));
+    // (copies by kernel, here and at the end of the chain: the runtime's copy path answers late next to the chains'
+    // kernels, and an H2D from pinned memory may block the enqueueing thread)
+    if (launch_copy_words(b.d_work, b.hp_work_dev, sizeof(BurstWork) * nb, st) != 0) return -1;
+    if (n_tiles && launch_copy_words(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
                             p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st) != 0)
@@ -1007,7 +1009,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     if (launch_demod(b.d_work, nb, b.d_frames, p->cfg.use_gardner, p->sps, b.d_demod_ws, b.d_demod, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[3], st));
-    IRDM_HIP_CHECK(hipMemcpyAsync(b.hp_work, b.d_work, sizeof(BurstWork) * nb, hipMemcpyDeviceToHost, st));
+    if (launch_copy_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, st) != 0) return -1;
     if (p->decode_frames) {
         // post-demod bit layer on the demodulator's device-resident output (frames that failed the unique word
         // have ok = 0 and decode to FRAME_UNKNOWN)
@@ -1019,7 +1021,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
                               b.d_ida, st) != 0)
             return -1;
     }
-    IRDM_HIP_CHECK(hipMemcpyAsync(b.hp_demod, b.d_demod, sizeof(DemodOut) * nb, hipMemcpyDeviceToHost, st));
+    if (launch_copy_to_host(b.hp_demod, b.d_demod, sizeof(DemodOut) * nb, st) != 0) return -1;
     return 0;
 }
 
@@ -1231,7 +1233,7 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
                          p->d_entries, p->d_pre, p->d_smin, p->d_gone, p->gone_cap, p->stream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->stream));
-    IRDM_HIP_CHECK(hipMemcpyAsync(p->h_pin + 96, p->band.ctl, sizeof(BandCtl), hipMemcpyDeviceToHost, p->stream));
+    // (the control block reaches the host with the records: scan_export)
     return 0;
 }
 
@@ -1272,6 +1274,15 @@ static int scan_legacy_enqueue(irdm_pipeline *p, const float *mag, int n_frames,
     return 0;
 }
 
+// the scan's records and header words into pinned host memory, behind whatever the scan stream holds
+static int scan_export(irdm_pipeline *p)
+{
+    const bool band = p->fl_mode == 2 && p->fl_band_ran;
+    return launch_gone_export(p->d_state, p->d_gone, std::min(p->gone_cap, p->hp_gone_cap), p->hp_gone,
+                              reinterpret_cast<uint32_t *>(p->h_pin + 64), band ? p->band.ctl : nullptr, p->h_pin + 96,
+                              (int)sizeof(BandCtl), p->stream);
+}
+
 static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_t c1)
 {
     IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
@@ -1294,6 +1305,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
     if (p->fl_mode == 2) {
         // nothing of the carried state is written before the band scan's commit: no snapshot
         memset(p->h_pin + 96, 0, sizeof(BandCtl));
+        p->fl_band_ran = done < n_frames;
         if (done < n_frames) {
             if (scan_band_enqueue(p, mag, n_frames, done, 0) != 0) return -1;
         } else {
@@ -1304,6 +1316,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
         if (scan_legacy_enqueue(p, mag, n_frames, done, p->fl_mode == 1) != 0) return -1;
     }
     IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
+    if (scan_export(p) != 0) return -1;
     p->fl_active = true;
     return 0;
 }
@@ -1313,8 +1326,16 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     *n_gone_out = 0;
     if (!p->fl_active) return 0;
     p->fl_active = false;
+    auto now_us = [] {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    };
+    double tq0 = now_us(), tq1;
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    tq1 = now_us(); p->host_us[6] += tq1 - tq0; tq0 = tq1;          // [6] waiting for the scan itself
     int redo_from = p->fl_done;       // where a dense redo restarts (the priming frames are never redone)
+    bool redone = false;              // something ran after the export the launch enqueued
     if (p->fl_mode == 2) {
         const BandCtl *ctl = reinterpret_cast<const BandCtl *>(p->h_pin + 96);
         int tries = 0;
@@ -1322,8 +1343,10 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             // a bin's running sum fell below what the prefilter lists assumed (the noise floor dropped by more than
             // 1.8x inside the chunk): rebuild the lists against the lowest sums seen and scan again
             tries++;
+            redone = true;
             p->stat_band_retries++;
             if (scan_band_enqueue(p, p->fl_mag, p->fl_frames, p->fl_done, 1) != 0) return -1;
+            if (scan_export(p) != 0) return -1;
             IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
         }
         p->stat_band_rounds += (uint64_t)ctl->rounds;
@@ -1335,6 +1358,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             // sequential kernels take the chunk
             p->stat_band_aborts++;
             p->stat_fallbacks++;
+            redone = true;
             p->last_band_flags = ctl->flags;
             if (getenv("IRDM_SCAN_DEBUG"))
                 fprintf(stderr, "irdm_hip: band scan declined the chunk (flags 0x%x, %d rounds, %d mismatches from frame %d) -> sequential scan\n",
@@ -1360,6 +1384,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         if (status != 0) {
             // a list overflowed, went stale, or missed a crossing: redo the chunk with the dense scan
             p->stat_fallbacks++;
+            redone = true;
             if (getenv("IRDM_SCAN_DEBUG")) fprintf(stderr, "irdm_hip: sparse scan aborted with status 0x%x -> dense scan\n", status);
             if (scan_restore(p) != 0) return -1;
             if (scan_dense(p, p->fl_mag + (size_t)redo_from * p->P.n, p->fl_frames - redo_from, true) != 0) return -1;
@@ -1368,11 +1393,13 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             p->stat_fast_chunks++;
         }
     }
-    uint32_t *counters = reinterpret_cast<uint32_t *>(p->h_pin + 64);
-    int32_t *hdr = p->h_pin + 66;
-    IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, p->stream));
-    IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, p->stream));
-    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    volatile uint32_t *counters = reinterpret_cast<volatile uint32_t *>(p->h_pin + 64);
+    volatile int32_t *hdr = p->h_pin + 66;
+    if (redone) {
+        if (scan_export(p) != 0) return -1;
+        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    }
+    tq1 = now_us(); p->host_us[7] += tq1 - tq0; tq0 = tq1;          // [7] retries / fallbacks + the counters' round trip
     p->host_hist_idx = hdr[0];
     p->host_primed = hdr[1];
     int n_gone = (int)counters[0];
@@ -1390,10 +1417,16 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         p->gone_cap = want;
         p->h_gone.resize(want);
         p->stat_fallbacks++;
+        if (p->gone_cap > p->hp_gone_cap) {
+            (void)hipHostFree(p->hp_gone);
+            p->hp_gone = nullptr;
+            p->hp_gone_cap = p->gone_cap;
+            if (hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) != hipSuccess)
+                return -1;
+        }
         if (scan_restore(p) != 0) return -1;
         if (scan_dense(p, p->fl_mag + (size_t)redo_from * p->P.n, p->fl_frames - redo_from, true) != 0) return -1;
-        IRDM_HIP_CHECK(hipMemcpyAsync(counters, &p->d_state->n_gone, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, p->stream));
-        IRDM_HIP_CHECK(hipMemcpyAsync(hdr, &p->d_state->hist_idx, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, p->stream));
+        if (scan_export(p) != 0) return -1;
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
         p->host_hist_idx = hdr[0];
         p->host_primed = hdr[1];
@@ -1403,19 +1436,8 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             return -1;
         }
     }
-    if (n_gone > 0) {
-        // (no null-stream hipMemcpy here: it would wait for every other stream, K1 of this chunk included)
-        if (n_gone > p->hp_gone_cap) {
-            (void)hipHostFree(p->hp_gone);
-            p->hp_gone = nullptr;
-            p->hp_gone_cap = p->gone_cap;
-            if (hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) != hipSuccess)
-                return -1;
-        }
-        IRDM_HIP_CHECK(hipMemcpyAsync(p->hp_gone, p->d_gone, sizeof(GoneBurst) * n_gone, hipMemcpyDeviceToHost, p->stream));
-        IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
-        memcpy(p->h_gone.data(), p->hp_gone, sizeof(GoneBurst) * n_gone);
-    }
+    if (n_gone > 0) memcpy(p->h_gone.data(), p->hp_gone, sizeof(GoneBurst) * n_gone);
+    tq1 = now_us(); p->host_us[8] += tq1 - tq0; tq0 = tq1;          // [8] the burst records' round trip
     float ms = 0;
     // the scan proper (band passes, the sparse kernel, or the dense one when it ran instead)
     p->last_ms[1] = hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
@@ -2128,7 +2150,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!p || !key) return -1;
     if (!strcmp(key, "scan_fast_chunks")) return (int64_t)p->stat_fast_chunks;
     if (!strcmp(key, "scan_fallbacks")) return (int64_t)p->stat_fallbacks;
-    if (!strncmp(key, "host_us_", 8) && key[8] >= '0' && key[8] <= '5') return (int64_t)p->host_us[key[8] - '0'];
+    if (!strncmp(key, "host_us_", 8) && key[8] >= '0' && key[8] <= '9') return (int64_t)p->host_us[key[8] - '0'];
     if (!strcmp(key, "band_chunks")) return (int64_t)p->stat_band_chunks;
     if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
     if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;
