@@ -684,7 +684,7 @@ def main():
                                                           "band_rounds", "band_retries", "band_aborts", "band_last_flags")},
                        "host_us_total": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(
                            ("k1_ring_enqueue", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync",
-                            "settle_wait_scan", "settle_counters", "settle_records"))}},
+                            "settle_wait_scan", "settle_counters", "settle_records", "build_records"))}},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_1core": cpu1,

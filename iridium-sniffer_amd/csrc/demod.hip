@@ -57,6 +57,9 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
                                                        const float2 *__restrict__ frames, int use_gardner, float sps,
                                                        float2 *__restrict__ ws, DemodOut *__restrict__ out)
 {
+    // a handful of wavefronts whose dependent chains decide when the chunk's records are complete, sharing SIMDs with
+    // the decimator's wavefronts of the next chunk: they go first when they have an instruction ready
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_bursts) return;
     if (work[b].drop_reason != 0) return;
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(64) void demod_par_kernel(const BurstWork *__restri
     __shared__ int s_sym[kMaxSymbols];        // quadrant | confidence flag << 2
     __shared__ int s_res[4];          // ok, direction, ns, confidence
     __shared__ float s_resf[3];       // level, total_phase, llr scale
+    __builtin_amdgcn_s_setprio(2);
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     if (b >= n_bursts) return;

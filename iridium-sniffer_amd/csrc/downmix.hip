@@ -1028,66 +1028,108 @@ __device__ __forceinline__ float parabolic(float alpha, float beta, float gamma)
 constexpr int kPostThreads = 256;
 
 // ---------------------------------------------------------------------------
-// post1: one workgroup per burst.
+// post1: one workgroup per burst.  Steps 2b and 3 walk the burst in tiles of kPostThreads outputs staged in LDS: the
+// noise filter reads its 25 neighbours and the start filter its 20 from LDS with unrolled loops (the first version read
+// them from HBM/L2 one dependent load per tap: 0.5 ms for 667 bursts).  The start filter's outputs are kept in the
+// burst's row of `dec` (as floats, behind the part of the row the tiles still read) for the threshold pass.
+// NT / SN: compile-time tap counts (25 / 20 at every supported rate), 0 = the runtime values.
 // ---------------------------------------------------------------------------
+constexpr int kPostMaxTaps = 64;
+
+template <int NT, int SN>
 __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
-    BurstWork *__restrict__ work, const float2 *__restrict__ dec, int dec_stride,
-    float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps,
-    const float *__restrict__ start_taps, int start_ntaps, int search_depth, int pre_start,
+    BurstWork *__restrict__ work, float2 *__restrict__ dec, int dec_stride,
+    float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps_rt,
+    const float *__restrict__ start_taps, int start_ntaps_rt, int search_depth, int pre_start,
     const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096)
 {
     __shared__ __attribute__((aligned(16))) float2 s[kCfoTotal];
     __shared__ float redf[4];
     __shared__ int redi[4];
+    __builtin_amdgcn_s_setprio(2);      // latency-bound, next to the decimator of the next chunk
     const int tid = threadIdx.x;
     BurstWork &w = work[blockIdx.x];
     if (w.drop_reason != 0) return;
+    const int noise_ntaps = NT ? NT : noise_ntaps_rt;
+    const int start_ntaps = SN ? SN : start_ntaps_rt;
     const int dec_len = w.dec_len;
-    const float2 *x = dec + (size_t)blockIdx.x * dec_stride;
+    float2 *x = dec + (size_t)blockIdx.x * dec_stride;
+    float *fscr = reinterpret_cast<float *>(x);         // start-filter outputs: float i aliases x[i / 2], read long before
     float2 *y = lpf + (size_t)blockIdx.x * dec_stride;
 
-    // step 2b (burst_downmix.c:683-698): centred 25-tap LPF over the zero-padded burst
-    if (dec_len - noise_ntaps + 1 > 0) {
-        const int half = (noise_ntaps - 1) / 2;
-        for (int i = tid; i < dec_len; i += kPostThreads) {
-            float ar = 0.0f, ai = 0.0f;
-            for (int k = 0; k < noise_ntaps; k++) {
-                const int j = i + k - half;
-                const float2 v = (j >= 0 && j < dec_len) ? x[j] : make_float2(0.0f, 0.0f);
-                const float t = noise_taps[k];
-                ar += t * v.x;
-                ai += t * v.y;
-            }
-            y[i] = make_float2(ar, ai);
-        }
-    } else {
-        for (int i = tid; i < dec_len; i += kPostThreads) y[i] = x[i];
-    }
-    __syncthreads();
-
-    // step 3 (burst_downmix.c:441-478)
+    // step 3 geometry (burst_downmix.c:441-478)
     int search = search_depth < dec_len ? search_depth : dec_len;
     int mag_len = search + start_ntaps - 1;
     if (mag_len > dec_len) mag_len = dec_len;
     int flen = mag_len - start_ntaps + 1;
+    if (flen > search) flen = search;
+
+    // the tile buffers live in the FFT's LDS (not in use yet)
+    float2 *xs = s;                                          // kPostThreads + 2 * kPostMaxTaps samples
+    float *m2 = reinterpret_cast<float *>(s + kPostThreads + 2 * kPostMaxTaps);      // kPostThreads + kPostMaxTaps
+    const bool do_lpf = dec_len - noise_ntaps + 1 > 0;       // burst_downmix.c:683-698
+    const int half = (noise_ntaps - 1) / 2;
+    const int span_y = kPostThreads + start_ntaps - 1;       // LPF outputs a tile's start filter needs
+    const int span_x = span_y + noise_ntaps - 1;
+    float mx = -1e30f;
+    for (int B = 0; B < dec_len; B += kPostThreads) {
+        for (int q = tid; q < span_x; q += kPostThreads) {
+            const int j = B - half + q;
+            xs[q] = (j >= 0 && j < dec_len) ? x[j] : make_float2(0.0f, 0.0f);
+        }
+        __syncthreads();
+        // step 2b: centred LPF over the zero-padded burst, outputs B .. B + span_y
+        for (int p = tid; p < span_y; p += kPostThreads) {
+            if (B + p >= dec_len) break;
+            float2 v;
+            if (do_lpf) {
+                float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+                for (int k = 0; k < (NT ? NT : 1); k++) {
+                    if (NT) {
+                        const float2 u = xs[p + k];
+                        const float t = noise_taps[k];
+                        ar += t * u.x;
+                        ai += t * u.y;
+                    }
+                }
+                if (!NT) {
+                    for (int k = 0; k < noise_ntaps; k++) {
+                        const float2 u = xs[p + k];
+                        const float t = noise_taps[k];
+                        ar += t * u.x;
+                        ai += t * u.y;
+                    }
+                }
+                v = make_float2(ar, ai);
+            } else {
+                v = xs[p + half];
+            }
+            if (p < kPostThreads) y[B + p] = v;
+            m2[p] = mag2(v);
+        }
+        __syncthreads();
+        // step 3, first half: the box filter over |y|^2
+        if (B + tid < flen) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < (SN ? SN : 1); k++)
+                if (SN) acc += start_taps[k] * m2[tid + k];
+            if (!SN)
+                for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[tid + k];
+            fscr[B + tid] = acc;
+            mx = acc > mx ? acc : mx;
+        }
+        __syncthreads();
+    }
+
     int start = 0;
     if (flen > 0) {
-        if (flen > search) flen = search;
-        auto filt = [&](int i) {
-            float acc = 0.0f;
-            for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * mag2(y[i + k]);
-            return acc;
-        };
-        float mx = -1e30f;
-        for (int i = tid; i < flen; i += kPostThreads) {
-            const float v = filt(i);
-            mx = v > mx ? v : mx;
-        }
         mx = block_max(mx, redf);
         const float thr = 0.45f * mx;                       // START_THRESHOLD
         int first = flen;
         for (int i = tid; i < flen; i += kPostThreads) {
-            if (filt(i) >= thr) { first = i; break; }
+            if (fscr[i] >= thr) { first = i; break; }
         }
         start = block_min_int(first, redi);
         if (start > 0) {
@@ -1135,24 +1177,66 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     }
 }
 
-int launch_downmix_post1(BurstWork *work, int n_bursts, const float2 *dec, int dec_stride,
+int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
+
+int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_stride,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
                          const float *cfo_window, const float2 *tw4096, hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
-    hipLaunchKernelGGL(downmix_post1_kernel, dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
-                       dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                       pre_start, cfo_window, tw4096);
+    if (noise_ntaps > kPostMaxTaps || start_ntaps > kPostMaxTaps) return -1;
+    if (noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic)
+        hipLaunchKernelGGL((downmix_post1_kernel<25, 20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
+                           dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
+                           pre_start, cfo_window, tw4096);
+    else
+        hipLaunchKernelGGL((downmix_post1_kernel<0, 0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
+                           dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
+                           pre_start, cfo_window, tw4096);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ---------------------------------------------------------------------------
-// post2: one workgroup per burst.
+// Step 5's phase sequence (burst_downmix.c:713-720): phase_0 = 1, phase_{k+1} = phase_k * incr in float -- a chain of
+// up to kFrameNeed dependent complex multiplies per burst (~45 cycles each: ~0.1 ms).  One LANE per burst: eleven
+// wavefronts walk 667 chains, instead of 667 workgroups each waiting for its lane 0 with 48 KB of LDS in hand.
+// The phases go to the burst's row of rrc_ws (post2 overwrites the row with the RRC output afterwards).
 // ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rot_phase_kernel(const BurstWork *__restrict__ work, int n_bursts,
+                                                       float2 *__restrict__ rrc_ws)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_bursts) return;
+    const BurstWork &w = work[b];
+    if (w.drop_reason != 0) return;
+    const int frame_len = w.dec_len - w.start_idx;
+    const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+    const float2 inc = make_float2(w.incr_re, w.incr_im);
+    float2 ph = make_float2(1.0f, 0.0f);
+    float2 *r = rrc_ws + (size_t)b * kFrameNeed;
+    // two phases per 16-byte store: every lane writes its own row, so a store instruction touches 64 cache lines and
+    // their number, not the multiply chain, set the pace with one phase per store (0.24 ms against 0.11 ms)
+    static_assert(kFrameNeed % 2 == 0, "rows start 16-byte aligned");
+    int k = 0;
+    for (; k + 2 <= L; k += 2) {
+        const float2 p0 = ph;
+        ph = cmul(ph, inc);
+        const float2 p1 = ph;
+        ph = cmul(ph, inc);
+        *reinterpret_cast<float4 *>(r + k) = make_float4(p0.x, p0.y, p1.x, p1.y);
+    }
+    if (k < L) r[k] = ph;
+}
+
+// ---------------------------------------------------------------------------
+// post2: one workgroup per burst.  RT: compile-time RRC tap count (51), 0 = the runtime value.
+// ---------------------------------------------------------------------------
+template <int RT>
 __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     BurstWork *__restrict__ work, const float2 *__restrict__ lpf, int dec_stride,
-    const float *__restrict__ rrc_taps, int rrc_ntaps, const float2 *__restrict__ tw2048,
+    const float *__restrict__ rrc_taps, int rrc_ntaps_rt, const float2 *__restrict__ tw2048,
     const float2 *__restrict__ dl_fft, const float2 *__restrict__ ul_fft, int dl_len, int ul_len,
     float sps, float2 *__restrict__ rrc_ws, float2 *__restrict__ frames)
 {
@@ -1166,6 +1250,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     static_assert(kFrameNeed <= 3 * kCorrN, "the frame buffer aliases the correlation buffers");
     float *redf = reinterpret_cast<float *>(fu + kCorrN);
     int *redi = reinterpret_cast<int *>(redf + 4);
+    __builtin_amdgcn_s_setprio(2);      // latency-bound, next to the decimator of the next chunk
     const int tid = threadIdx.x;
     BurstWork &w = work[blockIdx.x];
     if (w.drop_reason != 0) return;
@@ -1175,30 +1260,33 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     const float2 *x = lpf + (size_t)blockIdx.x * dec_stride + start;
     float2 *r = rrc_ws + (size_t)blockIdx.x * kFrameNeed;
 
-    // step 5 (burst_downmix.c:713-720): sequential float recurrence, phase_0 = 1
-    if (tid == 0) {
-        const float2 inc = make_float2(w.incr_re, w.incr_im);
-        float2 ph = make_float2(1.0f, 0.0f);
-        for (int k = 0; k < L; k++) {
-            rot[k] = ph;
-            ph = cmul(ph, inc);
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < L; k += kPostThreads) rot[k] = cmul(x[k], rot[k]);
+    // step 5 (burst_downmix.c:713-720): the phase sequence comes from rot_phase_kernel (in r)
+    const int rrc_ntaps = RT ? RT : rrc_ntaps_rt;
+    for (int k = tid; k < L; k += kPostThreads) rot[k] = cmul(x[k], r[k]);
     __syncthreads();
 
     // step 6 (burst_downmix.c:723-734): centred 51-tap RRC over the zero-padded frame
     const int half = (rrc_ntaps - 1) / 2;
     for (int i = tid; i < L; i += kPostThreads) {
         float ar = 0.0f, ai = 0.0f;
-        for (int k = 0; k < rrc_ntaps; k++) {
-            const int j = i + k - half;
-            // j >= L only for outputs that can never reach the frame (kFrameNeed margin)
-            const float2 v = (j >= 0 && j < L) ? rot[j] : make_float2(0.0f, 0.0f);
-            const float t = rrc_taps[k];
-            ar += t * v.x;
-            ai += t * v.y;
+        if (RT && i >= half && i + (RT - 1 - half) < L) {
+            // every tap inside the frame: no bounds checks, unrolled
+#pragma unroll
+            for (int k = 0; k < (RT ? RT : 1); k++) {
+                const float2 v = rot[i + k - half];
+                const float t = rrc_taps[k];
+                ar += t * v.x;
+                ai += t * v.y;
+            }
+        } else {
+            for (int k = 0; k < rrc_ntaps; k++) {
+                const int j = i + k - half;
+                // j >= L only for outputs that can never reach the frame (kFrameNeed margin)
+                const float2 v = (j >= 0 && j < L) ? rot[j] : make_float2(0.0f, 0.0f);
+                const float t = rrc_taps[k];
+                ar += t * v.x;
+                ai += t * v.y;
+            }
         }
         r[i] = make_float2(ar, ai);
     }
@@ -1276,11 +1364,20 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int d
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    (void)hipFuncSetAttribute((const void *)downmix_post2_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(downmix_post2_kernel, dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
-                       dec_stride, rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
-                       rrc_ws, frames);
+    hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws);
+    if (rrc_ntaps == 51 && !g_post_generic) {
+        (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((downmix_post2_kernel<51>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
+                           dec_stride, rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
+                           rrc_ws, frames);
+    } else {
+        (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<0>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((downmix_post2_kernel<0>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
+                           dec_stride, rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
+                           rrc_ws, frames);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

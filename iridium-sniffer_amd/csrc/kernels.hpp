@@ -94,7 +94,8 @@ int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stre
 int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hipStream_t stream);
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
                         float2 *out, hipStream_t stream);
-int launch_downmix_post1(BurstWork *work, int n_bursts, const float2 *dec, int dec_stride,
+extern int g_post_generic;        // 1: runtime-tap-count instances of post1 / post2 (test hook)
+int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_stride,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
                          const float *cfo_window, const float2 *tw4096, hipStream_t stream);
