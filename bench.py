@@ -681,7 +681,7 @@ def main():
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
                        "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": look,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
-                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags")},
+                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists")},
                        "host_us_total": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(
                            ("k1_ring_enqueue", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync",
                             "settle_wait_scan", "settle_counters", "settle_records", "build_records"))}},

@@ -106,12 +106,20 @@ __device__ __forceinline__ void dit_first16(float2 (&v)[16], const float2 *__res
     }
 }
 
-template <int LOGN, int FMT>
+// LISTS: the band scan's prefilter fused into the store stage -- the bins with |X|^2 > pre[bin] of this frame go to
+// the frame's candidate list (scan_fast.hip, prefilter_kernel: same entries, same unordered layout, count may exceed
+// cap) while the values are still in registers, instead of being read back from HBM by a kernel of their own
+// (n * 4 B per frame and 60-120 us on the detector's critical path).
+template <int LOGN, int FMT, bool LISTS>
 __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const void *__restrict__ iq,
                                                                        const float *__restrict__ window,
                                                                        const float2 *__restrict__ tw,
-                                                                       float *__restrict__ mag, int n_frames)
+                                                                       float *__restrict__ mag, int n_frames,
+                                                                       const float *__restrict__ pre,
+                                                                       unsigned *__restrict__ counts,
+                                                                       ListEntry *__restrict__ entries, int cap)
 {
+    __shared__ int s_cnt;
     constexpr int N = 1 << LOGN, T = N / 16, LB = LOGN - 8, NB = 1 << LB, ROW = NB + 1, RD = LOGN - 12;
     __builtin_amdgcn_s_setprio(2);      // the scan of this chunk waits for K1; it shares SIMDs with the per-burst chains
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -127,6 +135,18 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
         const int frame = blockIdx.x;
         if (frame >= n_frames) return;
         const size_t base = (size_t)frame * N;
+        if (LISTS && t == 0) s_cnt = 0;            // (several barriers before the first candidate)
+        ListEntry *const list = LISTS ? entries + (size_t)frame * cap : nullptr;
+        auto put = [&](int k, float m) {
+            __builtin_nontemporal_store(m, &mag[base + k]);
+            if (LISTS && m > pre[k]) {
+                const int slot = atomicAdd(&s_cnt, 1);
+                if (slot < cap) {
+                    list[slot].bin = k;
+                    list[slot].mag = m;
+                }
+            }
+        };
         float2 v[16];
         // ---- pass A ----
 #pragma unroll
@@ -163,7 +183,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int p = q * 256 + lo3;
-                __builtin_nontemporal_store(mag2(v[q]), &mag[base + ((p + N / 2) & (N - 1))]);
+                put((p + N / 2) & (N - 1), mag2(v[q]));
             }
             __syncthreads();
         } else {
@@ -184,15 +204,49 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
                 for (int q = 0; q < RQ; q++) {
                     const int k = pp + q * 4096;
-                    __builtin_nontemporal_store(mag2(d[q]), &mag[base + ((k + N / 2) & (N - 1))]);
+                    put((k + N / 2) & (N - 1), mag2(d[q]));
                 }
             }
             __syncthreads();
         }
+        if (LISTS && t == 0) counts[frame] = (unsigned)s_cnt;
     }
 }
 
 int g_fft_force_radix2 = 0;   // test hook: 1 = always use the radix-2 LDS kernel
+
+// K1 with the candidate lists of the band scan (see fft_mag_r16_kernel); 1 if this FFT size has no such kernel
+int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window, const float2 *tw, float *mag,
+                         int n_frames, const float *pre, unsigned *counts, ListEntry *entries, int cap,
+                         hipStream_t stream)
+{
+    if (n_frames <= 0) return 0;
+    if (fmt < 0 || fmt > 2 || log_n < 12 || log_n > 14 || g_fft_force_radix2) return 1;
+#define IRDM_LAUNCH_R16L_F(LOGN, F)                                                            \
+    do {                                                                                       \
+        constexpr int NB_ = 1 << (LOGN - 8);                                                   \
+        size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN)           \
+                                           ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));   \
+        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F, true>,             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, true>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
+                           stream, iq, window, tw, mag, n_frames, pre, counts, entries, cap);  \
+    } while (0)
+#define IRDM_LAUNCH_R16L(LOGN)                                                                 \
+    do {                                                                                       \
+        if (fmt == 2) IRDM_LAUNCH_R16L_F(LOGN, 2);                                             \
+        else if (fmt == 1) IRDM_LAUNCH_R16L_F(LOGN, 1);                                        \
+        else IRDM_LAUNCH_R16L_F(LOGN, 0);                                                      \
+    } while (0)
+    switch (log_n) {
+    case 12: IRDM_LAUNCH_R16L(12); break;
+    case 13: IRDM_LAUNCH_R16L(13); break;
+    default: IRDM_LAUNCH_R16L(14); break;
+    }
+#undef IRDM_LAUNCH_R16L
+#undef IRDM_LAUNCH_R16L_F
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
                    float *mag, int n_frames, hipStream_t stream)
@@ -220,10 +274,11 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
         constexpr int NB_ = 1 << (LOGN - 8);                                                   \
         size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN)           \
                                            ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));   \
-        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F>,                   \
+        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F, false>,            \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
-                           stream, iq, window, tw, mag, n_frames);                             \
+        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, false>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
+                           stream, iq, window, tw, mag, n_frames, (const float *)nullptr,      \
+                           (unsigned *)nullptr, (ListEntry *)nullptr, 0);                      \
     } while (0)
 #define IRDM_LAUNCH_R16(LOGN)                                                                  \
     do {                                                                                       \

@@ -6,6 +6,10 @@
 namespace irdm {
 
 // detect.hip
+int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window, const float2 *tw, float *mag,
+                         int n_frames, const float *pre, unsigned *counts, ListEntry *entries, int cap,
+                         hipStream_t stream);
+int launch_prefilter_threshold(const float *sum, float thr, float *pre, int n, hipStream_t stream);
 int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
                    float *mag, int n_frames, hipStream_t stream);
 int launch_detect_scan(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,

@@ -289,8 +289,17 @@ struct irdm_pipeline {
         float *mag;
         int frames;
         bool in_ring;           // the caller wrote the chunk where irdm_ingest_ptr() said: no copy into the ring
+        bool lists;             // K1 wrote the band scan's candidate lists of the chunk (k1_pre / k1_counts / k1_entries)
         hipEvent_t ev_start, ev_k1, ev_copy;
     } fs[3];
+    // candidate lists written by K1 (fft_mag_r16_kernel<.., LISTS>), one set per feed slot: the reference levels the
+    // lists were built against, the per-frame counts and entries
+    float *k1_pre[3];
+    unsigned *k1_counts[3];
+    ListEntry *k1_entries[3];
+    int k1_lists;               // option: 1 = let K1 build the lists where it can
+    const FeedSlot *fl_feed;    // feed slot of the scan in flight
+    uint64_t stat_k1_lists;
     uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % 3
     uint64_t begun_samples;     // absolute index the next irdm_feed_begin starts at
     float *d_mag3;
@@ -325,7 +334,9 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
                      p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
-                     p->d_fir_off, p->d_mag2, p->d_mag3, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
+                     p->d_fir_off, p->d_mag2, p->d_mag3, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
+                     p->k1_pre[0] != p->d_pre ? p->k1_pre[0] : nullptr, p->k1_counts[0] != p->d_counts ? p->k1_counts[0] : nullptr,
+                     p->k1_entries[0] != p->d_entries ? p->k1_entries[0] : nullptr, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -438,6 +449,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
     p->depth = cfg->pipeline_depth > 0 ? std::min(cfg->pipeline_depth, 2) : 0;
     p->k1_first = 1;
+    p->k1_lists = 1;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
     // the per-burst chains in flight read the previous depth+1 chunks while this one and the next (look-ahead) arrive
     if (p->depth) p->ring_len += (size_t)(p->depth + 3) * p->max_chunk;
@@ -597,6 +609,16 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_goff, unsigned, max_frames + 1);
         AL(p->d_compact, ListEntry, max_frames * kListCap);
         AL(p->d_pre, float, (size_t)P.n);
+        // pipeline_depth 0: one chunk at a time, K1's lists share the prefilter pass's buffers; otherwise a set per feed
+        // slot (the prefilter pass of a fallback may run while K1 of a later chunk writes its lists)
+        p->k1_pre[0] = p->d_pre;
+        p->k1_counts[0] = p->d_counts;
+        p->k1_entries[0] = p->d_entries;
+        for (int i = 0; i < 3 && p->depth; i++) {
+            AL(p->k1_pre[i], float, (size_t)P.n);
+            AL(p->k1_counts[i], unsigned, max_frames);
+            AL(p->k1_entries[i], ListEntry, max_frames * (size_t)std::max(kListCap, band_list_cap(P.n)));
+        }
         AL(p->d_sum_bak, float, (size_t)P.n);
         AL(p->d_hist_bak, float, (size_t)kHistory * P.n);
         AL(p->d_state_bak, DetState, 1);
@@ -1235,12 +1257,23 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
     const uint64_t idx0 = p->fl_c0 + (uint64_t)done * (uint64_t)P.n;     // chunks start on frame boundaries
-    if (launch_prefilter_lists(p->d_sum, P.threshold, p->d_pre, retry ? p->d_smin : nullptr, mag_rest, P.n, p->d_counts,
-                               p->d_entries, n_frames - done, band_list_cap(P.n), p->stream) != 0)
-        return -1;
+    // the candidate lists: K1's (whole chunk, frame 0 first: only when nothing of the chunk was primed away), else the
+    // prefilter pass; a retry rebuilds them in the same buffers against the lowered levels
+    const bool from_k1 = p->fl_feed && p->fl_feed->lists && done == 0;
+    const int ls = from_k1 && p->depth ? (int)(p->fl_feed - p->fs) : 0;
+    float *pre = from_k1 ? p->k1_pre[ls] : p->d_pre;
+    unsigned *counts = from_k1 ? p->k1_counts[ls] : p->d_counts;
+    ListEntry *entries = from_k1 ? p->k1_entries[ls] : p->d_entries;
+    if (!from_k1 || retry) {
+        if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
+                                   entries, n_frames - done, band_list_cap(P.n), p->stream) != 0)
+            return -1;
+    } else {
+        p->stat_k1_lists++;
+    }
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->stream));
-    if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, p->d_counts,
-                         p->d_entries, p->d_pre, p->d_smin, p->d_gone, p->gone_cap, p->stream) != 0)
+    if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
+                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, p->stream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->stream));
     // (the control block reaches the host with the records: scan_export)
@@ -1589,7 +1622,20 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
     const bool in_ring = p->depth && n_samples > 0 && pos + n_samples <= p->ring_len &&
                          d_iq == static_cast<const char *>(p->d_ring) + pos * p->bps;
     IRDM_HIP_CHECK(hipEventRecord(f.ev_start, p->fstream));
-    if (launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream) != 0)
+    // K1, with the band scan's candidate lists where the scan will want them: the reference levels are the running
+    // sums as they are NOW (the previous chunk's scan may still be at work on them -- any levels do, the scan checks the
+    // lists against the ones they were built with, scan_band.hip band_sum_kernel); not before the detector is primed
+    // (no sums yet: every bin would be listed)
+    const int ls = p->depth ? (int)(p->begin_no % 3) : 0;       // (pipeline_depth 0: one chunk at a time, one set)
+    f.lists = false;
+    if (p->k1_lists && p->host_primed && scan_pick(p) == 2 && p->k1_pre[ls] && n_frames > 0) {
+        if (launch_prefilter_threshold(p->d_sum, P.threshold, p->k1_pre[ls], P.n, p->fstream) != 0) return -1;
+        const int rc = launch_fft_mag_lists(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->k1_pre[ls],
+                                            p->k1_counts[ls], p->k1_entries[ls], band_list_cap(P.n), p->fstream);
+        if (rc < 0) return -1;
+        f.lists = rc == 0;
+    }
+    if (!f.lists && launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(f.ev_k1, p->fstream));
     // this chunk into the history ring, behind K1 on its stream (the ring keeps the chunks the per-burst chains in
@@ -1621,6 +1667,7 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
     int emitted = 0;
     if (!p->depth) {
         int n_gone = 0;
+        p->fl_feed = &f;
         if (scan_launch(p, mag, n_frames, c1) != 0 || scan_finish(p, &n_gone) != 0) return -1;
         p->last_bursts.clear();
         p->last_chunk = d_iq;
@@ -1643,21 +1690,35 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         double t0 = now_us(), t1;
 #define IRDM_HOST_PHASE(i) do { t1 = now_us(); p->host_us[i] += t1 - t0; t0 = t1; } while (0)
         IRDM_HOST_PHASE(0);
+        p->last_bursts.clear();
+        // 0. if the oldest chain has already finished, its records are built NOW, while the previous chunk's detector
+        //    scan is still running (0.3 ms of host work that would otherwise follow the wait for the scan)
+        BatchCtx &oldest = p->bc[p->chunk_no % p->n_bc];
+        bool finished_early = false;
+        if (oldest.n > 0 && !p->detect_only && p->fl_active && hipStreamQuery(oldest.stream) == hipSuccess) {
+            emitted = deferred_finish(p, oldest);
+            if (emitted < 0) return -1;
+            finished_early = true;
+        }
+        IRDM_HOST_PHASE(4);
         // 1. the previous chunk's detector must be done before this chunk's can start: collect its bursts
         if (settle(p) != 0) return -1;
         IRDM_HOST_PHASE(1);
-        // 2. their per-burst stages: enqueued on the idle batch context, nothing waits.  (The context of the chunk
-        //    before that is still at work: its tail overlaps this one's FIR.)
-        p->last_bursts.clear();
-        if (deferred_enqueue(p) != 0) return -1;
-        IRDM_HOST_PHASE(2);
-        // 3. this chunk's detector (needs K1's output), enqueued while the GPU works on 2.
+        // 2. this chunk's detector (needs K1's output) goes first: the next chunk's scan can only start when this one
+        //    has ended, so every microsecond before its launch is added to the period
         IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, f.ev_k1, 0));
+        p->fl_feed = &f;
         if (scan_launch(p, mag, n_frames, c1) != 0) return -1;
         IRDM_HOST_PHASE(3);
+        // 3. the per-burst stages of the chunk just settled: enqueued on the idle batch context, nothing waits.  (The
+        //    context of the chunk before that is still at work: its tail overlaps this one's FIR.)
+        if (deferred_enqueue(p) != 0) return -1;
+        IRDM_HOST_PHASE(2);
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
-        emitted = deferred_finish(p, p->bc[p->chunk_no % p->n_bc]);
-        if (emitted < 0) return -1;
+        if (!finished_early) {
+            emitted = deferred_finish(p, oldest);
+            if (emitted < 0) return -1;
+        }
         IRDM_HOST_PHASE(4);
         // 5. the caller may overwrite d_iq once we return: K1 and the ring copy are done with it.  (A chunk written in
         //    place stays where it is; K1 is waited for only so that its time can be read.)
@@ -2149,6 +2210,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_layout")) { irdm::g_fir_layout = value; return 0; }
     if (!strcmp(key, "fir_prof")) { irdm::g_fir_prof = value; return 0; }
     if (!strcmp(key, "k1_first")) { p->k1_first = value; return 0; }
+    if (!strcmp(key, "k1_lists")) { p->k1_lists = value; return 0; }
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
@@ -2163,6 +2225,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "scan_fallbacks")) return (int64_t)p->stat_fallbacks;
     if (!strncmp(key, "host_us_", 8) && key[8] >= '0' && key[8] <= '9') return (int64_t)p->host_us[key[8] - '0'];
     if (!strcmp(key, "band_chunks")) return (int64_t)p->stat_band_chunks;
+    if (!strcmp(key, "k1_lists")) return (int64_t)p->stat_k1_lists;
     if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
     if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;
     if (!strcmp(key, "band_aborts")) return (int64_t)p->stat_band_aborts;

@@ -143,6 +143,12 @@ __global__ void prefilter_lower_kernel(const float *__restrict__ smin, float thr
     if (i < n) pre[i] = fminf(pre[i], 0.45f * thr * smin[i]);
 }
 
+int launch_prefilter_threshold(const float *sum, float thr, float *pre, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
                            unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream)
 {

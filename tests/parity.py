@@ -11,7 +11,7 @@ def bits_of(x):
     return np.float32(x).view(np.uint32)
 
 
-def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="host", **kw):
+def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="host", options=None, **kw):
     """Feed `iq` through the HIP pipeline in the given chunk sizes (samples).
 
     feed: "host" irdm_feed_host per chunk; "ingest" every chunk written in place (irdm_ingest_ptr) and fed from there;
@@ -22,6 +22,8 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
                       pipeline_depth=depth, **kw)
     p.set_option("keep_frame_samples", 1)
     p.set_option("scan_mode", scan_mode)
+    for k, v in (options or {}).items():
+        p.set_option(k, v)
     per = 1 if fmt == irdm.FMT_CF32 else 2
     off = 0
     sizes = list(chunks or [n])
@@ -75,7 +77,7 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
     res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, tagged=p.tagged,
                n_samples=p.sample_count, timings=p.timings(),
                stats={k: p.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
-                                             "band_rounds", "band_retries", "band_aborts", "band_last_flags")})
+                                             "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists")})
     p.close()
     return res
 

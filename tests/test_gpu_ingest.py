@@ -84,3 +84,23 @@ def test_ingest_ptr_contract():
     finally:
         p.close()
         p0.close()
+
+
+def test_k1_builds_the_candidate_lists():
+    """10 MHz (8192-point frames, the radix-16 K1): after the first chunk has primed the detector, K1 writes the band
+    scan's candidate lists itself (fft_mag_r16_kernel<.., LISTS>); same records as with the prefilter pass, at every
+    pipeline depth, also when the chunk is fed in place with look-ahead."""
+    fs, iq = scenes.ALL["many_active_10m"]()
+    ref = orc.run_stream(iq, fs)
+    # the detector is primed after 512 frames (4.2 M samples of the 7.4 M): chunks of ~0.6 M samples leave four or five
+    # chunks behind that point, minus the one or two in flight when the host learns of it
+    blocks = max(1, (len(iq) // 32768) // 12)
+    chunks = _equal_chunks(len(iq), blocks)
+    for depth, feed in ((0, "host"), (1, "host"), (2, "ingest_lookahead")):
+        got = parity.run_gpu(iq, fs, chunks=chunks, depth=depth, feed=feed)
+        parity.compare(got, ref)
+        assert got["stats"]["k1_lists"] >= 2, got["stats"]
+        assert got["stats"]["scan_fallbacks"] == 0, got["stats"]
+    off = parity.run_gpu(iq, fs, chunks=chunks, depth=1, options={"k1_lists": 0})
+    parity.compare(off, ref)
+    assert off["stats"]["k1_lists"] == 0

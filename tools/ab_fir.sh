@@ -1,5 +1,5 @@
 mkdir -p gpurun_out/fir
-timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/fir/t.log 2>&1; tail -3 gpurun_out/fir/t.log
+timeout 900 python -m pytest tests/test_gpu_ingest.py tests/test_gpu_scenes.py tests/test_gpu_cfg5.py tests/test_gpu_timeshard.py -m gpu -x -q > gpurun_out/fir/t.log 2>&1; tail -12 gpurun_out/fir/t.log
 run() { # name, opts...
   n=$1; shift
   timeout 300 python bench.py --file-run 0 --cpu-samples 0 --detect-steps 0 --host-steps 0 "$@" > gpurun_out/fir/$n.json 2> gpurun_out/fir/$n.err
