@@ -28,6 +28,7 @@ int launch_detect_scan_fast(const DetParams &P, DetState *st, float *sum, float 
 
 // scan_band.hip (band-parallel speculative scan; band_core.hpp holds the per-band state machine)
 constexpr int kBandRounds = 5;           // speculation rounds before giving up (2-3 on the benchmark scenes)
+constexpr int kBandFirst = 3;            // rounds enqueued up front; the rest only if the verdict is still open
 struct BandRec;
 struct BandParams;
 struct BandCtl {                         // control block on the device, copied to the host after the scan
@@ -61,7 +62,7 @@ size_t band_work_bytes(int n, size_t max_chunk);
 int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
-                     float *smin, GoneBurst *gone, int gone_cap, hipStream_t stream);
+                     float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, hipStream_t stream);
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
                            unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream);

@@ -244,7 +244,7 @@ struct irdm_pipeline {
     bool band_ok;
     int fl_mode;                // scan in flight: 0 dense, 1 sparse (leader/updaters), 2 band
     int fl_done;                // frames the dense scan primed before the in-flight scan proper
-    uint64_t stat_band_chunks, stat_band_rounds, stat_band_retries, stat_band_aborts;
+    uint64_t stat_band_chunks, stat_band_rounds, stat_band_retries, stat_band_aborts, stat_band_extra;
     uint32_t last_band_flags;
 
     std::vector<GoneBurst> h_gone;
@@ -298,6 +298,9 @@ struct irdm_pipeline {
     unsigned *k1_counts[3];
     ListEntry *k1_entries[3];
     int k1_lists;               // option: 1 = let K1 build the lists where it can
+    int band_first;             // band-scan rounds enqueued up front: 0 = as many as the previous chunk needed (at least
+                                // 2, kBandFirst to begin with), n = always n (test hook)
+    int band_auto, fl_band_first;
     const FeedSlot *fl_feed;    // feed slot of the scan in flight
     uint64_t stat_k1_lists;
     uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % 3
@@ -450,6 +453,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->depth = cfg->pipeline_depth > 0 ? std::min(cfg->pipeline_depth, 2) : 0;
     p->k1_first = 1;
     p->k1_lists = 1;
+    p->band_first = 0;
+    p->band_auto = kBandFirst;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
     // the per-burst chains in flight read the previous depth+1 chunks while this one and the next (look-ahead) arrive
     if (p->depth) p->ring_len += (size_t)(p->depth + 3) * p->max_chunk;
@@ -1252,7 +1257,7 @@ static int scan_restore(irdm_pipeline *p)
 
 // the band scan proper over the primed frames [done, n_frames) of the chunk; retry = 1: the lists went stale, rebuild
 // them against the lowered reference first
-static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry)
+static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds = false)
 {
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
@@ -1264,6 +1269,12 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
     float *pre = from_k1 ? p->k1_pre[ls] : p->d_pre;
     unsigned *counts = from_k1 ? p->k1_counts[ls] : p->d_counts;
     ListEntry *entries = from_k1 ? p->k1_entries[ls] : p->d_entries;
+    if (!more_rounds && !retry) p->fl_band_first = p->band_first ? p->band_first : p->band_auto;
+    if (more_rounds) {
+        // the first rounds left the verdict open: the remaining rounds, on the same lists and workspace
+        return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
+                                p->d_smin, p->d_gone, p->gone_cap, p->fl_band_first, kBandRounds, p->stream);
+    }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
                                    entries, n_frames - done, band_list_cap(P.n), p->stream) != 0)
@@ -1273,7 +1284,7 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
     }
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->stream));
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
-                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, p->stream) != 0)
+                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, p->fl_band_first, p->stream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->stream));
     // (the control block reaches the host with the records: scan_export)
@@ -1382,6 +1393,17 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     if (p->fl_mode == 2) {
         const BandCtl *ctl = reinterpret_cast<const BandCtl *>(p->h_pin + 96);
         int tries = 0;
+        auto more_rounds = [&]() -> int {
+            // verdict still open after the rounds enqueued up front: run the rest
+            if (ctl->status != 0 || ctl->flags != 0 || !p->fl_band_ran) return 0;
+            redone = true;
+            p->stat_band_extra++;
+            if (scan_band_enqueue(p, p->fl_mag, p->fl_frames, p->fl_done, 0, true) != 0) return -1;
+            if (scan_export(p) != 0) return -1;
+            IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+            return 0;
+        };
+        if (more_rounds() != 0) return -1;
         while (ctl->status != 1 && ctl->flags == BAND_F_STALE && tries < 2) {
             // a bin's running sum fell below what the prefilter lists assumed (the noise floor dropped by more than
             // 1.8x inside the chunk): rebuild the lists against the lowest sums seen and scan again
@@ -1391,9 +1413,11 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             if (scan_band_enqueue(p, p->fl_mag, p->fl_frames, p->fl_done, 1) != 0) return -1;
             if (scan_export(p) != 0) return -1;
             IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+            if (more_rounds() != 0) return -1;
         }
         p->stat_band_rounds += (uint64_t)ctl->rounds;
         if (ctl->status == 1) {
+            p->band_auto = std::min(std::max(ctl->rounds, 2), kBandRounds);
             p->stat_band_chunks++;
             p->stat_fast_chunks++;
         } else {
@@ -2211,6 +2235,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_prof")) { irdm::g_fir_prof = value; return 0; }
     if (!strcmp(key, "k1_first")) { p->k1_first = value; return 0; }
     if (!strcmp(key, "k1_lists")) { p->k1_lists = value; return 0; }
+    if (!strcmp(key, "band_first")) { p->band_first = value < 0 ? 0 : value > kBandRounds ? kBandRounds : value; return 0; }
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
@@ -2225,6 +2250,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "scan_fallbacks")) return (int64_t)p->stat_fallbacks;
     if (!strncmp(key, "host_us_", 8) && key[8] >= '0' && key[8] <= '9') return (int64_t)p->host_us[key[8] - '0'];
     if (!strcmp(key, "band_chunks")) return (int64_t)p->stat_band_chunks;
+    if (!strcmp(key, "band_extra")) return (int64_t)p->stat_band_extra;
     if (!strcmp(key, "k1_lists")) return (int64_t)p->stat_k1_lists;
     if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
     if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;

@@ -584,12 +584,18 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
 // unless BandCtl::status ends as 1 (accepted); the caller reads the control block afterwards.
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
-                     float *smin, GoneBurst *gone, int gone_cap, hipStream_t stream)
+                     float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, hipStream_t stream)
 {
+    // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
+    // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
+    // verdict is still open (status 0, no flags), the rest up to kBandRounds with round_begin = kBandFirst: everything a
+    // round needs from the one before lives in the workspace.
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
-    IRDM_HIP_CHECK(hipMemsetAsync(W.ctl, 0, sizeof(BandCtl), stream));
-    IRDM_HIP_CHECK(hipMemsetAsync(W.flags, 0, 4, stream));
+    if (round_begin == 0) {
+        IRDM_HIP_CHECK(hipMemsetAsync(W.ctl, 0, sizeof(BandCtl), stream));
+        IRDM_HIP_CHECK(hipMemsetAsync(W.flags, 0, 4, stream));
+    }
     BandIO io;
     io.cross = W.cross;
     io.occ = W.occ;
@@ -613,9 +619,11 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         (void)hipFuncSetAttribute((const void *)band_commit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)commit_lds);
         attr_done = true;
     }
-    for (int round = 0; round <= kBandRounds; round++) {
-        hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, P, W, counts, st, round);
-        if (round == kBandRounds) break;
+    for (int round = round_begin; round <= round_end; round++) {
+        // (a continuation starts behind the plan its predecessor's verdict pass already made)
+        if (round > round_begin || round_begin == 0)
+            hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, P, W, counts, st, round);
+        if (round == round_end) break;
         hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
         if (P.band_w == 128)

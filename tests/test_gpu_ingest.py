@@ -104,3 +104,16 @@ def test_k1_builds_the_candidate_lists():
     off = parity.run_gpu(iq, fs, chunks=chunks, depth=1, options={"k1_lists": 0})
     parity.compare(off, ref)
     assert off["stats"]["k1_lists"] == 0
+
+
+@pytest.mark.parametrize("name", ["strong_simultaneous", "too_long", "many_active_10m"])
+def test_band_scan_continues_its_rounds(name):
+    """Only the first rounds of the band scan are enqueued up front; when their verdict is still open the host enqueues
+    the rest on the same workspace.  band_first = 1 forces that path on scenes that need two or three rounds."""
+    fs, iq = scenes.ALL[name]()
+    ref = orc.run_stream(iq, fs)
+    blocks = max(1, (len(iq) // 32768) // 4)
+    for depth in (0, 1):
+        got = parity.run_gpu(iq, fs, chunks=_equal_chunks(len(iq), blocks), depth=depth, options={"band_first": 1})
+        parity.compare(got, ref)
+        assert got["stats"]["band_extra"] >= 1 and got["stats"]["scan_fallbacks"] == 0, got["stats"]
