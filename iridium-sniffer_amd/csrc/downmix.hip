@@ -859,27 +859,13 @@ __global__ void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__
     __threadfence_system();
 }
 
-// The finished-burst records of a detector scan and its four header words (n_gone, overflow, hist_idx, primed), written
-// by the GPU straight into pinned host memory behind the scan's last kernel: the host needs ONE stream synchronise to
-// have them.  (The hipMemcpyAsync D2H round trips they replace cost 0.43 ms per chunk for 32 KB next to the per-burst
-// chains' kernels, 0.84 ms with three chains in flight -- more than the scan's own wait.)
+// the scan's records and header words into pinned host memory (types.hpp, gone_export_body): the stand-alone form, for
+// the sequential scans and the fallback paths; the band scan does this in its last kernel
 __global__ void gone_export_kernel(const DetState *__restrict__ st, const uint32_t *__restrict__ gone, int cap,
                                    uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr,
                                    const uint32_t *__restrict__ ctl, uint32_t *__restrict__ hp_ctl, int ctl_words)
 {
-    if (blockIdx.x == 0 && ctl && (int)threadIdx.x < ctl_words)
-        __hip_atomic_store(hp_ctl + threadIdx.x, ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t n = st->n_gone;
-    const size_t words = (size_t)(n < (uint32_t)cap ? n : (uint32_t)cap) * (sizeof(GoneBurst) / 4);
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
-        __hip_atomic_store(hp_gone + i, gone[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        __hip_atomic_store(hp_hdr + 0, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(hp_hdr + 1, st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(hp_hdr + 2, (uint32_t)st->hist_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(hp_hdr + 3, (uint32_t)st->primed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
+    gone_export_body(st, gone, cap, hp_gone, hp_hdr, ctl, hp_ctl, ctl_words, (int)gridDim.x);
 }
 
 int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneBurst *hp_gone, uint32_t *hp_hdr,

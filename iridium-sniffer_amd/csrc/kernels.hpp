@@ -62,7 +62,8 @@ size_t band_work_bytes(int n, size_t max_chunk);
 int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
-                     float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, hipStream_t stream);
+                     float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, hipStream_t stream);
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
                            unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream);

@@ -1273,7 +1273,8 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
     if (more_rounds) {
         // the first rounds left the verdict open: the remaining rounds, on the same lists and workspace
         return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
-                                p->d_smin, p->d_gone, p->gone_cap, p->fl_band_first, kBandRounds, p->stream);
+                                p->d_smin, p->d_gone, p->gone_cap, p->fl_band_first, kBandRounds, p->hp_gone,
+                                reinterpret_cast<uint32_t *>(p->h_pin + 64), p->h_pin + 96, p->hp_gone_cap, p->stream);
     }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
@@ -1284,7 +1285,8 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
     }
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->stream));
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
-                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, p->fl_band_first, p->stream) != 0)
+                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, p->fl_band_first, p->hp_gone,
+                         reinterpret_cast<uint32_t *>(p->h_pin + 64), p->h_pin + 96, p->hp_gone_cap, p->stream) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->stream));
     // (the control block reaches the host with the records: scan_export)
@@ -1339,9 +1341,10 @@ static int scan_export(irdm_pipeline *p)
 
 static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_t c1)
 {
-    IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[9], p->stream));
     p->fl_mode = scan_pick(p);
+    // (the band scan zeroes the chunk's finished-burst count in its first pass; the priming frames and the sequential
+    // scans append to it)
+    if (p->fl_mode != 2 || !p->host_primed) IRDM_HIP_CHECK(hipMemsetAsync(&p->d_state->n_gone, 0, sizeof(uint32_t), p->stream));
     p->fl_sparse = p->fl_mode == 1;
     p->fl_mag = mag;
     p->fl_frames = n_frames;
@@ -1369,8 +1372,8 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
         if (scan_snapshot(p) != 0) return -1;
         if (scan_legacy_enqueue(p, mag, n_frames, done, p->fl_mode == 1) != 0) return -1;
     }
-    IRDM_HIP_CHECK(hipEventRecord(p->ev[2], p->stream));
-    if (scan_export(p) != 0) return -1;
+    // (the band scan's last pass has exported its records and control block already)
+    if (!(p->fl_mode == 2 && p->fl_band_ran) && scan_export(p) != 0) return -1;
     p->fl_active = true;
     return 0;
 }

@@ -99,7 +99,7 @@ __device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, i
 }
 
 __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
-                                                                 const DetState *__restrict__ st, int round)
+                                                                 DetState *__restrict__ st, int round)
 {
     IRDM_DETECTOR_PRIO();
     __shared__ int32_t s_part[kPlanThreads];
@@ -107,6 +107,16 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
     __shared__ unsigned s_flags;
     const int tid = threadIdx.x;
     BandCtl *ctl = W.ctl;
+    if (round == 0) {
+        // a new scan: control block, abort flags and the chunk's finished-burst count start from zero (what three
+        // memset launches did before)
+        if (tid < (int)(sizeof(BandCtl) / 4)) reinterpret_cast<uint32_t *>(ctl)[tid] = 0;
+        if (tid == 0) {
+            *W.flags = 0;
+            st->n_gone = 0;
+        }
+        __syncthreads();
+    }
     if (ctl->status != 0) return;
     const int F = P.n_frames;
 
@@ -478,11 +488,20 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
     }
 }
 
+constexpr int kExportBlocks = 32;
+
 __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
-                                                           float *__restrict__ hist)
+                                                           float *__restrict__ hist, const DetState *__restrict__ st,
+                                                           const uint32_t *__restrict__ gone, int gone_cap,
+                                                           uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr,
+                                                           uint32_t *__restrict__ hp_ctl)
 {
     IRDM_DETECTOR_PRIO();
     const BandCtl *ctl = W.ctl;
+    // the scan's verdict and records go to the host whatever the verdict is (types.hpp, gone_export_body)
+    if (hp_hdr && blockIdx.x < kExportBlocks)
+        gone_export_body(st, gone, gone_cap, hp_gone, hp_hdr, reinterpret_cast<const uint32_t *>(ctl), hp_ctl,
+                         (int)(sizeof(BandCtl) / 4), kExportBlocks);
     if (ctl->status != 1 || !ctl->committed) return;
     const int k = ctl->n_upd - 1 - (int)blockIdx.x;
     if (k < 0) return;
@@ -584,7 +603,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
 // unless BandCtl::status ends as 1 (accepted); the caller reads the control block afterwards.
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
-                     float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, hipStream_t stream)
+                     float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, hipStream_t stream)
 {
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
@@ -592,10 +612,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     // round needs from the one before lives in the workspace.
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
-    if (round_begin == 0) {
-        IRDM_HIP_CHECK(hipMemsetAsync(W.ctl, 0, sizeof(BandCtl), stream));
-        IRDM_HIP_CHECK(hipMemsetAsync(W.flags, 0, 4, stream));
-    }
+    // (round 0's plan pass resets the control block, the flags and the finished-burst count)
     BandIO io;
     io.cross = W.cross;
     io.occ = W.occ;
@@ -632,7 +649,10 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             hipLaunchKernelGGL((band_walk_kernel<8>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
     }
     hipLaunchKernelGGL(band_commit_kernel, dim3(1), dim3(kPlanThreads), commit_lds, stream, P, W, st, sum, gone, gone_cap);
-    hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist);
+    static_assert(kHistory >= kExportBlocks, "the export rides on the history pass's first workgroups");
+    hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist, st,
+                       reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap,
+                       reinterpret_cast<uint32_t *>(hp_gone), hp_hdr, static_cast<uint32_t *>(hp_ctl));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

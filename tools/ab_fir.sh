@@ -5,7 +5,7 @@ run() { # name, opts...
   timeout 300 python bench.py --file-run 0 --cpu-samples 0 --detect-steps 0 --host-steps 0 --alone-steps 0 --steps 20 --warmup 5 "$@" > gpurun_out/fir/$n.json 2> gpurun_out/fir/$n.err
 }
 run a --depth 2
-run b --depth 2 --opt band_first=3
+run b --depth 2 --detect-steps 10
 run c --depth 2 --density 2
 run d --depth 1
 python - <<'PY'
