@@ -364,14 +364,12 @@ def main():
     if ingest:
         # inputs resident in HBM before the timed region: every chunk-sized slot of the history ring holds the chunk
         # (what a producer that writes in place -- an H2D copy, a conversion kernel -- leaves behind)
-        hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         ring_ptr, ring_len = pipe.ring()
         assert ring_len % n == 0, (ring_len, n)
-        for k in range(ring_len // n):
-            rc = hip.hipMemcpy(C.c_void_p(ring_ptr + k * n * bps), C.c_void_p(x.data_ptr()), n * bps, 3)
-            assert rc == 0, rc
         torch.cuda.synchronize()
+        for k in range(ring_len // n):
+            rc = irdm.lib().irdm_device_copy(C.c_void_p(ring_ptr + k * n * bps), C.c_void_p(x.data_ptr()), n * bps)
+            assert rc == 0, rc
     pending = [0]
 
     def feed_one():

@@ -239,6 +239,8 @@ void irdm_host_free(void *ptr);
 void *irdm_device_alloc(int device, size_t bytes);
 void irdm_device_free(void *dptr);
 int irdm_device_upload(void *dptr, const void *host, size_t bytes);
+/* synchronous device-to-device copy on the current device (e.g. a resident chunk into its irdm_ingest_ptr slot) */
+int irdm_device_copy(void *dst, const void *src, size_t bytes);
 
 /* Results of all chunks fed so far, in burst-emission order; each call drains up to max
  * entries.  bursts: one per emitted burst (burst_callback_t payload minus samples).

@@ -1822,6 +1822,13 @@ extern "C" int irdm_device_upload(void *dptr, const void *host, size_t bytes)
     return 0;
 }
 
+extern "C" int irdm_device_copy(void *dst, const void *src, size_t bytes)
+{
+    if ((!dst || !src) && bytes) return -1;
+    IRDM_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return 0;
+}
+
 extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples)
 {
     if (!p || (!h_iq && n_samples)) return -1;

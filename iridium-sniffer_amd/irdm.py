@@ -123,6 +123,7 @@ def lib():
         L.irdm_device_free.argtypes = [C.c_void_p]
         L.irdm_device_free.restype = None
         L.irdm_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
