@@ -483,14 +483,23 @@ struct FirW {
 };
 
 // one lane per tile: everything the decimator's workgroups need, in one record
-__global__ void fir_geom_kernel(const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles, int n_tiles, int M,
+__global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts, int n_tiles, int M,
                                 int tile_out, uint64_t ring_len, const float2 *__restrict__ rot_incr, int n_ckpt,
                                 int dec_stride, FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) *next_tile = 0;
     if (t >= n_tiles) return;
-    const FirTile tile = tiles[t];
+    // the burst whose tiles include t: the last one with tile_base <= t among those that have tiles (bursts without --
+    // dropped before the decimator -- carry the tile_base of the next one, so the LAST burst with tile_base <= t is it)
+    int lo = 0, hi = n_bursts - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (work[mid].tile_base <= t) lo = mid; else hi = mid - 1;
+    }
+    FirTile tile;
+    tile.burst = lo;
+    tile.first_out = (t - work[lo].tile_base) * tile_out;
     const BurstWork *w = work + tile.burst;
     const int o0 = tile.first_out;
     int n_out = w->dec_len - o0;
@@ -717,6 +726,9 @@ static int fir_wide_tile(int)
     return 128;
 }
 
+// 1: launch_fir_decimate() reads the FirTile list (the one-tile-per-workgroup kernels); 0: only BurstWork::tile_base
+int fir_needs_tile_list(int decim) { return fir_wide_ok(decim) ? 0 : 1; }
+
 // outputs per FirTile for the kernel launch_fir_decimate() will pick
 int fir_tile_out(int decim)
 {
@@ -771,7 +783,7 @@ static int launch_fir_w_fmt(const SampleSource &src, const FirGeom *geom, unsign
     return launch_fir_w<M, 0, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
 }
 
-int launch_fir_decimate(const SampleSource &src, const BurstWork *work, FirTile *tiles, size_t tiles_cap,
+int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream)
@@ -798,7 +810,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, FirTile 
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);      // (one spare record behind the last)
         const int to = fir_wide_tile(decim);
-        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, tiles, n_tiles, decim,
+        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
                            to, src.ring_len, rot_incr, n_ckpt, dec_stride, geom, next_tile);
         static int n_cu = 0;
         if (!n_cu) {
@@ -878,6 +890,7 @@ int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneB
 }
 
 int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream);
+int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t stream);
 
 // Device memory -> pinned host memory, 16 bytes per lane, when the stream gets there.  (Results of the per-burst chain:
 // a hipMemcpyAsync D2H is carried out by the runtime's copy path, which next to the chains' kernels answered late --
@@ -890,6 +903,35 @@ __global__ void copy_to_host_kernel(uint4 *__restrict__ dst, const uint4 *__rest
         dst[i] = src[i];
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
     __threadfence_system();
+}
+
+__global__ void copy2_to_host_kernel(uint4 *__restrict__ dst_a, const uint4 *__restrict__ src_a, size_t n_a,
+                                     uint4 *__restrict__ dst_b, const uint4 *__restrict__ src_b, size_t n_b)
+{
+    const size_t n = n_a + n_b;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n_a) dst_a[i] = src_a[i];
+        else dst_b[i - n_a] = src_b[i - n_a];
+    }
+    __threadfence_system();
+}
+
+// two ranges with one launch (both 16-byte aligned, lengths multiples of 16 bytes)
+int launch_copy2_to_host(void *dst_a, const void *src_a, size_t bytes_a, void *dst_b, const void *src_b, size_t bytes_b,
+                         hipStream_t stream)
+{
+    if (((reinterpret_cast<uintptr_t>(dst_a) | reinterpret_cast<uintptr_t>(src_a) | reinterpret_cast<uintptr_t>(dst_b) |
+          reinterpret_cast<uintptr_t>(src_b) | bytes_a | bytes_b) & 15) != 0) {
+        if (launch_copy_to_host(dst_a, src_a, bytes_a, stream) != 0) return -1;
+        return launch_copy_to_host(dst_b, src_b, bytes_b, stream);
+    }
+    const size_t n = (bytes_a + bytes_b) / 16;
+    if (!n) return 0;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, 512);
+    hipLaunchKernelGGL(copy2_to_host_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint4 *>(dst_a),
+                       static_cast<const uint4 *>(src_a), bytes_a / 16, static_cast<uint4 *>(dst_b),
+                       static_cast<const uint4 *>(src_b), bytes_b / 16);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t stream)
@@ -1022,12 +1064,23 @@ constexpr int kPostThreads = 256;
 // ---------------------------------------------------------------------------
 constexpr int kPostMaxTaps = 64;
 
+// what the host's fine-CFO step reads, stored straight into the burst's record in mapped pinned memory (system scope):
+// the helper thread is released by an event behind this kernel, no copy pass in between
+__device__ __forceinline__ void post1_publish(BurstWork &hp, const BurstWork &w)
+{
+    __hip_atomic_store(&hp.start_idx, w.start_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(&hp.center_offset), __float_as_uint(w.center_offset), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&hp.drop_reason, w.drop_reason, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+}
+
 template <int NT, int SN>
 __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     BurstWork *__restrict__ work, float2 *__restrict__ dec, int dec_stride,
     float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps_rt,
     const float *__restrict__ start_taps, int start_ntaps_rt, int search_depth, int pre_start,
-    const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096)
+    const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096, BurstWork *__restrict__ hp_work)
 {
     __shared__ __attribute__((aligned(16))) float2 s[kCfoTotal];
     __shared__ float redf[4];
@@ -1124,7 +1177,11 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
         }
     }
     if (start >= dec_len - 100) {                           // burst_downmix.c:702-705
-        if (tid == 0) { w.start_idx = start; w.drop_reason = 3; }
+        if (tid == 0) {
+            w.start_idx = start;
+            w.drop_reason = 3;
+            if (hp_work) post1_publish(hp_work[blockIdx.x], w);
+        }
         return;
     }
     const int frame_len = dec_len - start;
@@ -1160,6 +1217,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
         }
         w.start_idx = start;
         w.center_offset = ((float)idx + corr) / (float)kCfoTotal / 2.0f;
+        if (hp_work) post1_publish(hp_work[blockIdx.x], w);
     }
 }
 
@@ -1168,18 +1226,18 @@ int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of 
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_stride,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
-                         const float *cfo_window, const float2 *tw4096, hipStream_t stream)
+                         const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
     if (noise_ntaps > kPostMaxTaps || start_ntaps > kPostMaxTaps) return -1;
     if (noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic)
         hipLaunchKernelGGL((downmix_post1_kernel<25, 20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
                            dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                           pre_start, cfo_window, tw4096);
+                           pre_start, cfo_window, tw4096, hp_work);
     else
         hipLaunchKernelGGL((downmix_post1_kernel<0, 0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
                            dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                           pre_start, cfo_window, tw4096);
+                           pre_start, cfo_window, tw4096, hp_work);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1189,13 +1247,22 @@ int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_str
 // wavefronts walk 667 chains, instead of 667 workgroups each waiting for its lane 0 with 48 KB of LDS in hand.
 // The phases go to the burst's row of rrc_ws (post2 overwrites the row with the RRC output afterwards).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rot_phase_kernel(const BurstWork *__restrict__ work, int n_bursts,
-                                                       float2 *__restrict__ rrc_ws)
+__global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ work, int n_bursts,
+                                                       float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work)
 {
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_bursts) return;
-    const BurstWork &w = work[b];
+    BurstWork &w = work[b];
+    if (hp_work) {
+        // what the host's fine-CFO step left in the mapped pinned record (system-scope loads: the wait kernel in front
+        // of this one has seen the helper thread's sequence number)
+        w.incr_re = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_re), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+        w.incr_im = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_im), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+        w.simplex = __hip_atomic_load(&hp_work[b].simplex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (w.drop_reason != 0) return;
     const int frame_len = w.dec_len - w.start_idx;
     const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
@@ -1346,11 +1413,11 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
 int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
-                         float sps, float2 *rrc_ws, float2 *frames, hipStream_t stream)
+                         float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws);
+    hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work);
     if (rrc_ntaps == 51 && !g_post_generic) {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

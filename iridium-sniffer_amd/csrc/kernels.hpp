@@ -89,13 +89,16 @@ extern int g_fir_budget;          // persistent kernel: tiles per workgroup befo
 extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the other streams
 int fir_tile_out(int decim);      // outputs per FirTile of the kernel launch_fir_decimate() picks
 extern int g_fft_force_radix2;    // 1: always the radix-2 LDS FFT kernel
-int launch_fir_decimate(const SampleSource &src, const BurstWork *work, FirTile *tiles, size_t tiles_cap,
+int fir_needs_tile_list(int decim);
+int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
                         hipStream_t stream);
 int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneBurst *hp_gone, uint32_t *hp_hdr,
                        const void *ctl, void *hp_ctl, int ctl_bytes, hipStream_t stream);
 int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t stream);
+int launch_copy2_to_host(void *dst_a, const void *src_a, size_t bytes_a, void *dst_b, const void *src_b, size_t bytes_b,
+                         hipStream_t stream);
 int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream);   // bytes % 4 == 0
 int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hipStream_t stream);
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
@@ -104,11 +107,11 @@ extern int g_post_generic;        // 1: runtime-tap-count instances of post1 / p
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_stride,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
-                         const float *cfo_window, const float2 *tw4096, hipStream_t stream);
+                         const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream);
 int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
-                         float sps, float2 *rrc_ws, float2 *frames, hipStream_t stream);
+                         float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, hipStream_t stream);
 
 // demod.hip
 int launch_ida_decode(const DemodOut *frames, int n_frames, const int2 *syn_da, const int2 *syn_l1, const int2 *syn_l2,

@@ -980,9 +980,11 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             w.dec_len = n_out;
             if (n_out < 100) w.drop_reason = 2;                          // burst_downmix.c:677
         }
+        w.tile_base = (int32_t)n_tiles;
         if (!w.drop_reason) n_tiles += (size_t)(w.dec_len + tile_out - 1) / tile_out;
     }
     if (p->detect_only || nb == 0) return 0;      // stage A alone: burst records, no downmix / demod
+    const bool tile_list = fir_needs_tile_list(p->decim) != 0;
     if (n_tiles > b.tiles_cap) {
         (void)hipFree(b.d_tiles);
         if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
@@ -994,31 +996,32 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) != hipSuccess)
             return -1;
     }
-    n_tiles = 0;
-    for (int i = 0; i < nb; i++) {
-        const BurstWork &w = b.hp_work[i];
-        if (!w.drop_reason)
-            for (int o = 0; o < w.dec_len; o += tile_out) b.hp_tiles[n_tiles++] = FirTile{ i, o };
+    if (tile_list) {
+        n_tiles = 0;
+        for (int i = 0; i < nb; i++) {
+            const BurstWork &w = b.hp_work[i];
+            if (!w.drop_reason)
+                for (int o = 0; o < w.dec_len; o += tile_out) b.hp_tiles[n_tiles++] = FirTile{ i, o };
+        }
     }
     hipStream_t st = b.stream;
     IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));
     // (copies by kernel, here and at the end of the chain: the runtime's copy path answers late next to the chains'
     // kernels, and an H2D from pinned memory may block the enqueueing thread)
     if (launch_copy_words(b.d_work, b.hp_work_dev, sizeof(BurstWork) * nb, st) != 0) return -1;
-    if (n_tiles && launch_copy_words(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, st) != 0) return -1;
+    if (tile_list && n_tiles && launch_copy_words(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
-    if (launch_fir_decimate(src, b.d_work, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
+    if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
                             p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
     if (launch_downmix_post1(b.d_work, nb, b.d_dec, p->dec_stride, b.d_lpf, p->d_noise_taps,
                              p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
-                             p->pre_start, p->d_cfo_window, p->d_tw4096, st) != 0)
+                             p->pre_start, p->d_cfo_window, p->d_tw4096, b.hp_work_dev, st) != 0)
         return -1;
-    // host libm step, ordered on the stream: work records down (mapped pinned buffer), helper thread, records up.
-    // (Copies by kernel: they move the data when the stream gets there, not when they are enqueued, and with
-    // system-scope accesses.)
-    if (launch_copy_words(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, st) != 0) return -1;
+    // host libm step, ordered on the stream: post1 has stored what the step reads into the burst's record in the mapped
+    // pinned buffer (system scope), the helper thread runs behind this event and publishes a sequence number, a one-lane
+    // kernel waits for it, and rot_phase_kernel picks the step's results up from the same records.
     IRDM_HIP_CHECK(hipEventRecord(b.ev_cfo, st));
     b.cfo_seq++;
     {
@@ -1027,16 +1030,14 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     }
     p->cfo_cv.notify_one();
     if (launch_wait_host_flag(b.hp_flag_dev, b.cfo_seq, b.hp_flag_dev + 1, st) != 0) return -1;
-    if (launch_copy_words(b.d_work, b.hp_work_dev, sizeof(BurstWork) * nb, st) != 0) return -1;
     if (launch_downmix_post2(b.d_work, nb, b.d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
                              p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
-                             b.d_rrc_ws, b.d_frames, st) != 0)
+                             b.d_rrc_ws, b.d_frames, b.hp_work_dev, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[2], st));
     if (launch_demod(b.d_work, nb, b.d_frames, p->cfg.use_gardner, p->sps, b.d_demod_ws, b.d_demod, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[3], st));
-    if (launch_copy_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, st) != 0) return -1;
     if (p->decode_frames) {
         // post-demod bit layer on the demodulator's device-resident output (frames that failed the unique word
         // have ok = 0 and decode to FRAME_UNKNOWN)
@@ -1048,7 +1049,10 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
                               b.d_ida, st) != 0)
             return -1;
     }
-    if (launch_copy_to_host(b.hp_demod, b.d_demod, sizeof(DemodOut) * nb, st) != 0) return -1;
+    // the chain's results: work records and demodulator output, one launch
+    if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_demod, b.d_demod, sizeof(DemodOut) * nb,
+                             st) != 0)
+        return -1;
     return 0;
 }
 

@@ -125,7 +125,9 @@ struct BurstWork {
     float incr_re, incr_im;  // cexpf(-2 pi center_offset i), host libm
     int32_t direction, uw_start, num_samples, drop_reason;
     float uw_corr, corr_re, corr_im;
+    int32_t tile_base;       // index of the burst's first decimator tile (host; the persistent decimator's geometry pass)
 };
+static_assert(sizeof(BurstWork) == 80, "BurstWork is mirrored word by word between device and pinned host memory");
 
 struct DemodOut {
     int32_t ok, direction, confidence, n_symbols;
