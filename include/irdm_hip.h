@@ -318,11 +318,18 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  * "detect_only" (0/1, default 0: 1 = stage A alone, burst_detector_feed's role: only burst records are produced --
  * irdm_poll_bursts, irdm_burst_samples; no downmix / demodulation),
  * "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
- * "scan_mode" (0 = sparse detector scan with exact dense fallback -- multi-CU form (one leader workgroup + "scan_updaters"
- *   baseline-update workgroups) on devices with >= 64 CUs, single-CU form otherwise; 1 = dense scan only; 2 = sparse,
- *   single-CU form; 3 = sparse, multi-CU form),
- * "scan_updaters" (1..32, default 7: updater workgroups of the multi-CU sparse scan).
- * Stats: "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames". */
+ * "scan_mode" (0 = band-parallel speculative scan (scan_band.hip) where the FFT size supports it, with the sequential
+ *   scans as its exact fallback -- default; 1 = dense sequential scan only; 2 / 3 = round 1's sparse leader scan on one
+ *   CU / with "scan_updaters" baseline-update workgroups, dense fallback; 4 = band scan with the dense scan as fallback),
+ * "scan_updaters" (1..32, default 7: updater workgroups of the multi-CU sparse scan),
+ * "k1_lists" (default 1: the FFT kernel writes the band scan's candidate lists; 0 = a prefilter pass does),
+ * "k1_first" (default 1: a per-burst chain is enqueued behind the FFT of the newest chunk),
+ * "band_first" (default 0 = as many band-scan rounds up front as the previous chunk needed; n = always n; test hook),
+ * kernel-variant switches for A/B runs and tests: "fir_layout" (2 persistent decimator -- default, 1 / 0 one tile per
+ *   workgroup, column-major / polyphase rows), "fir_budget" (tiles per workgroup of the persistent decimator, default 4),
+ *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof".
+ * Stats (irdm_get_stat): "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks", "band_rounds",
+ * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "host_us_0".."host_us_9". */
 int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);
 int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);
 
