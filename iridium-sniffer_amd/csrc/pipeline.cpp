@@ -1838,6 +1838,12 @@ extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_sam
     if (!p || (!h_iq && n_samples)) return -1;
     if (n_samples > p->max_chunk) return -1;
     (void)hipSetDevice(p->cfg.device);
+    // throughput mode: the H2D copy lands in the chunk's slot of the history ring and the chunk is fed in place (no staging
+    // buffer, no device-to-device copy behind K1)
+    if (void *slot = irdm_ingest_ptr(p, n_samples)) {
+        IRDM_HIP_CHECK(hipMemcpyAsync(slot, h_iq, n_samples * p->bps, hipMemcpyHostToDevice, p->fstream));
+        return irdm_feed_device(p, slot, n_samples, p->fstream);
+    }
     if (!p->d_stage) {
         if (hipMalloc(&p->d_stage, p->max_chunk * p->bps) != hipSuccess) return -1;
     }
