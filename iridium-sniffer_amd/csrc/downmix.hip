@@ -533,6 +533,8 @@ __device__ unsigned long long g_fir_prof_dev[8];
         }                                                                        \
     } while (0)
 
+#include "fir_mac.inc"
+
 template <int M, int FMT, int TO, bool PROF = false>
 __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_w(
     SampleSource src, const FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile, int n_tiles, int budget,
@@ -637,41 +639,36 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         FIR_PROF_MARK(3);
 
         if (tid < g.n_out) {
-            float ar = 0.0f, ai = 0.0f;
             const unsigned char *col = s + (size_t)tid * CS;
-            float4 va[T / 2], vb[T / 2];
-            float ta[T], tb[T];
-            auto issue = [&](int st, float4 (&v)[T / 2], float (&tt)[T]) {
-                const float4 *c4 = reinterpret_cast<const float4 *>(col + (size_t)(st / SPR) * CS + (size_t)(st % SPR) * (T * 8));
+            // the multiply-add groups are inline asm (fir_mac.inc): taps straight from SGPR pairs, products one tap ahead
+            v2f acc = { 0.0f, 0.0f };
+            v4f va[T / 2], vb[T / 2];
+            uint64_t ta[T / 2], tb[T / 2];
+            const uint64_t *taps64 = reinterpret_cast<const uint64_t *>(taps);      // (T is even: pairs never straddle a step)
+            auto issue = [&](int st, v4f (&v)[T / 2], uint64_t (&tt)[T / 2]) {
+                const v4f *c4 = reinterpret_cast<const v4f *>(col + (size_t)(st / SPR) * CS + (size_t)(st % SPR) * (T * 8));
 #pragma unroll
                 for (int q = 0; q < T / 2; q++) v[q] = c4[q];
 #pragma unroll
-                for (int q = 0; q < T; q++) tt[q] = taps[st * T + q];
-            };
-            // taps [q0, q1) of a step
-            auto mac = [&](const float4 (&v)[T / 2], const float (&tt)[T], int q0, int q1) {
-#pragma unroll
-                for (int q = q0; q < q1; q += 2) {
-                    ar += tt[q] * v[q / 2].x;     ai += tt[q] * v[q / 2].y;
-                    ar += tt[q + 1] * v[q / 2].z; ai += tt[q + 1] * v[q / 2].w;
-                }
+                for (int q = 0; q < T / 2; q++) tt[q] = taps64[(st * T) / 2 + q];
             };
             issue(0, va, ta);
 #pragma unroll 1
             for (int st = 0; st < NS; st += 2) {
-                // the first multiply of a step comes before the next step's requests: whatever the step waits for
-                // was requested a whole step ago (scalar loads return out of order, so the wait is for everything)
-                mac(va, ta, 0, 2);
+                // the first tap pair of a step comes before the next step's requests: whatever the step waits for was
+                // requested a whole step ago (scalar loads return out of order, so the wait is for everything)
+                fir_mac<1>(acc, va, ta);
                 __builtin_amdgcn_sched_barrier(0);
                 issue(st + 1, vb, tb);
                 __builtin_amdgcn_sched_barrier(0);
-                mac(va, ta, 2, T);
-                mac(vb, tb, 0, 2);
+                fir_mac<T / 2 - 1>(acc, va + 1, ta + 1);
+                fir_mac<1>(acc, vb, tb);
                 __builtin_amdgcn_sched_barrier(0);
                 issue(st + 2 < NS ? st + 2 : 0, va, ta);       // (the last round's request is not used)
                 __builtin_amdgcn_sched_barrier(0);
-                mac(vb, tb, 2, T);
+                fir_mac<T / 2 - 1>(acc, vb + 1, tb + 1);
             }
+            float ar = acc.x, ai = acc.y;
             {
                 const float2 *c2 = reinterpret_cast<const float2 *>(col + (size_t)NR * CS);
 #pragma unroll
