@@ -5,14 +5,20 @@
 
 One "step" = one pass of the whole hot path (K1..K7) over one chunk of
 synthetic 10 MHz cf32 IQ that is already resident in HBM (complex
-AWGN + 10 DQPSK bursts per Msample).  Every rank processes its own stream (the path
+AWGN + 10 DQPSK bursts per Msample) -- by default in the chunk's slot of the context's
+history ring (irdm_ingest_ptr: where a producer that feeds in place writes it; every slot
+is filled before the timed region), fed with one chunk of look-ahead at pipeline_depth 2;
+the drain of the last chunks' per-burst chains is inside the timed region.  Every rank
+processes its own stream (the path
 partitions by stream / time-chunk, no data-path collective); per step the demodulated
 frame records are gathered to rank 0 over RCCL.  `value` = samples all ranks processed
 / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline       dominant kernel (largest mean HIP-event time per step, measured inside the timed
-                 region, i.e. with the other stages of neighbouring chunks running beside it):
+  roofline       dominant KERNEL (the decimator, or K1 on scenes with few bursts; the detector scan is a
+                 chain of ~11 short launches and is reported under stage_ms only) by mean HIP-event time
+                 per step on its own stream, measured inside the timed region, i.e. with the other
+                 stages of neighbouring chunks running beside it:
                  achieved = algorithmic bytes per launch / mean launch duration, vs the 8 TB/s HBM peak.
                  stage_ms_alone = the same stages from a few extra steps at pipeline_depth 0 (one
                  kernel on the chip at a time).
