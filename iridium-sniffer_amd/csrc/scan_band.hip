@@ -39,7 +39,7 @@ namespace irdm {
 
 namespace {
 
-constexpr int kPlanThreads = 1024;
+constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
 constexpr int kSumDepth = 16;             // update steps per batch of the sums pass (two batches of loads in flight)
 
 // exclusive scan of in[0..len) into out[0..len), total returned to every thread; one workgroup, kPlanThreads threads
@@ -396,9 +396,8 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
     }
     __syncthreads();
     // the bands' own bursts (16 threads per band, only over the records that exist)
-    {
-        const int band = tid >> 4;
-        if (band < P.n_bands) {
+    for (int band = tid >> 4; band < P.n_bands; band += kPlanThreads / 16) {
+        {
             const int cnt = min((int)W.rec_count[band], kBandRecCap);
             for (int j = tid & 15; j < cnt; j += 16) {
                 const int i = band * kBandRecCap + j;
