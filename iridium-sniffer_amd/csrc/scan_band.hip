@@ -40,7 +40,7 @@ namespace irdm {
 namespace {
 
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
-constexpr int kSumDepth = 16;             // update steps per batch of the sums pass (two batches of loads in flight)
+constexpr int kSumDepth = 32;             // update steps per batch of the sums pass (two batches of loads in flight)
 
 // exclusive scan of in[0..len) into out[0..len), total returned to every thread; one workgroup, kPlanThreads threads
 // (each thread a contiguous run; wave scans on the shuffle network, the 16 wave totals through LDS)
