@@ -10,29 +10,9 @@
 #include "common.hpp"
 #include "types.hpp"
 #include "kernels.hpp"
+#include "burst_src.hpp"
 
 namespace irdm {
-
-// ---- burst window sample access (ringbuf_extract, burst_detect.c:401-422) ----
-// Samples at absolute index >= avail_end had not been written when the reference
-// extracted the burst: it read whatever the ring slot held, i.e. the sample one
-// ring length earlier (or the zero page before the ring first wrapped).
-__device__ __forceinline__ float2 load_abs(const SampleSource &src, uint64_t a)
-{
-    if (a >= src.chunk_start) return load_iq(src.fmt, src.chunk, (size_t)(a - src.chunk_start));
-    return load_iq(src.fmt, src.ring, (size_t)(a % src.ring_len));
-}
-
-__device__ __forceinline__ float2 burst_sample(const SampleSource &src, uint64_t start,
-                                               uint64_t avail_end, int k)
-{
-    uint64_t a = start + (uint64_t)k;
-    if (a >= avail_end) {
-        if (a < src.ref_ring) return make_float2(0.0f, 0.0f);
-        a -= src.ref_ring;
-    }
-    return load_abs(src, a);
-}
 
 // 16 consecutive samples (one rotator segment, 16-sample aligned) with the widest loads the format allows, converted
 // exactly as load_iq does
@@ -484,7 +464,7 @@ struct FirW {
 
 // one lane per tile: everything the decimator's workgroups need, in one record
 __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts, int n_tiles, int M,
-                                int tile_out, uint64_t ring_len, const float2 *__restrict__ rot_incr, int n_ckpt,
+                                int tile_out, uint64_t ring_len, uint64_t ref_ring, const float2 *__restrict__ rot_incr, int n_ckpt,
                                 int dec_stride, FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -519,7 +499,8 @@ __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts
     g.inc_im = inc.y;
     g.ck_index = (uint64_t)cb * (uint64_t)n_ckpt + (uint64_t)(g.s0 / kRotSeg);
     g.out_base = (int64_t)tile.burst * dec_stride + o0;
-    for (int i = 0; i < 6; i++) g.pad[i] = 0;
+    g.stale_pos = (g.ring_pos + ring_len - ref_ring % ring_len) % ring_len;
+    for (int i = 0; i < 4; i++) g.pad[i] = 0;
     geom[t] = g;
 }
 
@@ -697,7 +678,8 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 int g_fir_force_generic = 0;   // test hook: 1 = always use the runtime-M kernel
-int g_fir_layout = 2;          // 2: persistent column-major kernel (fir_decimate_kernel_w), 1: column-major, one tile per
+int g_fir_layout = 3;          // 3: register-resident columns, travelling accumulators (fir_reg.hip; M = 40 / 48, else 2),
+                               // 2: persistent column-major LDS kernel (fir_decimate_kernel_w), 1: column-major, one tile per
                                // workgroup (fir_decimate_kernel_c), 0: polyphase rows (fir_decimate_kernel_m)
 int g_fir_prof = 0;
 
@@ -711,9 +693,16 @@ int fir_tile_row(int decim)
 int g_fir_reserve_cus = 0;     // persistent kernel: CUs left to the other streams' kernels
 int g_fir_budget = 4;          // persistent kernel: tiles per workgroup before it retires (0: one resident grid)
 
-static bool fir_wide_ok(int decim)
+// `aligned`: the pipeline's ring lengths are multiples of 8 samples (fir_reg.hip fetches columns in pieces of 8)
+static bool fir_reg_ok(int decim, int aligned)
 {
-    return !g_fir_force_generic && g_fir_layout == 2 && (decim == 8 || decim == 16 || decim == 40 || decim == 48);
+    return !g_fir_force_generic && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
+}
+
+static bool fir_wide_ok(int decim, int aligned)
+{
+    return !g_fir_force_generic && (g_fir_layout == 2 || (g_fir_layout == 3 && !fir_reg_ok(decim, aligned))) &&
+           (decim == 8 || decim == 16 || decim == 40 || decim == 48);
 }
 
 static int fir_wide_tile(int)
@@ -724,12 +713,13 @@ static int fir_wide_tile(int)
 }
 
 // 1: launch_fir_decimate() reads the FirTile list (the one-tile-per-workgroup kernels); 0: only BurstWork::tile_base
-int fir_needs_tile_list(int decim) { return fir_wide_ok(decim) ? 0 : 1; }
+int fir_needs_tile_list(int decim, int aligned) { return fir_wide_ok(decim, aligned) || fir_reg_ok(decim, aligned) ? 0 : 1; }
 
 // outputs per FirTile for the kernel launch_fir_decimate() will pick
-int fir_tile_out(int decim)
+int fir_tile_out(int decim, int aligned)
 {
-    return fir_wide_ok(decim) ? fir_wide_tile(decim) : kFirTileOut;
+    if (fir_reg_ok(decim, aligned)) return fir_reg_tile_out(decim);
+    return fir_wide_ok(decim, aligned) ? fir_wide_tile(decim) : kFirTileOut;
 }
 
 template <int M, int FMT, int TO>
@@ -803,12 +793,20 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
                            work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
-    if (fir_wide_ok(decim) && tiles_cap >= (size_t)n_tiles) {
+    const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0;
+    if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
+        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
+        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
+        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
+                           fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+        return launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream) == 0 ? 0 : -1;
+    }
+    if (fir_wide_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);      // (one spare record behind the last)
         const int to = fir_wide_tile(decim);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           to, src.ring_len, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+                           to, src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;

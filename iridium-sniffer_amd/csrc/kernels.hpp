@@ -87,9 +87,16 @@ extern int g_fir_layout;          // 2 (default): persistent column-major kernel
 extern int g_fir_prof;            // 1: time the persistent decimator's phases (debug)
 extern int g_fir_budget;          // persistent kernel: tiles per workgroup before it retires
 extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the other streams
-int fir_tile_out(int decim);      // outputs per FirTile of the kernel launch_fir_decimate() picks
+// fir_reg.hip: the register-resident decimator (M = 40, 48)
+extern int g_fir_strip;           // double blocks of 128 columns per strip
+int fir_reg_supported(int decim);
+int fir_reg_tile_out(int decim);
+int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
+                   const float2 *rot_table, float2 *dec, hipStream_t stream);   // 0 ok, -1 error, 1 not applicable
+int fir_tile_out(int decim, int aligned);   // outputs per FirTile of the kernel launch_fir_decimate() picks (aligned:
+                                  // ring_len and ref_ring are multiples of 8 samples)
 extern int g_fft_force_radix2;    // 1: always the radix-2 LDS FFT kernel
-int fir_needs_tile_list(int decim);
+int fir_needs_tile_list(int decim, int aligned);
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,

@@ -943,7 +943,8 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     b.n = nb;
     b.recs.assign(nb, irdm_burst_t());
     size_t n_tiles = 0;
-    const int tile_out = fir_tile_out(p->decim);
+    const int fir_aligned = p->ring_len % 8 == 0 && p->ref_ring % 8 == 0;
+    const int tile_out = fir_tile_out(p->decim, fir_aligned);
     for (int i = 0; i < nb; i++) {
         const GoneBurst &g = gone_list[i];
         irdm_burst_t &r = b.recs[i];
@@ -984,7 +985,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         if (!w.drop_reason) n_tiles += (size_t)(w.dec_len + tile_out - 1) / tile_out;
     }
     if (p->detect_only || nb == 0) return 0;      // stage A alone: burst records, no downmix / demod
-    const bool tile_list = fir_needs_tile_list(p->decim) != 0;
+    const bool tile_list = fir_needs_tile_list(p->decim, fir_aligned) != 0;
     if (n_tiles > b.tiles_cap) {
         (void)hipFree(b.d_tiles);
         if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
@@ -2258,6 +2259,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_first")) { p->band_first = value < 0 ? 0 : value > kBandRounds ? kBandRounds : value; return 0; }
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
+    if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
     return -1;

@@ -106,7 +106,8 @@ struct FirGeom {
     float inc_re, inc_im;    // rotator increment of the burst's centre bin
     int32_t s0, span, n_seg, n_out;
     int64_t out_base;        // index of the tile's first output in dec[]
-    int32_t pad[6];
+    uint64_t stale_pos;      // (a_tile - reference ring length) mod ring_len: where the tile's stale samples start
+    int32_t pad[4];
 };
 static_assert(sizeof(FirGeom) == 96, "FirGeom is read with scalar loads");
 // device tile lists are allocated with room for the FirGeom records behind the FirTile array

@@ -181,8 +181,8 @@ def test_kernel_variants_agree():
     grid / the smallest tile budget give the same records as the default kernels and the oracle."""
     fs, iq = _scene_2m(seed=19, n_bursts=6, secs=2.0)
     ref = orc.run_stream(iq, fs)
-    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 2, "fir_budget": 4, "post_generic": 0}
-    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"fir_layout": 0}, {"fir_layout": 1}, {"fir_budget": 0}, {"fir_budget": 2},
+    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0}
+    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"fir_layout": 0}, {"fir_layout": 1}, {"fir_layout": 2}, {"fir_budget": 0}, {"fir_budget": 2},
                  {"post_generic": 1}):
         p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)
         p.set_option("keep_frame_samples", 1)
