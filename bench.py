@@ -258,6 +258,9 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                          "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
             "cpu_baseline": None,
         }
+        if world > 1 and not (out["config"]["records"]["produced"] == out["config"]["records"]["sent"] ==
+                              out["config"]["records"]["gathered_on_rank0"]):
+            raise SystemExit("bench: record gather lost frames: %r" % (out["config"]["records"],))
         print(json.dumps(out), flush=True)
     pipe.close()
 
@@ -342,21 +345,52 @@ def main():
     elif args.format == "ci8":      # siggen.to_ci8 with headroom for the burst peaks
         x = torch.clamp(torch.round(x * 512.0 * 4), -128, 127).to(torch.int8)
     torch.cuda.synchronize()
-    pipe = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192,
+    pipe = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192,      # (= MAX_BURSTS below)
                          device=local, pipeline_depth=args.depth)
     pipe.L.irdm_feed_device.restype = C.c_int
     for kv in args.opt:
         key, val = kv.split("=")
         pipe.set_option(key, int(val))
     stream = None        # the chunk is complete in HBM before the timed region: nothing to order against
-    REC = C.sizeof(irdm.Demod)
-    cap = 2048
-    # record gather to rank 0 (RCCL over xGMI): fixed-size padded buffers, double-buffered and asynchronous so the
-    # collective of step i overlaps the detector scan of step i+1
-    gather_bufs = [torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) for _ in range(2)] if world > 1 else None
-    gather_lists = ([[torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
+    # record gather to rank 0 (RCCL over xGMI): what frame_output_print needs of a demodulated frame (frame_output.c:
+    # 168-197) -- the record's head (id, timestamp, frequency, magnitude, noise, confidence, level, symbol counts) and
+    # the hard bits packed 8 per byte: 176 bytes per frame, a count word in front.  Fixed-size messages sized for the
+    # context's max_bursts_per_chunk (a step with more frames than that is an error, never a silent truncation),
+    # double-buffered and asynchronous so the collective of step i overlaps the detector scan of step i+1.
+    MAX_BURSTS = 8192
+    HEAD = irdm.Demod.bits.offset
+    NBITS = irdm.Demod.bits.size
+    RECP = HEAD + NBITS // 8
+    cap = MAX_BURSTS
+    MSG = 8 + cap * RECP
+    gather_host = [torch.zeros((MSG,), dtype=torch.uint8).pin_memory() for _ in range(2)] if world > 1 else None
+    gather_bufs = [torch.zeros((MSG,), dtype=torch.uint8, device=cdev) for _ in range(2)] if world > 1 else None
+    gather_lists = ([[torch.zeros((MSG,), dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
                     if (world > 1 and rank == 0) else [None, None])
     gather_work = [None, None]
+    gathered = torch.zeros((1,), dtype=torch.int64, device=cdev)        # rank 0: records received, from the count words
+
+    def gather_wait(slot):
+        if gather_work[slot] is None:
+            return
+        gather_work[slot].wait()
+        gather_work[slot] = None
+        if rank == 0:
+            gathered.add_(torch.stack([l[:8] for l in gather_lists[slot]]).view(torch.int64).sum())
+
+    def gather_send(slot, demods):
+        k = len(demods)
+        if k > cap:
+            raise SystemExit("bench: %d demodulated frames in one step exceed the gather message (%d)" % (k, cap))
+        hb = gather_host[slot].numpy()
+        hb[:8] = np.array([k], dtype=np.int64).view(np.uint8)
+        if k:
+            rec = hb[8:8 + k * RECP].reshape(k, RECP)
+            rec[:, :HEAD] = demods[:, :HEAD]
+            rec[:, HEAD:] = np.packbits(demods[:, HEAD:HEAD + NBITS], axis=1)
+        gather_bufs[slot].copy_(gather_host[slot], non_blocking=True)
+        gather_work[slot] = dist.gather(gather_bufs[slot], gather_lists[slot], dst=0, async_op=True)
+        return k
     step_no = [0]
     counts = torch.zeros((3,), dtype=torch.int64, device=cdev)
 
@@ -411,12 +445,8 @@ def main():
         if world > 1:
             slot = step_no[0] & 1
             step_no[0] += 1
-            if gather_work[slot] is not None:
-                gather_work[slot].wait()
-            k = min(len(demods), cap)
-            if k:
-                gather_bufs[slot][:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(cdev, non_blocking=True)
-            gather_work[slot] = dist.gather(gather_bufs[slot], gather_lists[slot], dst=0, async_op=True)
+            gather_wait(slot)
+            k = gather_send(slot, demods)
             if record:
                 counts[0] += nb_step
                 counts[1] += len(demods)
@@ -437,6 +467,9 @@ def main():
         pipe.flush()
         pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
     if world > 1:
+        for slot in (0, 1):
+            gather_wait(slot)
+        gathered.zero_()
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -454,12 +487,15 @@ def main():
         if world > 1:
             counts[0] += len(tb_)
             counts[1] += len(tail)
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            gather_wait(slot)
+            counts[2] += gather_send(slot, tail)
         ns_off = irdm.Burst.num_samples.offset
         totals["burst_samples"] += int(tb_[:, ns_off:ns_off + 8].copy().view(np.uint64).sum()) if len(tb_) else 0
     if world > 1:
-        for w in gather_work:
-            if w is not None:
-                w.wait()
+        for slot in (0, 1):
+            gather_wait(slot)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)      # whole-job burst / record counts
     torch.cuda.synchronize()
     if world > 1:
@@ -686,8 +722,11 @@ def main():
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
                        "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": look,
+                       "records": ({"produced": int(counts[1].item()), "sent": int(counts[2].item()),
+                                    "gathered_on_rank0": int(gathered.item())} if world > 1 else None),
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
-                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists")},
+                                                          "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists",
+                                                          "scan_chained", "scan_chain_undone")},
                        "host_us_total": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(
                            ("k1_ring_enqueue", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync",
                             "settle_wait_scan", "settle_counters", "settle_records", "build_records"))}},

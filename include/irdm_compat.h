@@ -82,6 +82,9 @@ burst_detector_t *burst_detector_create(burst_config_t *config);
 void burst_detector_feed(burst_detector_t *det, const int8_t *iq, size_t num_samples, burst_callback_t cb, void *user);
 void burst_detector_feed_cf32(burst_detector_t *det, const float *iq, size_t num_samples, burst_callback_t cb, void *user);
 uint64_t burst_detector_total_count(burst_detector_t *det);
+int burst_detector_active_count(burst_detector_t *det);       /* burst_detect.h:82; values as of the end of the last feed */
+float burst_detector_noise_floor(burst_detector_t *det);      /* burst_detect.h:88 */
+float burst_detector_peak_signal(burst_detector_t *det);      /* burst_detect.h:91 */
 void burst_detector_destroy(burst_detector_t *det);
 
 typedef enum {                  /* burst_downmix.h:24-28 */

@@ -254,10 +254,23 @@ int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max);
 uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p);
 uint64_t irdm_sample_count(const irdm_pipeline_t *p);
 int irdm_fft_size(const irdm_pipeline_t *p);
+int irdm_set_stream_origin(irdm_pipeline_t *p, double center_frequency, uint64_t start_time_ns);  /* for the stage-level calls */
 uint64_t irdm_start_time_ns(const irdm_pipeline_t *p);   /* burst_data_t.start_time_ns (burst_detect.c:849-853) */
 
 /* Stage probes (parity tests): magnitudes of the last chunk (frames x fft_size floats,
  * device -> host copy), current baseline sum. */
+/* What the reference's stats thread asks the detector (main.c:455-456): burst_detector_active_count / _noise_floor /
+ * _peak_signal (burst_detect.c:355-395).  Settles the scan in flight and reads the detector state back (a few tens of
+ * KB): call it from the feeding thread, at most once per feed.  peak_signal_db covers the bursts finished or still
+ * active; bursts a squelch dumped (burst_detect.c:594-631) were seen by the reference's running maximum only. */
+typedef struct {
+    int32_t active_bursts;
+    int32_t primed;
+    float noise_floor_dbfs_hz;
+    float peak_signal_db;
+} irdm_detector_stats_t;
+int irdm_detector_stats(irdm_pipeline_t *p, irdm_detector_stats_t *out);
+
 int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_frames);
 int irdm_baseline_sum(irdm_pipeline_t *p, float *out);
 /* burst_data_t.samples of the i-th burst emitted by the LAST chunk (re-gathered) */
@@ -356,6 +369,11 @@ long long irdm_format_raw_batch(const irdm_demod_t *f, int n, const char *file_i
  * samples: 2 * info->num_samples floats as returned by irdm_poll_frames with "keep_frame_samples" = 1.
  * Returns 0, or -1 (no frame / I/O error, message on stderr as the reference prints). */
 int irdm_save_burst(const irdm_frame_info_t *info, const float *samples, const char *dir);
+
+/* The fine-CFO step's cexpf(i x) (burst_downmix.c:716-717) as the device evaluates it -- glibc's sincosf restated,
+ * csrc/libm_port.hpp -- for n arbitrary arguments (test / audit surface: tests/test_gpu_libm.py,
+ * tools/check_sincosf_gpu.c compare it with the host's libm).  0 ok, -1 error; NaN where |x| >= 120. */
+int irdm_sincosf_probe(int device, const float *x, size_t n, float *re, float *im);
 
 const char *irdm_version(void);
 

@@ -46,6 +46,8 @@ enum : uint32_t {
     BAND_F_TOTAL = 128,      // more records than kBandMaxTotal
     BAND_F_GONECAP = 256,    // more finished bursts than the caller's record buffer holds
     BAND_F_SNAP = 512,       // more sum snapshots than the buffer holds
+    BAND_F_CHAIN = 2048,     // a chained launch found that the scan in front of it had not committed (it wrote nothing)
+    BAND_F_COOP = 1024,      // the cooperative kernel's grid barrier timed out (not every workgroup became resident)
 };
 
 struct BandParams {
@@ -58,6 +60,9 @@ struct BandParams {
     int32_t list_cap;            // entries per frame in the prefilter lists
     float thr;
     uint64_t idx0;               // absolute sample index of frame 0
+    int32_t serial = 0;          // launch number: a launch that finds itself void (below) marks BandWork::bar[5] with it
+    int32_t chained = 0;         // 1: enqueued behind a band scan whose verdict the host had not seen: valid only if that
+                                 // scan committed (BandWork::bar[4]), else every pass of this launch returns untouched
 };
 
 struct BandRec {

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -88,6 +89,11 @@ struct _burst_detector {
     std::vector<unsigned char> stage;   // input not yet making up a whole block
     uint64_t start_time_ns;
     uint64_t total;
+    burst_callback_t last_cb;           // the callback of the last feed: the tail of the stream is delivered through it
+    void *last_user;
+    // what main.c's stats thread reads while the detector thread feeds (main.c:455-456): refreshed after every feed
+    std::atomic<int> active;
+    std::atomic<float> noise_floor, peak_signal;
 };
 
 extern "C" _burst_detector *burst_detector_create(burst_config_t *config)
@@ -110,6 +116,11 @@ extern "C" _burst_detector *burst_detector_create(burst_config_t *config)
     d->fmt = -1;
     d->start_time_ns = 0;
     d->total = 0;
+    d->last_cb = nullptr;
+    d->last_user = nullptr;
+    d->active = 0;
+    d->noise_floor = 0.0f;             // burst_detect.c:364-365: no baseline yet
+    d->peak_signal = 0.0f;
     return d;
 }
 
@@ -134,6 +145,40 @@ static int detector_open(_burst_detector *d, int fmt)
     return 0;
 }
 
+// the bursts a feed finished -> malloc'd burst_data_t through the callback (ownership passes, burst_detect.h:69-71)
+static void detector_emit(_burst_detector *d, int emitted, burst_callback_t cb, void *user)
+{
+    std::vector<irdm_burst_t> recs((size_t)(emitted > 0 ? emitted : 0));
+    const int got = emitted > 0 ? irdm_poll_bursts(d->p, recs.data(), emitted) : 0;
+    for (int i = 0; i < got; i++) {
+        const irdm_burst_t &r = recs[i];
+        burst_data_t *b = static_cast<burst_data_t *>(malloc(sizeof(burst_data_t)));
+        float *s = static_cast<float *>(malloc(sizeof(float) * 2 * (size_t)r.num_samples));
+        if (!b || !s || irdm_burst_samples(d->p, i, s, (size_t)r.num_samples) != (int)r.num_samples) {
+            free(b);
+            free(s);
+            continue;
+        }
+        b->info.id = r.id; b->info.start = r.start; b->info.stop = r.stop; b->info.last_active = r.last_active;
+        b->info.center_bin = r.center_bin; b->info.magnitude = r.magnitude; b->info.noise = r.noise;
+        b->center_frequency = d->cfg.center_frequency;
+        b->sample_rate = d->cfg.sample_rate;
+        b->fft_size = irdm_fft_size(d->p);
+        b->start_time_ns = irdm_start_time_ns(d->p);
+        b->num_samples = (size_t)r.num_samples;
+        b->samples = s;
+        d->total++;
+        if (cb) cb(b, user);                   // ownership of b and b->samples passes to the callee
+        else { free(s); free(b); }
+    }
+    irdm_detector_stats_t st;
+    if (irdm_detector_stats(d->p, &st) == 0) {
+        d->active = st.active_bursts;
+        d->noise_floor = st.noise_floor_dbfs_hz;
+        d->peak_signal = st.peak_signal_db;
+    }
+}
+
 static void detector_feed(_burst_detector *d, const void *iq, size_t num_samples, int fmt, burst_callback_t cb, void *user)
 {
     if (!d || !iq || !num_samples) return;
@@ -145,6 +190,8 @@ static void detector_feed(_burst_detector *d, const void *iq, size_t num_samples
         fprintf(stderr, "irdm_hip: burst_detector_feed: a detector takes one sample format\n");
         return;
     }
+    d->last_cb = cb;
+    d->last_user = user;
     const size_t bps = fmt == IRDM_FMT_CF32 ? 8 : 2;
     const unsigned char *src = static_cast<const unsigned char *>(iq);
     d->stage.insert(d->stage.end(), src, src + num_samples * bps);
@@ -158,29 +205,7 @@ static void detector_feed(_burst_detector *d, const void *iq, size_t num_samples
             fprintf(stderr, "irdm_hip: burst_detector_feed: device path failed, samples dropped\n");
             break;
         }
-        std::vector<irdm_burst_t> recs((size_t)emitted);
-        const int got = emitted ? irdm_poll_bursts(d->p, recs.data(), emitted) : 0;
-        for (int i = 0; i < got; i++) {
-            const irdm_burst_t &r = recs[i];
-            burst_data_t *b = static_cast<burst_data_t *>(malloc(sizeof(burst_data_t)));
-            float *s = static_cast<float *>(malloc(sizeof(float) * 2 * (size_t)r.num_samples));
-            if (!b || !s || irdm_burst_samples(d->p, i, s, (size_t)r.num_samples) != (int)r.num_samples) {
-                free(b);
-                free(s);
-                continue;
-            }
-            b->info.id = r.id; b->info.start = r.start; b->info.stop = r.stop; b->info.last_active = r.last_active;
-            b->info.center_bin = r.center_bin; b->info.magnitude = r.magnitude; b->info.noise = r.noise;
-            b->center_frequency = d->cfg.center_frequency;
-            b->sample_rate = d->cfg.sample_rate;
-            b->fft_size = irdm_fft_size(d->p);
-            b->start_time_ns = irdm_start_time_ns(d->p);
-            b->num_samples = (size_t)r.num_samples;
-            b->samples = s;
-            d->total++;
-            if (cb) cb(b, user);                   // ownership of b and b->samples passes to the callee
-            else { free(s); free(b); }
-        }
+        detector_emit(d, emitted, cb, user);
     }
     d->stage.erase(d->stage.begin(), d->stage.begin() + off * bps);
 }
@@ -198,9 +223,25 @@ extern "C" void burst_detector_feed_cf32(_burst_detector *det, const float *iq, 
 
 extern "C" uint64_t burst_detector_total_count(_burst_detector *det) { return det ? det->total : 0; }
 
+// burst_detect.c:355-395, as main.c's stats thread calls them (any thread; values as of the end of the last feed)
+extern "C" int burst_detector_active_count(_burst_detector *det) { return det ? det->active.load() : 0; }
+extern "C" float burst_detector_noise_floor(_burst_detector *det) { return det ? det->noise_floor.load() : 0.0f; }
+extern "C" float burst_detector_peak_signal(_burst_detector *det) { return det ? det->peak_signal.load() : 0.0f; }
+
 extern "C" void burst_detector_destroy(_burst_detector *det)
 {
     if (!det) return;
+    if (det->p && !det->stage.empty()) {
+        // The end of the stream: the samples that never made up a whole 32768-sample block.  The reference's reader
+        // feeds its short last read like any other (main.c:223-271) and the detector processes every whole frame of it
+        // (burst_detect.c:746-842), so bursts that expire there are emitted; destroy is called by the detector thread
+        // right behind its feed loop (burst_detect.c:941-960), with the burst queue still open: they go through the
+        // callback of the last feed.
+        const size_t bps = det->fmt == IRDM_FMT_CF32 ? 8 : 2;
+        const int emitted = irdm_feed_host(det->p, det->stage.data(), det->stage.size() / bps);
+        if (emitted >= 0) detector_emit(det, emitted, det->last_cb, det->last_user);
+        det->stage.clear();
+    }
     if (det->p) {
         // burst_detect.c:350-351: the line the reference's test script greps
         fprintf(stderr, "burst_detect: tagged %llu bursts total\n", (unsigned long long)irdm_tagged_bursts(det->p));
@@ -210,46 +251,67 @@ extern "C" void burst_detector_destroy(_burst_detector *det)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// stage B: one context per worker thread, as in the reference (burst_downmix.c:107-112); the device context is created
-// at the first burst (its sample rate is not known earlier)
+// stages B and C.  The reference gives every downmix worker a context of its own because the context IS the scratch
+// memory (burst_downmix.c:107-112) and qpsk_demod() takes none.  Here a handle is a few words: all workers and the
+// demodulator share ONE device context per capture sample rate behind a mutex (a device context holds the rotator
+// table, the history ring and the per-burst scratch: one of them instead of five for main.c's layout, main.c:175).
 // ---------------------------------------------------------------------------------------------------------------
-struct _burst_downmix {
-    downmix_config_t cfg;
+namespace {
+std::mutex g_stage_mu;
+struct StageCtx {
     irdm_pipeline_t *p;
     int sample_rate;
-    std::vector<float> frame;
+};
+std::vector<StageCtx> g_stage;
+std::vector<float> g_row;                          // one frame's samples, guarded by g_stage_mu
+irdm_demod_t g_demod_rec;                          // 4.5 KB: kept off the stack, guarded by g_stage_mu
+
+// the context for `sample_rate` (0: any, the demodulator works at the downmixer's 250 kHz whatever the capture rate);
+// g_stage_mu held
+irdm_pipeline_t *stage_ctx(int sample_rate, double center_frequency)
+{
+    for (const StageCtx &c : g_stage)
+        if (!sample_rate || c.sample_rate == sample_rate) return c.p;
+    irdm_config_t c;
+    memset(&c, 0, sizeof(c));
+    c.center_frequency = center_frequency;
+    c.sample_rate = sample_rate ? sample_rate : 2000000;
+    c.format = IRDM_FMT_CF32;
+    c.use_gardner = gardner_setting();
+    c.start_time_ns = 1;
+    c.max_chunk_samples = kBlock;
+    c.max_bursts_per_chunk = 16;
+    irdm_pipeline_t *p = irdm_create(&c);
+    if (!p) return nullptr;
+    g_stage.push_back(StageCtx{ p, c.sample_rate });
+    if (g_row.empty()) g_row.assign(2 * IRDM_MAX_FRAME_SAMPLES, 0.0f);
+    return p;
+}
+}  // namespace
+
+struct _burst_downmix {
+    downmix_config_t cfg;
 };
 
 extern "C" _burst_downmix *burst_downmix_create(downmix_config_t *config)
 {
+    // burst_downmix.c:228-239: 0 selects the default; only the defaults are implemented (250 kHz = 10 samples per
+    // symbol, search depth = the output rate; handle_multiple_frames is stored and never read by the reference either)
+    if (config && ((config->output_sample_rate && config->output_sample_rate != 250000) ||
+                   (config->search_depth && config->search_depth != 250000))) {
+        fprintf(stderr, "irdm_hip: burst_downmix_create: only the default downmix configuration is supported\n");
+        return nullptr;
+    }
     _burst_downmix *dm = new _burst_downmix();
     if (config) dm->cfg = *config;
     else memset(&dm->cfg, 0, sizeof(dm->cfg));
-    dm->p = nullptr;
-    dm->sample_rate = 0;
-    dm->frame.resize(2 * IRDM_MAX_FRAME_SAMPLES);
     return dm;
 }
 
 extern "C" int burst_downmix_process(_burst_downmix *dm, burst_data_t *burst, downmix_frame_t **frames_out)
 {
     if (frames_out) *frames_out = nullptr;
-    if (!dm || !burst || !frames_out || !burst->samples) return 0;
-    if (!dm->p) {
-        irdm_config_t c;
-        memset(&c, 0, sizeof(c));
-        c.center_frequency = burst->center_frequency;
-        c.sample_rate = burst->sample_rate;
-        c.format = IRDM_FMT_CF32;
-        c.use_gardner = gardner_setting();
-        c.start_time_ns = burst->start_time_ns ? burst->start_time_ns : 1;
-        c.max_chunk_samples = kBlock;
-        c.max_bursts_per_chunk = 16;
-        dm->p = irdm_create(&c);
-        dm->sample_rate = burst->sample_rate;
-        if (!dm->p) return 0;
-    }
-    if (burst->sample_rate != dm->sample_rate) return 0;
+    if (!dm || !burst || !frames_out || !burst->samples || burst->sample_rate <= 0) return 0;
     irdm_burst_t info;
     memset(&info, 0, sizeof(info));
     info.id = burst->info.id; info.start = burst->info.start; info.stop = burst->info.stop;
@@ -257,8 +319,17 @@ extern "C" int burst_downmix_process(_burst_downmix *dm, burst_data_t *burst, do
     info.magnitude = burst->info.magnitude; info.noise = burst->info.noise;
     info.num_samples = burst->num_samples;
     irdm_frame_info_t fi;
-    const int rc = irdm_downmix_burst(dm->p, &info, burst->samples, burst->num_samples, &fi, dm->frame.data());
-    if (rc != 1) return 0;
+    std::vector<float> frame;
+    {
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        irdm_pipeline_t *p = stage_ctx(burst->sample_rate, burst->center_frequency);
+        if (!p) return 0;
+        // every burst carries its stream's centre frequency and start time (burst_detect.h:40-48, burst_downmix.c:659-671)
+        if (irdm_set_stream_origin(p, burst->center_frequency, burst->start_time_ns ? burst->start_time_ns : 1) != 0) return 0;
+        const int rc = irdm_downmix_burst(p, &info, burst->samples, burst->num_samples, &fi, g_row.data());
+        if (rc != 1) return 0;
+        frame.assign(g_row.begin(), g_row.begin() + 2 * (size_t)fi.num_samples);
+    }
     downmix_frame_t *f = static_cast<downmix_frame_t *>(malloc(sizeof(downmix_frame_t)));
     float *s = static_cast<float *>(malloc(sizeof(float) * 2 * (size_t)fi.num_samples));
     if (!f || !s) {
@@ -266,7 +337,7 @@ extern "C" int burst_downmix_process(_burst_downmix *dm, burst_data_t *burst, do
         free(s);
         return 0;
     }
-    memcpy(s, dm->frame.data(), sizeof(float) * 2 * (size_t)fi.num_samples);
+    memcpy(s, frame.data(), sizeof(float) * 2 * (size_t)fi.num_samples);
     f->id = fi.id; f->timestamp = fi.timestamp; f->center_frequency = fi.center_frequency;
     f->sample_rate = fi.sample_rate; f->samples_per_symbol = fi.samples_per_symbol; f->direction = fi.direction;
     f->magnitude = fi.magnitude; f->noise = fi.noise; f->uw_start = fi.uw_start;
@@ -278,43 +349,23 @@ extern "C" int burst_downmix_process(_burst_downmix *dm, burst_data_t *burst, do
 
 extern "C" void burst_downmix_destroy(_burst_downmix *dm)
 {
-    if (!dm) return;
-    if (dm->p) irdm_destroy(dm->p);
-    delete dm;
+    delete dm;                  // (the shared device context lives until irdm_compat_shutdown)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// stage C: qpsk_demod() has no context argument; one process-wide device context, created on first use
+// stage C: qpsk_demod() has no context argument
 // ---------------------------------------------------------------------------------------------------------------
-namespace {
-std::mutex g_demod_mu;
-irdm_pipeline_t *g_demod = nullptr;
-std::vector<float> g_demod_row;
-}  // namespace
-
 extern "C" int qpsk_demod(downmix_frame_t *in, demod_frame_t **out)
 {
     if (out) *out = nullptr;
     if (!in || !out || !in->samples || in->num_samples > IRDM_MAX_FRAME_SAMPLES) return 0;
-    std::lock_guard<std::mutex> lk(g_demod_mu);
-    if (!g_demod) {
-        irdm_config_t c;
-        memset(&c, 0, sizeof(c));
-        c.center_frequency = 1622000000.0;
-        c.sample_rate = 2000000;                   // stage C works at the downmixer's 250 kHz whatever the capture rate
-        c.format = IRDM_FMT_CF32;
-        c.use_gardner = gardner_setting();
-        c.start_time_ns = 1;
-        c.max_chunk_samples = kBlock;
-        c.max_bursts_per_chunk = 16;
-        g_demod = irdm_create(&c);
-        if (!g_demod) return 0;
-        g_demod_row.assign(2 * IRDM_MAX_FRAME_SAMPLES, 0.0f);
-    }
-    memcpy(g_demod_row.data(), in->samples, sizeof(float) * 2 * in->num_samples);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    irdm_pipeline_t *p = stage_ctx(0, 1622000000.0);
+    if (!p) return 0;
+    memcpy(g_row.data(), in->samples, sizeof(float) * 2 * in->num_samples);
     const int ns = (int)in->num_samples, dir = in->direction;
-    static irdm_demod_t d;                         // 4.5 KB: kept off the stack, guarded by g_demod_mu
-    if (irdm_qpsk_demod_batch(g_demod, g_demod_row.data(), &ns, &dir, 1, &d) != 0 || !d.ok) return 0;
+    irdm_demod_t &d = g_demod_rec;
+    if (irdm_qpsk_demod_batch(p, g_row.data(), &ns, &dir, 1, &d) != 0 || !d.ok) return 0;
     demod_frame_t *f = static_cast<demod_frame_t *>(calloc(1, sizeof(demod_frame_t)));
     uint8_t *bits = static_cast<uint8_t *>(malloc(d.n_bits > 0 ? (size_t)d.n_bits : 1));
     float *llr = static_cast<float *>(malloc(sizeof(float) * (d.n_bits > 0 ? (size_t)d.n_bits : 1)));
@@ -344,7 +395,7 @@ extern "C" int qpsk_demod(downmix_frame_t *in, demod_frame_t **out)
 
 extern "C" void irdm_compat_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g_demod_mu);
-    if (g_demod) irdm_destroy(g_demod);
-    g_demod = nullptr;
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    for (StageCtx &c : g_stage) irdm_destroy(c.p);
+    g_stage.clear();
 }

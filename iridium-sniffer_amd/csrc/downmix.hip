@@ -11,6 +11,7 @@
 #include "types.hpp"
 #include "kernels.hpp"
 #include "burst_src.hpp"
+#include "libm_port.hpp"
 
 namespace irdm {
 
@@ -1242,14 +1243,39 @@ int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_str
 // wavefronts walk 667 chains, instead of 667 workgroups each waiting for its lane 0 with 48 KB of LDS in hand.
 // The phases go to the burst's row of rrc_ws (post2 overwrites the row with the RRC output afterwards).
 // ---------------------------------------------------------------------------
+// cfo.on_device: the libm step between post1 and post2 -- cexpf(-2 pi offset i) and the centre frequency that decides
+// between the normal and the simplex frame limits (burst_downmix.c:663-671, :716-719, :764) -- is taken HERE, with
+// glibc's sincosf restated in libm_port.hpp (bit-identical to the host's over every float of the step's range:
+// tools/check_sincosf.cpp, tools/check_sincosf_gpu.hip) and the reference's own mixed float / double expression for
+// the frequency.  The chain then never leaves the GPU (before: event -> helper thread -> sequence number -> a kernel
+// spinning on pinned memory, 0.4 ms per chunk in run).
 __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ work, int n_bursts,
-                                                       float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work)
+                                                       float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
+                                                       CfoStep cfo)
 {
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_bursts) return;
     BurstWork &w = work[b];
-    if (hp_work) {
+    if (cfo.on_device) {
+        const float rel = (w.center_bin - cfo.n_fft / 2) / (float)cfo.n_fft;
+        double cf = cfo.center_frequency;
+        cf += rel * cfo.sample_rate;                                        // burst_downmix.c:663-671 (float product)
+        if (!w.drop_reason) {
+            const float phase_inc = -2.0f * 3.14159274101257324f * w.center_offset;       // -2.0f * (float)M_PI * offset
+            float re, im;
+            if (libm_cexpf_i<true>(phase_inc, &re, &im) != 0) {
+                // (outside the restated domain: cannot happen, |offset| <= 1/4; drop rather than be wrong)
+                w.drop_reason = 9;
+                re = 1.0f;
+                im = 0.0f;
+            }
+            w.incr_re = re;
+            w.incr_im = im;
+            cf += w.center_offset * cfo.out_rate;
+        }
+        w.simplex = cf > 1626000000 ? 1 : 0;                                // iridium.h:18
+    } else if (hp_work) {
         // what the host's fine-CFO step left in the mapped pinned record (system-scope loads: the wait kernel in front
         // of this one has seen the helper thread's sequence number)
         w.incr_re = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_re), __ATOMIC_RELAXED,
@@ -1405,14 +1431,33 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     }
 }
 
+// libm_port.hpp on the device for arbitrary arguments (tests/test_gpu_libm.py, tools/check_sincosf_gpu.hip)
+__global__ void sincosf_probe_kernel(const float *__restrict__ x, size_t n, float *__restrict__ re, float *__restrict__ im)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float r = 0.0f, q = 0.0f;
+        if (libm_cexpf_i<true>(x[i], &r, &q) != 0) r = q = __uint_as_float(0x7fc00000u);
+        re[i] = r;
+        im[i] = q;
+    }
+}
+
+int launch_sincosf_probe(const float *x, size_t n, float *re, float *im, hipStream_t stream)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(sincosf_probe_kernel, dim3(2048), dim3(256), 0, stream, x, n, re, im);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
-                         float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, hipStream_t stream)
+                         float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, const CfoStep &cfo,
+                         hipStream_t stream)
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work);
+    hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     if (rrc_ntaps == 51 && !g_post_generic) {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

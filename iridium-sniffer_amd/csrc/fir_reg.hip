@@ -229,20 +229,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             carry.x = lane_set0(carry.x, bx);
             carry.y = lane_set0(carry.y, by);
         };
+        // The taps of a row reach the SGPRs half a row ahead (scalar loads return out of order, so a wait is for
+        // everything outstanding: each half's request is issued right behind the first multiply-add group of the
+        // half before it, and is waited for a whole half -- 80 to 96 packed instructions -- later).
+        constexpr int H = M / 2;                             // taps per half row (20 / 24)
+        uint64_t ta[H / 2], tb[H / 2];
+        auto request = [&](uint64_t (&t)[H / 2], int tap0) {
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) t[i] = taps64[tap0 / 2 + i];
+        };
+        auto mac_head = [&](const uint64_t *t, int p0) { fir_mac2x8(acc[0], acc[1], &y[0][p0], &y[1][p0], t); };
+        auto mac_rest = [&](const uint64_t *t, int p0) {
+            fir_mac2x8(acc[0], acc[1], &y[0][p0 + 8], &y[1][p0 + 8], t + 4);
+            if constexpr (H == 24) fir_mac2x8(acc[0], acc[1], &y[0][p0 + 16], &y[1][p0 + 16], t + 8);
+            else fir_mac2x4(acc[0], acc[1], &y[0][p0 + 16], &y[1][p0 + 16], t + 8);
+        };
+        static_assert(H == 20 || H == 24, "half rows of 8 + 8 + 4 or 8 + 8 + 8 taps");
+        request(ta, 0);
 #pragma unroll 1
         for (int r = 0; r < NR; r++) {
             shift();                                         // (row 0: zeros move)
-            const uint64_t *t = taps64 + r * (M / 2);
-#pragma unroll
-            for (int gq = 0; gq < M / 8; gq++) fir_mac2x8(acc[0], acc[1], &y[0][8 * gq], &y[1][8 * gq], t + 4 * gq);
+            mac_head(ta, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            request(tb, r * M + H);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_rest(ta, 0);
+            mac_head(tb, H);
+            __builtin_amdgcn_sched_barrier(0);
+            // the next row's first half; behind the last full row: the partial row's, if it has that many taps
+            request(ta, (r + 1 < NR || REM >= H) ? (r + 1) * M : 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mac_rest(tb, H);
         }
         shift();
         {
-            const uint64_t *t = taps64 + NR * (M / 2);
+            constexpr int P0 = REM >= H ? H : 0;             // taps of the partial row already in `ta`
+            if constexpr (REM >= H) {
+                mac_head(ta, 0);
+                mac_rest(ta, 0);
+            }
+            const uint64_t *t = taps64 + (NR * M + P0) / 2;
 #pragma unroll
-            for (int gq = 0; gq < REM / 8; gq++) fir_mac2x8(acc[0], acc[1], &y[0][8 * gq], &y[1][8 * gq], t + 4 * gq);
+            for (int gq = 0; gq < (REM - P0) / 8; gq++)
+                fir_mac2x8(acc[0], acc[1], &y[0][P0 + 8 * gq], &y[1][P0 + 8 * gq], t + 4 * gq);
 #pragma unroll
-            for (int p = REM / 8 * 8; p < REM; p++) {
+            for (int p = P0 + (REM - P0) / 8 * 8; p < REM; p++) {
                 const float tq = taps[NR * M + p];
                 acc[0] = acc[0] + y[0][p] * tq;
                 acc[1] = acc[1] + y[1][p] * tq;

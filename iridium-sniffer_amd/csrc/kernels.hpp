@@ -55,7 +55,11 @@ struct BandWork {                        // device workspace, carved out of one 
     uint32_t *tot;
     uint64_t *ids;
     uint32_t *flags;
+    uint32_t *rank;                      // commit: record -> place in creation order
+    unsigned *bar;                       // [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
+                                         // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
+extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass
 int band_list_cap(int n);                // entries per frame the band scan's lists hold
 int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0);
 size_t band_work_bytes(int n, size_t max_chunk);
@@ -63,7 +67,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, hipStream_t stream);
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, hipStream_t stream);
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
                            unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream);
@@ -115,10 +119,18 @@ int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_str
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
                          const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream);
+// the fine-CFO libm step of the per-burst chain (rot_phase_kernel): on the device, or taken from the host's records
+struct CfoStep {
+    int on_device;
+    int n_fft, sample_rate, out_rate;
+    double center_frequency;
+};
 int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
-                         float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, hipStream_t stream);
+                         float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, const CfoStep &cfo,
+                         hipStream_t stream);
+int launch_sincosf_probe(const float *x, size_t n, float *re, float *im, hipStream_t stream);
 
 // demod.hip
 int launch_ida_decode(const DemodOut *frames, int n_frames, const int2 *syn_da, const int2 *syn_l1, const int2 *syn_l2,

@@ -32,6 +32,7 @@
 #include "common.hpp"
 #include "host_design.hpp"
 #include "kernels.hpp"
+#include "libm_port.hpp"
 #include "band_core.hpp"
 #include "types.hpp"
 
@@ -80,6 +81,8 @@ struct gpu_burst_fft {
     hipStream_t stream;
 };
 
+extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, float *output, int batch_count);
+
 extern "C" gpu_burst_fft_t *gpu_burst_fft_create(int fft_size, int batch_size, const float *window)
 {
     const int lg = ilog2(fft_size);
@@ -104,6 +107,35 @@ extern "C" gpu_burst_fft_t *gpu_burst_fft_create(int fft_size, int batch_size, c
         hipStreamCreate(&g->stream) != hipSuccess) {
         gpu_burst_fft_destroy(g);
         return nullptr;
+    }
+    // Does the device actually compute?  One DC frame through the context's own path, as the reference's Vulkan back
+    // end does at init (vulkan/burst_fft.c:324-394: DC in, all the energy in bin 0, within a factor of two).  The window
+    // is fused here, so the DC bin (index N/2 after the fftshift) holds (sum of the window)^2; the check is tighter than
+    // the reference's because the arithmetic is pinned.  A context that fails is not handed out: NULL sends the caller
+    // to its CPU path (burst_detect.c:316-318).
+    {
+        std::vector<float> in((size_t)2 * fft_size), out((size_t)fft_size);
+        for (int i = 0; i < fft_size; i++) {
+            in[2 * i] = 1.0f;
+            in[2 * i + 1] = 0.0f;
+        }
+        double wsum = 0;
+        for (int i = 0; i < fft_size; i++) wsum += window[i];
+        const double expected = wsum * wsum;
+        bool good = gpu_burst_fft_process(g, in.data(), out.data(), 1) == 0;
+        if (good) {
+            const double dc = out[fft_size / 2], far = out[0];
+            good = expected > 0 && fabs(dc - expected) <= 1e-3 * expected && far <= 1e-3 * expected;
+            if (!good)
+                fprintf(stderr, "irdm_hip: gpu_burst_fft_create: DC self-test failed (expected %.6g in bin N/2, got %.6g; bin 0 %.6g)\n",
+                        expected, dc, far);
+        } else {
+            fprintf(stderr, "irdm_hip: gpu_burst_fft_create: DC self-test could not run\n");
+        }
+        if (!good) {
+            gpu_burst_fft_destroy(g);
+            return nullptr;
+        }
     }
     return g;
 }
@@ -166,6 +198,7 @@ struct BatchCtx {
     DemodOut *hp_demod;
     uint32_t *hp_flag, *hp_flag_dev;    // [0] sequence number the helper publishes, [1] time-out flag of the waiting kernel
     uint32_t cfo_seq;
+    bool cfo_on_device;          // this batch's libm step ran on the device: h_cfreq is filled from the returned records
     std::vector<double> h_cfreq;
     std::vector<irdm_burst_t> recs;
     int n;                       // bursts in flight (0: idle)
@@ -181,6 +214,8 @@ struct irdm_pipeline {
                                 // main.c:245-246), 2 cf32
     size_t bps;                 // bytes per device sample
     int feed_block, decim, out_rate;
+    float peak_signal_db;    // burst_detector_peak_signal over the finished bursts (starts at 0 like the reference's calloc)
+    bool dev_cfo;            // the fine-CFO libm step runs on the device (the port reproduces this host's cexpf)
     float sps;
     uint64_t ref_ring, ring_len;
     size_t l_cap;
@@ -244,7 +279,7 @@ struct irdm_pipeline {
     bool band_ok;
     int fl_mode;                // scan in flight: 0 dense, 1 sparse (leader/updaters), 2 band
     int fl_done;                // frames the dense scan primed before the in-flight scan proper
-    uint64_t stat_band_chunks, stat_band_rounds, stat_band_retries, stat_band_aborts, stat_band_extra;
+    uint64_t stat_band_chunks, stat_band_rounds, stat_band_retries, stat_band_aborts, stat_band_extra, stat_chain_undone, stat_chained;
     uint32_t last_band_flags;
 
     std::vector<GoneBurst> h_gone;
@@ -278,6 +313,17 @@ struct irdm_pipeline {
     bool cfo_quit;
     GoneBurst *hp_gone;         // pinned copy of the finished-burst records of a scan
     int hp_gone_cap;
+    // Two sets of the scan's export targets (pinned words, pinned records, timing events): a band scan launched BEHIND
+    // the one still in flight (scan_chain) exports into the other set.  h_pin / hp_gone / ev_sk / ev_end alias the set of
+    // the scan that scan_finish settles next.
+    int *h_pin_set[2];
+    GoneBurst *hp_gone_set[2];
+    hipEvent_t ev_sk_set[2][2], ev_end_set[2], ev_end;
+    int out_sel;
+    int scan_chain;             // option (default 1): enqueue chunk k's band scan before waiting for chunk k-1's
+    bool chain_pending;         // feed_end has enqueued this chunk's scan behind the previous one
+    int chain_sel, chain_band_first;
+    bool settle_clean;          // the scan settled last committed on its own (no continuation, retry or fallback)
     hipEvent_t ev_rot;          // the rotator checkpoint table is complete
     hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
     uint64_t chunk_no;          // chunks fed so far
@@ -343,7 +389,13 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    if (p->h_pin) (void)hipHostFree(p->h_pin);
+    for (int s = 0; s < 2; s++) {
+        if (p->h_pin_set[s]) (void)hipHostFree(p->h_pin_set[s]);
+        if (p->hp_gone_set[s]) (void)hipHostFree(p->hp_gone_set[s]);
+        if (p->ev_end_set[s]) (void)hipEventDestroy(p->ev_end_set[s]);
+        for (auto &e : p->ev_sk_set[s])
+            if (e) (void)hipEventDestroy(e);
+    }
     if (p->cfo_thread.joinable()) {
         {
             std::lock_guard<std::mutex> lk(p->cfo_mu);
@@ -369,7 +421,6 @@ static void pipeline_free(irdm_pipeline *p)
             if (b.stream) (void)hipStreamDestroy(b.stream);
         }
     }
-    if (p->hp_gone) (void)hipHostFree(p->hp_gone);
     if (p->ev_ring) (void)hipEventDestroy(p->ev_ring);
     for (auto &f : p->fs) {
         if (f.ev_start) (void)hipEventDestroy(f.ev_start);
@@ -380,8 +431,6 @@ static void pipeline_free(irdm_pipeline *p)
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
-    for (auto &e : p->ev_sk)
-        if (e) (void)hipEventDestroy(e);
     if (p->ev_scan_in) (void)hipEventDestroy(p->ev_scan_in);
     if (p->ev_scan_out) (void)hipEventDestroy(p->ev_scan_out);
     if (p->fstream && p->fstream != p->stream) (void)hipStreamDestroy(p->fstream);
@@ -508,8 +557,12 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     bool ok = true;
     p->stream2 = nullptr;
     if (p->depth) {
+        // (K1's stream one level below the scan's: streams of one priority share hardware queues, and with the scans
+        // chained the detector's queue is never empty -- K1 of the next chunk sat behind a whole scan, 1.35 -> 1.9 ms)
+        int prio_k1 = prio_hi < prio_lo - 1 ? prio_hi + 1 : prio_hi;
+        if (const char *e = getenv("IRDM_K1_PRIO")) prio_k1 = atoi(e);
         ok = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
-             hipStreamCreateWithPriority(&p->fstream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+             hipStreamCreateWithPriority(&p->fstream, hipStreamNonBlocking, prio_k1) == hipSuccess &&
              hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) == hipSuccess;
         p->bstream = p->stream2;
     } else {
@@ -522,10 +575,24 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->ev_scan_in = p->ev_scan_out = nullptr;
     p->has_pending = false;
     p->pend_c1 = 0;
-    for (auto &e : p->ev_sk) ok = ok && hipEventCreate(&e) == hipSuccess;
     p->h_pin = nullptr;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_pin), sizeof(int) * 128, hipHostMallocDefault) == hipSuccess;
-    if (ok) memset(p->h_pin, 0, sizeof(int) * 128);
+    for (int s = 0; s < 2; s++) {
+        p->h_pin_set[s] = nullptr;
+        p->hp_gone_set[s] = nullptr;
+        p->ev_end_set[s] = nullptr;
+        for (auto &e : p->ev_sk_set[s]) ok = ok && hipEventCreate(&e) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->ev_end_set[s], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->h_pin_set[s]), sizeof(int) * 128, hipHostMallocDefault) == hipSuccess;
+        if (ok) memset(p->h_pin_set[s], 0, sizeof(int) * 128);
+    }
+    p->out_sel = 0;
+    p->scan_chain = 1;
+    p->chain_pending = false;
+    p->settle_clean = true;
+    p->h_pin = p->h_pin_set[0];
+    p->ev_sk[0] = p->ev_sk_set[0][0];
+    p->ev_sk[1] = p->ev_sk_set[0][1];
+    p->ev_end = p->ev_end_set[0];
     for (auto &e : p->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
 #define UP(dst, vec) ok = ok && ((dst = reinterpret_cast<decltype(dst)>(dev_upload((vec).data(), (vec).size()))) != nullptr)
 #define AL(dst, T, count) ok = ok && ((dst = dev_alloc<T>(count)) != nullptr)
@@ -637,6 +704,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_smin, float, (size_t)P.n);
         if (ok) ok = hipMalloc(&p->d_band, band_work_bytes(P.n, p->max_chunk)) == hipSuccess;
         if (ok) band_work_carve(&p->band, p->d_band, P.n, p->max_chunk);
+        if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // the cooperative kernel's grid barrier starts idle
     }
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
     // batch contexts: [0] aliases the pipeline's per-burst scratch and runs on bstream; [1] (pipeline_depth >= 1) has
@@ -680,7 +748,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         b.h_cfreq.assign((size_t)p->burst_cap, 0.0);
     }
     p->hp_gone_cap = p->gone_cap;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) == hipSuccess;
+    for (int s = 0; s < 2; s++)
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone_set[s]), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) == hipSuccess;
+    p->hp_gone = p->hp_gone_set[0];
     ok = ok && hipEventCreateWithFlags(&p->ev_ring, hipEventDisableTiming) == hipSuccess;
     for (auto &f : p->fs)
         ok = ok && hipEventCreate(&f.ev_start) == hipSuccess && hipEventCreate(&f.ev_k1) == hipSuccess &&
@@ -732,14 +802,62 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->fl_done = 0;
     p->host_primed = 0;
     p->host_hist_idx = 0;
+    // Does libm_port.hpp reproduce THIS host's cexpf?  (Every float of the step's range is compared by
+    // tools/check_sincosf.cpp; this is the same question asked of the running process on a probe set: 2^18 offsets
+    // across [-0.26, 0.26], the neighbourhoods of the quadrant boundaries, zero and the tiny-argument branch.)
+    p->dev_cfo = true;
+    {
+        auto same = [](float off) {
+            const cfloat h = fine_rotator_incr(off);
+            const float phase_inc = -2.0f * (float)M_PI * off;
+            float re, im;
+            if (libm_cexpf_i<true>(phase_inc, &re, &im) != 0) return false;
+            const float hr = h.real(), hi = h.imag();
+            return memcmp(&re, &hr, 4) == 0 && memcmp(&im, &hi, 4) == 0;
+        };
+        bool all = true;
+        for (int i = 0; i < (1 << 18) && all; i++) all = same(-0.26f + 0.52f * (float)i / (float)(1 << 18));
+        const float edges[] = { 0.0f, -0.0f, 1e-45f, -1e-45f, 1e-39f, 3e-5f, -3e-5f, 0.125f, -0.125f, 0.25f, -0.25f, 0.2499999f, 0.1250001f };
+        for (float e : edges) all = all && same(e);
+        if (!all) {
+            fprintf(stderr, "irdm_hip: this host's cexpf differs from the restated glibc routine: the fine-CFO step stays on the host\n");
+            p->dev_cfo = false;
+        }
+    }
     p->cfo_thread = std::thread(cfo_helper_main, p);
     return p;
+}
+
+// libm_port.hpp as the device executes it, for arbitrary arguments: re + i im = cexpf(i x[k]) (NaN outside |x| < 120)
+extern "C" int irdm_sincosf_probe(int device, const float *x, size_t n, float *re, float *im)
+{
+    if (!x || !re || !im) return -1;
+    if (!n) return 0;
+    IRDM_HIP_CHECK(hipSetDevice(device));
+    float *d = nullptr;
+    IRDM_HIP_CHECK(hipMalloc(&d, 3 * n * sizeof(float)));
+    int rc = hipMemcpy(d, x, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+    if (!rc) rc = launch_sincosf_probe(d, n, d + n, d + 2 * n, nullptr);
+    if (!rc) rc = hipMemcpy(re, d + n, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    if (!rc) rc = hipMemcpy(im, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    (void)hipFree(d);
+    return rc;
 }
 
 extern "C" uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p) { return p ? p->tagged : 0; }
 extern "C" uint64_t irdm_sample_count(const irdm_pipeline_t *p) { return p ? p->total_samples : 0; }
 extern "C" int irdm_fft_size(const irdm_pipeline_t *p) { return p ? p->P.n : -1; }
 extern "C" uint64_t irdm_start_time_ns(const irdm_pipeline_t *p) { return p ? p->start_time_ns : 0; }
+
+// The stream a stage-level call (irdm_downmix_burst) belongs to: its centre frequency and the wall-clock time of its
+// sample 0 (burst_data_t carries both per burst, burst_detect.h:40-48).  Host fields only; not while a feed is begun.
+extern "C" int irdm_set_stream_origin(irdm_pipeline_t *p, double center_frequency, uint64_t start_time_ns)
+{
+    if (!p || p->begin_no != p->end_no) return -1;
+    p->cfg.center_frequency = center_frequency;
+    if (start_time_ns) p->start_time_ns = start_time_ns;
+    return 0;
+}
 
 static SampleSource make_source(const irdm_pipeline *p, const void *chunk, uint64_t c0, uint64_t c1)
 {
@@ -897,6 +1015,23 @@ static irdm_ida_t finish_ida(const IdaOut &d, const irdm_demod_t &f)
 // (burst_downmix.c:716-717) and the centre frequency that decides the frame-length rules (:719, :763-767) -- is done by
 // a helper thread over a mapped pinned copy of the work records: the stream records an event, the helper waits for it,
 // does the arithmetic and publishes a sequence number that a one-lane kernel on the stream is waiting for.
+// the centre frequency of the finished frames when the libm step ran on the device (rot_phase_kernel): the same
+// expression, from the records the chain brought back (only frames that passed every drop rule read it)
+static void cfreq_from_records(BatchCtx &b)
+{
+    irdm_pipeline *p = b.owner;
+    const DetParams &P = p->P;
+    const int fs = p->cfg.sample_rate;
+    for (int i = 0; i < b.n; i++) {
+        const BurstWork &w = b.hp_work[i];
+        const float rel = (w.center_bin - P.n / 2) / (float)P.n;
+        double cf = p->cfg.center_frequency;
+        cf += rel * fs;                                                   // burst_downmix.c:663-671
+        if (w.drop_reason == 0) cf += w.center_offset * p->out_rate;
+        b.h_cfreq[i] = cf;
+    }
+}
+
 static void fine_cfo_host(BatchCtx &b)
 {
     irdm_pipeline *p = b.owner;
@@ -953,6 +1088,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         r.peak_rel = g.peak_rel; r.base_sum = g.base_sum;
         // burst_detect.c:572, :583-586 with the host libm
         r.magnitude = 10.0f * log10f(g.peak_rel * kHistory * 1.72f);
+        if (r.magnitude > p->peak_signal_db) p->peak_signal_db = r.magnitude;      // burst_detect.c:575-576
         r.noise = 10.0f * log10f(g.base_sum / kHistory / ((float)P.n * P.n) / 1.72f /
                                  ((float)fs / P.n));
         r.num_samples = g.stop + (uint64_t)P.pre_len - g.start;          // burst_detect.c:708-712
@@ -1018,22 +1154,33 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
     if (launch_downmix_post1(b.d_work, nb, b.d_dec, p->dec_stride, b.d_lpf, p->d_noise_taps,
                              p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
-                             p->pre_start, p->d_cfo_window, p->d_tw4096, b.hp_work_dev, st) != 0)
+                             p->pre_start, p->d_cfo_window, p->d_tw4096, p->dev_cfo ? nullptr : b.hp_work_dev, st) != 0)
         return -1;
     // host libm step, ordered on the stream: post1 has stored what the step reads into the burst's record in the mapped
     // pinned buffer (system scope), the helper thread runs behind this event and publishes a sequence number, a one-lane
     // kernel waits for it, and rot_phase_kernel picks the step's results up from the same records.
-    IRDM_HIP_CHECK(hipEventRecord(b.ev_cfo, st));
-    b.cfo_seq++;
-    {
-        std::lock_guard<std::mutex> lk(p->cfo_mu);
-        p->cfo_jobs.push_back(&b);
+    // (default: the step is part of rot_phase_kernel -- libm_port.hpp -- and the chain never leaves the GPU; the host
+    // form remains for a host whose libm the port does not reproduce, irdm_create checks, and as the test hook host_cfo)
+    CfoStep cfo;
+    cfo.on_device = p->dev_cfo ? 1 : 0;
+    cfo.n_fft = P.n;
+    cfo.sample_rate = fs;
+    cfo.out_rate = p->out_rate;
+    cfo.center_frequency = p->cfg.center_frequency;
+    b.cfo_on_device = p->dev_cfo;
+    if (!p->dev_cfo) {
+        IRDM_HIP_CHECK(hipEventRecord(b.ev_cfo, st));
+        b.cfo_seq++;
+        {
+            std::lock_guard<std::mutex> lk(p->cfo_mu);
+            p->cfo_jobs.push_back(&b);
+        }
+        p->cfo_cv.notify_one();
+        if (launch_wait_host_flag(b.hp_flag_dev, b.cfo_seq, b.hp_flag_dev + 1, st) != 0) return -1;
     }
-    p->cfo_cv.notify_one();
-    if (launch_wait_host_flag(b.hp_flag_dev, b.cfo_seq, b.hp_flag_dev + 1, st) != 0) return -1;
     if (launch_downmix_post2(b.d_work, nb, b.d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
                              p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
-                             b.d_rrc_ws, b.d_frames, b.hp_work_dev, st) != 0)
+                             b.d_rrc_ws, b.d_frames, p->dev_cfo ? nullptr : b.hp_work_dev, cfo, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[2], st));
     if (launch_demod(b.d_work, nb, b.d_frames, p->cfg.use_gardner, p->sps, b.d_demod_ws, b.d_demod, st) != 0)
@@ -1076,6 +1223,7 @@ static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
     struct timespec ts_;
     clock_gettime(CLOCK_MONOTONIC, &ts_);
     const double t_rec0 = ts_.tv_sec * 1e6 + ts_.tv_nsec * 1e-3;
+    if (b.cfo_on_device) cfreq_from_records(b);
     b.n = 0;                     // only now: the helper thread reads it while the chain is in flight
     if (b.hp_flag[1]) {
         fprintf(stderr, "irdm_hip: the host step of the per-burst chain did not answer\n");
@@ -1262,24 +1410,26 @@ static int scan_restore(irdm_pipeline *p)
 
 // the band scan proper over the primed frames [done, n_frames) of the chunk; retry = 1: the lists went stale, rebuild
 // them against the lowered reference first
-static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds = false)
+static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds,
+                                uint64_t c0, const irdm_pipeline::FeedSlot *feed, int sel, int first, int chained)
 {
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
-    const uint64_t idx0 = p->fl_c0 + (uint64_t)done * (uint64_t)P.n;     // chunks start on frame boundaries
+    const uint64_t idx0 = c0 + (uint64_t)done * (uint64_t)P.n;           // chunks start on frame boundaries
     // the candidate lists: K1's (whole chunk, frame 0 first: only when nothing of the chunk was primed away), else the
     // prefilter pass; a retry rebuilds them in the same buffers against the lowered levels
-    const bool from_k1 = p->fl_feed && p->fl_feed->lists && done == 0;
-    const int ls = from_k1 && p->depth ? (int)(p->fl_feed - p->fs) : 0;
+    const bool from_k1 = feed && feed->lists && done == 0;
+    const int ls = from_k1 && p->depth ? (int)(feed - p->fs) : 0;
     float *pre = from_k1 ? p->k1_pre[ls] : p->d_pre;
     unsigned *counts = from_k1 ? p->k1_counts[ls] : p->d_counts;
     ListEntry *entries = from_k1 ? p->k1_entries[ls] : p->d_entries;
-    if (!more_rounds && !retry) p->fl_band_first = p->band_first ? p->band_first : p->band_auto;
+    int *pin = p->h_pin_set[sel];
+    GoneBurst *hpg = p->hp_gone_set[sel];
     if (more_rounds) {
         // the first rounds left the verdict open: the remaining rounds, on the same lists and workspace
         return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
-                                p->d_smin, p->d_gone, p->gone_cap, p->fl_band_first, kBandRounds, p->hp_gone,
-                                reinterpret_cast<uint32_t *>(p->h_pin + 64), p->h_pin + 96, p->hp_gone_cap, p->stream);
+                                p->d_smin, p->d_gone, p->gone_cap, first, kBandRounds, hpg,
+                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, p->stream);
     }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
@@ -1288,14 +1438,21 @@ static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, i
     } else {
         p->stat_k1_lists++;
     }
-    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
-                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, p->fl_band_first, p->hp_gone,
-                         reinterpret_cast<uint32_t *>(p->h_pin + 64), p->h_pin + 96, p->hp_gone_cap, p->stream) != 0)
+                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, first, hpg,
+                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, p->stream) != 0)
         return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[1], p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
     return 0;
+}
+
+// ... of the scan in flight (fl_*)
+static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds = false)
+{
+    if (!more_rounds && !retry) p->fl_band_first = p->band_first ? p->band_first : p->band_auto;
+    return scan_band_enqueue_at(p, mag, n_frames, done, retry, more_rounds, p->fl_c0, p->fl_feed, p->out_sel, p->fl_band_first, 0);
 }
 
 // the sequential forms: the sparse leader scan with the dense kernel as its exact fallback, or the dense kernel alone
@@ -1344,8 +1501,64 @@ static int scan_export(irdm_pipeline *p)
                               (int)sizeof(BandCtl), p->stream);
 }
 
+// the export targets the next scan_finish reads
+static void scan_select_outputs(irdm_pipeline *p, int sel)
+{
+    p->out_sel = sel;
+    p->h_pin = p->h_pin_set[sel];
+    p->hp_gone = p->hp_gone_set[sel];
+    p->ev_sk[0] = p->ev_sk_set[sel][0];
+    p->ev_sk[1] = p->ev_sk_set[sel][1];
+    p->ev_end = p->ev_end_set[sel];
+}
+
+// scan_chain: chunk k's band scan enqueued BEHIND chunk k-1's, before the host has seen that one's verdict.  The two
+// are on the same stream, so the GPU starts scan k the moment scan k-1 ends; without this the scan engine idled for the
+// host's wake-up from the wait plus the enqueue of the first pass (0.2-0.3 ms of a 1.4 ms period, and the scans in
+// sequence ARE the period).  Safe because a band scan writes nothing of the carried state before its commit and commits
+// only as the last thing it does: the chained scan's first pass checks on the device that its predecessor committed
+// (BandWork::bar[4]) and declines itself otherwise (BAND_F_CHAIN), the host sees the predecessor's trouble when it
+// settles it, drains the declined launch and launches again the ordinary way.  Exports go to the other set of pinned
+// targets.
+static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f)
+{
+    p->chain_pending = false;
+    // (only with K1's own candidate lists: the prefilter pass that builds them otherwise writes the one set of buffers
+    // the scan in front may still need for a continuation or a retry, and it runs before the chained launch's check)
+    if (!p->scan_chain || !p->fl_active || p->fl_mode != 2 || !p->fl_band_ran || !p->host_primed || scan_pick(p) != 2 ||
+        f.frames < 1 || !f.lists)
+        return 0;
+    const int sel = p->out_sel ^ 1;
+    IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, f.ev_k1, 0));
+    memset(p->h_pin_set[sel] + 96, 0, sizeof(BandCtl));
+    p->chain_band_first = p->band_first ? p->band_first : p->band_auto;
+    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_end_set[sel], p->stream));
+    p->chain_pending = true;
+    p->chain_sel = sel;
+    p->stat_chained++;
+    return 0;
+}
+
 static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_t c1)
 {
+    if (p->chain_pending) {
+        // enqueued by scan_chain_try (a band scan of a primed detector from frame 0): the bookkeeping only
+        p->chain_pending = false;
+        p->fl_mode = 2;
+        p->fl_sparse = false;
+        p->fl_mag = mag;
+        p->fl_frames = n_frames;
+        p->fl_c1 = c1;
+        p->fl_c0 = p->total_samples;
+        p->fl_no = p->chunk_no;
+        p->fl_done = 0;
+        p->fl_band_ran = true;
+        p->fl_band_first = p->chain_band_first;
+        scan_select_outputs(p, p->chain_sel);
+        p->fl_active = true;
+        return 0;
+    }
     p->fl_mode = scan_pick(p);
     // (the band scan zeroes the chunk's finished-burst count in its first pass; the priming frames and the sequential
     // scans append to it)
@@ -1379,6 +1592,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
     }
     // (the band scan's last pass has exported its records and control block already)
     if (!(p->fl_mode == 2 && p->fl_band_ran) && scan_export(p) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_end, p->stream));
     p->fl_active = true;
     return 0;
 }
@@ -1394,7 +1608,8 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
     };
     double tq0 = now_us(), tq1;
-    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    // (the scan's own end, not the stream's: the next chunk's scan may be enqueued behind it already)
+    IRDM_HIP_CHECK(hipEventSynchronize(p->ev_end));
     tq1 = now_us(); p->host_us[6] += tq1 - tq0; tq0 = tq1;          // [6] waiting for the scan itself
     int redo_from = p->fl_done;       // where a dense redo restarts (the priming frames are never redone)
     bool redone = false;              // something ran after the export the launch enqueued
@@ -1470,6 +1685,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     }
     volatile uint32_t *counters = reinterpret_cast<volatile uint32_t *>(p->h_pin + 64);
     volatile int32_t *hdr = p->h_pin + 66;
+    p->settle_clean = !redone;
     if (redone) {
         if (scan_export(p) != 0) return -1;
         IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
@@ -1479,6 +1695,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     p->host_primed = hdr[1];
     int n_gone = (int)counters[0];
     if (counters[1] || n_gone > p->gone_cap) {
+        p->settle_clean = false;
         // more finished bursts in this chunk than the record buffer holds (the reference's lists grow without bound,
         // burst_detect.c:148-154): grow it, restore the pre-chunk state and redo the chunk with the dense scan
         const int want = std::max(n_gone, p->gone_cap) + 4096;
@@ -1493,11 +1710,16 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         p->h_gone.resize(want);
         p->stat_fallbacks++;
         if (p->gone_cap > p->hp_gone_cap) {
-            (void)hipHostFree(p->hp_gone);
-            p->hp_gone = nullptr;
+            // (no other scan can be exporting: one chained behind this one has declined itself and was drained by the
+            // retry's stream synchronise above)
             p->hp_gone_cap = p->gone_cap;
-            if (hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) != hipSuccess)
-                return -1;
+            for (int s = 0; s < 2; s++) {
+                (void)hipHostFree(p->hp_gone_set[s]);
+                p->hp_gone_set[s] = nullptr;
+                if (hipHostMalloc(reinterpret_cast<void **>(&p->hp_gone_set[s]), sizeof(GoneBurst) * (size_t)p->hp_gone_cap, hipHostMallocDefault) != hipSuccess)
+                    return -1;
+            }
+            p->hp_gone = p->hp_gone_set[p->out_sel];
         }
         if (scan_restore(p) != 0) return -1;
         if (scan_dense(p, p->fl_mag + (size_t)redo_from * p->P.n, p->fl_frames - redo_from, true) != 0) return -1;
@@ -1733,8 +1955,16 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
             finished_early = true;
         }
         IRDM_HOST_PHASE(4);
-        // 1. the previous chunk's detector must be done before this chunk's can start: collect its bursts
+        // 1. this chunk's band scan goes behind the previous chunk's (scan_chain_try), then the previous chunk's is
+        //    settled and its bursts collected
+        if (scan_chain_try(p, f) != 0) return -1;
         if (settle(p) != 0) return -1;
+        if (p->chain_pending && !p->settle_clean) {
+            // the scan in front did not commit on its own: the chained launch has declined itself (nothing written)
+            IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+            p->chain_pending = false;
+            p->stat_chain_undone++;
+        }
         IRDM_HOST_PHASE(1);
         // 2. this chunk's detector (needs K1's output) goes first: the next chunk's scan can only start when this one
         //    has ended, so every microsecond before its launch is added to the period
@@ -1906,6 +2136,37 @@ extern "C" int irdm_last_magnitudes(irdm_pipeline_t *p, float *out, size_t max_f
     if (!nf) return 0;
     IRDM_HIP_CHECK(hipMemcpy(out, p->d_mag_last, nf * p->P.n * sizeof(float), hipMemcpyDeviceToHost));
     return (int)nf;
+}
+
+extern "C" int irdm_detector_stats(irdm_pipeline_t *p, irdm_detector_stats_t *out)
+{
+    if (!p || !out || quiesce(p) != 0) return -1;
+    const DetParams &P = p->P;
+    std::vector<float> sum((size_t)P.n);
+    IRDM_HIP_CHECK(hipMemcpy(sum.data(), p->d_sum, sizeof(float) * (size_t)P.n, hipMemcpyDeviceToHost));
+    DetState head;
+    IRDM_HIP_CHECK(hipMemcpy(&head, p->d_state, offsetof(DetState, act), hipMemcpyDeviceToHost));
+    const int n_act = head.n_act < 0 ? 0 : (head.n_act > kMaxActive ? kMaxActive : head.n_act);
+    std::vector<ActiveBurst> act((size_t)n_act);
+    if (n_act)
+        IRDM_HIP_CHECK(hipMemcpy(act.data(), reinterpret_cast<const char *>(p->d_state) + offsetof(DetState, act),
+                                 sizeof(ActiveBurst) * (size_t)n_act, hipMemcpyDeviceToHost));
+    out->active_bursts = n_act;
+    out->primed = head.primed;
+    // burst_detect.c:363-380
+    double s = 0;
+    for (int i = 0; i < P.n; i++) s += sum[i];
+    const float avg = (float)(s / ((double)P.n * kHistory));
+    const float bin_width = (float)p->cfg.sample_rate / P.n;
+    out->noise_floor_dbfs_hz = (avg > 0 && bin_width > 0) ? 10.0f * log10f(avg / bin_width) : -120.0f;
+    // burst_detect.c:572-576: the running maximum of the magnitude a burst is created with
+    float peak = p->peak_signal_db;
+    for (const ActiveBurst &a : act) {
+        const float m = 10.0f * log10f(a.peak_rel * kHistory * 1.72f);
+        if (m > peak) peak = m;
+    }
+    out->peak_signal_db = peak;
+    return 0;
 }
 
 extern "C" int irdm_baseline_sum(irdm_pipeline_t *p, float *out)
@@ -2245,6 +2506,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
 {
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
+    if (!strcmp(key, "host_cfo")) { p->dev_cfo = value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
     if (!strcmp(key, "scan_updaters")) { if (value < 1 || value > 32) return -1; p->mc_updaters = value; return 0; }
     if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
@@ -2260,6 +2522,8 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
+    if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
+    if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
     return -1;
@@ -2273,6 +2537,8 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strncmp(key, "host_us_", 8) && key[8] >= '0' && key[8] <= '9') return (int64_t)p->host_us[key[8] - '0'];
     if (!strcmp(key, "band_chunks")) return (int64_t)p->stat_band_chunks;
     if (!strcmp(key, "band_extra")) return (int64_t)p->stat_band_extra;
+    if (!strcmp(key, "scan_chained")) return (int64_t)p->stat_chained;
+    if (!strcmp(key, "scan_chain_undone")) return (int64_t)p->stat_chain_undone;
     if (!strcmp(key, "k1_lists")) return (int64_t)p->stat_k1_lists;
     if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
     if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;

@@ -39,15 +39,22 @@ namespace irdm {
 
 namespace {
 
+// a launch voided by its own first pass (see BandParams::chained): bar[5] carries its serial number
+__device__ __forceinline__ bool band_void(const BandParams &P, const BandWork &W)
+{
+    return __hip_atomic_load(W.bar + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)P.serial;
+}
+
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
 constexpr int kSumDepth = 32;             // update steps per batch of the sums pass (two batches of loads in flight)
 
-// exclusive scan of in[0..len) into out[0..len), total returned to every thread; one workgroup, kPlanThreads threads
-// (each thread a contiguous run; wave scans on the shuffle network, the 16 wave totals through LDS)
+// exclusive scan of in[0..len) into out[0..len), total returned to every thread; one workgroup of NT threads
+// (each thread a contiguous run; wave scans on the shuffle network, the wave totals through LDS)
+template <int NT>
 __device__ int block_scan(const int32_t *in, int32_t *out, int len, int32_t *s_part)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (len + kPlanThreads - 1) / kPlanThreads;
+    const int per = (len + NT - 1) / NT;
     const int lo = tid * per, hi = min(lo + per, len);
     int s = 0;
     for (int i = lo; i < hi; i++) s += in[i];
@@ -59,7 +66,7 @@ __device__ int block_scan(const int32_t *in, int32_t *out, int len, int32_t *s_p
     if (lane == 63) s_part[wave] = incl;
     __syncthreads();
     int wave_base = 0, total = 0;
-    for (int w = 0; w < kPlanThreads / 64; w++) {
+    for (int w = 0; w < NT / 64; w++) {
         const int v = s_part[w];
         if (w < wave) wave_base += v;
         total += v;
@@ -85,7 +92,8 @@ __device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, i
         if (A[a].cb < X - P.hw || A[a].cb >= X + P.hw) continue;
         ca++;
         bool found = false;
-        for (int b = 0; b < nb && !found; b++) found = band_rec_same(A[a], B[b]);
+        // (only B's records in the same zone can match: the centre bin is compared first)
+        for (int b = 0; b < nb && !found; b++) found = B[b].cb == A[a].cb && band_rec_same(A[a], B[b]);
         if (!found) bad = 1;
     }
     for (int b = lane; b < nb; b += 64)
@@ -98,15 +106,38 @@ __device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, i
     return !(bad || ca != cb);
 }
 
-__global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
-                                                                 DetState *__restrict__ st, int round)
+// shared scratch of the plan pass
+struct PlanShared {
+    int32_t part[kPlanThreads / 64 + 1];
+    int mismatch, first, status, agree_fail;
+    unsigned flags;
+};
+
+template <int NT>
+__device__ void band_plan_body(const BandParams &P, const BandWork &W, const unsigned *__restrict__ counts,
+                               DetState *__restrict__ st, int round, PlanShared &sh)
 {
-    IRDM_DETECTOR_PRIO();
-    __shared__ int32_t s_part[kPlanThreads];
-    __shared__ int s_mismatch, s_first, s_status, s_agree_fail;
-    __shared__ unsigned s_flags;
+    constexpr int kPlanThreads = NT;      // (shadows the launch constant: every stride below is the workgroup's size)
+    int32_t *s_part = sh.part;
+    int &s_mismatch = sh.mismatch, &s_first = sh.first, &s_status = sh.status, &s_agree_fail = sh.agree_fail;
+    unsigned &s_flags = sh.flags;
     const int tid = threadIdx.x;
     BandCtl *ctl = W.ctl;
+    if (round == 0) {
+        // the scan in front committed (bar[4], set by its commit pass)?  A chained launch that finds it did not leaves
+        // everything -- workspace, control block, carried state -- as it is: the host continues or redoes that scan
+        if (tid == 0) {
+            const unsigned prev = W.bar[4];
+            s_status = (P.chained && prev != 1u) ? 1 : 0;
+            if (s_status) __hip_atomic_store(W.bar + 5, (unsigned)P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else W.bar[4] = 0;
+        }
+        __syncthreads();
+        if (s_status) return;
+        __syncthreads();
+    } else if (band_void(P, W)) {
+        return;
+    }
     if (round == 0) {
         // a new scan: control block, abort flags and the chunk's finished-burst count start from zero (what three
         // memset launches did before)
@@ -201,7 +232,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
     // ---- update steps ----
     for (int f = tid; f < F; f += kPlanThreads) W.tmp[f] = W.uq[f] + W.uf[f];
     __syncthreads();
-    const int n_upd = block_scan(W.tmp, W.cnt_before, F, s_part);
+    const int n_upd = block_scan<NT>(W.tmp, W.cnt_before, F, s_part);
     for (int k = tid; k <= n_upd; k += kPlanThreads) W.need[k] = 0;
     __syncthreads();
     for (int f = tid; f < F; f += kPlanThreads) {
@@ -214,7 +245,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
         if (W.uq[f]) W.upd_frame[k] = f;
     }
     __syncthreads();
-    const int n_snap = block_scan(W.need, W.tmp, n_upd + 1, s_part);
+    const int n_snap = block_scan<NT>(W.need, W.tmp, n_upd + 1, s_part);
     for (int k = tid; k <= n_upd; k += kPlanThreads) W.snap_slot[k] = W.need[k] ? W.tmp[k] : -1;
     __syncthreads();
     const int h0 = ctl->h0;
@@ -244,17 +275,23 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
     }
 }
 
-// ---- sums: one lane per bin along the planned update steps ----
-
-__global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
-                                                      const float *__restrict__ hist, const float *__restrict__ sum,
-                                                      const float *__restrict__ pre, float *__restrict__ smin_out,
-                                                      const int4 *__restrict__ steps, float *__restrict__ snap)
+__global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
+                                                                 DetState *__restrict__ st, int round)
 {
     IRDM_DETECTOR_PRIO();
+    __shared__ PlanShared sh;
+    band_plan_body<kPlanThreads>(P, W, counts, st, round, sh);
+}
+
+// ---- sums: one lane per bin along the planned update steps ----
+
+// (b: this lane's bin)
+__device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWork &W, const float *__restrict__ mag,
+                                              const float *__restrict__ hist, const float *__restrict__ sum,
+                                              const float *__restrict__ pre, float *__restrict__ smin_out,
+                                              const int4 *steps, float *snap, int b)
+{
     const BandCtl *ctl = W.ctl;
-    if (ctl->status != 0) return;
-    const int b = blockIdx.x * 64 + threadIdx.x;
     const int N = P.n;
     const int n = ctl->n_upd;
     // steps: (frame, old row, snapshot slot after the step, -) per update step, padded with no-ops; a kernel argument of
@@ -301,13 +338,23 @@ __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, 
     if (!(pre[b] <= 0.9f * P.thr * smin)) atomicOr(W.flags, BAND_F_STALE);
 }
 
+__global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
+                                                      const float *__restrict__ hist, const float *__restrict__ sum,
+                                                      const float *__restrict__ pre, float *__restrict__ smin_out,
+                                                      const int4 *__restrict__ steps, float *__restrict__ snap)
+{
+    IRDM_DETECTOR_PRIO();
+    if (band_void(P, W) || W.ctl->status != 0) return;
+    band_sum_body(P, W, mag, hist, sum, pre, smin_out, steps, snap, blockIdx.x * 64 + threadIdx.x);
+}
+
 // ---- crossing bits of one frame ----
 __global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                          const ListEntry *__restrict__ entries)
 {
     IRDM_DETECTOR_PRIO();
     __shared__ uint32_t s_bits[16384 / 32];
-    if (W.ctl->status != 0) return;
+    if (band_void(P, W) || W.ctl->status != 0) return;
     const int f = blockIdx.x, tid = threadIdx.x, N = P.n;
     const unsigned c = counts[f];
     if (c == 0 || c > (unsigned)P.list_cap) return;
@@ -340,15 +387,13 @@ __global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork 
 }
 
 // ---- walk: lane = band, workgroup = 64-frame block ----
+// one wavefront: lane = band, blk = 64-frame block; smem_raw: kBandSlots * 64 * 36 bytes of slot storage
 template <int NW>
-__global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W, BandIO io, const DetState *__restrict__ st)
+__device__ __forceinline__ void band_walk_body(const BandParams &P, BandIO io, const DetState *__restrict__ st,
+                                               unsigned char *smem_raw, int band, int blk)
 {
-    IRDM_DETECTOR_PRIO();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (W.ctl->status != 0) return;
     io.act_in = st->act;
     io.n_act_in = st->n_act;
-    const int band = threadIdx.x, blk = blockIdx.x;
     if (band >= P.n_bands) return;
     int64_t *l_start = reinterpret_cast<int64_t *>(smem_raw);
     int64_t *l_la = l_start + kBandSlots * 64;
@@ -376,7 +421,183 @@ __global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W,
     }
 }
 
+template <int NW>
+__global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W, BandIO io, const DetState *__restrict__ st)
+{
+    IRDM_DETECTOR_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (band_void(P, W) || W.ctl->status != 0) return;
+    band_walk_body<NW>(P, io, st, smem_raw, threadIdx.x, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The rounds as ONE launch (option band_coop): kCoopGroups workgroups stay resident through plan -> sums -> cross ->
+// walk -> plan ... until a round is accepted or the scan declines, with a grid-wide barrier between the passes.  What
+// this buys over a launch per pass (11 for two rounds): a pass does not queue for wavefront slots behind the per-burst
+// chains' long-running kernels (measured at 12 MHz / 40 bursts per Msample: plan 160-260 us, walk 430-620 us, commit
+// 310-590 us per launch in run against a fraction of that alone), the verdict is taken where the rounds run (no round
+// is enqueued that is not needed, none is missing), and the crossing pass walks its frames instead of asking the
+// dispatcher for 8192 workgroups.
+//
+// Grid barrier: arrive counter + generation word in the workspace, agent-scope release / acquire around them; one lane
+// per workgroup spins (s_sleep).  Every workgroup must be resident for the others to make progress: the grid is far
+// below what the chip holds beside anything else (128 workgroups, 56 KB of LDS each), and the spin is bounded -- a
+// workgroup that waits longer than ~50 ms raises `abort`, every workgroup leaves, the scan reports BAND_F_COOP and the
+// caller falls back to the sequential scan (nothing of the carried state has been written: the commit is a launch of
+// its own behind this one).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kCoopThreads = 256;
+constexpr int kCoopGroups = 128;
+
+__device__ __forceinline__ bool grid_sync(unsigned *bar, unsigned n_groups)
+{
+    __shared__ int s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        // release: what this workgroup wrote is visible to the agent before it counts as arrived
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (__hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            ok = 0;
+        } else {
+            const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) {
+                __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // (relaxed polls: an acquire per poll would invalidate the L2 under the workgroups still working)
+                long long spins = 0;
+                while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > 400000 || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+        }
+        // acquire: what the other workgroups wrote before they arrived
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+// crossing bits of frame f by ONE wavefront (band_cross_kernel's work; s_bits: N / 32 words of this wavefront's own)
+__device__ __forceinline__ void band_cross_wave(const BandParams &P, const BandWork &W, unsigned c,
+                                                const ListEntry *__restrict__ entries, int f, uint32_t *s_bits, int lane)
+{
+    const int N = P.n;
+    for (int w = lane; w < N / 32; w += 64) s_bits[w] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float *srow = W.snap + (size_t)W.slot_pre[f] * N;
+    const ListEntry *e = entries + (size_t)f * P.list_cap;
+    float *rq = W.relq + (size_t)f * N;
+    for (unsigned i = lane; i < c; i += 64) {
+        const int bin = e[i].bin;
+        const float base = srow[bin];
+        const float rel = base > 0 ? e[i].mag / base : 0.0f;      // simd_relative_mag (simd_generic.c:137-145)
+        if (rel > P.thr) {
+            atomicOr(&s_bits[bin >> 5], 1u << (bin & 31));
+            rq[bin] = rel;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t *out = reinterpret_cast<uint32_t *>(W.cross) + (size_t)f * (N / 32);
+    for (int w = lane; w < N / 32; w += 64) out[w] = s_bits[w];
+    if (lane < P.n_bands) {
+        const int w0 = (lane * P.band_w - P.band_w / 2) / 32, nw = 2 * P.band_w / 32;
+        uint32_t any = 0;
+        for (int k = 0; k < nw; k++) {
+            const int w = w0 + k;
+            if (w >= 0 && w < N / 32) any |= s_bits[w];
+        }
+        if (any) atomicOr(reinterpret_cast<unsigned long long *>(&W.occ[(size_t)lane * P.occ_words + (f >> 6)]), 1ull << (f & 63));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NW>
+__global__ __launch_bounds__(kCoopThreads) void band_coop_kernel(BandParams P, BandWork W, BandIO io,
+                                                                 const unsigned *__restrict__ counts,
+                                                                 const ListEntry *__restrict__ entries, DetState *st,
+                                                                 const float *__restrict__ mag, const float *hist,
+                                                                 const float *sum, const float *__restrict__ pre,
+                                                                 float *smin, int round_begin, int round_end)
+{
+    IRDM_DETECTOR_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = (int)gridDim.x, gw = (int)blockIdx.x * (kCoopThreads / 64) + wave, n_waves = G * (kCoopThreads / 64);
+    unsigned *bar = W.bar;
+    BandCtl *ctl = W.ctl;
+    bool ok = true;
+    for (int round = round_begin;; round++) {
+        // ---- plan (one workgroup): the verdict on the round before, the update steps of this one ----
+        if (blockIdx.x == 0 && (round > round_begin || round_begin == 0))
+            band_plan_body<kCoopThreads>(P, W, counts, st, round, *reinterpret_cast<PlanShared *>(smem_raw));
+        if (!(ok = grid_sync(bar, G))) break;
+        if (band_void(P, W)) return;
+        if (__hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || round >= round_end) break;
+        // ---- sums: a lane per bin ----
+        for (int vb = gw; vb < P.n / 64; vb += n_waves)
+            band_sum_body(P, W, mag, hist, sum, pre, smin, W.steps, W.snap, vb * 64 + lane);
+        if (!(ok = grid_sync(bar, G))) break;
+        // ---- cross: a wavefront per frame with list entries ----
+        {
+            uint32_t *s_bits = reinterpret_cast<uint32_t *>(smem_raw) + (size_t)wave * (P.n / 32);
+            for (int f0 = gw; f0 < P.n_frames; f0 += 64 * n_waves) {
+                // (the counts of this wavefront's next 64 frames with one load)
+                const int fl = f0 + lane * n_waves;
+                const unsigned cl = fl < P.n_frames ? counts[fl] : 0u;
+                uint64_t todo = __builtin_amdgcn_ballot_w64(cl != 0 && cl <= (unsigned)P.list_cap);
+                while (todo) {
+                    const int j = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cl, j);
+                    band_cross_wave(P, W, c, entries, f0 + j * n_waves, s_bits, lane);
+                }
+            }
+        }
+        if (!(ok = grid_sync(bar, G))) break;
+        // ---- walk: a wavefront per 64-frame block, lane = band ----
+        if (wave == 0)
+            for (int blk = (int)blockIdx.x; blk < P.occ_words; blk += G) band_walk_body<NW>(P, io, st, smem_raw, lane, blk);
+        if (!(ok = grid_sync(bar, G))) break;
+    }
+    if (!ok && blockIdx.x == 0 && tid == 0) {
+        ctl->flags |= BAND_F_COOP;
+        ctl->status = 2;
+    }
+}
+
 // ---- commit ----
+// ascending bitonic sort of np = 2^m (key, payload) pairs in LDS by the whole workgroup (keys are unique; padding = ~0)
+__device__ void lds_bitonic_sort(uint64_t *key, uint16_t *val, int np)
+{
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np / 2; i += blockDim.x) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo | j;
+                const uint64_t a = key[lo], b = key[hi];
+                if ((a > b) == ((lo & k) == 0)) {
+                    key[lo] = b;
+                    key[hi] = a;
+                    const uint16_t va = val[lo];
+                    val[lo] = val[hi];
+                    val[hi] = va;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P, BandWork W, DetState *__restrict__ st,
                                                                    float *__restrict__ sum, GoneBurst *__restrict__ gone,
                                                                    int gone_cap)
@@ -384,10 +605,11 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
     IRDM_DETECTOR_PRIO();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *s_key = reinterpret_cast<uint64_t *>(smem_raw);                    // kBandMaxTotal
-    uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_key + kBandMaxTotal);      // kBandMaxTotal
+    uint16_t *s_val = reinterpret_cast<uint16_t *>(s_key + kBandMaxTotal);       // kBandMaxTotal
+    uint32_t *rank_of = W.rank;                                                  // record -> place in creation order
     __shared__ unsigned s_n, s_carried, s_gone;
     BandCtl *ctl = W.ctl;
-    if (ctl->status != 1) return;
+    if (band_void(P, W) || ctl->status != 1) return;
     const int tid = threadIdx.x;
     if (tid == 0) {
         s_n = 0;
@@ -432,32 +654,40 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
             key = (1ull << 63) | ((uint64_t)r.cf << 46) | ((uint64_t)(0xffffffffu - rb) << 14) | (uint64_t)r.cb;
         }
         s_key[t] = key;
+        s_val[t] = (uint16_t)t;
+    }
+    // (the two orders are sorts: the all-pairs count this replaces took 0.3-0.6 ms of one workgroup at 2600 bursts)
+    int np = 2;
+    while (np < n) np <<= 1;
+    for (int t = n + tid; t < np; t += kPlanThreads) {
+        s_key[t] = ~0ull;
+        s_val[t] = 0xffff;
     }
     __syncthreads();
-    for (int t = tid; t < n; t += kPlanThreads) {
-        const uint64_t k = s_key[t];
-        int rank = 0;
-        for (int u = 0; u < n; u++) rank += s_key[u] < k ? 1 : 0;
-        s_rank[t] = (uint16_t)rank;
-    }
+    lds_bitonic_sort(s_key, s_val, np);
+    for (int q = tid; q < n; q += kPlanThreads) rank_of[s_val[q]] = (uint32_t)q;
     __syncthreads();
     const uint64_t id0 = st->burst_id;
     for (int t = tid; t < n; t += kPlanThreads) {
         const BandRec &r = W.recs[W.tot[t]];
-        W.ids[t] = r.cf < 0 ? st->act[r.seq].id : id0 + 10ull * (uint64_t)(s_rank[t] - n_carried);
+        W.ids[t] = r.cf < 0 ? st->act[r.seq].id : id0 + 10ull * (uint64_t)((int)rank_of[t] - n_carried);
     }
     // emission order: by the frame that deleted the burst, within a frame in list (= creation) order (:490-514);
     // bursts still active follow in creation order
     for (int t = tid; t < n; t += kPlanThreads) {
         const BandRec &r = W.recs[W.tot[t]];
-        s_key[t] = r.stop >= 0 ? (((uint64_t)((r.stop - (int64_t)P.idx0) / P.n)) << 32) | s_rank[t]
-                               : (1ull << 63) | s_rank[t];
+        s_key[t] = r.stop >= 0 ? (((uint64_t)((r.stop - (int64_t)P.idx0) / P.n)) << 32) | rank_of[t]
+                               : (1ull << 63) | rank_of[t];
+        s_val[t] = (uint16_t)t;
+    }
+    for (int t = n + tid; t < np; t += kPlanThreads) {
+        s_key[t] = ~0ull;
+        s_val[t] = 0xffff;
     }
     __syncthreads();
-    for (int t = tid; t < n; t += kPlanThreads) {
-        const uint64_t k = s_key[t];
-        int pos = 0;
-        for (int u = 0; u < n; u++) pos += s_key[u] < k ? 1 : 0;
+    lds_bitonic_sort(s_key, s_val, np);
+    for (int pos = tid; pos < n; pos += kPlanThreads) {
+        const int t = s_val[pos];
         const BandRec &r = W.recs[W.tot[t]];
         const uint64_t id = W.ids[t];
         if (r.stop >= 0) {
@@ -484,6 +714,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
         ctl->n_gone = n_gone;
         ctl->n_total = n;
         ctl->committed = 1;
+        W.bar[4] = 1;                // a scan chained behind this one may run
     }
 }
 
@@ -497,6 +728,16 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
 {
     IRDM_DETECTOR_PRIO();
     const BandCtl *ctl = W.ctl;
+    if (blockIdx.x == 0 && threadIdx.x < 3) W.bar[threadIdx.x] = 0;      // (the cooperative kernel's barrier: idle here)
+    if (band_void(P, W)) {
+        // (the host drains and ignores a void launch; its export slot says so for whoever looks)
+        if (hp_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+            __hip_atomic_store(hp_ctl + 2, (uint32_t)BAND_F_CHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // flags
+            __hip_atomic_store(hp_ctl + 0, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                      // status
+            __threadfence_system();
+        }
+        return;
+    }
     // the scan's verdict and records go to the host whatever the verdict is (types.hpp, gone_export_body)
     if (hp_hdr && blockIdx.x < kExportBlocks)
         gone_export_body(st, gone, gone_cap, hp_gone, hp_hdr, reinterpret_cast<const uint32_t *>(ctl), hp_ctl,
@@ -510,6 +751,10 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
 }
 
 }  // namespace
+
+int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan": 1.21 ms alone / 1.64 ms in run against 0.56 / 1.10 ms for
+                            // a launch per pass -- one workgroup plans at a quarter of the lanes, the step descriptors of the sums pass
+                            // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
 
@@ -560,6 +805,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(((F + 63) / 64) * 8); add(((F + 63) / 64) * 8); add(((F + 63) / 64) * 4);   // busy, forced, conc
     add(sizeof(BandRec) * 64 * kBandRecCap); add(4 * 64);                            // recs, rec_count
     add(4 * (size_t)n); add(4 * kBandMaxTotal); add(8 * kBandMaxTotal); add(256);    // sum_new, tot, ids, flags
+    add(256); add(4 * kBandMaxTotal);                                                // bar, rank
     return b;
 }
 
@@ -595,6 +841,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->tot = static_cast<uint32_t *>(take(4 * kBandMaxTotal));
     W->ids = static_cast<uint64_t *>(take(8 * kBandMaxTotal));
     W->flags = static_cast<uint32_t *>(take(256));
+    W->bar = static_cast<unsigned *>(take(256));
+    W->rank = static_cast<uint32_t *>(take(4 * kBandMaxTotal));
     return 0;
 }
 
@@ -603,7 +851,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, hipStream_t stream)
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, hipStream_t stream)
 {
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
@@ -611,6 +859,10 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     // round needs from the one before lives in the workspace.
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
+    static unsigned launch_serial = 0;
+    launch_serial = launch_serial + 1 ? launch_serial + 1 : 1;      // (never 0: the idle value of bar[5])
+    P.serial = (int32_t)launch_serial;
+    P.chained = chained;
     // (round 0's plan pass resets the control block, the flags and the finished-burst count)
     BandIO io;
     io.cross = W.cross;
@@ -628,13 +880,23 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     io.flags = W.flags;
     const size_t walk_lds = (size_t)kBandSlots * 64 * (8 + 8 + 4 + 4 + 4 + 4 + 4);
     const size_t commit_lds = (size_t)kBandMaxTotal * (8 + 2);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)band_walk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
-        (void)hipFuncSetAttribute((const void *)band_walk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
-        (void)hipFuncSetAttribute((const void *)band_commit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)commit_lds);
-        attr_done = true;
-    }
+    // (per launch: the attribute belongs to the device the calling thread is on)
+    (void)hipFuncSetAttribute((const void *)band_walk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+    (void)hipFuncSetAttribute((const void *)band_walk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+    (void)hipFuncSetAttribute((const void *)band_commit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)commit_lds);
+    if (g_band_coop) {
+        // every round up to the verdict in one launch (the kernel leaves as soon as a round is accepted or declined)
+        (void)round_end;
+        if (P.band_w == 128) {
+            (void)hipFuncSetAttribute((const void *)band_coop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+            hipLaunchKernelGGL((band_coop_kernel<4>), dim3(kCoopGroups), dim3(kCoopThreads), walk_lds, stream, P, W, io, counts,
+                               entries, st, mag, hist, sum, pre, smin, round_begin, kBandRounds);
+        } else {
+            (void)hipFuncSetAttribute((const void *)band_coop_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
+            hipLaunchKernelGGL((band_coop_kernel<8>), dim3(kCoopGroups), dim3(kCoopThreads), walk_lds, stream, P, W, io, counts,
+                               entries, st, mag, hist, sum, pre, smin, round_begin, kBandRounds);
+        }
+    } else
     for (int round = round_begin; round <= round_end; round++) {
         // (a continuation starts behind the plan its predecessor's verdict pass already made)
         if (round > round_begin || round_begin == 0)

@@ -76,8 +76,11 @@ int main(int argc, char **argv)
         if (cf32) burst_detector_feed_cf32(det, (const float *)blk, n, on_burst, NULL);
         else burst_detector_feed(det, (const int8_t *)blk, n, on_burst, NULL);
     }
-    printf("T %llu %d %d %d\n", (unsigned long long)burst_detector_total_count(det), n_bursts, n_frames, n_demods);
-    burst_detector_destroy(det);
+    /* what main.c's stats thread reads (main.c:455-456) */
+    printf("S %d %.9g %.9g\n", burst_detector_active_count(det), burst_detector_noise_floor(det), burst_detector_peak_signal(det));
+    const unsigned long long before = (unsigned long long)burst_detector_total_count(det);
+    burst_detector_destroy(det);        /* delivers the bursts of the stream's last, short block */
+    printf("T %d %d %d %d %llu\n", n_bursts, n_bursts, n_frames, n_demods, before);
     burst_downmix_destroy(g_dm);
     irdm_compat_shutdown();
     free(blk);

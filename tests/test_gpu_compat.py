@@ -76,6 +76,59 @@ def test_reference_stage_api_matches_the_oracle(compat_exe, tmp_path, fmt):
             assert int(f[5]) == demod_ids[int(f[1])]
 
 
+def test_stream_tail_and_stats_getters(compat_exe, tmp_path):
+    """A file that is not a multiple of the reader's 32768-sample block, with a burst that expires inside the short
+    last block: the reference feeds that block like any other (main.c:223-271, burst_detect.c:746-842), so the burst is
+    emitted and counted.  And the getters main.c's stats thread calls (burst_detect.c:355-395)."""
+    fs = 2_000_000
+    n = 40 * 32768 + 30000
+    # the last burst ends ~45 k samples before the end of the file: it expires (16 ms = 32 k samples after its last
+    # active frame) inside the final, short block
+    iq, _ = siggen.make_stream(fs, n, [
+        dict(start=520 * 2048 + 3000, freq_hz=siggen.channel_freq(4), payload=list(np.random.default_rng(1).integers(0, 4, 150))),
+        dict(start=n - 45000 - 17000, freq_hz=siggen.channel_freq(-9), payload=list(np.random.default_rng(2).integers(0, 4, 140)))],
+        seed=9)
+    path = str(tmp_path / "tail.cf32")
+    iq.tofile(path)
+    ref = orc.run_stream(iq, fs)
+    whole = orc.run_stream(iq[:40 * 32768], fs)
+    assert ref.n_tagged > whole.n_tagged, "the scene does not exercise the tail"
+    B, F, D, T, err = _run(compat_exe, path, fs, "cf32")
+    assert "burst_detect: tagged %d bursts total" % ref.n_tagged in err
+    assert int(T[1]) == ref.n_tagged == len(B) and int(T[5]) == whole.n_tagged
+    assert [int(b[1]) for b in B] == [r.id for r in ref.bursts]
+    assert len(D) == len(ref.demods)
+    S = [l.split() for l in subprocess.run([compat_exe, path, str(fs), "cf32"], stdout=subprocess.PIPE).stdout.decode().splitlines()
+         if l.startswith("S ")][0]
+    active, noise, peak = int(S[1]), float(S[2]), float(S[3])
+    assert active >= 0 and -140.0 < noise < 0.0
+    # (the burst of the tail is still active when the driver asks: the running maximum covers it, burst_detect.c:575-576)
+    assert abs(peak - max(np.float32(r.magnitude) for r in ref.bursts)) < 1e-4
+
+
+def test_detector_stats_formula():
+    """irdm_detector_stats against burst_detect.c:363-380 evaluated on the baseline sums read back"""
+    import ctypes as C
+    fs = 2_000_000
+    iq, _ = siggen.standard_scene(fs, 48 * 32768, 3, seed=12)
+    p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=256)
+    p.feed_host(iq)
+
+    class St(C.Structure):
+        _fields_ = [("active", C.c_int32), ("primed", C.c_int32), ("noise", C.c_float), ("peak", C.c_float)]
+    st = St()
+    L = irdm.lib()
+    L.irdm_detector_stats.argtypes = [C.c_void_p, C.POINTER(St)]
+    assert L.irdm_detector_stats(p.h, C.byref(st)) == 0
+    base = p.baseline_sum().astype(np.float64)
+    avg = np.float32(base.sum() / (2048 * 512))
+    want = np.float32(10.0) * np.log10(avg / np.float32(fs / 2048), dtype=np.float32)
+    assert st.primed == 1 and abs(st.noise - float(want)) < 1e-4
+    bursts = p.poll_bursts()
+    assert bursts and abs(st.peak - max(b.magnitude for b in bursts)) < 1e-6
+    p.close()
+
+
 def test_non_default_geometry_is_refused(compat_exe):
     import ctypes as C
     L = irdm.lib()
@@ -89,3 +142,13 @@ def test_non_default_geometry_is_refused(compat_exe):
     L.burst_detector_create.argtypes = [C.POINTER(Cfg)]
     c = Cfg(1.622e9, 2_000_000, 4096, 0, 0, 0, 0, 0, 0.0, 0, 1)
     assert not L.burst_detector_create(C.byref(c))
+
+    class Dm(C.Structure):
+        _fields_ = [("output_sample_rate", C.c_int), ("search_depth", C.c_int), ("handle_multiple_frames", C.c_int)]
+    L.burst_downmix_create.restype = C.c_void_p
+    L.burst_downmix_create.argtypes = [C.POINTER(Dm)]
+    assert not L.burst_downmix_create(C.byref(Dm(500000, 0, 0)))            # burst_downmix.c:228-239: not the default
+    h = L.burst_downmix_create(C.byref(Dm(250000, 250000, 0)))
+    assert h
+    L.burst_downmix_destroy.argtypes = [C.c_void_p]
+    L.burst_downmix_destroy(h)

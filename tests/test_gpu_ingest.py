@@ -109,7 +109,9 @@ def test_k1_builds_the_candidate_lists():
 @pytest.mark.parametrize("name", ["strong_simultaneous", "too_long", "many_active_10m"])
 def test_band_scan_continues_its_rounds(name):
     """Only the first rounds of the band scan are enqueued up front; when their verdict is still open the host enqueues
-    the rest on the same workspace.  band_first = 1 forces that path on scenes that need two or three rounds."""
+    the rest on the same workspace.  band_first = 1 forces that path on scenes that need two or three rounds.  The
+    cooperative form (option band_coop: every round inside one launch, grid barriers between the passes) needs no
+    continuation and gives the same records."""
     fs, iq = scenes.ALL[name]()
     ref = orc.run_stream(iq, fs)
     blocks = max(1, (len(iq) // 32768) // 4)
@@ -117,3 +119,11 @@ def test_band_scan_continues_its_rounds(name):
         got = parity.run_gpu(iq, fs, chunks=_equal_chunks(len(iq), blocks), depth=depth, options={"band_first": 1})
         parity.compare(got, ref)
         assert got["stats"]["band_extra"] >= 1 and got["stats"]["scan_fallbacks"] == 0, got["stats"]
+    try:
+        got = parity.run_gpu(iq, fs, chunks=_equal_chunks(len(iq), blocks), depth=1, options={"band_first": 1, "band_coop": 1})
+    finally:
+        p = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        p.set_option("band_coop", 0)
+        p.close()
+    parity.compare(got, ref)
+    assert got["stats"]["band_extra"] == 0 and got["stats"]["scan_fallbacks"] == 0 and got["stats"]["band_chunks"] >= 1, got["stats"]

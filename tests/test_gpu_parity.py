@@ -58,6 +58,13 @@ def test_gpu_burst_fft_create_rejects_bad_arguments():
     assert not L.gpu_burst_fft_create(2000, 16, irdm._fp(w))     # not a power of two -> NULL => CPU fallback in caller
     assert not L.gpu_burst_fft_create(2048, 0, irdm._fp(w))
     L.gpu_burst_fft_destroy(None)                                # NULL-safe
+    # the DC self-test at create (vulkan/burst_fft.c:324-394): a context that does not compute is not handed out
+    bad = w.copy()
+    bad[7] = np.nan
+    assert not L.gpu_burst_fft_create(2048, 16, irdm._fp(bad))
+    g = L.gpu_burst_fft_create(2048, 16, irdm._fp(w))
+    assert g
+    L.gpu_burst_fft_destroy(g)
 
 
 def _scene_2m(seed=11, n_bursts=8, secs=2.4, **kw):
