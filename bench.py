@@ -155,6 +155,29 @@ def cpu_reference_layout(orc, host, fs, fmt, workers=4):
     return dict(seconds=dt, bursts=counts["bursts"], demods=counts["demods"])
 
 
+def record_msg_bytes(irdm, cap):
+    """bytes of one rank's record message: a count word + cap compact records (pack_records)"""
+    return 8 + cap * (irdm.Demod.bits.offset + irdm.Demod.bits.size // 8)
+
+
+def pack_records(irdm, demods, hb, cap):
+    """What frame_output_print needs of the demodulated frames of one step (frame_output.c:168-197) into the message
+    buffer `hb` (numpy uint8 view of pinned memory): a count word, then per frame the record's head (id, timestamp,
+    frequency, magnitude, noise, confidence, level, symbol counts) and the hard bits packed 8 per byte = 176 bytes.
+    More frames than the message holds is an error: nothing is ever dropped silently."""
+    head, nbits = irdm.Demod.bits.offset, irdm.Demod.bits.size
+    recp = head + nbits // 8
+    k = len(demods)
+    if k > cap:
+        raise SystemExit("bench: %d demodulated frames in one step exceed the gather message (%d)" % (k, cap))
+    hb[:8] = np.array([k], dtype=np.int64).view(np.uint8)
+    if k:
+        rec = hb[8:8 + k * recp].reshape(k, recp)
+        rec[:, :head] = demods[:, :head]
+        rec[:, head:] = np.packbits(demods[:, head:head + nbits], axis=1)
+    return k
+
+
 def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, backend):
     """BASELINE config 4: ONE 12 MHz cf32 stream, 16384-point detect, consecutive time-chunks on consecutive ranks.
     Rank 0 holds one period of the stream (world chunks) in HBM and scatters [overlap | chunk] slices every super-step;
@@ -189,11 +212,12 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
         key, val = kv.split("=")
         pipe.set_option(key, int(val))
     ts = sharding.TimeShard(dist, pipe, torch, device, chunk, bps, ov) if world > 1 else None
-    REC = C.sizeof(irdm.Demod)
-    cap = 4096
-    gbuf = torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) if world > 1 else None
-    glist = [torch.zeros((cap * REC,), dtype=torch.uint8, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
-    counts = torch.zeros((2,), dtype=torch.int64, device=cdev)
+    cap = 8192                           # = max_bursts_per_chunk above: more frames in one chunk are an error, not truncated
+    msg = record_msg_bytes(irdm, cap)
+    ghost = torch.zeros((msg,), dtype=torch.uint8).pin_memory() if world > 1 else None
+    gbuf = torch.zeros((msg,), dtype=torch.uint8, device=cdev) if world > 1 else None
+    glist = [torch.zeros((msg,), dtype=torch.uint8, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    counts = torch.zeros((4,), dtype=torch.int64, device=cdev)       # bursts, frames produced, frames sent, frames gathered
     step_no = [0]
 
     def super_step(record):
@@ -210,14 +234,17 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
         nbst = len(pipe.poll_bursts_raw())
         pipe.drop_frames()
         demods = pipe.poll_demods_raw()
+        k = 0
         if world > 1:
-            k = min(len(demods), cap)
-            if k:
-                gbuf[:k * REC] = torch.from_numpy(demods[:k].reshape(-1)).to(cdev)
+            k = pack_records(irdm, demods, ghost.numpy(), cap)
+            gbuf.copy_(ghost)
             dist.gather(gbuf, glist, dst=0)
         if record:
             counts[0] += nbst
             counts[1] += len(demods)
+            counts[2] += k
+            if world > 1 and rank == 0:
+                counts[3] += torch.stack([l[:8] for l in glist]).view(torch.int64).sum()
 
     for _ in range(args.warmup):
         super_step(False)
@@ -252,6 +279,8 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                                    % (fs // 1_000_000, nfft, world, chunk, ov, state_mb, args.density),
                        "samples_per_step_per_gpu": chunk, "parallelism": "time-chunks x%d" % world,
                        "job_bursts_per_step": int(counts[0].item()) / K, "raw_frames_per_step": int(counts[1].item()) / K,
+                       "records": ({"produced": int(counts[1].item()), "sent": int(counts[2].item()),
+                                    "gathered_on_rank0": int(counts[3].item())} if world > 1 else None),
                        "pipeline_depth": args.depth, "backend": backend,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
             "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_w", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -291,7 +320,8 @@ def main():
                     help="extra steps at pipeline_depth 0 (stage times with one kernel on the chip at a time, and the records "
                          "for the parity check; 0 = skip)")
     ap.add_argument("--detect-steps", type=int, default=10, help="extra detect-only steps (BASELINE config 2; 0 = skip)")
-    ap.add_argument("--file-run", type=int, default=1, help="1: also time the C99 binary on the chunk written to a file")
+    ap.add_argument("--file-run", type=int, default=2,
+                    help="1: also time the C99 binary on the chunk written to a file; 2: and on a 600 Msample recording")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="irdm_set_option before the run (kernel-variant A/B: fir_generic=1, fft_radix2=1, scan_mode=1)")
     ap.add_argument("--ingest", type=int, default=1,
@@ -345,7 +375,7 @@ def main():
     elif args.format == "ci8":      # siggen.to_ci8 with headroom for the burst peaks
         x = torch.clamp(torch.round(x * 512.0 * 4), -128, 127).to(torch.int8)
     torch.cuda.synchronize()
-    pipe = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192,      # (= MAX_BURSTS below)
+    pipe = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192,      # (= the gather message's cap below)
                          device=local, pipeline_depth=args.depth)
     pipe.L.irdm_feed_device.restype = C.c_int
     for kv in args.opt:
@@ -357,12 +387,8 @@ def main():
     # the hard bits packed 8 per byte: 176 bytes per frame, a count word in front.  Fixed-size messages sized for the
     # context's max_bursts_per_chunk (a step with more frames than that is an error, never a silent truncation),
     # double-buffered and asynchronous so the collective of step i overlaps the detector scan of step i+1.
-    MAX_BURSTS = 8192
-    HEAD = irdm.Demod.bits.offset
-    NBITS = irdm.Demod.bits.size
-    RECP = HEAD + NBITS // 8
-    cap = MAX_BURSTS
-    MSG = 8 + cap * RECP
+    cap = 8192                                                         # = max_bursts_per_chunk above
+    MSG = record_msg_bytes(irdm, cap)
     gather_host = [torch.zeros((MSG,), dtype=torch.uint8).pin_memory() for _ in range(2)] if world > 1 else None
     gather_bufs = [torch.zeros((MSG,), dtype=torch.uint8, device=cdev) for _ in range(2)] if world > 1 else None
     gather_lists = ([[torch.zeros((MSG,), dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)]
@@ -379,15 +405,7 @@ def main():
             gathered.add_(torch.stack([l[:8] for l in gather_lists[slot]]).view(torch.int64).sum())
 
     def gather_send(slot, demods):
-        k = len(demods)
-        if k > cap:
-            raise SystemExit("bench: %d demodulated frames in one step exceed the gather message (%d)" % (k, cap))
-        hb = gather_host[slot].numpy()
-        hb[:8] = np.array([k], dtype=np.int64).view(np.uint8)
-        if k:
-            rec = hb[8:8 + k * RECP].reshape(k, RECP)
-            rec[:, :HEAD] = demods[:, :HEAD]
-            rec[:, HEAD:] = np.packbits(demods[:, HEAD:HEAD + NBITS], axis=1)
+        k = pack_records(irdm, demods, gather_host[slot].numpy(), cap)
         gather_bufs[slot].copy_(gather_host[slot], non_blocking=True)
         gather_work[slot] = dist.gather(gather_bufs[slot], gather_lists[slot], dst=0, async_op=True)
         return k
@@ -431,6 +449,10 @@ def main():
             nb += pipe.feed_end()
         return nb
 
+    # the records of the stream's FIRST chunk as the timed context produces them (pipeline_depth 2, fed in place with
+    # look-ahead, the other chunks' stages running beside it): what parity_checked compares with the oracle
+    first_chunk = {"bursts": None, "demods": None}
+
     def step(record):
         ta = time.perf_counter()
         nb_step = feed_one()
@@ -439,6 +461,8 @@ def main():
         pipe.drop_frames()
         demods = pipe.poll_demods_raw()          # [n, 4544] bytes: everything frame_output_print needs
         tc = time.perf_counter()
+        if first_chunk["bursts"] is None and len(bursts):
+            first_chunk["bursts"], first_chunk["demods"] = bursts.copy(), demods.copy()
         if record:
             host["feed_call"] += (tb - ta) * 1e3
             host["poll"] += (tc - tb) * 1e3
@@ -637,15 +661,47 @@ def main():
             x.cpu().numpy().tofile(path)
             exe = os.path.join(ROOT, "iridium-sniffer_amd", "iridium-sniffer-hip")
             tf = time.perf_counter()
-            r = subprocess.run([exe, "-f", path, "-r", str(fs), "--format", args.format, "--file-info", "bench"],
+            r = subprocess.run([exe, "-f", path, "-r", str(fs), "--format", args.format, "--file-info", "bench", "--timing"],
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             fdt = time.perf_counter() - tf
             os.remove(path)
             lines = r.stdout.count(b"\nRAW:") + (1 if r.stdout.startswith(b"RAW:") else 0)
+
+            def timing_of(err):
+                import re
+                mt = re.search(rb"startup ([0-9.]+) s .* stream ([0-9.]+) s", err)
+                return (float(mt.group(1)), float(mt.group(2))) if mt else (None, None)
+            st_up, st_run = timing_of(r.stderr)
             file_to_raw = {"value": round(n / fdt / 1e6, 2), "unit": "Msamples/s", "wall_s": round(fdt, 3),
+                           "startup_s": st_up, "stream_s": st_run,
                            "raw_lines": lines, "rc": r.returncode,
                            "note": "iridium-sniffer-hip -f <%d samples %s>, process start to exit (HIP init, "
                                    "context creation, fread from the page cache, H2D, GPU, RAW lines to a pipe)" % (n, args.format)}
+            # BASELINE.md's only published workload: a 60 s / 600 Msample cf32 recording (12.0 s on an i7-11800H, AVX2).
+            # Here: the chunk nine times over (604 Msamples, 4.8 GB) through the same binary.
+            if args.file_run >= 2 and args.format == "cf32":
+                import shutil
+                reps = max(1, int(round(600e6 / n)))
+                big_dir = shm if shutil.disk_usage(shm).free > (reps + 1) * n * bps else tempfile.gettempdir()
+                big = os.path.join(big_dir, "irdm_bench_%d_big.cf32" % os.getpid())
+                host_chunk = x.cpu().numpy()
+                with open(big, "wb") as fbig:
+                    for _ in range(reps):
+                        host_chunk.tofile(fbig)
+                del host_chunk
+                tf = time.perf_counter()
+                r = subprocess.run([exe, "-f", big, "-r", str(fs), "--format", "cf32", "--file-info", "bench", "--timing"],
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                bdt = time.perf_counter() - tf
+                os.remove(big)
+                st_up, st_run = timing_of(r.stderr)
+                file_to_raw["recording_600Msamples"] = {
+                    "samples": reps * n, "wall_s": round(bdt, 3), "startup_s": st_up, "stream_s": st_run,
+                    "value": round(reps * n / bdt / 1e6, 2), "unit": "Msamples/s", "rc": r.returncode,
+                    "raw_lines": r.stdout.count(b"\nRAW:") + (1 if r.stdout.startswith(b"RAW:") else 0),
+                    "published_reference_s": 12.0,
+                    "note": "process start to exit; the reference's README publishes 12.0 s wall for its 600 Msample recording on "
+                            "an i7-11800H (AVX2, no GPU); file read from %s" % big_dir}
         except Exception as e:
             file_to_raw = {"error": str(e)[:200]}
 
@@ -681,7 +737,15 @@ def main():
         except Exception as e:
             cpu = dict(cpu1)
             cpu["sample"] += " [thread-layout run failed: %s]" % str(e)[:80]
-        # (c) parity of the benchmark scene itself: the chunk's records through the HIP path vs the oracle's
+        # (c) parity of the benchmark scene itself: the first chunk's records through the HIP path vs the oracle's --
+        #     from the TIMED context when it has delivered them (else from the pipeline_depth 0 context above)
+        which = None
+        if first_chunk["bursts"] is not None and m == n:
+            gpu_recs = ([irdm.Burst.from_buffer_copy(bytes(r)) for r in first_chunk["bursts"]],
+                        [irdm.Demod.from_buffer_copy(bytes(r)) for r in first_chunk["demods"]])
+            which = "the timed context (pipeline_depth %d, in place %s, look-ahead %s)" % (args.depth, ingest, look)
+        elif gpu_recs is not None:
+            which = "a pipeline_depth 0 context on the same chunk"
         if gpu_recs is not None and m == n:
             gb, gd = gpu_recs
             ok = len(gb) == len(ref.bursts) and len(gd) == len(ref.demods)
@@ -702,7 +766,7 @@ def main():
                     max_soft = max(max_soft, soft)
                 ok = ok and max_soft <= 1e-4
             parity_checked = {"ok": bool(ok), "bursts": len(gb), "frames": len(gd), "oracle_bursts": len(ref.bursts),
-                              "oracle_frames": len(ref.demods), "max_soft": max_soft,
+                              "oracle_frames": len(ref.demods), "max_soft": max_soft, "records_of": which,
                               "what": "ids / indices / centre bins / dB fields / hard bits / confidence exact, level and LLR within 1e-4"}
 
     if rank == 0:
@@ -738,6 +802,9 @@ def main():
             "file_to_raw": file_to_raw,
             "pcie_inclusive": pcie,
         }
+        if world > 1 and not (out["config"]["records"]["produced"] == out["config"]["records"]["sent"] ==
+                              out["config"]["records"]["gathered_on_rank0"]):
+            raise SystemExit("bench: record gather lost frames: %r" % (out["config"]["records"],))
         print(json.dumps(out), flush=True)
     pipe.close()
     if world > 1:

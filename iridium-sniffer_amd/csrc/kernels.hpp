@@ -59,6 +59,7 @@ struct BandWork {                        // device workspace, carved out of one 
     unsigned *bar;                       // [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
+extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass
 int band_list_cap(int n);                // entries per frame the band scan's lists hold
 int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0);

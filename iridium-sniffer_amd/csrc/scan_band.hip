@@ -522,6 +522,33 @@ __device__ __forceinline__ void band_cross_wave(const BandParams &P, const BandW
     __builtin_amdgcn_wave_barrier();
 }
 
+// The crossing pass as a fixed grid of wavefronts that walk their frames (a wavefront per frame with list entries, the
+// empty frames skipped 64 at a time): beside the per-burst chains' kernels the one-workgroup-per-frame form spent its
+// time asking the dispatcher for 8192 workgroups (10 us alone, 50-150 us in run).
+constexpr int kCrossGroups = 256;
+
+__global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
+                                                           const ListEntry *__restrict__ entries)
+{
+    IRDM_DETECTOR_PRIO();
+    __shared__ uint32_t s_bits_all[4][16384 / 32];
+    if (band_void(P, W) || W.ctl->status != 0) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gw = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
+    uint32_t *s_bits = s_bits_all[wave];
+    for (int f0 = gw; f0 < P.n_frames; f0 += 64 * n_waves) {
+        const int fl = f0 + lane * n_waves;
+        const unsigned cl = fl < P.n_frames ? counts[fl] : 0u;
+        uint64_t todo = __builtin_amdgcn_ballot_w64(cl != 0 && cl <= (unsigned)P.list_cap);
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cl, j);
+            band_cross_wave(P, W, c, entries, f0 + j * n_waves, s_bits, lane);
+        }
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(kCoopThreads) void band_coop_kernel(BandParams P, BandWork W, BandIO io,
                                                                  const unsigned *__restrict__ counts,
@@ -756,6 +783,8 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // a launch per pass -- one workgroup plans at a quarter of the lanes, the step descriptors of the sums pass
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
+int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
+
 int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
 
 int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0)
@@ -903,7 +932,10 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, P, W, counts, st, round);
         if (round == round_end) break;
         hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
-        hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
+        if (g_band_cross_wave)
+            hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
+        else
+            hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
         if (P.band_w == 128)
             hipLaunchKernelGGL((band_walk_kernel<4>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
         else

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <pthread.h>
 #include <semaphore.h>
 
@@ -78,8 +79,18 @@ static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, ui
     }
 }
 
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int main(int argc, char **argv)
 {
+    const double t_main = now_s();
+    int timing = 0;
+    unsigned long long fed = 0;
     const char *file = NULL, *file_info = NULL, *format = NULL;
     double rate = 0, freq = 1622000000.0, db = 0;
     int gardner = 1, verbose = 0;
@@ -100,6 +111,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--save-bursts")) save_dir = NEXT();   /* options.c --save-bursts: IQ + .meta per downmixed frame */
         else if (!strcmp(a, "--depth")) depth = atoi(NEXT());       /* 0: per-chunk latency, 1: throughput (default) */
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) verbose = 1;
+        else if (!strcmp(a, "--timing")) timing = 1;                /* start-up and streaming time on stderr */
         else if (!strcmp(a, "--no-simd") || !strcmp(a, "--no-gpu")) {
             fprintf(stderr, "%s: this binary is the GPU path; use the reference binary for the CPU path\n", a);
             return 2;
@@ -157,6 +169,7 @@ int main(int argc, char **argv)
     sem_init(&rd.empty, 0, 2);
     pthread_t th;
     if (pthread_create(&th, NULL, reader_main, &rd) != 0) { fprintf(stderr, "pthread_create failed\n"); return 1; }
+    const double t_ready = now_s();
     irdm_demod_t *d = malloc(sizeof(*d) * 256);
     static char line[256 * IRDM_RAW_LINE_MAX];
     uint64_t t0 = 0;
@@ -169,6 +182,7 @@ int main(int argc, char **argv)
             fprintf(stderr, "burst_detect: GPU processing failed\n");
             rc = 1;
         }
+        fed += r;
         sem_post(&rd.empty);                        /* irdm_feed_host has consumed the buffer when it returns */
         if (rc == 0) drain(p, d, file_info, &t0, line, sizeof line);
         if (r < chunk) { rd.stop = 1; sem_post(&rd.empty); break; }   /* ragged last chunk = end of stream */
@@ -179,6 +193,11 @@ int main(int argc, char **argv)
     if (rc == 0 && irdm_flush(p) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; }
     drain(p, d, file_info, &t0, line, sizeof line);
     fflush(stdout);
+    if (timing) {
+        const double t_done = now_s();
+        fprintf(stderr, "irdm timing: startup %.3f s (HIP initialisation + device context), stream %.3f s for %llu samples = %.1f Msamples/s\n",
+                t_ready - t_main, t_done - t_ready, fed, t_done > t_ready ? fed / (t_done - t_ready) / 1e6 : 0.0);
+    }
     fprintf(stderr, "burst_detect: tagged %lu bursts total\n", (unsigned long)irdm_tagged_bursts(p));
     irdm_destroy(p);
     irdm_host_free(rd.buf[0]);

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/p13
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+timeout 1500 python -m pytest tests -x -q -m gpu > "$OUT/t1.log" 2>&1
+Q="--cpu-samples 0 --host-steps 0 --detect-steps 0 --file-run 0 --alone-steps 0"
+for rep in 1 2; do
+timeout 120 python bench.py $Q 2>"$OUT/b_$rep.err" | tail -1 > "$OUT/b_$rep.json"
+timeout 120 python bench.py $Q --opt band_cross_wave=0 2>"$OUT/b_cw0_$rep.err" | tail -1 > "$OUT/b_cw0_$rep.json"
+done
+timeout 120 python bench.py --steps 10 --warmup 3 $Q --density 40 --sample-rate 12000000 2>"$OUT/cfg5.err" | tail -1 > "$OUT/cfg5.json"
+tail -n 6 "$OUT/t1.log"
