@@ -283,7 +283,7 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                                     "gathered_on_rank0": int(counts[3].item())} if world > 1 else None),
                        "pipeline_depth": args.depth, "backend": backend,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
-            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_w", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_r", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
             "cpu_baseline": None,
         }
@@ -489,7 +489,11 @@ def main():
     if args.depth:
         drain_feed()
         pipe.flush()
-        pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
+        wb = pipe.poll_bursts_raw(); pipe.drop_frames(); wd = pipe.poll_demods_raw()
+        if first_chunk["bursts"] is None and len(wb):
+            # (the warm-up chunks' records leave together here when the warm-up is shorter than the pipeline: records
+            # are emitted in chunk order, so the stream's first chunk is the head of them)
+            first_chunk["bursts"], first_chunk["demods"] = wb.copy(), wd.copy()
     if world > 1:
         for slot in (0, 1):
             gather_wait(slot)
@@ -542,10 +546,13 @@ def main():
         "scan": 8.0 * n,                          # history row read + write per bin-frame (B_det = 16 B/sample with K1)
         "fir": float(bps) * lb + 8.0 * lb / decim,   # burst-window re-read + decimated (cf32) write
     }
-    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "band_* (scan_band.hip passes)", "fir": "fir_decimate_kernel_w"}
+    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "band_* (scan_band.hip passes)",
+               "fir": "fir_decimate_kernel_r" if decim in (40, 48) else "fir_decimate_kernel_w"}
     # the dominant KERNEL: the scan is a chain of ~25 short launches of six kernels (its stage time is their sum plus
     # what they wait for each other), so it is reported in stage_ms / stage_GBps but not as "the" kernel
-    dom = max(("fft_mag", "fir"), key=lambda k: ms[k])
+    # (the decimator does 57 % of the step's algorithmic bytes and all of its arithmetic; K1 only where bursts are so few
+    # that the decimator's launch is less than half of K1's)
+    dom = "fir" if ms["fir"] >= 0.5 * ms["fft_mag"] else "fft_mag"
     ach = alg_bytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs and
     # corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py -> profiles/<round>_pmc.json)
@@ -741,8 +748,8 @@ def main():
         #     from the TIMED context when it has delivered them (else from the pipeline_depth 0 context above)
         which = None
         if first_chunk["bursts"] is not None and m == n:
-            gpu_recs = ([irdm.Burst.from_buffer_copy(bytes(r)) for r in first_chunk["bursts"]],
-                        [irdm.Demod.from_buffer_copy(bytes(r)) for r in first_chunk["demods"]])
+            gpu_recs = ([irdm.Burst.from_buffer_copy(bytes(r)) for r in first_chunk["bursts"][:len(ref.bursts)]],
+                        [irdm.Demod.from_buffer_copy(bytes(r)) for r in first_chunk["demods"][:len(ref.demods)]])
             which = "the timed context (pipeline_depth %d, in place %s, look-ahead %s)" % (args.depth, ingest, look)
         elif gpu_recs is not None:
             which = "a pipeline_depth 0 context on the same chunk"
@@ -750,23 +757,38 @@ def main():
             gb, gd = gpu_recs
             ok = len(gb) == len(ref.bursts) and len(gd) == len(ref.demods)
             max_soft = 0.0
+            first_bad = None
+
+            def bad(what):
+                nonlocal first_bad
+                if first_bad is None:
+                    first_bad = what
+                return False
             if ok:
                 for g, r_ in zip(gb, ref.bursts):
-                    ok = ok and (g.id, g.start, g.stop, g.last_active, g.center_bin, g.num_samples) == \
-                        (r_.id, r_.start, r_.stop, r_.last_active, r_.center_bin, r_.num_samples)
-                    ok = ok and np.float32(g.magnitude).view(np.uint32) == np.float32(r_.magnitude).view(np.uint32)
-                    ok = ok and np.float32(g.noise).view(np.uint32) == np.float32(r_.noise).view(np.uint32)
+                    for fld in ("id", "start", "stop", "last_active", "center_bin", "num_samples"):
+                        if getattr(g, fld) != getattr(r_, fld):
+                            ok = bad("burst id %d: %s %r != %r" % (r_.id, fld, getattr(g, fld), getattr(r_, fld)))
+                    for fld in ("magnitude", "noise"):
+                        if np.float32(getattr(g, fld)).view(np.uint32) != np.float32(getattr(r_, fld)).view(np.uint32):
+                            ok = bad("burst id %d: %s %r != %r" % (r_.id, fld, getattr(g, fld), getattr(r_, fld)))
                 for g, r_ in zip(gd, ref.demods):
-                    ok = ok and (g.id, g.timestamp, g.n_symbols, g.n_bits, g.confidence, g.direction) == \
-                        (r_.id, r_.timestamp, r_.n_symbols, r_.n_bits, r_.confidence, r_.direction)
-                    ok = ok and bytes(g.bits[:g.n_bits]) == bytes(r_.bits[:r_.n_bits])
+                    for fld in ("id", "timestamp", "n_symbols", "n_bits", "confidence", "direction"):
+                        if getattr(g, fld) != getattr(r_, fld):
+                            ok = bad("frame id %d: %s %r != %r" % (r_.id, fld, getattr(g, fld), getattr(r_, fld)))
+                    if bytes(g.bits[:g.n_bits]) != bytes(r_.bits[:r_.n_bits]):
+                        ok = bad("frame id %d: hard bits differ" % r_.id)
                     soft = max(abs(g.level - r_.level),
                                float(np.max(np.abs(np.array(g.llr[:g.n_bits], np.float32) - np.array(r_.llr[:r_.n_bits], np.float32))))
                                if g.n_bits else 0.0)
                     max_soft = max(max_soft, soft)
-                ok = ok and max_soft <= 1e-4
+                if max_soft > 1e-4:
+                    ok = bad("soft outputs differ by %g" % max_soft)
+            else:
+                bad("record counts differ")
             parity_checked = {"ok": bool(ok), "bursts": len(gb), "frames": len(gd), "oracle_bursts": len(ref.bursts),
                               "oracle_frames": len(ref.demods), "max_soft": max_soft, "records_of": which,
+                              "first_mismatch": first_bad,
                               "what": "ids / indices / centre bins / dB fields / hard bits / confidence exact, level and LLR within 1e-4"}
 
     if rank == 0:

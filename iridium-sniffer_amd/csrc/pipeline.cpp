@@ -1215,7 +1215,6 @@ static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
         for (int i = 0; i < nb; i++) {
             p->q_bursts.push_back(b.recs[i]);
             p->last_bursts.push_back(b.recs[i]);
-            p->tagged++;
         }
         return nb;
     }
@@ -1253,7 +1252,6 @@ static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
         irdm_burst_t &r = b.recs[i];
         p->q_bursts.push_back(r);
         p->last_bursts.push_back(r);
-        p->tagged++;
 
         irdm_frame_info_t f;
         memset(&f, 0, sizeof(f));
@@ -1740,6 +1738,9 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     p->last_ms[1] = hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
     p->last_frames = p->fl_frames;
     p->d_mag_last = p->fl_mag;
+    // burst_detect.c:739: counted where the detector hands the burst over -- here, when the scan settles -- so that the
+    // count is complete for a state export while the bursts' per-burst chains are still in flight
+    p->tagged += (uint64_t)n_gone;
     *n_gone_out = n_gone;
     return 0;
 }
@@ -2235,7 +2236,7 @@ extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
     IRDM_HIP_CHECK(hipMemcpy(p->d_sum, i, sizeof(float) * p->P.n, hipMemcpyHostToDevice));
     i += sizeof(float) * p->P.n;
     IRDM_HIP_CHECK(hipMemcpy(p->d_hist, i, sizeof(float) * (size_t)kHistory * p->P.n, hipMemcpyHostToDevice));
-    p->total_samples = p->begun_samples = h.total_samples;
+    if (p->begin_no == p->end_no) p->total_samples = p->begun_samples = h.total_samples;     // (a feed already begun has fixed its own position)
     p->tagged = h.tagged;
     p->start_time_ns = h.start_time_ns;
     p->host_primed = h.host_primed;
@@ -2309,7 +2310,7 @@ extern "C" int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, si
 
 extern "C" int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, uint64_t abs_start)
 {
-    if (!p || (!h_iq && n_samples) || n_samples > abs_start) return -1;
+    if (!p || (!h_iq && n_samples) || n_samples > abs_start || p->begin_no != p->end_no) return -1;
     if (quiesce(p) != 0) return -1;
     if (n_samples > p->ring_len) {       // only the most recent ring_len samples can matter
         h_iq = static_cast<const char *>(h_iq) + (n_samples - p->ring_len) * p->bps;

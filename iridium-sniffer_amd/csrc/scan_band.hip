@@ -160,12 +160,45 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
     }
     __syncthreads();
     if (round == 0) {
+        // Round 0 speculates "no update in this chunk": no update steps, and one snapshot -- the carried sums -- if any
+        // frame has list entries.  Everything the general path below derives from u is a constant then; written in one
+        // pass (the general path's ten dependent passes took 100 us of one workgroup in run for this).
+        int any = 0;
         for (int f = tid; f < F; f += kPlanThreads) {
+            const unsigned c = counts[f];
             W.uq[f] = 0;
             W.uf[f] = 0;
-            if (counts[f] > (unsigned)P.list_cap) atomicOr(&s_flags, BAND_F_LIST);
+            W.cnt_before[f] = 0;
+            const int slot = c > 0 ? 0 : -1;
+            W.slot_pre[f] = slot;
+            W.slot_post[f] = slot;
+            any |= c > 0 ? 1 : 0;
+            if (c > (unsigned)P.list_cap) atomicOr(&s_flags, BAND_F_LIST);
         }
-        if (tid == 0) ctl->h0 = st->hist_idx;
+        if (any) atomicOr(&s_mismatch, 1);          // (s_mismatch doubles as "some frame has entries" here)
+        for (int i = tid; i < P.n_bands * P.occ_words; i += kPlanThreads) W.occ[i] = 0;
+        for (int i = tid; i < P.occ_words; i += kPlanThreads) {
+            W.busy[i] = 0;
+            W.forced[i] = 0;
+            W.conc[i] = 0;
+        }
+        for (int i = tid; i < P.n_bands; i += kPlanThreads) W.rec_count[i] = 0;
+        for (int k = tid; k < 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = make_int4(0, 0, -1, 0);
+        __syncthreads();
+        if (tid == 0) {
+            const int some = s_mismatch;
+            ctl->h0 = st->hist_idx;
+            W.need[0] = some;
+            W.snap_slot[0] = some ? 0 : -1;
+            ctl->n_upd = 0;
+            ctl->n_snap = some;
+            ctl->rounds = 1;
+            if (s_flags) {
+                ctl->flags = s_flags;
+                ctl->status = 2;
+            }
+        }
+        return;
     } else {
         // verdict on the previous round
         for (int f = tid; f < F; f += kPlanThreads) {

@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/<dir> (rocprofv3 --kernel-trace --stats and the two --pmc passes) into
-profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json.  FETCH_SIZE is doubled for the wide coalesced
-readers as MI355X_MICROARCH.md (HBM section) prescribes; WRITE_SIZE is taken as reported.  Units: bytes."""
+"""Condense gpurun_out/<dir> (tools/measure_round.sh: rocprofv3 --kernel-trace --stats runs, the FETCH_SIZE / WRITE_SIZE
+passes and the decimator's SQ-counter passes, 10 MHz cfg3 and 12 MHz / 40 bursts per Msample) into
+  profiles/<tag>_kernel_stats[_depth0|_cfg5|_cfg5_depth0].csv   per-kernel launches / total / average
+  profiles/<tag>_pmc.json, <tag>_pmc_cfg5.json                  HBM bytes per launch (FETCH_SIZE doubled for the wide
+                                                                coalesced readers as MI355X_MICROARCH.md prescribes)
+  profiles/<tag>_fir_pmc.json                                   the decimator's SQ counters per launch, both scenes
+  profiles/<tag>_bench_*.json                                   the bench lines of the run
+Usage: python profiles/summarize.py gpurun_out/<dir> <tag>"""
 import collections
 import csv
 import json
+import os
+import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
@@ -15,38 +22,79 @@ def short(name):
     return name.split("(")[0][:70]
 
 
-rows = list(csv.DictReader(open(f"{src}/r1_kernel_stats.csv")))
-import os
-if os.path.exists(f"{src}/r1d0_kernel_stats.csv"):
-    with open(f"profiles/{tag}_kernel_stats_depth0.csv", "w") as f:
+def stats(infile, outfile):
+    if not os.path.exists(infile):
+        return
+    with open(outfile, "w") as f:
         f.write("kernel,calls,total_ms,avg_us,pct\n")
-        for r in csv.DictReader(open(f"{src}/r1d0_kernel_stats.csv")):
+        for r in csv.DictReader(open(infile)):
             if "irdm::" not in r["Name"] and "rocclr" not in r["Name"]:
                 continue
             f.write("%s,%s,%.3f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                              float(r["AverageNs"]) / 1e3, r["Percentage"]))
-with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-    f.write("kernel,calls,total_ms,avg_us,pct\n")
-    for r in rows:
-        if "irdm::" not in r["Name"] and "rocclr" not in r["Name"]:
+
+
+stats(f"{src}/r1_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+stats(f"{src}/r1d0_kernel_stats.csv", f"profiles/{tag}_kernel_stats_depth0.csv")
+stats(f"{src}/c5_kernel_stats.csv", f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40.csv")
+stats(f"{src}/c5d0_kernel_stats.csv", f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40_depth0.csv")
+
+
+def pmc(prefix, outfile):
+    acc = collections.defaultdict(dict)
+    for name, key in ((prefix + "pmc_fetch", "FETCH_SIZE"), (prefix + "pmc_write", "WRITE_SIZE")):
+        path = f"{src}/{name}_counter_collection.csv"
+        if not os.path.exists(path):
+            return
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if "irdm::" in r["Kernel_Name"]:
+                agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            acc[k][key + "_KB_mean"] = sum(v) / len(v)
+            acc[k]["launches_" + key] = len(v)
+    out = {}
+    for k, d in acc.items():
+        fetch = d.get("FETCH_SIZE_KB_mean", 0.0) * 1024 * 2      # gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads
+        write = d.get("WRITE_SIZE_KB_mean", 0.0) * 1024
+        out[k] = dict(d, hbm_read_bytes=fetch, hbm_write_bytes=write, traffic_bytes=fetch + write)
+    json.dump(out, open(outfile, "w"), indent=1, sort_keys=True)
+    for k, d in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes"])[:6]:
+        print("%-22s %-50s traffic %.1f MB" % (os.path.basename(outfile), k, d["traffic_bytes"] / 1e6))
+
+
+pmc("", f"profiles/{tag}_pmc.json")
+pmc("c5_", f"profiles/{tag}_pmc_cfg5.json")
+
+sq = {}
+for scene, prefix in (("cfg3_10mhz_d10", "sq"), ("cfg5_12mhz_d40", "c5_sq")):
+    vals = collections.defaultdict(list)
+    dur = []
+    for i in (1, 2):
+        path = f"{src}/{prefix}{i}/pmc_counter_collection.csv"
+        if not os.path.exists(path):
             continue
-        f.write("%s,%s,%.3f,%.2f,%s\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
-                                         float(r["AverageNs"]) / 1e3, r["Percentage"]))
-pmc = collections.defaultdict(dict)
-for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f"{src}/{name}_counter_collection.csv")):
-        if "irdm::" in r["Kernel_Name"]:
-            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        pmc[k][key + "_KB_mean"] = sum(v) / len(v)
-        pmc[k]["launches_" + key] = len(v)
-out = {}
-for k, d in pmc.items():
-    fetch = d.get("FETCH_SIZE_KB_mean", 0.0) * 1024 * 2      # gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads
-    write = d.get("WRITE_SIZE_KB_mean", 0.0) * 1024
-    out[k] = dict(d, hbm_read_bytes=fetch, hbm_write_bytes=write, traffic_bytes=fetch + write)
-json.dump(out, open(f"profiles/{tag}_pmc.json", "w"), indent=1, sort_keys=True)
-print(open(f"profiles/{tag}_kernel_stats.csv").read())
-for k, d in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes"])[:8]:
-    print("%-50s traffic %.1f MB" % (k, d["traffic_bytes"] / 1e6))
+        seen = set()
+        for r in csv.DictReader(open(path)):
+            if "fir_decimate" not in r["Kernel_Name"]:
+                continue
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            kernel, grid, vg = short(r["Kernel_Name"]), int(r["Grid_Size"]), r["VGPR_Count"]
+    if vals:
+        sq[scene] = {"kernel": kernel, "grid_threads_last_launch": grid, "launch_us_mean_with_counters": sum(dur) / len(dur),
+                     "per_launch_mean": {k: sum(v) / len(v) for k, v in sorted(vals.items())}}
+if sq:
+    json.dump(sq, open(f"profiles/{tag}_fir_pmc.json", "w"), indent=1, sort_keys=True)
+    print(json.dumps(sq, indent=1))
+
+for name in ("b", "b0", "d2", "d40", "cfg5_12mhz_d40", "lds_fir", "cfg4_n1"):
+    if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
+        shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_bench_{name}.json")
+for f in (f"profiles/{tag}_kernel_stats.csv", f"profiles/{tag}_kernel_stats_depth0.csv",
+          f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40.csv", f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40_depth0.csv"):
+    if os.path.exists(f):
+        print("==", f)
+        print("".join(open(f).readlines()[:24]))
