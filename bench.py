@@ -160,6 +160,16 @@ def record_msg_bytes(irdm, cap):
     return 8 + cap * (irdm.Demod.bits.offset + irdm.Demod.bits.size // 8)
 
 
+def unpack_demods(irdm, packed):
+    """[n, 176] irdm_demod_packed_t bytes -> [n, 4544] irdm_demod_t bytes with the LLRs zero (for the parity check)"""
+    head, nbits = irdm.Demod.bits.offset, irdm.Demod.bits.size
+    full = np.zeros((len(packed), C.sizeof(irdm.Demod)), np.uint8)
+    if len(packed):
+        full[:, :head] = packed[:, :head]
+        full[:, head:head + nbits] = np.unpackbits(packed[:, head:head + nbits // 8], axis=1)
+    return full
+
+
 def pack_records(irdm, demods, hb, cap):
     """What frame_output_print needs of the demodulated frames of one step (frame_output.c:168-197) into the message
     buffer `hb` (numpy uint8 view of pinned memory): a count word, then per frame the record's head (id, timestamp,
@@ -171,7 +181,9 @@ def pack_records(irdm, demods, hb, cap):
     if k > cap:
         raise SystemExit("bench: %d demodulated frames in one step exceed the gather message (%d)" % (k, cap))
     hb[:8] = np.array([k], dtype=np.int64).view(np.uint8)
-    if k:
+    if k and demods.shape[1] == recp:              # already irdm_demod_packed_t (option packed_records)
+        hb[8:8 + k * recp] = demods.reshape(-1)
+    elif k:
         rec = hb[8:8 + k * recp].reshape(k, recp)
         rec[:, :head] = demods[:, :head]
         rec[:, head:] = np.packbits(demods[:, head:head + nbits], axis=1)
@@ -324,6 +336,8 @@ def main():
                     help="1: also time the C99 binary on the chunk written to a file; 2: and on a 600 Msample recording")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="irdm_set_option before the run (kernel-variant A/B: fir_generic=1, fft_radix2=1, scan_mode=1)")
+    ap.add_argument("--packed", type=int, default=1,
+                    help="1: the timed context queues compact frame records (irdm_demod_packed_t: no LLRs, bits 8 per byte)")
     ap.add_argument("--ingest", type=int, default=1,
                     help="pipeline_depth >= 1: 1 = the chunk lives in its slot of the history ring (irdm_ingest_ptr; the ring is "
                          "filled with the synthetic chunk before the timed region), 0 = fed from a separate buffer and copied")
@@ -381,6 +395,10 @@ def main():
     for kv in args.opt:
         key, val = kv.split("=")
         pipe.set_option(key, int(val))
+    packed = bool(args.packed)
+    if packed:
+        pipe.set_option("packed_records", 1)
+    poll_demods = pipe.poll_demods_packed_raw if packed else pipe.poll_demods_raw
     stream = None        # the chunk is complete in HBM before the timed region: nothing to order against
     # record gather to rank 0 (RCCL over xGMI): what frame_output_print needs of a demodulated frame (frame_output.c:
     # 168-197) -- the record's head (id, timestamp, frequency, magnitude, noise, confidence, level, symbol counts) and
@@ -459,7 +477,7 @@ def main():
         tb = time.perf_counter()
         bursts = pipe.poll_bursts_raw()          # [n, 72] bytes
         pipe.drop_frames()
-        demods = pipe.poll_demods_raw()          # [n, 4544] bytes: everything frame_output_print needs
+        demods = poll_demods()          # [n, 4544] bytes: everything frame_output_print needs
         tc = time.perf_counter()
         if first_chunk["bursts"] is None and len(bursts):
             first_chunk["bursts"], first_chunk["demods"] = bursts.copy(), demods.copy()
@@ -489,7 +507,7 @@ def main():
     if args.depth:
         drain_feed()
         pipe.flush()
-        wb = pipe.poll_bursts_raw(); pipe.drop_frames(); wd = pipe.poll_demods_raw()
+        wb = pipe.poll_bursts_raw(); pipe.drop_frames(); wd = poll_demods()
         if first_chunk["bursts"] is None and len(wb):
             # (the warm-up chunks' records leave together here when the warm-up is shorter than the pipeline: records
             # are emitted in chunk order, so the stream's first chunk is the head of them)
@@ -509,7 +527,7 @@ def main():
         pipe.flush()
         tb_ = pipe.poll_bursts_raw()
         pipe.drop_frames()
-        tail = pipe.poll_demods_raw()
+        tail = poll_demods()
         totals["demods"] += len(tail)
         totals["bursts"] += len(tb_)
         if world > 1:
@@ -589,15 +607,15 @@ def main():
         hview[:] = x.view(torch.uint8).reshape(-1).cpu().numpy()
         for _ in range(2):
             pipe.feed_host_ptr(hptr, n)
-            pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
+            pipe.poll_bursts_raw(); pipe.drop_frames(); poll_demods()
         torch.cuda.synchronize()
         th = time.perf_counter()
         for _ in range(args.host_steps):
             pipe.feed_host_ptr(hptr, n)
-            pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
+            pipe.poll_bursts_raw(); pipe.drop_frames(); poll_demods()
         if args.depth:
             pipe.flush()
-            pipe.poll_bursts_raw(); pipe.drop_frames(); pipe.poll_demods_raw()
+            pipe.poll_bursts_raw(); pipe.drop_frames(); poll_demods()
         torch.cuda.synchronize()
         hdt = time.perf_counter() - th
         pcie = {"value": round(n * args.host_steps / hdt / 1e6, 2), "unit": "Msamples/s",
@@ -747,9 +765,14 @@ def main():
         # (c) parity of the benchmark scene itself: the first chunk's records through the HIP path vs the oracle's --
         #     from the TIMED context when it has delivered them (else from the pipeline_depth 0 context above)
         which = None
+        timed_llr = True
         if first_chunk["bursts"] is not None and m == n:
+            fd = first_chunk["demods"][:len(ref.demods)]
+            if packed:
+                fd = unpack_demods(irdm, fd)           # (no LLRs in the compact records: the level is compared, the
+                timed_llr = False                      # LLRs by the pipeline_depth 0 context's check in the tests)
             gpu_recs = ([irdm.Burst.from_buffer_copy(bytes(r)) for r in first_chunk["bursts"][:len(ref.bursts)]],
-                        [irdm.Demod.from_buffer_copy(bytes(r)) for r in first_chunk["demods"][:len(ref.demods)]])
+                        [irdm.Demod.from_buffer_copy(bytes(r)) for r in fd])
             which = "the timed context (pipeline_depth %d, in place %s, look-ahead %s)" % (args.depth, ingest, look)
         elif gpu_recs is not None:
             which = "a pipeline_depth 0 context on the same chunk"
@@ -780,7 +803,7 @@ def main():
                         ok = bad("frame id %d: hard bits differ" % r_.id)
                     soft = max(abs(g.level - r_.level),
                                float(np.max(np.abs(np.array(g.llr[:g.n_bits], np.float32) - np.array(r_.llr[:r_.n_bits], np.float32))))
-                               if g.n_bits else 0.0)
+                               if (g.n_bits and timed_llr) else 0.0)
                     max_soft = max(max_soft, soft)
                 if max_soft > 1e-4:
                     ok = bad("soft outputs differ by %g" % max_soft)
@@ -789,7 +812,8 @@ def main():
             parity_checked = {"ok": bool(ok), "bursts": len(gb), "frames": len(gd), "oracle_bursts": len(ref.bursts),
                               "oracle_frames": len(ref.demods), "max_soft": max_soft, "records_of": which,
                               "first_mismatch": first_bad,
-                              "what": "ids / indices / centre bins / dB fields / hard bits / confidence exact, level and LLR within 1e-4"}
+                              "what": "ids / indices / centre bins / dB fields / hard bits / confidence exact, level%s within 1e-4"
+                                      % (" and LLR" if timed_llr else " (compact records carry no LLRs)")}
 
     if rank == 0:
         roofline["stage_ms_alone"] = alone

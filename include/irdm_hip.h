@@ -148,6 +148,27 @@ typedef struct {
     float llr[IRDM_MAX_BITS];
 } irdm_demod_t;
 
+/* The same frame without the soft outputs, hard bits 8 per byte (MSB first: bit i of the frame is
+ * (bits[i / 8] >> (7 - i % 8)) & 1): everything frame_output_print reads (frame_output.c:168-197) in 176 bytes.  With
+ * option "packed_records" 1 a context queues ONLY these (and the burst records): irdm_poll_demods / irdm_poll_frames
+ * then return nothing, and 136 bytes per burst cross PCIe instead of 4.5 KB. */
+typedef struct {
+    uint64_t id;
+    uint64_t timestamp;
+    double center_frequency;
+    int32_t direction;
+    float magnitude;
+    float noise;
+    int32_t confidence;
+    float level;
+    int32_t n_symbols;
+    int32_t n_payload_symbols;
+    int32_t n_bits;
+    int32_t ok;
+    float total_phase;
+    uint8_t bits[IRDM_MAX_BITS / 8];
+} irdm_demod_packed_t;
+
 /* decoded_frame_t (frame_decode.h:26-60), flattened: the post-demod bit layer's result for one demodulated frame */
 typedef struct {
     int32_t type;              /* frame_type_t: 0 FRAME_UNKNOWN, 1 FRAME_IRA, 2 FRAME_IBC */
@@ -249,6 +270,7 @@ int irdm_device_copy(void *dst, const void *src, size_t bytes);
 int irdm_poll_bursts(irdm_pipeline_t *p, irdm_burst_t *out, int max);
 int irdm_poll_frames(irdm_pipeline_t *p, irdm_frame_info_t *out, float *samples_out /* max*2*4440 or NULL */, int max);
 int irdm_poll_demods(irdm_pipeline_t *p, irdm_demod_t *out, int max);
+int irdm_poll_demods_packed(irdm_pipeline_t *p, irdm_demod_packed_t *out, int max);   /* option "packed_records" 1 */
 
 /* "tagged N bursts total" (burst_detect.c:350-351) and stat_sample_count (main.c:199) */
 uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p);

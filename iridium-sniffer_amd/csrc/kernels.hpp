@@ -139,6 +139,7 @@ int launch_ida_decode(const DemodOut *frames, int n_frames, const int2 *syn_da, 
                       hipStream_t stream);
 int launch_frame_decode(const DemodOut *frames, int n_frames, const int2 *syn_ra, const int2 *syn_hdr, int use_llr,
                         const int *n_bits, DecodedOut *out, hipStream_t stream);
+int launch_demod_pack(const DemodOut *in, int n_bursts, DemodPacked *out, hipStream_t stream);
 int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,
                  float sps, float2 *ws, DemodOut *out, hipStream_t stream);
 

@@ -196,8 +196,10 @@ struct BatchCtx {
     BurstWork *hp_work, *hp_work_dev;   // host / device view of the same mapped pinned buffer
     FirTile *hp_tiles;
     DemodOut *hp_demod;
+    DemodPacked *d_packed, *hp_packed;      // packed_records: the demodulator's result without LLRs, bits 8 per byte
     uint32_t *hp_flag, *hp_flag_dev;    // [0] sequence number the helper publishes, [1] time-out flag of the waiting kernel
     uint32_t cfo_seq;
+    bool packed;                 // this batch came back as DemodPacked records
     bool cfo_on_device;          // this batch's libm step ran on the device: h_cfreq is filled from the returned records
     std::vector<double> h_cfreq;
     std::vector<irdm_burst_t> recs;
@@ -362,6 +364,8 @@ struct irdm_pipeline {
     std::deque<irdm_frame_info_t> q_frames;
     std::deque<std::vector<float>> q_frame_samples;
     std::deque<irdm_demod_t> q_demods;
+    std::deque<irdm_demod_packed_t> q_packed;
+    int packed_records;         // option: queue irdm_demod_packed_t records only
 
     uint64_t total_samples, tagged, start_time_ns;
     bool stream_closed;
@@ -413,6 +417,8 @@ static void pipeline_free(irdm_pipeline *p)
         if (b.hp_work) (void)hipHostFree(b.hp_work);
         if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
         if (b.hp_demod) (void)hipHostFree(b.hp_demod);
+        if (b.hp_packed) (void)hipHostFree(b.hp_packed);
+        if (b.d_packed) (void)hipFree(b.d_packed);
         if (b.owns_buffers) {
             void *own[] = { b.d_work, b.d_tiles, b.d_dec, b.d_lpf, b.d_rrc_ws, b.d_frames, b.d_demod_ws, b.d_demod,
                             b.d_decoded, b.d_ida };
@@ -740,6 +746,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_work_dev), b.hp_work, 0) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_demod), sizeof(DemodOut) * (size_t)p->burst_cap, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_packed), sizeof(DemodPacked) * (size_t)p->burst_cap, hipHostMallocDefault) == hipSuccess;
+        AL(b.d_packed, DemodPacked, (size_t)p->burst_cap);
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_flag), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_flag_dev), b.hp_flag, 0) == hipSuccess;
         if (ok) memset(b.hp_flag, 0, 64);
@@ -1198,6 +1206,15 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             return -1;
     }
     // the chain's results: work records and demodulator output, one launch
+    b.packed = p->packed_records && !p->decode_frames && !p->decode_ida && !p->keep_frame_samples;
+    if (b.packed) {
+        // (136 bytes per burst instead of 4.5 KB: hard bits 8 per byte, no LLRs)
+        if (launch_demod_pack(b.d_demod, nb, b.d_packed, st) != 0) return -1;
+        if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_packed, b.d_packed,
+                                 sizeof(DemodPacked) * nb, st) != 0)
+            return -1;
+        return 0;
+    }
     if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_demod, b.d_demod, sizeof(DemodOut) * nb,
                              st) != 0)
         return -1;
@@ -1247,6 +1264,45 @@ static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
                                       hipMemcpyDeviceToHost, b.stream));
     }
     if (p->decode_frames || p->decode_ida || p->keep_frame_samples) IRDM_HIP_CHECK(hipStreamSynchronize(b.stream));
+    if (b.packed) {
+        // packed_records: burst records and the compact frame records only (no frame-info queue, no LLRs); the same
+        // expressions as below for the timestamp (burst_downmix.c:659-660, :431-433, :783) and the refined frequency
+        // (qpsk_demod.c:521-527)
+        for (int i = 0; i < nb; i++) {
+            const BurstWork &w = b.hp_work[i];
+            const irdm_burst_t &r = b.recs[i];
+            p->q_bursts.push_back(r);
+            p->last_bursts.push_back(r);
+            const DemodPacked &d = b.hp_packed[i];
+            if (w.drop_reason != 0 || !d.ok) continue;
+            uint64_t timestamp = p->start_time_ns + (uint64_t)((double)r.start / fs * 1e9);
+            if (w.dec_len > 0) timestamp += (uint64_t)((p->in_ntaps / 2) * 1000000000ULL / fs);
+            p->q_packed.emplace_back();
+            irdm_demod_packed_t &o = p->q_packed.back();
+            o.id = r.id;
+            o.timestamp = timestamp + (uint64_t)((double)w.start_idx / p->out_rate * 1e9);
+            o.direction = d.direction;
+            o.magnitude = r.magnitude;
+            o.noise = r.noise;
+            o.confidence = d.confidence;
+            o.level = d.level;
+            o.n_symbols = d.n_symbols;
+            o.n_payload_symbols = d.n_symbols - 12;
+            o.n_bits = 2 * d.n_symbols;
+            o.ok = 1;
+            o.total_phase = d.total_phase;
+            memcpy(o.bits, d.bits, sizeof(o.bits));
+            if (d.n_symbols > 0) {
+                const double duration = (double)d.n_symbols / 25000;
+                o.center_frequency = b.h_cfreq[i] + d.total_phase / duration / M_PI / 2.0;
+            } else {
+                o.center_frequency = b.h_cfreq[i];
+            }
+        }
+        clock_gettime(CLOCK_MONOTONIC, &ts_);
+        p->host_us[9] += ts_.tv_sec * 1e6 + ts_.tv_nsec * 1e-3 - t_rec0;
+        return nb;
+    }
     for (int i = 0; i < nb; i++) {
         const BurstWork &w = b.hp_work[i];
         irdm_burst_t &r = b.recs[i];
@@ -2098,6 +2154,12 @@ static int drain(std::deque<T> &q, T *out, int max)
     return n;
 }
 
+extern "C" int irdm_poll_demods_packed(irdm_pipeline_t *p, irdm_demod_packed_t *out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    return drain(p->q_packed, out, max);
+}
+
 extern "C" int irdm_poll_bursts(irdm_pipeline_t *p, irdm_burst_t *out, int max)
 {
     if (!p || !out || max < 0) return -1;
@@ -2507,6 +2569,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
 {
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
+    if (!strcmp(key, "packed_records")) { p->packed_records = value; return 0; }
     if (!strcmp(key, "host_cfo")) { p->dev_cfo = value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
     if (!strcmp(key, "scan_updaters")) { if (value < 1 || value > 32) return -1; p->mc_updaters = value; return 0; }

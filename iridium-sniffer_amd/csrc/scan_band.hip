@@ -45,6 +45,8 @@ __device__ __forceinline__ bool band_void(const BandParams &P, const BandWork &W
     return __hip_atomic_load(W.bar + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)P.serial;
 }
 
+__device__ __constant__ int g_plan_lds_on = 1;       // (test hook: 0 = the plan pass through the workspace arrays only)
+
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
 constexpr int kSumDepth = 32;             // update steps per batch of the sums pass (two batches of loads in flight)
 
@@ -113,9 +115,13 @@ struct PlanShared {
     unsigned flags;
 };
 
+constexpr int kPlanLdsFrames = 8192;     // frames the LDS form of the plan holds (need flags + snapshot slots: 80 KB)
+constexpr size_t kPlanLdsBytes = ((2 * kPlanLdsFrames + 2 + 15) & ~15) + sizeof(int32_t) * (2 * kPlanLdsFrames + 2);
+
+// lds: kPlanLdsBytes of dynamic LDS, or nullptr (the general path through the workspace arrays)
 template <int NT>
 __device__ void band_plan_body(const BandParams &P, const BandWork &W, const unsigned *__restrict__ counts,
-                               DetState *__restrict__ st, int round, PlanShared &sh)
+                               DetState *__restrict__ st, int round, PlanShared &sh, uint8_t *lds)
 {
     constexpr int kPlanThreads = NT;      // (shadows the launch constant: every stride below is the workgroup's size)
     int32_t *s_part = sh.part;
@@ -253,6 +259,124 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         return;
     }
 
+    if (lds != nullptr && F <= kPlanLdsFrames) {
+        // ---- the same plan with everything between the passes in registers and LDS (F <= 8192 frames: 10 / 12 MHz
+        // chunks up to 64 Mi samples): a thread owns a contiguous run of frames, the scans run over one count per thread,
+        // the need flags and snapshot slots live in LDS.  The general path below does ten passes through global
+        // arrays, each a round trip through the L2 beside the per-burst chains' traffic (44 us alone, 100-140 us in run).
+        constexpr int FPT = kPlanLdsFrames / NT;              // frames per thread
+        uint8_t *s_need = lds;                                   // [2 F + 2]
+        int32_t *s_slot = reinterpret_cast<int32_t *>(lds + ((2 * kPlanLdsFrames + 2 + 15) & ~15));   // [2 F + 2]
+        const int f0 = tid * FPT;
+        int uqb = 0, ufb = 0, cnz = 0, c_t = 0;
+#pragma unroll
+        for (int j = 0; j < FPT; j++) {
+            const int f = f0 + j;
+            if (f < F) {
+                const int q = ((W.busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
+                const int fc = (int)((W.forced[f >> 6] >> (f & 63)) & 1);
+                uqb |= q << j;
+                ufb |= fc << j;
+                cnz |= (counts[f] > 0 ? 1 : 0) << j;
+                c_t += q + fc;
+            }
+        }
+        __syncthreads();                      // (every thread has read the bitmaps: they may be cleared)
+        for (int i = tid; i < P.n_bands * P.occ_words; i += kPlanThreads) W.occ[i] = 0;
+        for (int i = tid; i < P.occ_words; i += kPlanThreads) {
+            W.busy[i] = 0;
+            W.forced[i] = 0;
+            W.conc[i] = 0;
+        }
+        for (int i = tid; i < P.n_bands; i += kPlanThreads) W.rec_count[i] = 0;
+        // exclusive scan of the per-thread update counts
+        const int lane = tid & 63, wave = tid >> 6;
+        auto scan1 = [&](int v, int &total) {
+            int incl = v;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_part[wave] = incl;
+            __syncthreads();
+            int wb = 0, tot = 0;
+            for (int w = 0; w < NT / 64; w++) {
+                const int o = s_part[w];
+                if (w < wave) wb += o;
+                tot += o;
+            }
+            __syncthreads();
+            total = tot;
+            return wb + incl - v;
+        };
+        int n_upd = 0;
+        const int base = scan1(c_t, n_upd);
+        for (int k = tid; k <= n_upd + 1; k += kPlanThreads) s_need[k] = 0;
+        __syncthreads();
+        {
+            int k = base;
+#pragma unroll
+            for (int j = 0; j < FPT; j++) {
+                const int f = f0 + j;
+                if (f < F) {
+                    const int q = (uqb >> j) & 1, fc = (ufb >> j) & 1;
+                    if ((cnz >> j) & 1) {
+                        s_need[k] = 1;
+                        if (fc) s_need[k + 1] = 1;
+                    }
+                    if (fc) W.upd_frame[k++] = f;      // the forced update comes first (:516-517, then :698)
+                    if (q) W.upd_frame[k++] = f;
+                }
+            }
+        }
+        __syncthreads();
+        // snapshot slots: exclusive scan of the need flags, a contiguous run of steps per thread
+        const int kpt = (n_upd + 1 + NT - 1) / NT;
+        const int k0 = tid * kpt, k1 = min(k0 + kpt, n_upd + 1);
+        int nn = 0;
+        for (int k = k0; k < k1; k++) nn += s_need[k];
+        int n_snap = 0;
+        int run = scan1(nn, n_snap);
+        for (int k = k0; k < k1; k++) {
+            const int nd = s_need[k];
+            s_slot[k] = nd ? run : -1;
+            run += nd;
+        }
+        if (tid == 0) W.snap_slot[0] = s_need[0] ? 0 : -1;      // (the sums pass reads slot 0 from the workspace)
+        __syncthreads();
+        const int h0 = ctl->h0;
+        for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = make_int4(0, 0, -1, 0);
+        for (int k = tid; k < n_upd; k += kPlanThreads) {
+            const int uf_k = W.upd_frame[k];
+            const int old = k < kHistory ? -(((h0 + k) % kHistory) + 1) : W.upd_frame[k - kHistory];
+            W.steps[k] = make_int4(uf_k, old, s_slot[k + 1], 0);
+        }
+        {
+            int k = base;
+#pragma unroll
+            for (int j = 0; j < FPT; j++) {
+                const int f = f0 + j;
+                if (f < F) {
+                    const int q = (uqb >> j) & 1, fc = (ufb >> j) & 1, has = (cnz >> j) & 1;
+                    const int pre = has ? s_slot[k] : -1;
+                    W.slot_pre[f] = pre;
+                    W.slot_post[f] = (has && fc) ? s_slot[k + 1] : pre;
+                    k += q + fc;
+                }
+            }
+        }
+        if (tid == 0) {
+            ctl->n_upd = n_upd;
+            ctl->n_snap = n_snap;
+            ctl->rounds = round + 1;
+            if (n_snap > W.snap_cap) {
+                ctl->flags = BAND_F_SNAP;
+                ctl->status = 2;
+            }
+        }
+        return;
+    }
+
     // ---- clear what the round accumulates ----
     for (int i = tid; i < P.n_bands * P.occ_words; i += kPlanThreads) W.occ[i] = 0;
     for (int i = tid; i < P.occ_words; i += kPlanThreads) {
@@ -313,7 +437,8 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
 {
     IRDM_DETECTOR_PRIO();
     __shared__ PlanShared sh;
-    band_plan_body<kPlanThreads>(P, W, counts, st, round, sh);
+    extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
+    band_plan_body<kPlanThreads>(P, W, counts, st, round, sh, g_plan_lds_on ? plan_lds : nullptr);
 }
 
 // ---- sums: one lane per bin along the planned update steps ----
@@ -600,7 +725,7 @@ __global__ __launch_bounds__(kCoopThreads) void band_coop_kernel(BandParams P, B
     for (int round = round_begin;; round++) {
         // ---- plan (one workgroup): the verdict on the round before, the update steps of this one ----
         if (blockIdx.x == 0 && (round > round_begin || round_begin == 0))
-            band_plan_body<kCoopThreads>(P, W, counts, st, round, *reinterpret_cast<PlanShared *>(smem_raw));
+            band_plan_body<kCoopThreads>(P, W, counts, st, round, *reinterpret_cast<PlanShared *>(smem_raw), nullptr);
         if (!(ok = grid_sync(bar, G))) break;
         if (band_void(P, W)) return;
         if (__hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || round >= round_end) break;
@@ -946,6 +1071,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     (void)hipFuncSetAttribute((const void *)band_walk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     (void)hipFuncSetAttribute((const void *)band_walk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     (void)hipFuncSetAttribute((const void *)band_commit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)commit_lds);
+    (void)hipFuncSetAttribute((const void *)band_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
     if (g_band_coop) {
         // every round up to the verdict in one launch (the kernel leaves as soon as a round is accepted or declined)
         (void)round_end;
@@ -962,7 +1088,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     for (int round = round_begin; round <= round_end; round++) {
         // (a continuation starts behind the plan its predecessor's verdict pass already made)
         if (round > round_begin || round_begin == 0)
-            hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), 0, stream, P, W, counts, st, round);
+            hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), kPlanLdsBytes, stream, P, W, counts, st, round);
         if (round == round_end) break;
         hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         if (g_band_cross_wave)

@@ -137,6 +137,15 @@ struct DemodOut {
     float llr[kMaxBits];
 };
 
+// the demodulator's result without the soft outputs, hard bits 8 per byte, MSB first (frame_output.c:168-197 needs no
+// more of a frame): what the chain brings back in the packed_records mode, 136 bytes per burst instead of 4.5 KB
+struct DemodPacked {
+    int32_t ok, direction, confidence, n_symbols;
+    float level, total_phase;
+    uint8_t bits[kMaxBits / 8];
+};
+static_assert(sizeof(DemodPacked) == 136 && sizeof(DemodPacked) % 8 == 0, "copied 16 bytes at a time in pairs");
+
 // frame_decode() result per demodulated frame (bitlayer.hip); lat / lon / alt are completed on the host
 struct DecodedOut {
     int32_t type, sat_id, beam_id, pos_xyz[3], n_pages;

@@ -56,6 +56,16 @@ class Demod(C.Structure):
                 ("llr", C.c_float * MAX_BITS)]
 
 
+class DemodPacked(C.Structure):
+    """irdm_demod_packed_t: the frame without LLRs, hard bits 8 per byte (MSB first)"""
+    _fields_ = [("id", C.c_uint64), ("timestamp", C.c_uint64),
+                ("center_frequency", C.c_double), ("direction", C.c_int32),
+                ("magnitude", C.c_float), ("noise", C.c_float), ("confidence", C.c_int32),
+                ("level", C.c_float), ("n_symbols", C.c_int32),
+                ("n_payload_symbols", C.c_int32), ("n_bits", C.c_int32), ("ok", C.c_int32),
+                ("total_phase", C.c_float), ("bits", C.c_uint8 * (MAX_BITS // 8))]
+
+
 class Decoded(C.Structure):
     _fields_ = [("type", C.c_int32), ("sat_id", C.c_int32), ("beam_id", C.c_int32), ("pos_xyz", C.c_int32 * 3),
                 ("alt", C.c_int32), ("n_pages", C.c_int32), ("lat", C.c_double), ("lon", C.c_double),
@@ -127,6 +137,7 @@ def lib():
         L.irdm_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
         L.irdm_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
         L.irdm_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
+        L.irdm_poll_demods_packed.argtypes = [C.c_void_p, C.POINTER(DemodPacked), C.c_int]
         L.irdm_poll_decoded.argtypes = [C.c_void_p, C.POINTER(Decoded), C.c_int]
         L.irdm_poll_ida.argtypes = [C.c_void_p, C.POINTER(Ida), C.c_int]
         L.irdm_ida_decode_batch.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int, C.c_int, C.POINTER(Ida)]
@@ -371,6 +382,13 @@ class Pipeline:
 
     def poll_demods_raw(self, chunk=2048):
         return self._poll_raw(self.L.irdm_poll_demods, Demod, chunk)
+
+    def poll_demods_packed_raw(self, chunk=8192):
+        """option packed_records 1: [n, 176] bytes, irdm_demod_packed_t records"""
+        return self._poll_raw(self.L.irdm_poll_demods_packed, DemodPacked, chunk)
+
+    def poll_demods_packed(self):
+        return self._poll(self.L.irdm_poll_demods_packed, DemodPacked)
 
     def drop_frames(self, chunk=4096):
         """Discard queued frame records (metadata only path)."""
