@@ -385,6 +385,10 @@ int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uint64_t *t0_i
 #define IRDM_RAW_LINE_MAX 1280          /* 256 B of prefix (file_info <= 128 chars) + IRDM_MAX_BITS + newline, rounded up */
 long long irdm_format_raw_batch(const irdm_demod_t *f, int n, const char *file_info, uint64_t *t0_io,
                                 char *buf, size_t cap);
+/* the same lines from compact records (option "packed_records") */
+int irdm_format_raw_packed(const irdm_demod_packed_t *f, const char *file_info, uint64_t *t0_io, char *buf, size_t cap);
+long long irdm_format_raw_packed_batch(const irdm_demod_packed_t *f, int n, const char *file_info, uint64_t *t0_io,
+                                       char *buf, size_t cap);
 
 /* --save-bursts (qpsk_demod.c:339-389): writes <dir>/<timestamp>_<freq>_<id>_<DL|UL|UN>.cf32 (the frame's cf32 samples at
  * 250 kHz) and the matching .meta text file for one downmixed frame (info->drop_reason == 0), creating dir if needed.

@@ -2647,6 +2647,45 @@ extern "C" int irdm_format_raw(const irdm_demod_t *f, const char *file_info, uin
     return pos;
 }
 
+// the same line from a compact record (option packed_records): bits 8 per byte, MSB first
+extern "C" int irdm_format_raw_packed(const irdm_demod_packed_t *f, const char *file_info, uint64_t *t0_io, char *buf,
+                                      size_t cap)
+{
+    if (!f || !t0_io || !buf) return -1;
+    char auto_info[64];
+    if (*t0_io == 0) *t0_io = (f->timestamp / 1000000000ULL) * 1000000000ULL;
+    const uint64_t t0 = *t0_io;
+    if (!file_info || !file_info[0]) {
+        snprintf(auto_info, sizeof(auto_info), "i-%llu-t1", (unsigned long long)(t0 / 1000000000ULL));
+        file_info = auto_info;
+    }
+    const double ts_ms = (double)(f->timestamp - t0) / 1000000.0;
+    const int freq_hz = (int)(f->center_frequency + 0.5);
+    const int payload = f->n_payload_symbols < 0 ? 0 : f->n_payload_symbols;
+    int pos = snprintf(buf, cap, "RAW: %s %012.4f %010d N:%05.2f%+06.2f I:%011llu %3d%% %.5f %3d ", file_info,
+                       ts_ms, freq_hz, f->magnitude, f->noise, (unsigned long long)f->id, f->confidence,
+                       f->level, payload);
+    const int nb = f->n_bits < 0 ? 0 : (f->n_bits > IRDM_MAX_BITS ? IRDM_MAX_BITS : f->n_bits);
+    if (pos < 0 || (size_t)pos + (size_t)nb + 2 > cap) return -1;
+    for (int i = 0; i < nb; i++) buf[pos++] = (char)('0' + ((f->bits[i >> 3] >> (7 - (i & 7))) & 1));
+    buf[pos++] = '\n';
+    buf[pos] = 0;
+    return pos;
+}
+
+extern "C" long long irdm_format_raw_packed_batch(const irdm_demod_packed_t *f, int n, const char *file_info, uint64_t *t0_io,
+                                                  char *buf, size_t cap)
+{
+    if (!f || n < 0 || !t0_io || !buf) return -1;
+    size_t pos = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = irdm_format_raw_packed(&f[i], file_info, t0_io, buf + pos, cap - pos);
+        if (len < 0) return -1;
+        pos += (size_t)len;
+    }
+    return (long long)pos;
+}
+
 // ===========================================================================
 // 4. --save-bursts (qpsk_demod.c:339-389)
 // ===========================================================================

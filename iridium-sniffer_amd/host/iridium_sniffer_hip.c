@@ -60,6 +60,14 @@ static void *reader_main(void *arg)
 static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, uint64_t *t0, char *line, size_t cap)
 {
     int n;
+    if (!g_save_dir) {
+        /* RAW lines need no LLRs: compact records (hard bits 8 per byte), 176 bytes per frame instead of 4.5 KB */
+        static irdm_demod_packed_t dp[256];
+        while ((n = irdm_poll_demods_packed(p, dp, 256)) > 0) {
+            const long long len = irdm_format_raw_packed_batch(dp, n, file_info, t0, line, cap);   /* one write per batch */
+            if (len > 0) fwrite(line, 1, (size_t)len, stdout);
+        }
+    }
     while ((n = irdm_poll_demods(p, d, 256)) > 0) {
         const long long len = irdm_format_raw_batch(d, n, file_info, t0, line, cap);     /* one write per batch */
         if (len > 0) fwrite(line, 1, (size_t)len, stdout);
@@ -148,6 +156,7 @@ int main(int argc, char **argv)
         return 1;
     }
     if (save_dir) irdm_set_option(p, "keep_frame_samples", 1);
+    else irdm_set_option(p, "packed_records", 1);
     g_save_dir = save_dir;
     if (verbose) fprintf(stderr, "%s: fft_size=%d chunk=%zu samples\n", irdm_version(), irdm_fft_size(p), chunk);
 

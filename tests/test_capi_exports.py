@@ -91,6 +91,42 @@ def test_format_raw_batch_is_the_concatenation_of_lines():
     assert irdm.format_raw_batch([], "x") == ""
 
 
+def test_packed_records_print_the_same_raw_lines():
+    """irdm_format_raw_packed[_batch]: the RAW line of a compact record (hard bits 8 per byte, MSB first) is byte for byte the
+    line of the full record (frame_output.c:160-199)."""
+    import ctypes as C
+    import numpy as np
+    L = irdm.lib()
+    L.irdm_format_raw_packed_batch.restype = C.c_longlong
+    L.irdm_format_raw_packed_batch.argtypes = [C.POINTER(irdm.DemodPacked), C.c_int, C.c_char_p, C.POINTER(C.c_uint64),
+                                               C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(4)
+    full, packed = [], (irdm.DemodPacked * 6)()
+    for k in range(6):
+        d = irdm.Demod()
+        d.id = 10 * k
+        d.timestamp = 1700000000 * 10**9 + 533072000 + 90_000_000 * k
+        d.center_frequency = 1622209567.6 + 41666.7 * k
+        d.magnitude, d.noise, d.confidence, d.level = 20.0 + k, -114.1, 90 + k, 0.016 + 0.001 * k
+        d.n_symbols, d.n_payload_symbols, d.n_bits, d.ok = 191 - k, 179 - k, 2 * (191 - k), 1
+        bits = rng.integers(0, 2, d.n_bits).astype(np.uint8)
+        for i, bv in enumerate(bits):
+            d.bits[i] = int(bv)
+        full.append(d)
+        q = packed[k]
+        for fld in ("id", "timestamp", "center_frequency", "direction", "magnitude", "noise", "confidence", "level",
+                    "n_symbols", "n_payload_symbols", "n_bits", "ok", "total_phase"):
+            setattr(q, fld, getattr(d, fld))
+        pb = np.packbits(np.concatenate([bits, np.zeros(irdm.MAX_BITS - len(bits), np.uint8)]))
+        for i, bv in enumerate(pb):
+            q.bits[i] = int(bv)
+    for fi in ("golden", ""):
+        t0 = C.c_uint64(0)
+        buf = C.create_string_buffer(6 * 2048)
+        n = L.irdm_format_raw_packed_batch(packed, 6, fi.encode(), C.byref(t0), buf, len(buf))
+        assert n > 0 and buf.raw[:n].decode() == irdm.format_raw_batch(full, fi)
+
+
 def test_save_burst_writes_the_reference_file_pair(tmp_path):
     """irdm_save_burst == save_burst_iq (qpsk_demod.c:339-389): file names, .meta text, raw cf32 payload."""
     import numpy as np
