@@ -39,11 +39,18 @@ struct BandCtl {                         // control block on the device, copied 
     int32_t n_gone, n_total, committed, h0;
     int32_t pad[4];
 };
+struct SumStep {                         // one update step of the sums pass, as the byte offsets its buffer accesses take
+    uint32_t nw_off;                     // the magnitude row that enters the sum (offset into the chunk's magnitudes)
+    uint32_t ol_off;                     // the row it replaces: steps < kHistory a row of the carried history ring, later ones
+                                         // the magnitude row that entered 512 steps earlier
+    uint32_t snap_off;                   // offset into BandWork::snap of the snapshot after the step, ~0u: none
+    uint32_t pad;
+};
 struct BandWork {                        // device workspace, carved out of one allocation (band_work_carve)
     BandCtl *ctl;
     uint8_t *uq, *uf;                    // speculated per-frame updates: frame ends quiet / forces an update
     int32_t *cnt_before, *tmp, *upd_frame, *old_row, *snap_after, *need, *snap_slot, *slot_pre, *slot_post;
-    int4 *steps;                         // packed (frame, old row, snapshot slot) per update step, padded
+    SumStep *steps;                      // per update step, padded (the padding reads row 0 and is not applied)
     uint64_t *cross;
     float *relq, *snap;
     int snap_cap;
@@ -59,6 +66,7 @@ struct BandWork {                        // device workspace, carved out of one 
     unsigned *bar;                       // [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
+extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
 extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass
 int band_list_cap(int n);                // entries per frame the band scan's lists hold

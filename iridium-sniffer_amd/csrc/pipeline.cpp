@@ -2588,6 +2588,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
+    if (!strcmp(key, "band_sum_bins")) { irdm::g_band_sum_bins = value; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }

@@ -108,6 +108,29 @@ __device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, i
     return !(bad || ca != cb);
 }
 
+// step descriptor of an update step: frame uf, the row it replaces (old < 0: row -old - 1 of the carried history, else the
+// magnitude row of frame old), snapshot slot after the step (< 0: none).  Rows are at most 64 KB and there are at most
+// max_chunk / n + 2 of them: every offset is far below 4 GB.
+__device__ __forceinline__ SumStep make_step(const BandParams &P, int uf, int old, int slot)
+{
+    SumStep s;
+    const uint32_t row = (uint32_t)P.n * 4u;
+    s.nw_off = (uint32_t)uf * row;
+    s.ol_off = (uint32_t)(old < 0 ? -old - 1 : old) * row;
+    s.snap_off = slot >= 0 ? (uint32_t)slot * row : ~0u;
+    s.pad = 0;
+    return s;
+}
+__device__ __forceinline__ SumStep noop_step()
+{
+    SumStep s;
+    s.nw_off = 0;
+    s.ol_off = 0;
+    s.snap_off = ~0u;
+    s.pad = 0;
+    return s;
+}
+
 // shared scratch of the plan pass
 struct PlanShared {
     int32_t part[kPlanThreads / 64 + 1];
@@ -189,7 +212,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             W.conc[i] = 0;
         }
         for (int i = tid; i < P.n_bands; i += kPlanThreads) W.rec_count[i] = 0;
-        for (int k = tid; k < 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = make_int4(0, 0, -1, 0);
+        for (int k = tid; k < 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = noop_step();
         __syncthreads();
         if (tid == 0) {
             const int some = s_mismatch;
@@ -345,11 +368,11 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         if (tid == 0) W.snap_slot[0] = s_need[0] ? 0 : -1;      // (the sums pass reads slot 0 from the workspace)
         __syncthreads();
         const int h0 = ctl->h0;
-        for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = make_int4(0, 0, -1, 0);
+        for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = noop_step();
         for (int k = tid; k < n_upd; k += kPlanThreads) {
             const int uf_k = W.upd_frame[k];
             const int old = k < kHistory ? -(((h0 + k) % kHistory) + 1) : W.upd_frame[k - kHistory];
-            W.steps[k] = make_int4(uf_k, old, s_slot[k + 1], 0);
+            W.steps[k] = make_step(P, uf_k, old, s_slot[k + 1]);
         }
         {
             int k = base;
@@ -407,13 +430,13 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
     __syncthreads();
     const int h0 = ctl->h0;
     // (the sums pass reads whole batches of step descriptors: pad them with no-ops that touch valid memory)
-    for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = make_int4(0, 0, -1, 0);
+    for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = noop_step();
     for (int k = tid; k < n_upd; k += kPlanThreads) {
         W.snap_after[k] = W.snap_slot[k + 1];
         // the row an update replaces: one of the carried history for the first 512 steps, after that the magnitude
         // row written 512 steps earlier (the ring is only materialised by the commit)
         W.old_row[k] = k < kHistory ? -(((h0 + k) % kHistory) + 1) : W.upd_frame[k - kHistory];
-        W.steps[k] = make_int4(W.upd_frame[k], W.old_row[k], W.snap_after[k], 0);
+        W.steps[k] = make_step(P, W.upd_frame[k], W.old_row[k], W.snap_after[k]);
     }
     for (int f = tid; f < F; f += kPlanThreads) {
         const int k = W.cnt_before[f];
@@ -443,42 +466,67 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
 
 // ---- sums: one lane per bin along the planned update steps ----
 
+// buffer resource over [p, p + bytes): raw (stride 0), 32-bit float data format, out-of-range reads return zero
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t band_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+
 // (b: this lane's bin)
 __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWork &W, const float *__restrict__ mag,
                                               const float *__restrict__ hist, const float *__restrict__ sum,
                                               const float *__restrict__ pre, float *__restrict__ smin_out,
-                                              const int4 *steps, float *snap, int b)
+                                              const SumStep *steps, float *snap, int b)
 {
     const BandCtl *ctl = W.ctl;
     const int N = P.n;
     const int n = ctl->n_upd;
-    // steps: (frame, old row, snapshot slot after the step, -) per update step, padded with no-ops; a kernel argument of
-    // its own (like snap) so that the compiler knows nothing here writes it and fetches it with scalar loads
     float s = sum[b], smin = s;
     const int slot0 = W.snap_slot[0];
     if (slot0 >= 0) snap[(size_t)slot0 * N + b] = s;
+    // This pass is one wavefront per 64 bins with nothing to hide behind, so what a step costs is its instruction count:
+    // with row numbers in the descriptors the 64-bit address arithmetic (13 scalar and one vector instruction per load)
+    // was most of the 140 ns a step took.  The rows are read as buffer loads instead -- resource = the whole array, the
+    // lane's byte offset in a register that never changes, the row's byte offset straight from the descriptor in the
+    // scalar-offset operand -- which leaves two loads, three float operations and the snapshot test per step.
+    const size_t row = (size_t)N * 4;
+    const __amdgpu_buffer_rsrc_t r_mag = band_rsrc(mag, (size_t)P.n_frames * row);
+    const __amdgpu_buffer_rsrc_t r_hist = band_rsrc(hist, (size_t)kHistory * row);
+    const __amdgpu_buffer_rsrc_t r_snap = band_rsrc(snap, (size_t)W.snap_cap * row);
+    const int boff = b * 4;
 
     // Two batches of kSumDepth steps are in flight: the loads of batch i+1 are issued before batch i is consumed.  The
     // step descriptors are wave-uniform and read a batch at a time (scalar loads of 16 bytes per step, unguarded: the
-    // plan pads the list), so that the per-step work is two vector loads and two float operations.
+    // plan pads the list).  A batch lies on one side of step kHistory (512 = 16 batches), where the replaced rows change
+    // from the carried history ring to the chunk's own magnitude rows.
+    static_assert(kHistory % kSumDepth == 0, "a batch of steps must not straddle the history ring's length");
     float nwA[kSumDepth], olA[kSumDepth], nwB[kSumDepth], olB[kSumDepth];
-    int slA[kSumDepth], slB[kSumDepth];
-#define IRDM_SUM_LOAD(nw, ol, sl, k0)                                                                   \
-    _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) {                                             \
-        const int4 st = steps[(k0) + j];                                                                \
-        const float *po = st.y < 0 ? hist + (size_t)(-st.y - 1) * N : mag + (size_t)st.y * N;           \
-        nw[j] = mag[(size_t)st.x * N + b];                                                              \
-        ol[j] = po[b];                                                                                  \
-        sl[j] = st.z;                                                                                   \
-    }
-#define IRDM_SUM_CONSUME(nw, ol, sl, k0)                                                                \
-    _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) {                                             \
-        if ((k0) + j < n) {                                                                             \
-            const float d = s - ol[j]; /* simd_baseline_update: two separately rounded operations */    \
-            s = d + nw[j];                                                                              \
-            smin = fminf(smin, s);                                                                      \
-            if (sl[j] >= 0) snap[(size_t)sl[j] * N + b] = s;                                            \
+    uint32_t slA[kSumDepth], slB[kSumDepth];
+#define IRDM_SUM_LOAD(NWv, OLv, SLv, k0)                                                                \
+    {                                                                                                   \
+        const __amdgpu_buffer_rsrc_t r_old = (k0) < kHistory ? r_hist : r_mag;                          \
+        _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) {                                         \
+            const SumStep st = steps[(k0) + j];                                                         \
+            NWv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_mag, boff, (int)st.nw_off, 0)); \
+            OLv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_old, boff, (int)st.ol_off, 0)); \
+            SLv[j] = st.snap_off;                                                                       \
         }                                                                                               \
+    }
+#define IRDM_SUM_STEP(NWv, OLv, SLv)                                                                    \
+    {                                                                                                   \
+        const float d = s - OLv[j]; /* simd_baseline_update: two separately rounded operations */       \
+        s = d + NWv[j];                                                                                 \
+        smin = s < smin ? s : smin;                                                                     \
+        if (SLv[j] != ~0u)                                                                              \
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s), r_snap, boff, (int)SLv[j], 0); \
+    }
+    // (a whole batch inside the list runs without the per-step test of the list's end)
+#define IRDM_SUM_CONSUME(NWv, OLv, SLv, k0)                                                             \
+    if ((k0) + kSumDepth <= n) {                                                                        \
+        _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) IRDM_SUM_STEP(NWv, OLv, SLv)              \
+    } else {                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < kSumDepth; j++)                                           \
+            if ((k0) + j < n) IRDM_SUM_STEP(NWv, OLv, SLv)                                              \
     }
     IRDM_SUM_LOAD(nwA, olA, slA, 0)
     for (int k0 = 0; k0 < n; k0 += 2 * kSumDepth) {
@@ -489,6 +537,7 @@ __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWor
     }
 #undef IRDM_SUM_LOAD
 #undef IRDM_SUM_CONSUME
+#undef IRDM_SUM_STEP
     W.sum_new[b] = s;
     smin_out[b] = smin;
     // the prefilter listed mag > pre = 0.5 * thr * sum_at_chunk_start; a crossing needs mag > thr * sum (within one
@@ -496,14 +545,18 @@ __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWor
     if (!(pre[b] <= 0.9f * P.thr * smin)) atomicOr(W.flags, BAND_F_STALE);
 }
 
+// BPW bins per wavefront (lanes beyond BPW repeat the first ones: same addresses, same values).  64, 32 and 16 measure the
+// same (10 MHz, 1000 and 7600 update steps): the pass is bound by what a step costs one wavefront, not by the cache lines a
+// CU has in flight.
+template <int BPW>
 __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
                                                       const float *__restrict__ hist, const float *__restrict__ sum,
                                                       const float *__restrict__ pre, float *__restrict__ smin_out,
-                                                      const int4 *__restrict__ steps, float *__restrict__ snap)
+                                                      const SumStep *__restrict__ steps, float *__restrict__ snap)
 {
     IRDM_DETECTOR_PRIO();
     if (band_void(P, W) || W.ctl->status != 0) return;
-    band_sum_body(P, W, mag, hist, sum, pre, smin_out, steps, snap, blockIdx.x * 64 + threadIdx.x);
+    band_sum_body(P, W, mag, hist, sum, pre, smin_out, steps, snap, (int)blockIdx.x * BPW + (int)(threadIdx.x % BPW));
 }
 
 // ---- crossing bits of one frame ----
@@ -941,6 +994,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // a launch per pass -- one workgroup plans at a quarter of the lanes, the step descriptors of the sums pass
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
+int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
 int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 
 int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
@@ -982,7 +1036,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(F); add(F);                                  // uq, uf
     add(4 * (F + 2)); add(4 * (2 * F + 4));          // cnt_before, tmp
     add(4 * (2 * F + 4)); add(4 * (2 * F + 4)); add(4 * (2 * F + 4));   // upd_frame, old_row, snap_after
-    add(16 * (2 * F + 4 + 3 * kSumDepth));                              // steps
+    add(sizeof(SumStep) * (2 * F + 4 + 3 * kSumDepth));                // steps
     add(4 * (2 * F + 4)); add(4 * (2 * F + 4));      // need, snap_slot
     add(4 * F); add(4 * F);                          // slot_pre, slot_post
     add(F * (size_t)n / 8);                          // cross
@@ -1009,7 +1063,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->upd_frame = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->old_row = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->snap_after = static_cast<int32_t *>(take(4 * (2 * F + 4)));
-    W->steps = static_cast<int4 *>(take(16 * (2 * F + 4 + 3 * kSumDepth)));
+    W->steps = static_cast<SumStep *>(take(sizeof(SumStep) * (2 * F + 4 + 3 * kSumDepth)));
     W->need = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->snap_slot = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->slot_pre = static_cast<int32_t *>(take(4 * F));
@@ -1090,7 +1144,12 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         if (round > round_begin || round_begin == 0)
             hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), kPlanLdsBytes, stream, P, W, counts, st, round);
         if (round == round_end) break;
-        hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+        if (g_band_sum_bins == 32)
+            hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+        else if (g_band_sum_bins == 16)
+            hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+        else
+            hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         if (g_band_cross_wave)
             hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
         else
