@@ -837,6 +837,23 @@ def main():
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
                                                           "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists",
                                                           "scan_chained", "scan_chain_undone")},
+                       # the plan pass's own phase stamps, us per chunk (round 1: verdict loops, boundaries, bitmaps read,
+                       # step count scan, step list, slot scan, end; last verdict: loops, boundaries)
+                       # (--opt band_timeline=1) device timeline of the scan's passes, us per chunk: [time from the first
+                       # workgroup's start to the last one's end, idle time in front of the pass, launches per chunk]
+                       "scan_timeline_us": ({("%s%d" % (("plan", "sums", "cross", "walk")[i % 4], i // 4) if i < 24 else
+                                              ("commit", "history")[i - 24]):
+                                             [round(pipe.stat("tl_dur_%d" % i) / 100.0 / max(1, pipe.stat("band_chunks")), 1),
+                                              round(pipe.stat("tl_gap_%d" % i) / 100.0 / max(1, pipe.stat("band_chunks")), 1),
+                                              round(pipe.stat("tl_n_%d" % i) / max(1, pipe.stat("band_chunks")), 2)]
+                                             for i in range(26) if pipe.stat("tl_n_%d" % i) > 0} or None),
+                       "walk_events": ({"round0_longest_lane": pipe.stat("tl_dur_26") / max(1, pipe.stat("band_chunks")),
+                                        "round0_all": pipe.stat("tl_dur_27") / max(1, pipe.stat("band_chunks")),
+                                        "later_longest_lane": pipe.stat("tl_dur_28") / max(1, pipe.stat("band_chunks")),
+                                        "later_all": pipe.stat("tl_dur_29") / max(1, pipe.stat("band_chunks"))}
+                                       if pipe.stat("tl_n_0") > 0 else None),
+                       "plan_phase_us": [round(pipe.stat("plan_tp_%d" % i) / 100.0 / max(1, pipe.stat("band_chunks")), 1)
+                                         for i in range(16)],
                        "host_us_total": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(
                            ("k1_ring_enqueue", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync",
                             "settle_wait_scan", "settle_counters", "settle_records", "build_records"))}},

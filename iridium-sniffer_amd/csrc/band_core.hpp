@@ -47,11 +47,13 @@ enum : uint32_t {
     BAND_F_GONECAP = 256,    // more finished bursts than the caller's record buffer holds
     BAND_F_SNAP = 512,       // more sum snapshots than the buffer holds
     BAND_F_CHAIN = 2048,     // a chained launch found that the scan in front of it had not committed (it wrote nothing)
+    BAND_F_CHECK = 4096,     // (option band_selfcheck) the two forms of the boundary test gave different answers
     BAND_F_COOP = 1024,      // the cooperative kernel's grid barrier timed out (not every workgroup became resident)
 };
 
 struct BandParams {
     int32_t n, nw64;             // FFT size, u64 words per row of crossing bits
+    int32_t log_n;               // n == 1 << log_n
     int32_t n_frames, occ_words; // frames in this scan, ceil(n_frames / 64)
     int32_t hw;                  // burst_width / 2
     int32_t pre_len, post_len, max_len, max_bursts;
@@ -61,6 +63,10 @@ struct BandParams {
     float thr;
     uint64_t idx0;               // absolute sample index of frame 0
     int32_t serial = 0;          // launch number: a launch that finds itself void (below) marks BandWork::bar[5] with it
+    int32_t selfcheck = 0;       // test hook (option band_selfcheck): bit 0 run both forms of the boundary test and compare,
+                                 // bit 1 spoil band i+1's copy of every record in a boundary zone first (both must object)
+    int32_t tl_sel = -1;         // >= 0: the passes stamp their first workgroup's start and last one's end into half tl_sel of
+                                 // BandWork::tl (diagnostic, option band_timeline)
     int32_t chained = 0;         // 1: enqueued behind a band scan whose verdict the host had not seen: valid only if that
                                  // scan committed (BandWork::bar[4]), else every pass of this launch returns untouched
 };
@@ -192,6 +198,7 @@ struct BandWalker {
     int last_occ;
     int acc_blk;
     uint32_t acc_max;
+    int n_events = 0;            // frames processed (diagnostic)
 
     IRDM_HD BandWalker(const BandParams &p, const BandIO &i, BandSlots s, int b) : P(p), io(i), S(s), band(b)
     {
@@ -317,7 +324,8 @@ struct BandWalker {
         for (uint32_t v = valid; v; v &= v - 1) {
             const int i = __builtin_ctz(v);
             const int64_t num = S.la[i * S.stride] + (int64_t)P.post_len - (int64_t)P.idx0;
-            const int64_t ef = num <= 0 ? 0 : (num + P.n - 1) / P.n;
+            // (n is a power of two: a 64-bit division here was most of what an event cost a lane)
+            const int64_t ef = num <= 0 ? 0 : (num + P.n - 1) >> P.log_n;
             if (ef < best) best = ef;
         }
         return (int)best;
@@ -443,6 +451,7 @@ struct BandWalker {
         }
         while (f < P.n_frames) {
             process(f);
+            n_events++;
             const uint32_t c = owned_count();
             const int nf = next_event(f);
             account(f, (nf < P.n_frames ? nf : P.n_frames) - 1, c);

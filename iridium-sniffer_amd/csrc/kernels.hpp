@@ -38,6 +38,7 @@ struct BandCtl {                         // control block on the device, copied 
     int32_t n_upd, n_snap, agree_fail, mismatch, first_mismatch;
     int32_t n_gone, n_total, committed, h0;
     int32_t pad[4];
+    uint32_t tp[16];                     // plan pass phase stamps (10 ns ticks since the pass began): [0..7] round 1, [8..15] the last verdict
 };
 struct SumStep {                         // one update step of the sums pass, as the byte offsets its buffer accesses take
     uint32_t nw_off;                     // the magnitude row that enters the sum (offset into the chunk's magnitudes)
@@ -63,10 +64,13 @@ struct BandWork {                        // device workspace, carved out of one 
     uint64_t *ids;
     uint32_t *flags;
     uint32_t *rank;                      // commit: record -> place in creation order
+    unsigned long long *tl;              // [2 halves][2][32] pass timeline (BandParams::tl_sel): per slot earliest start | latest end, 10 ns ticks
     unsigned *bar;                       // [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
+extern int g_band_timeline;              // 1: the band scan's passes record a device timeline (read back by the pipeline per chunk)
+extern int g_band_selfcheck;             // test hook: BandParams::selfcheck of the launches that follow
 extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass
 int band_list_cap(int n);                // entries per frame the band scan's lists hold
@@ -76,7 +80,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, hipStream_t stream);
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream);
+constexpr int kBandTlSlots = 32;         // plan / sums / cross / walk of round r: 4 r + 0..3; commit 24; history 25
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,
                            unsigned *counts, ListEntry *entries, int n_frames, int cap, hipStream_t stream);

@@ -233,6 +233,7 @@ struct irdm_pipeline {
     hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream with CUs of its own (CU mask), so that the
                              // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
     hipEvent_t ev_scan_in, ev_scan_out;
+    int scan_events = 1;     // 0: no timing events around the band scan (stage time of the scan reads -1)
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
     hipEvent_t ev[10];   // 0 start,1 fft,2 scan,3 pre-fir,4 fir,5 post,6 demod,7 end,8 caller sync
 
@@ -281,6 +282,8 @@ struct irdm_pipeline {
     bool band_ok;
     int fl_mode;                // scan in flight: 0 dense, 1 sparse (leader/updaters), 2 band
     int fl_done;                // frames the dense scan primed before the in-flight scan proper
+    uint64_t stat_plan_tp[16] = {};
+    uint64_t stat_tl_dur[32] = {}, stat_tl_gap[32] = {}, stat_tl_n[32] = {};
     uint64_t stat_band_chunks, stat_band_rounds, stat_band_retries, stat_band_aborts, stat_band_extra, stat_chain_undone, stat_chained;
     uint32_t last_band_flags;
 
@@ -458,6 +461,23 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         return nullptr;
     }
     if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
+    // IRDM_CREATE_DEBUG: where the time and the device memory of a context go (stderr)
+    const bool dbg = getenv("IRDM_CREATE_DEBUG") != nullptr;
+    size_t mem_free0 = 0, mem_total = 0;
+    if (dbg) (void)hipMemGetInfo(&mem_free0, &mem_total);
+    auto t_now = [] {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    };
+    const double t_create0 = t_now();
+    auto mark = [&](const char *what) {
+        if (!dbg) return;
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        fprintf(stderr, "irdm_create: %-28s %8.2f ms  %8.1f MB on the device\n", what, t_now() - t_create0,
+                ((double)mem_free0 - (double)fr) / 1e6);
+    };
 
     irdm_pipeline *p = new (std::nothrow) irdm_pipeline();
     if (!p) return nullptr;
@@ -558,6 +578,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     // priorities the scan's small kernels queue up behind the FIR workgroups of two chains (measured: the host waited
     // 1.3 ms per feed for a 0.6 ms scan).  (Round 1 confined a sequential leader scan to CUs of its own with CU masks;
     // the band scan is wide and short, masks would only take CUs away from it.)
+    mark("host designs");
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
     bool ok = true;
@@ -621,6 +642,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         for (int k = 0; k < kFirTaps; k++) off[k] = ((k % p->decim) * row + k / p->decim) * (int)sizeof(float2);
         UP(p->d_fir_off, off);
     }
+    mark("streams, uploads");
     AL(p->d_hist, float, (size_t)kHistory * P.n);
     AL(p->d_sum, float, (size_t)P.n);
     AL(p->d_mag, float, p->max_chunk);
@@ -630,7 +652,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_gone, GoneBurst, (size_t)p->gone_cap);
     AL(p->d_cand_a, PeakCand, (size_t)P.n);
     AL(p->d_cand_b, PeakCand, (size_t)P.n);
+    mark("detector buffers");
     AL(p->d_rot_table, float2, (size_t)P.n * p->n_ckpt);
+    mark("rotator table alloc");
     AL(p->d_work, BurstWork, (size_t)p->burst_cap);
     p->tiles_cap = (size_t)p->burst_cap * 64;
     AL(p->d_tiles, FirTile, (p->tiles_cap + 1) * kFirTileUnits);
@@ -705,6 +729,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_mc_ops, unsigned long long, (size_t)p->mc_ops_cap);
         AL(p->d_mc_done, unsigned, 32 * 16);
     }
+    mark("per-burst scratch, lists");
     p->band_ok = band_scan_supported(P, nullptr, 1, 0) != 0;
     if (p->band_ok) {
         AL(p->d_smin, float, (size_t)P.n);
@@ -712,7 +737,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         if (ok) band_work_carve(&p->band, p->d_band, P.n, p->max_chunk);
         if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // the cooperative kernel's grid barrier starts idle
     }
+    mark("band scan workspace");
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
+    mark("history ring");
     // batch contexts: [0] aliases the pipeline's per-burst scratch and runs on bstream; [1] (pipeline_depth >= 1) has
     // scratch and a stream of its own
     p->n_bc = p->depth ? std::min(p->depth + 1, 3) : 1;
@@ -771,11 +798,13 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         pipeline_free(p);
         return nullptr;
     }
+    mark("batch contexts");
     ok = hipMemset(p->d_hist, 0, sizeof(float) * (size_t)kHistory * P.n) == hipSuccess &&
          hipMemset(p->d_sum, 0, sizeof(float) * P.n) == hipSuccess &&
          hipMemset(p->d_state, 0, sizeof(DetState)) == hipSuccess &&
          hipMemset(p->d_ring, 0, p->ring_len * p->bps) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
+    mark("memsets, sync");
     // The rotator checkpoint table (one sequential float recurrence per FFT bin, 12.5 ms of one-lane-per-bin work at
     // 10 MHz) is not needed before the first burst reaches the decimator -- at the earliest 512 priming frames into
     // the stream -- so irdm_create does not wait for it: it runs on a per-burst stream, the chains wait for ev_rot.
@@ -832,7 +861,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             p->dev_cfo = false;
         }
     }
+    mark("libm self-check");
     p->cfo_thread = std::thread(cfo_helper_main, p);
+    mark("done");
     return p;
 }
 
@@ -1483,7 +1514,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
         // the first rounds left the verdict open: the remaining rounds, on the same lists and workspace
         return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
                                 p->d_smin, p->d_gone, p->gone_cap, first, kBandRounds, hpg,
-                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, p->stream);
+                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, sel, p->stream);
     }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
@@ -1492,12 +1523,12 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
     } else {
         p->stat_k1_lists++;
     }
-    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
+    if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
                          entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, first, hpg,
-                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, p->stream) != 0)
+                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream) != 0)
         return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
+    if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
     return 0;
 }
@@ -1693,6 +1724,22 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             if (more_rounds() != 0) return -1;
         }
         p->stat_band_rounds += (uint64_t)ctl->rounds;
+        if (irdm::g_band_timeline && p->fl_band_ran) {
+            // (diagnostic) the passes' device timeline of this scan: durations, and the idle time in front of each pass
+            unsigned long long tl[2 * kBandTlSlots];
+            IRDM_HIP_CHECK(hipMemcpy(tl, p->band.tl + (size_t)p->out_sel * 2 * kBandTlSlots, sizeof(tl), hipMemcpyDeviceToHost));
+            for (int i = 26; i < 30; i++) p->stat_tl_dur[i] += tl[kBandTlSlots + i];      // (event counts of the walk passes)
+            unsigned long long prev_end = 0;
+            for (int i = 0; i < 26; i++) {
+                const unsigned long long lo = tl[i], hi = tl[kBandTlSlots + i];
+                if (lo == ~0ull || hi == 0 || hi < lo) continue;
+                p->stat_tl_dur[i] += hi - lo;
+                if (prev_end && lo > prev_end) p->stat_tl_gap[i] += lo - prev_end;
+                p->stat_tl_n[i]++;
+                prev_end = hi;
+            }
+        }
+        for (int i = 0; i < 16; i++) p->stat_plan_tp[i] += ctl->tp[i];
         if (ctl->status == 1) {
             p->band_auto = std::min(std::max(ctl->rounds, 2), kBandRounds);
             p->stat_band_chunks++;
@@ -1791,7 +1838,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     tq1 = now_us(); p->host_us[8] += tq1 - tq0; tq0 = tq1;          // [8] the burst records' round trip
     float ms = 0;
     // the scan proper (band passes, the sparse kernel, or the dense one when it ran instead)
-    p->last_ms[1] = hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
+    p->last_ms[1] = (p->scan_events || p->fl_mode != 2) && hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
     p->last_frames = p->fl_frames;
     p->d_mag_last = p->fl_mag;
     // burst_detect.c:739: counted where the detector hands the burst over -- here, when the scan settles -- so that the
@@ -2589,6 +2636,9 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
     if (!strcmp(key, "band_sum_bins")) { irdm::g_band_sum_bins = value; return 0; }
+    if (!strcmp(key, "band_selfcheck")) { irdm::g_band_selfcheck = value; return 0; }
+    if (!strcmp(key, "band_timeline")) { irdm::g_band_timeline = value; return 0; }
+    if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
@@ -2609,6 +2659,13 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "band_rounds")) return (int64_t)p->stat_band_rounds;
     if (!strcmp(key, "band_retries")) return (int64_t)p->stat_band_retries;
     if (!strcmp(key, "band_aborts")) return (int64_t)p->stat_band_aborts;
+    if (!strncmp(key, "tl_dur_", 7)) { const int i = atoi(key + 7); return i >= 0 && i < 32 ? (int64_t)p->stat_tl_dur[i] : -1; }
+    if (!strncmp(key, "tl_gap_", 7)) { const int i = atoi(key + 7); return i >= 0 && i < 32 ? (int64_t)p->stat_tl_gap[i] : -1; }
+    if (!strncmp(key, "tl_n_", 5)) { const int i = atoi(key + 5); return i >= 0 && i < 32 ? (int64_t)p->stat_tl_n[i] : -1; }
+    if (!strncmp(key, "plan_tp_", 8)) {
+        const int i = atoi(key + 8);
+        return i >= 0 && i < 16 ? (int64_t)p->stat_plan_tp[i] : -1;
+    }
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
     return -1;

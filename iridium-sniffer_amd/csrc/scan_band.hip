@@ -45,6 +45,23 @@ __device__ __forceinline__ bool band_void(const BandParams &P, const BandWork &W
     return __hip_atomic_load(W.bar + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)P.serial;
 }
 
+// diagnostic timeline (BandParams::tl_sel >= 0): earliest start and latest end over the workgroups of a pass
+struct TlScope {
+    unsigned long long *lo, *hi;
+    __device__ __forceinline__ TlScope(const BandParams &P, const BandWork &W, int slot) : lo(nullptr), hi(nullptr)
+    {
+        if (P.tl_sel >= 0 && threadIdx.x == 0 && slot >= 0 && slot < kBandTlSlots) {
+            lo = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + slot;
+            hi = lo + kBandTlSlots;
+            atomicMin(lo, (unsigned long long)wall_clock64());
+        }
+    }
+    __device__ __forceinline__ ~TlScope()
+    {
+        if (hi) atomicMax(hi, (unsigned long long)wall_clock64());
+    }
+};
+
 __device__ __constant__ int g_plan_lds_on = 1;       // (test hook: 0 = the plan pass through the workspace arrays only)
 
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
@@ -108,6 +125,76 @@ __device__ bool boundary_agrees(const BandParams &P, const BandWork &W, int i, i
     return !(bad || ca != cb);
 }
 
+// The same test for every boundary at once (16 lanes per boundary, one workgroup of >= 1008 threads): the wavefront form
+// above walks band i+1's records one dependent load after the other for every record of band i in the zone -- 29 us
+// alone and 49 us in run of a plan pass.  Here the records of both bands inside the zone (a handful: bursts whose centre
+// lies within burst_width/2 of the boundary) are listed in LDS first -- band i by index, band i+1 by (centre bin, low
+// word of the start, index) -- and each zone record of band i looks its partner up in that list; only a candidate whose
+// key matches is fetched and compared in full.  More than kZoneCap zone records on one side: the plain search.
+struct ZoneEnt {
+    uint32_t cb, start_lo, idx;
+};
+constexpr int kZoneCap = 32;
+constexpr size_t kZoneLdsBytes = 64 * kZoneCap * (sizeof(ZoneEnt) + sizeof(uint32_t)) + 128 * sizeof(uint32_t);
+
+__device__ void boundaries_agree_lds(const BandParams &P, const BandWork &W, uint8_t *lds, int *s_fail)
+{
+    ZoneEnt *zb = reinterpret_cast<ZoneEnt *>(lds);                           // [64][kZoneCap]
+    uint32_t *za = reinterpret_cast<uint32_t *>(zb + 64 * kZoneCap);           // [64][kZoneCap]
+    uint32_t *zc = za + 64 * kZoneCap;                                         // [64][2]
+    const int tid = threadIdx.x, i = tid >> 4, gl = tid & 15;
+    const bool on = i + 1 < P.n_bands;
+    if (tid < 128) zc[tid] = 0;
+    __syncthreads();
+    const int X = (i + 1) * P.band_w;
+    const BandRec *A = W.recs + (size_t)i * kBandRecCap, *B = W.recs + (size_t)(i + 1) * kBandRecCap;
+    int na = 0, nb = 0;
+    if (on) {
+        na = min((int)W.rec_count[i], kBandRecCap);
+        nb = min((int)W.rec_count[i + 1], kBandRecCap);
+        const int nmax = max(na, nb);
+        for (int k = gl; k < nmax; k += 16) {
+            // (both bands' loads of a stride are in flight together)
+            const int cba = k < na ? A[k].cb : -0x40000000;
+            const int cbb = k < nb ? B[k].cb : -0x40000000;
+            const uint32_t stb = k < nb ? (uint32_t)B[k].start : 0u;
+            if (cba >= X - P.hw && cba < X + P.hw) {
+                const uint32_t at = atomicAdd(&zc[2 * i], 1u);
+                if (at < (uint32_t)kZoneCap) za[i * kZoneCap + at] = (uint32_t)k;
+            }
+            if (cbb >= X - P.hw && cbb < X + P.hw) {
+                const uint32_t at = atomicAdd(&zc[2 * i + 1], 1u);
+                if (at < (uint32_t)kZoneCap) zb[i * kZoneCap + at] = ZoneEnt{ (uint32_t)cbb, stb, (uint32_t)k };
+            }
+        }
+    }
+    __syncthreads();
+    if (!on) return;
+    const int ca = (int)zc[2 * i], cb = (int)zc[2 * i + 1];
+    int bad = 0;
+    if (ca != cb) {
+        bad = 1;
+    } else if (ca > kZoneCap) {
+        for (int a = gl; a < na; a += 16) {
+            if (A[a].cb < X - P.hw || A[a].cb >= X + P.hw) continue;
+            bool found = false;
+            for (int b = 0; b < nb && !found; b++) found = B[b].cb == A[a].cb && band_rec_same(A[a], B[b]);
+            if (!found) bad = 1;
+        }
+    } else {
+        for (int k = gl; k < ca; k += 16) {
+            const BandRec ra = A[za[i * kZoneCap + k]];
+            bool found = false;
+            for (int j = 0; j < cb && !found; j++) {
+                const ZoneEnt e = zb[i * kZoneCap + j];
+                if (e.cb == (uint32_t)ra.cb && e.start_lo == (uint32_t)ra.start) found = band_rec_same(ra, B[e.idx]);
+            }
+            if (!found) bad = 1;
+        }
+    }
+    if (bad) atomicOr(s_fail, 1);
+}
+
 // step descriptor of an update step: frame uf, the row it replaces (old < 0: row -old - 1 of the carried history, else the
 // magnitude row of frame old), snapshot slot after the step (< 0: none).  Rows are at most 64 KB and there are at most
 // max_chunk / n + 2 of them: every offset is far below 4 GB.
@@ -140,6 +227,7 @@ struct PlanShared {
 
 constexpr int kPlanLdsFrames = 8192;     // frames the LDS form of the plan holds (need flags + snapshot slots: 80 KB)
 constexpr size_t kPlanLdsBytes = ((2 * kPlanLdsFrames + 2 + 15) & ~15) + sizeof(int32_t) * (2 * kPlanLdsFrames + 2);
+static_assert(kZoneLdsBytes <= kPlanLdsBytes, "the boundary test's lists live in the plan's LDS before the plan needs it");
 
 // lds: kPlanLdsBytes of dynamic LDS, or nullptr (the general path through the workspace arrays)
 template <int NT>
@@ -179,6 +267,12 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
     }
     if (ctl->status != 0) return;
     const int F = P.n_frames;
+    // phase stamps of the pass (diagnostic: exported with the control block, stat keys "plan_tp_<i>")
+    const uint64_t t_begin = wall_clock64();
+    uint32_t *tp = ctl->tp + (round == 1 ? 0 : 8);
+    auto stamp = [&](int i) {
+        if (tid == 0 && round >= 1) tp[i] = (uint32_t)(wall_clock64() - t_begin);
+    };
 
     if (tid == 0) {
         s_mismatch = 0;
@@ -240,9 +334,36 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         }
         for (int b = tid; b < P.occ_words; b += kPlanThreads)
             if (W.conc[b] >= (unsigned)P.max_bursts) atomicOr(&s_flags, BAND_F_SQUELCH);
-        for (int i = tid >> 6; i + 1 < P.n_bands; i += kPlanThreads / 64)
-            if (!boundary_agrees(P, W, i, tid & 63) && (tid & 63) == 0) atomicOr(&s_agree_fail, 1);
         __syncthreads();
+        stamp(0);
+        if (P.selfcheck & 2) {
+            // (test hook) band i+1's view of every burst near its lower boundary is made to differ from band i's
+            for (int i = 1; i < P.n_bands; i++) {
+                BandRec *B = W.recs + (size_t)i * kBandRecCap;
+                const int X = i * P.band_w, nb = min((int)W.rec_count[i], kBandRecCap);
+                for (int k = tid; k < nb; k += kPlanThreads)
+                    if (B[k].cb >= X - P.hw && B[k].cb < X + P.hw) B[k].last_active += 1;
+            }
+            __syncthreads();
+        }
+        if (lds != nullptr && NT >= 16 * 64) {
+            boundaries_agree_lds(P, W, lds, &s_agree_fail);
+            if (P.selfcheck & 1) {
+                // (test hook) the wavefront form must give the same answer
+                __shared__ int s_other;
+                if (tid == 0) s_other = 0;
+                __syncthreads();
+                for (int i = tid >> 6; i + 1 < P.n_bands; i += kPlanThreads / 64)
+                    if (!boundary_agrees(P, W, i, tid & 63) && (tid & 63) == 0) atomicOr(&s_other, 1);
+                __syncthreads();
+                if (tid == 0 && s_other != s_agree_fail) atomicOr(&s_flags, BAND_F_CHECK);
+            }
+        } else {
+            for (int i = tid >> 6; i + 1 < P.n_bands; i += kPlanThreads / 64)
+                if (!boundary_agrees(P, W, i, tid & 63) && (tid & 63) == 0) atomicOr(&s_agree_fail, 1);
+        }
+        __syncthreads();
+        stamp(1);
         if (tid == 0) {
             unsigned fl = s_flags | *W.flags;
             int status = 0;
@@ -305,6 +426,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             }
         }
         __syncthreads();                      // (every thread has read the bitmaps: they may be cleared)
+        stamp(2);
         for (int i = tid; i < P.n_bands * P.occ_words; i += kPlanThreads) W.occ[i] = 0;
         for (int i = tid; i < P.occ_words; i += kPlanThreads) {
             W.busy[i] = 0;
@@ -334,6 +456,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         };
         int n_upd = 0;
         const int base = scan1(c_t, n_upd);
+        stamp(3);
         for (int k = tid; k <= n_upd + 1; k += kPlanThreads) s_need[k] = 0;
         __syncthreads();
         {
@@ -353,6 +476,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             }
         }
         __syncthreads();
+        stamp(4);
         // snapshot slots: exclusive scan of the need flags, a contiguous run of steps per thread
         const int kpt = (n_upd + 1 + NT - 1) / NT;
         const int k0 = tid * kpt, k1 = min(k0 + kpt, n_upd + 1);
@@ -367,6 +491,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         }
         if (tid == 0) W.snap_slot[0] = s_need[0] ? 0 : -1;      // (the sums pass reads slot 0 from the workspace)
         __syncthreads();
+        stamp(5);
         const int h0 = ctl->h0;
         for (int k = n_upd + tid; k < n_upd + 2 * kSumDepth + 1; k += kPlanThreads) W.steps[k] = noop_step();
         for (int k = tid; k < n_upd; k += kPlanThreads) {
@@ -388,6 +513,8 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
                 }
             }
         }
+        __syncthreads();
+        stamp(6);
         if (tid == 0) {
             ctl->n_upd = n_upd;
             ctl->n_snap = n_snap;
@@ -459,6 +586,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, B
                                                                  DetState *__restrict__ st, int round)
 {
     IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 4 * round);
     __shared__ PlanShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
     band_plan_body<kPlanThreads>(P, W, counts, st, round, sh, g_plan_lds_on ? plan_lds : nullptr);
@@ -555,6 +683,7 @@ __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, 
                                                       const SumStep *__restrict__ steps, float *__restrict__ snap)
 {
     IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 1);
     if (band_void(P, W) || W.ctl->status != 0) return;
     band_sum_body(P, W, mag, hist, sum, pre, smin_out, steps, snap, (int)blockIdx.x * BPW + (int)(threadIdx.x % BPW));
 }
@@ -601,7 +730,8 @@ __global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork 
 // one wavefront: lane = band, blk = 64-frame block; smem_raw: kBandSlots * 64 * 36 bytes of slot storage
 template <int NW>
 __device__ __forceinline__ void band_walk_body(const BandParams &P, BandIO io, const DetState *__restrict__ st,
-                                               unsigned char *smem_raw, int band, int blk)
+                                               unsigned char *smem_raw, int band, int blk,
+                                               unsigned long long *tl_stat = nullptr)
 {
     io.act_in = st->act;
     io.n_act_in = st->n_act;
@@ -616,11 +746,13 @@ __device__ __forceinline__ void band_walk_body(const BandParams &P, BandIO io, c
     BandSlots S{ l_start + band, l_la + band, l_cb + band, l_cf + band, l_seq + band, l_rel + band, l_base + band, 64 };
 
     bool carried = false;
+    int events = 0;
     if (blk == 0) {
         BandWalker<NW> w(P, io, S, band);
         if (w.load_carried() > 0) {
             carried = true;
             w.run(0, true);
+            events += w.n_events;
         }
     }
     uint64_t starts = band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, carried);
@@ -629,6 +761,12 @@ __device__ __forceinline__ void band_walk_body(const BandParams &P, BandIO io, c
         starts &= starts - 1;
         BandWalker<NW> w(P, io, S, band);
         w.run(64 * blk + j, false);
+        events += w.n_events;
+    }
+    if (tl_stat) {
+        // (diagnostic timeline: the longest lane's and all lanes' event counts of this pass)
+        atomicMax(tl_stat, (unsigned long long)events);
+        atomicAdd(tl_stat + 1, (unsigned long long)events);
     }
 }
 
@@ -636,9 +774,16 @@ template <int NW>
 __global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W, BandIO io, const DetState *__restrict__ st)
 {
     IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (band_void(P, W) || W.ctl->status != 0) return;
-    band_walk_body<NW>(P, io, st, smem_raw, threadIdx.x, blockIdx.x);
+    unsigned long long *tl_stat = nullptr;
+    if (P.tl_sel >= 0) {
+        const int r = W.ctl->rounds - 1;
+        // (slots 26 / 27: round 0's longest lane and total, 28 / 29: the later rounds'; in the "end" half of the timeline)
+        tl_stat = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + (r == 0 ? 26 : 28);
+    }
+    band_walk_body<NW>(P, io, st, smem_raw, threadIdx.x, blockIdx.x, tl_stat);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -742,6 +887,7 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
                                                            const ListEntry *__restrict__ entries)
 {
     IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 2);
     __shared__ uint32_t s_bits_all[4][16384 / 32];
     if (band_void(P, W) || W.ctl->status != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -841,6 +987,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
                                                                    int gone_cap)
 {
     IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 24);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t *s_key = reinterpret_cast<uint64_t *>(smem_raw);                    // kBandMaxTotal
     uint16_t *s_val = reinterpret_cast<uint16_t *>(s_key + kBandMaxTotal);       // kBandMaxTotal
@@ -914,7 +1061,7 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
     // bursts still active follow in creation order
     for (int t = tid; t < n; t += kPlanThreads) {
         const BandRec &r = W.recs[W.tot[t]];
-        s_key[t] = r.stop >= 0 ? (((uint64_t)((r.stop - (int64_t)P.idx0) / P.n)) << 32) | rank_of[t]
+        s_key[t] = r.stop >= 0 ? (((uint64_t)((r.stop - (int64_t)P.idx0) >> P.log_n)) << 32) | rank_of[t]
                                : (1ull << 63) | rank_of[t];
         s_val[t] = (uint16_t)t;
     }
@@ -965,6 +1112,7 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
                                                            uint32_t *__restrict__ hp_ctl)
 {
     IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 25);
     const BandCtl *ctl = W.ctl;
     if (blockIdx.x == 0 && threadIdx.x < 3) W.bar[threadIdx.x] = 0;      // (the cooperative kernel's barrier: idle here)
     if (band_void(P, W)) {
@@ -995,6 +1143,8 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
+int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
 int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 
 int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
@@ -1003,6 +1153,7 @@ int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint6
 {
     BandParams P;
     P.n = D.n;
+    P.log_n = 31 - __builtin_clz((unsigned)(D.n > 0 ? D.n : 1));
     P.nw64 = D.n / 64;
     P.n_frames = n_frames;
     P.occ_words = (n_frames + 63) / 64;
@@ -1020,7 +1171,7 @@ int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint6
     if (out) *out = P;
     // what the kernels assume: at most 64 bands (one wavefront), the halo wider than two masks, a segment cut within
     // one 64-frame word, at least one whole band
-    if (D.n < 2048 || D.n > 16384 || P.n_bands < 1 || P.n_bands > 64) return 0;
+    if (D.n < 2048 || D.n > 16384 || D.n != (1 << P.log_n) || P.n_bands < 1 || P.n_bands > 64) return 0;
     if (P.hw < 1 || 2 * P.hw + 8 > P.band_w / 2) return 0;
     if (P.gap < 1 || P.gap >= 64) return 0;
     if (D.max_bursts <= 0 || D.max_bursts > kMaxActive - 64) return 0;
@@ -1047,6 +1198,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(sizeof(BandRec) * 64 * kBandRecCap); add(4 * 64);                            // recs, rec_count
     add(4 * (size_t)n); add(4 * kBandMaxTotal); add(8 * kBandMaxTotal); add(256);    // sum_new, tot, ids, flags
     add(256); add(4 * kBandMaxTotal);                                                // bar, rank
+    add(8 * 4 * kBandTlSlots);                                                       // tl
     return b;
 }
 
@@ -1084,6 +1236,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->flags = static_cast<uint32_t *>(take(256));
     W->bar = static_cast<unsigned *>(take(256));
     W->rank = static_cast<uint32_t *>(take(4 * kBandMaxTotal));
+    W->tl = static_cast<unsigned long long *>(take(8 * 4 * kBandTlSlots));
     return 0;
 }
 
@@ -1092,7 +1245,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, hipStream_t stream)
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream)
 {
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
@@ -1104,6 +1257,13 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     launch_serial = launch_serial + 1 ? launch_serial + 1 : 1;      // (never 0: the idle value of bar[5])
     P.serial = (int32_t)launch_serial;
     P.chained = chained;
+    P.selfcheck = g_band_selfcheck;
+    P.tl_sel = g_band_timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;
+    if (P.tl_sel >= 0 && round_begin == 0) {
+        unsigned long long *half = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots;
+        (void)hipMemsetAsync(half, 0xff, 8 * kBandTlSlots, stream);
+        (void)hipMemsetAsync(half + kBandTlSlots, 0, 8 * kBandTlSlots, stream);
+    }
     // (round 0's plan pass resets the control block, the flags and the finished-burst count)
     BandIO io;
     io.cross = W.cross;

@@ -56,7 +56,7 @@ int band_chunk(Host &H, const float *mag, int n_frames, std::vector<GoneBurst> &
     const DetParams &D = H.D;
     const int N = D.n, F = n_frames;
     BandParams P;
-    P.n = N; P.nw64 = N / 64; P.n_frames = F; P.occ_words = (F + 63) / 64; P.hw = D.width / 2;
+    P.n = N; P.log_n = 31 - __builtin_clz((unsigned)N); P.nw64 = N / 64; P.n_frames = F; P.occ_words = (F + 63) / 64; P.hw = D.width / 2;
     P.pre_len = D.pre_len; P.post_len = D.post_len; P.max_len = D.max_len; P.max_bursts = D.max_bursts;
     P.band_w = band_w_override ? band_w_override : (P.hw <= 20 ? 128 : 256);
     P.list_cap = std::min(kBandListCap, N); P.n_bands = N / P.band_w; P.gap = (D.post_len + N - 1) / N; P.thr = D.threshold; P.idx0 = H.st.index;

@@ -166,3 +166,41 @@ def test_burst_record_buffer_grows_when_a_chunk_has_more_bursts_than_configured(
         finally:
             p.close()
         parity.compare(got, ref)
+
+
+def _zone_scene():
+    """10 MHz, bursts on random channels: with 8192 bins in 64 bands of 128 and burst_width/2 = 14 bins each side of a
+    boundary, about a fifth of the bursts lie in a boundary zone"""
+    import siggen
+    fs = 10_000_000
+    n = int(1.2 * fs) // 32768 * 32768
+    iq, _ = siggen.standard_scene(fs, n, 40, seed=2024)
+    return fs, iq
+
+
+def _restore_selfcheck():
+    p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
+    p.set_option("band_selfcheck", 0)
+    p.close()
+
+
+def test_boundary_test_forms_agree_and_both_object():
+    """the plan pass's boundary test (scan_band.hip: all boundaries at once from zone lists in LDS) against the plain
+    wavefront search it replaced: option band_selfcheck 1 runs both on every verdict and declines the chunk with
+    BAND_F_CHECK (4096) if their answers differ; 3 additionally spoils one band's copy of every record in a boundary
+    zone, so both must object (BAND_F_AGREE, 32) and the sequential kernels take the chunk.  Parity either way
+    (burst_detect.c:426-632)."""
+    fs, iq = _zone_scene()
+    ref = orc.run_stream(iq, fs)
+    try:
+        for chunks in (None, _chunks(len(iq), 3)):
+            got = parity.run_gpu(iq, fs, chunks=chunks, depth=1 if chunks else 0, options={"band_selfcheck": 1})
+            parity.compare(got, ref)
+            assert got["stats"]["band_aborts"] == 0 and got["stats"]["band_chunks"] >= 1, got["stats"]
+        spoiled = parity.run_gpu(iq, fs, options={"band_selfcheck": 3})
+        parity.compare(spoiled, ref)
+        st = spoiled["stats"]
+        assert st["band_aborts"] >= 1 and st["scan_fallbacks"] >= 1, st
+        assert st["band_last_flags"] & 32 and not st["band_last_flags"] & 4096, st
+    finally:
+        _restore_selfcheck()
