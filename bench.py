@@ -850,7 +850,9 @@ def main():
                        "walk_events": ({"round0_longest_lane": pipe.stat("tl_dur_26") / max(1, pipe.stat("band_chunks")),
                                         "round0_all": pipe.stat("tl_dur_27") / max(1, pipe.stat("band_chunks")),
                                         "later_longest_lane": pipe.stat("tl_dur_28") / max(1, pipe.stat("band_chunks")),
-                                        "later_all": pipe.stat("tl_dur_29") / max(1, pipe.stat("band_chunks"))}
+                                        "later_all": pipe.stat("tl_dur_29") / max(1, pipe.stat("band_chunks")),
+                                        "later_busiest_wave": pipe.stat("tl_dur_30") / max(1, pipe.stat("band_chunks")),
+                                        "later_longest_wave_us": pipe.stat("tl_dur_31") / 100.0 / max(1, pipe.stat("band_chunks"))}
                                        if pipe.stat("tl_n_0") > 0 else None),
                        "plan_phase_us": [round(pipe.stat("plan_tp_%d" % i) / 100.0 / max(1, pipe.stat("band_chunks")), 1)
                                          for i in range(16)],

@@ -35,6 +35,7 @@ namespace irdm {
 #include "fir_mac.inc"
 
 int g_fir_strip = 3;           // double blocks (128 columns) per strip: a strip yields 128*g_fir_strip - NR outputs
+int g_fir_grid = 0;            // > 0: at most this many single-wavefront workgroups in flight, each walking strips (0: one per strip)
 
 template <int M>
 struct FirR {
@@ -118,12 +119,15 @@ __device__ __forceinline__ float lane_shr1(float v)
 template <int M, int FMT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_r(
     SampleSource src, const FirGeom *__restrict__ geom, const float *__restrict__ taps,
-    const float2 *__restrict__ rot_table, float2 *__restrict__ dec)
+    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles)
 {
     using R = FirR<M>;
     constexpr int NR = R::NR, REM = R::REM;
     const int lane = threadIdx.x;
-    const FirGeom g = geom[blockIdx.x];
+    // (a grid smaller than the strip count -- option fir_grid -- walks the strips with the grid's stride)
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const FirGeom g = geom[tile];
     const int n_cols = g.n_out + NR;                 // columns that feed a stored output
     const int n_blk = (n_cols + 127) >> 7;
     const v2f inc = { g.inc_re, g.inc_im };
@@ -287,15 +291,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (q >= 0 && q < g.n_out) dec[g.out_base + q] = make_float2(acc[j].x, acc[j].y);
         }
     }
+    }
 }
 
 template <int M>
 static int launch_fir_r_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
                             const float2 *rot_table, float2 *dec, hipStream_t stream)
 {
-    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 2>), dim3(n_tiles), dim3(64), 0, stream, src, geom, taps, rot_table, dec);
-    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 1>), dim3(n_tiles), dim3(64), 0, stream, src, geom, taps, rot_table, dec);
-    else hipLaunchKernelGGL((fir_decimate_kernel_r<M, 0>), dim3(n_tiles), dim3(64), 0, stream, src, geom, taps, rot_table, dec);
+    const int grid = g_fir_grid > 0 && g_fir_grid < n_tiles ? g_fir_grid : n_tiles;
+    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles);
+    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles);
+    else hipLaunchKernelGGL((fir_decimate_kernel_r<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -69,6 +69,7 @@ struct BandWork {                        // device workspace, carved out of one 
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
+extern int g_band_walk_wave;             // 1 (default): the walk pass with a wavefront per band and segment; 0: a lane per band
 extern int g_band_timeline;              // 1: the band scan's passes record a device timeline (read back by the pipeline per chunk)
 extern int g_band_selfcheck;             // test hook: BandParams::selfcheck of the launches that follow
 extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed grid of frame-walking wavefronts; 0: a workgroup per frame
@@ -107,6 +108,7 @@ extern int g_fir_budget;          // persistent kernel: tiles per workgroup befo
 extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the other streams
 // fir_reg.hip: the register-resident decimator (M = 40, 48)
 extern int g_fir_strip;           // double blocks of 128 columns per strip
+extern int g_fir_grid;            // workgroups of the register-resident decimator (0: one per strip)
 int fir_reg_supported(int decim);
 int fir_reg_tile_out(int decim);
 int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,

@@ -381,11 +381,64 @@ struct irdm_pipeline {
     int keep_frame_samples;
 };
 
+// The rotator checkpoint table (4.5 GB at 10 MHz, 10.9 GB at 12 MHz) is a function of the FFT size and the longest burst
+// only: contexts of one sample rate on one device share it (several streams per GPU, the reference-API layer's
+// workers).  The entry owns the table and the event that says it is complete; the last user frees both.
+struct RotTableEntry {
+    int device, n, n_ckpt, refs;
+    float2 *table;
+    hipEvent_t ready;
+};
+static std::mutex g_rot_mu;
+static std::vector<RotTableEntry> g_rot_tables;
+
+static bool rot_table_acquire(int device, int n, int n_ckpt, const float2 *d_incr, hipStream_t st, float2 **table,
+                              hipEvent_t *ready)
+{
+    std::lock_guard<std::mutex> lk(g_rot_mu);
+    for (auto &e : g_rot_tables)
+        if (e.device == device && e.n == n && e.n_ckpt == n_ckpt) {
+            e.refs++;
+            *table = e.table;
+            *ready = e.ready;
+            return true;
+        }
+    RotTableEntry e{ device, n, n_ckpt, 1, nullptr, nullptr };
+    if (hipMalloc(reinterpret_cast<void **>(&e.table), sizeof(float2) * (size_t)n * n_ckpt) != hipSuccess) return false;
+    // (not needed before the first burst reaches the decimator: built asynchronously on the caller's per-burst stream)
+    if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess ||
+        launch_rotator_table(d_incr, e.table, n, n_ckpt, st) != 0 || hipEventRecord(e.ready, st) != hipSuccess) {
+        if (e.ready) (void)hipEventDestroy(e.ready);
+        (void)hipFree(e.table);
+        return false;
+    }
+    g_rot_tables.push_back(e);
+    *table = e.table;
+    *ready = e.ready;
+    return true;
+}
+
+static void rot_table_release(const float2 *table)
+{
+    if (!table) return;
+    std::lock_guard<std::mutex> lk(g_rot_mu);
+    for (size_t i = 0; i < g_rot_tables.size(); i++)
+        if (g_rot_tables[i].table == table) {
+            if (--g_rot_tables[i].refs == 0) {
+                (void)hipEventSynchronize(g_rot_tables[i].ready);
+                (void)hipEventDestroy(g_rot_tables[i].ready);
+                (void)hipFree(g_rot_tables[i].table);
+                g_rot_tables.erase(g_rot_tables.begin() + (long)i);
+            }
+            return;
+        }
+}
+
 static void pipeline_free(irdm_pipeline *p)
 {
     if (!p) return;
     void *ptrs[] = { p->d_window, p->d_hist, p->d_sum, p->d_mag, p->d_tw, p->d_tw4096, p->d_tw2048,
-                     p->d_dl_fft, p->d_ul_fft, p->d_rot_incr, p->d_rot_table, p->d_state, p->d_gone,
+                     p->d_dl_fft, p->d_ul_fft, p->d_rot_incr, p->d_state, p->d_gone,
                      p->d_cand_a, p->d_cand_b, p->d_ring, p->d_stage, p->d_in_taps, p->d_noise_taps,
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
@@ -436,7 +489,7 @@ static void pipeline_free(irdm_pipeline *p)
         if (f.ev_k1) (void)hipEventDestroy(f.ev_k1);
         if (f.ev_copy) (void)hipEventDestroy(f.ev_copy);
     }
-    if (p->ev_rot) (void)hipEventDestroy(p->ev_rot);
+    rot_table_release(p->d_rot_table);       // (ev_rot belongs to the shared table)
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
@@ -653,8 +706,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_cand_a, PeakCand, (size_t)P.n);
     AL(p->d_cand_b, PeakCand, (size_t)P.n);
     mark("detector buffers");
-    AL(p->d_rot_table, float2, (size_t)P.n * p->n_ckpt);
-    mark("rotator table alloc");
+    p->d_rot_table = nullptr;
+    p->ev_rot = nullptr;
     AL(p->d_work, BurstWork, (size_t)p->burst_cap);
     p->tiles_cap = (size_t)p->burst_cap * 64;
     AL(p->d_tiles, FirTile, (p->tiles_cap + 1) * kFirTileUnits);
@@ -808,9 +861,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     // The rotator checkpoint table (one sequential float recurrence per FFT bin, 12.5 ms of one-lane-per-bin work at
     // 10 MHz) is not needed before the first burst reaches the decimator -- at the earliest 512 priming frames into
     // the stream -- so irdm_create does not wait for it: it runs on a per-burst stream, the chains wait for ev_rot.
-    ok = ok && hipEventCreateWithFlags(&p->ev_rot, hipEventDisableTiming) == hipSuccess;
-    ok = ok && launch_rotator_table(p->d_rot_incr, p->d_rot_table, P.n, p->n_ckpt, p->bc[0].stream) == 0;
-    ok = ok && hipEventRecord(p->ev_rot, p->bc[0].stream) == hipSuccess;
+    ok = ok && rot_table_acquire(cfg->device, P.n, p->n_ckpt, p->d_rot_incr, p->bc[0].stream, &p->d_rot_table, &p->ev_rot);
+    mark("rotator table");
     if (!ok) {
         fprintf(stderr, "irdm_hip: device initialisation failed\n");
         pipeline_free(p);
@@ -1728,7 +1780,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             // (diagnostic) the passes' device timeline of this scan: durations, and the idle time in front of each pass
             unsigned long long tl[2 * kBandTlSlots];
             IRDM_HIP_CHECK(hipMemcpy(tl, p->band.tl + (size_t)p->out_sel * 2 * kBandTlSlots, sizeof(tl), hipMemcpyDeviceToHost));
-            for (int i = 26; i < 30; i++) p->stat_tl_dur[i] += tl[kBandTlSlots + i];      // (event counts of the walk passes)
+            for (int i = 26; i < 32; i++) p->stat_tl_dur[i] += tl[kBandTlSlots + i];      // (event counts of the walk passes)
             unsigned long long prev_end = 0;
             for (int i = 0; i < 26; i++) {
                 const unsigned long long lo = tl[i], hi = tl[kBandTlSlots + i];
@@ -2633,11 +2685,13 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
+    if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
     if (!strcmp(key, "band_sum_bins")) { irdm::g_band_sum_bins = value; return 0; }
     if (!strcmp(key, "band_selfcheck")) { irdm::g_band_selfcheck = value; return 0; }
     if (!strcmp(key, "band_timeline")) { irdm::g_band_timeline = value; return 0; }
+    if (!strcmp(key, "band_walk_wave")) { irdm::g_band_walk_wave = value; return 0; }
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }

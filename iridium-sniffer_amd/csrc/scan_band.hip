@@ -34,6 +34,7 @@
 #include "types.hpp"
 #include "kernels.hpp"
 #include "band_core.hpp"
+#include "band_wave.hpp"
 
 namespace irdm {
 
@@ -786,6 +787,74 @@ __global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W,
     band_walk_body<NW>(P, io, st, smem_raw, threadIdx.x, blockIdx.x, tl_stat);
 }
 
+// ---- the walk with a wavefront per band and activity segment (band_wave.hpp) ----
+// A fixed grid of wavefronts shares out the (band, 64-frame block) pairs; a pair has work if a segment starts inside the
+// block (or, block 0, if bursts are carried into the band).  64 pairs are tested at once, a lane each.
+constexpr int kWalkWaveGroups = 256;         // workgroups of 4 wavefronts
+
+template <int NW>
+__global__ __launch_bounds__(256) void band_walk_wave_kernel(BandParams P, BandWork W, BandIO io, const DetState *__restrict__ st)
+{
+    IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 3);
+    if (band_void(P, W) || W.ctl->status != 0) return;
+    io.act_in = st->act;
+    io.n_act_in = (int32_t)wv_first((uint32_t)st->n_act);
+    const int lane = threadIdx.x & 63;
+    const int gw = (int)wv_first((uint32_t)(blockIdx.x * 4 + (threadIdx.x >> 6))), n_waves = (int)gridDim.x * 4;
+    const int n_pairs = P.n_bands * P.occ_words;
+    unsigned long long *tl_stat = nullptr;
+    if (P.tl_sel >= 0)
+        tl_stat = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + (W.ctl->rounds - 1 == 0 ? 26 : 28);
+    int wave_events = 0;
+    const unsigned long long t_wave = tl_stat ? wall_clock64() : 0;
+    for (int p0 = gw; p0 < n_pairs; p0 += 64 * n_waves) {
+        const int pl = p0 + lane * n_waves;
+        bool work = false;
+        if (pl < n_pairs) {
+            // (a wavefront's pairs: one time block, different bands -- busy bands stay busy for a whole chunk)
+            const int band = pl / P.occ_words, blk = pl % P.occ_words;
+            work = blk == 0 || band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, false) != 0;
+        }
+        uint64_t todo = __builtin_amdgcn_ballot_w64(work);
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int p = p0 + j * n_waves;
+            const int band = p / P.occ_words, blk = p % P.occ_words;
+            bool carried = false;
+            int events = 0;
+            if (blk == 0) {
+                WaveWalker<NW> w(P, io, band, lane);
+                if (w.load_carried() > 0) {
+                    carried = true;
+                    w.run(0, true);
+                    events += w.n_events;
+                }
+            }
+            uint64_t starts = wv_first64(band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, carried));
+            while (starts) {
+                const int q = __builtin_ctzll(starts);
+                starts &= starts - 1;
+                WaveWalker<NW> w(P, io, band, lane);
+                w.run(64 * blk + q, false);
+                events += w.n_events;
+            }
+            wave_events += events;
+            if (tl_stat && lane == 0) {
+                atomicMax(tl_stat, (unsigned long long)events);
+                atomicAdd(tl_stat + 1, (unsigned long long)events);
+            }
+        }
+    }
+    if (tl_stat && lane == 0 && W.ctl->rounds - 1 != 0) {
+        // (slots 30 / 31: the busiest wavefront's events, the longest wavefront's time in 10 ns ticks)
+        unsigned long long *x = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + 30;
+        atomicMax(x, (unsigned long long)wave_events);
+        atomicMax(x + 1, wall_clock64() - t_wave);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The rounds as ONE launch (option band_coop): kCoopGroups workgroups stay resident through plan -> sums -> cross ->
 // walk -> plan ... until a round is accepted or the scan declines, with a grid-wide barrier between the passes.  What
@@ -1143,6 +1212,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment (band_wave.hpp); 0: a lane per band (band_core.hpp)
 int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
 int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
 int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
@@ -1314,7 +1384,12 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
         else
             hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
-        if (P.band_w == 128)
+        if (g_band_walk_wave) {
+            if (P.band_w == 128)
+                hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
+            else
+                hipLaunchKernelGGL((band_walk_wave_kernel<8>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
+        } else if (P.band_w == 128)
             hipLaunchKernelGGL((band_walk_kernel<4>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
         else
             hipLaunchKernelGGL((band_walk_kernel<8>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);

@@ -204,3 +204,22 @@ def test_boundary_test_forms_agree_and_both_object():
         assert st["band_last_flags"] & 32 and not st["band_last_flags"] & 4096, st
     finally:
         _restore_selfcheck()
+
+
+@pytest.mark.parametrize("case", ["too_long", "dc_and_edges", "strong_simultaneous", "many_active_10m"])
+def test_lane_per_band_walk_still_agrees(case):
+    """option band_walk_wave 0: the walk pass with a lane per band (band_core.hpp's BandWalker, the form the CPU test
+    drives) instead of a wavefront per band and segment (band_wave.hpp) -- same records as the oracle either way"""
+    if case not in scenes.ALL:
+        pytest.skip("no such scene")
+    fs, iq = scenes.ALL[case]()
+    ref = orc.run_stream(iq, fs)
+    try:
+        got = parity.run_gpu(iq, fs, options={"band_walk_wave": 0})
+        parity.compare(got, ref)
+        chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, options={"band_walk_wave": 0})
+        parity.compare(chunked, ref)
+    finally:
+        p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        p.set_option("band_walk_wave", 1)
+        p.close()
