@@ -64,7 +64,9 @@ struct BandParams {
     uint64_t idx0;               // absolute sample index of frame 0
     int32_t serial = 0;          // launch number: a launch that finds itself void (below) marks BandWork::bar[5] with it
     int32_t selfcheck = 0;       // test hook (option band_selfcheck): bit 0 run both forms of the boundary test and compare,
-                                 // bit 1 spoil band i+1's copy of every record in a boundary zone first (both must object)
+                                 // bit 1 spoil band i+1's copy of every record in a boundary zone first (both must object),
+                                 // bit 3 the wavefront walk without its 64-frame look-ahead (band_wave.hpp: skim),
+                                 // bit 4 the plan pass without its LDS (through the workspace arrays, wavefront boundary test)
     int32_t tl_sel = -1;         // >= 0: the passes stamp their first workgroup's start and last one's end into half tl_sel of
                                  // BandWork::tl (diagnostic, option band_timeline)
     int32_t chained = 0;         // 1: enqueued behind a band scan whose verdict the host had not seen: valid only if that

@@ -60,15 +60,17 @@ struct WaveWalker {
     int last_occ;
     int acc_blk;
     uint32_t acc_max;
+    int busy_blk;                            // 64-frame block whose busy bits are collected in busy_acc (-1: none)
+    uint64_t busy_acc;
     int n_events;
     int occ_blk;                             // 64-frame block whose occupancy word is cached
     uint64_t occ_w;
-    int pre_f;                               // frame whose crossing words were requested ahead (-1: none)
+    int cwu_f;                               // frame whose crossing words skim() left in cwu (-1: none)
+    uint64_t cwu[NW];
     // ---- per lane: burst slot `lane` ----
     int64_t s_start, s_la;
     int32_t s_cb, s_cf, s_seq;
     float s_rel, s_base;
-    uint64_t pre_cwv;                        // lane k < NW: crossing word k of frame pre_f
 
     __device__ __forceinline__ WaveWalker(const BandParams &p, const BandIO &i, int b, int ln) : P(p), io(i), lane(ln), band(b)
     {
@@ -91,11 +93,14 @@ struct WaveWalker {
         last_occ = -1;
         acc_blk = -1;
         acc_max = 0;
+        busy_blk = -1;
+        busy_acc = 0;
         n_events = 0;
         occ_blk = -1;
         occ_w = 0;
-        pre_f = -1;
-        pre_cwv = 0;
+        cwu_f = -1;
+#pragma unroll
+        for (int k = 0; k < NW; k++) cwu[k] = 0;
         s_start = s_la = 0;
         s_cb = s_cf = s_seq = 0;
         s_rel = s_base = 0.0f;
@@ -182,13 +187,31 @@ struct WaveWalker {
         acc_max = 0;
     }
 
+    // The busy bits of a 64-frame block go out once, when the walk leaves the block: 64 bands OR into the same few words,
+    // and device-scope atomics on one address are served one after the other at the memory side -- with an atomic per
+    // event (36 000 per pass at 12 MHz / 2600 bursts on 64 addresses) the kernel's last atomics landed 200-300 us after
+    // its last wavefront had finished, and the next pass waited for them.
+    __device__ __forceinline__ void flush_busy()
+    {
+        if (busy_blk >= 0 && busy_acc && lane == 0) band_or64(&io.busy[busy_blk], busy_acc);
+        busy_blk = -1;
+        busy_acc = 0;
+    }
+
     // frames a..b end with c of this band's own bursts active
     __device__ __forceinline__ void account(int a, int b, uint32_t c)
     {
         if (c == 0 || a > b) return;
         for (int blk = a >> 6; blk <= (b >> 6); blk++) {
             const int lo = blk == (a >> 6) ? (a & 63) : 0, hi = blk == (b >> 6) ? (b & 63) : 63;
-            if (lane == 0) band_or64(&io.busy[blk], (~0ull >> (63 - hi)) & (~0ull << lo));
+            const uint64_t bits = (~0ull >> (63 - hi)) & (~0ull << lo);
+            if (blk != busy_blk) {
+                flush_busy();
+                busy_blk = blk;
+                busy_acc = bits;
+            } else {
+                busy_acc |= bits;
+            }
             if (blk != acc_blk) {
                 flush_conc();
                 acc_blk = blk;
@@ -262,14 +285,16 @@ struct WaveWalker {
     {
         const int64_t index = (int64_t)P.idx0 + (int64_t)f * P.n;
         const bool occupied = (occ_word(f >> 6) >> (f & 63)) & 1;
-        const uint64_t cwv = pre_f == f ? pre_cwv : fetch_cw(f);
-        // (most events are consecutive frames of a burst: the next frame's words are on their way while this one is
-        // worked on)
-        pre_f = f + 1;
-        pre_cwv = fetch_cw(f + 1);
         uint64_t cw[NW];
+        if (cwu_f == f) {
+            // (skim() stopped at this frame: its words are at hand, zero if the frame is not occupied)
 #pragma unroll
-        for (int k = 0; k < NW; k++) cw[k] = occupied ? wv_lane64(cwv, k) : 0;
+            for (int k = 0; k < NW; k++) cw[k] = cwu[k];
+        } else {
+            const uint64_t cwv = fetch_cw(f);
+#pragma unroll
+            for (int k = 0; k < NW; k++) cw[k] = occupied ? wv_lane64(cwv, k) : 0;
+        }
         if (occupied) last_occ = f;
         const int r = s_cb - e0;                      // (this lane's slot; meaningless unless mine())
 
@@ -353,6 +378,99 @@ struct WaveWalker {
         }
     }
 
+    // OR of H << d for d in [0, g)
+    static __device__ __forceinline__ uint64_t smear(uint64_t h, int g)
+    {
+        int have = 1;
+        while (2 * have <= g) {
+            h |= h << have;
+            have *= 2;
+        }
+        if (have < g) h |= h << (g - have);
+        return h;
+    }
+
+    // Most events change nothing but a burst's last_active: the frames of a burst between its creation and its end.
+    // skim(f) looks at the 64 frames from f on at once, a lane per frame -- which of them carry a peak outside the
+    // masks (a new burst), and per active burst in which of them its centre is hit, when it would run out
+    // (:505, gap frames after its last hit) and whether a hit comes after max_burst_len (:499) -- and returns the first
+    // frame that needs process(); the frames in front of it only move last_active (and last_occ), which is applied
+    // here.  f must be the next event frame, valid != 0.  Exact: between two frames that create or delete a burst the
+    // masks and the set of bursts are constant, an event frame in between does nothing but (:458-469), and every frame
+    // at which the walk would delete a burst is an event frame (the minimum of the expiries is).
+    __device__ __forceinline__ int skim(int f)
+    {
+        while (f < P.n_frames) {
+            const int wl = P.n_frames - f < 64 ? P.n_frames - f : 64;
+            const int blk = f >> 6, sh = f & 63;
+            uint64_t om = occ_word(blk) >> sh;
+            if (sh && blk + 1 < P.occ_words) om |= wv_load64(occ + blk + 1) << (64 - sh);
+            if (wl < 64) om &= (1ull << wl) - 1;
+            const bool occ_j = (om >> lane) & 1;
+            uint64_t cw[NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const int w = word0 + k;
+                cw[k] = (occ_j && w >= 0 && w < P.nw64) ? io.cross[(size_t)(f + lane) * P.nw64 + w] : 0;
+            }
+            bool pkj = false;
+#pragma unroll
+            for (int k = 0; k < NW; k++) pkj |= (cw[k] & ~M[k] & elig[k]) != 0;
+            uint64_t stop = __builtin_amdgcn_ballot_w64(pkj);
+            uint64_t hit[NW];
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                hit[k] = cw[k] | (cw[k] << 1) | (cw[k] >> 1);
+                if (k > 0) hit[k] |= cw[k - 1] >> 63;
+                if (k < NW - 1) hit[k] |= cw[k + 1] << 63;
+            }
+            // this lane's slot: the frame at which it runs out as last_active stands, the first frame at which a hit
+            // makes it longer than max_burst_len
+            const int64_t num = s_la + (int64_t)P.post_len - (int64_t)P.idx0;
+            int64_t e64 = num <= 0 ? 0 : (num + P.n - 1) >> P.log_n;
+            if (e64 > 0x7fffffff) e64 = 0x7fffffff;
+            int64_t l64 = ((s_start + (int64_t)P.max_len - (int64_t)P.idx0) >> P.log_n) + 1;
+            if (l64 > 0x7fffffff || P.max_len <= 0) l64 = 0x7fffffff;
+            if (l64 < -0x40000000) l64 = -0x40000000;
+            const bool over = P.max_len > 0 && (s_la - s_start > (int64_t)P.max_len);
+            const int my_exp = (int)e64, my_lng = over ? -0x40000000 : (int)l64;
+            uint64_t my_h = 0;
+            for (uint32_t v = valid; v; v &= v - 1) {
+                const int sl = __builtin_ctz(v);
+                const int r = __builtin_amdgcn_readlane(s_cb, sl) - e0;
+                const int ex = __builtin_amdgcn_readlane(my_exp, sl), lg = __builtin_amdgcn_readlane(my_lng, sl);
+                const uint64_t H = __builtin_amdgcn_ballot_w64(bm_test<NW>(hit, r));
+                uint64_t alive = smear(H, P.gap);
+                const int d0 = ex - f;
+                if (d0 >= 64) alive = ~0ull;
+                else if (d0 > 0) alive |= (1ull << d0) - 1;
+                stop |= ~alive;
+                const int l0 = lg - f;
+                if (l0 <= -0x20000000) stop |= 1;                  // (already longer: the frame we were called with)
+                else if (l0 < 64) stop |= l0 <= 0 ? H : (H & (~0ull << l0));
+                if (lane == sl) my_h = H;
+            }
+            if (wl < 64) stop &= (1ull << wl) - 1;
+            const int e = stop ? __builtin_ctzll(stop) : 64;
+            const uint64_t below = e >= 64 ? ~0ull : (1ull << e) - 1;
+            const uint64_t hb = my_h & below;
+            if (mine() && hb) s_la = (int64_t)P.idx0 + (int64_t)(f + 63 - __builtin_clzll(hb)) * P.n;
+            const uint64_t ob = om & below;
+            if (ob) {
+                last_occ = f + 63 - __builtin_clzll(ob);
+                n_events += __builtin_popcountll(ob);
+            }
+            if (e < wl) {
+                cwu_f = f + e;
+#pragma unroll
+                for (int k = 0; k < NW; k++) cwu[k] = wv_lane64(cw[k], e);
+                return f + e;
+            }
+            f += wl;
+        }
+        return f;
+    }
+
     // walk one segment: from frame f_start, or (carried; load_carried() > 0 was called) from the bursts handed over
     // at the chunk boundary
     __device__ __forceinline__ void run(int f_start, bool carried)
@@ -362,6 +480,7 @@ struct WaveWalker {
             last_occ = -1;
             const uint32_t c0 = owned_count();
             f = next_event(-1);
+            if (P.selfcheck & 8 ? false : (valid != 0 && f < P.n_frames)) f = skim(f);
             account(0, (f < P.n_frames ? f : P.n_frames) - 1, c0);
         } else {
             f = f_start;
@@ -370,12 +489,15 @@ struct WaveWalker {
             process(f);
             n_events++;
             const uint32_t c = owned_count();
-            const int nf = next_event(f);
+            int nf = next_event(f);
+            // (between this frame and the next one that creates or deletes a burst, valid and so c stay as they are)
+            if (P.selfcheck & 8 ? false : (valid != 0 && nf < P.n_frames)) nf = skim(nf);
             account(f, (nf < P.n_frames ? nf : P.n_frames) - 1, c);
             if (valid == 0 && nf == 0x7fffffff) break;
             f = nf;
         }
         flush_conc();
+        flush_busy();
         // still active at the end of the chunk: handed to the next one
         emit(__builtin_amdgcn_ballot_w64(mine()), -1, false);
     }

@@ -51,7 +51,7 @@ struct TlScope {
     unsigned long long *lo, *hi;
     __device__ __forceinline__ TlScope(const BandParams &P, const BandWork &W, int slot) : lo(nullptr), hi(nullptr)
     {
-        if (P.tl_sel >= 0 && threadIdx.x == 0 && slot >= 0 && slot < kBandTlSlots) {
+        if (P.tl_sel >= 0 && (threadIdx.x & 63) == 0 && slot >= 0 && slot < kBandTlSlots) {      // (every wavefront)
             lo = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + slot;
             hi = lo + kBandTlSlots;
             atomicMin(lo, (unsigned long long)wall_clock64());
@@ -63,7 +63,6 @@ struct TlScope {
     }
 };
 
-__device__ __constant__ int g_plan_lds_on = 1;       // (test hook: 0 = the plan pass through the workspace arrays only)
 
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
 constexpr int kSumDepth = 32;             // update steps per batch of the sums pass (two batches of loads in flight)
@@ -138,21 +137,19 @@ struct ZoneEnt {
 constexpr int kZoneCap = 32;
 constexpr size_t kZoneLdsBytes = 64 * kZoneCap * (sizeof(ZoneEnt) + sizeof(uint32_t)) + 128 * sizeof(uint32_t);
 
-__device__ void boundaries_agree_lds(const BandParams &P, const BandWork &W, uint8_t *lds, int *s_fail)
+// (nt: threads of the workgroup, a multiple of 16; 16 lanes per boundary, the boundaries in passes of nt / 16)
+__device__ void boundaries_agree_lds(const BandParams &P, const BandWork &W, uint8_t *lds, int *s_fail, int nt)
 {
     ZoneEnt *zb = reinterpret_cast<ZoneEnt *>(lds);                           // [64][kZoneCap]
     uint32_t *za = reinterpret_cast<uint32_t *>(zb + 64 * kZoneCap);           // [64][kZoneCap]
     uint32_t *zc = za + 64 * kZoneCap;                                         // [64][2]
-    const int tid = threadIdx.x, i = tid >> 4, gl = tid & 15;
-    const bool on = i + 1 < P.n_bands;
-    if (tid < 128) zc[tid] = 0;
+    const int tid = threadIdx.x, gl = tid & 15;
+    for (int t = tid; t < 128; t += nt) zc[t] = 0;
     __syncthreads();
-    const int X = (i + 1) * P.band_w;
-    const BandRec *A = W.recs + (size_t)i * kBandRecCap, *B = W.recs + (size_t)(i + 1) * kBandRecCap;
-    int na = 0, nb = 0;
-    if (on) {
-        na = min((int)W.rec_count[i], kBandRecCap);
-        nb = min((int)W.rec_count[i + 1], kBandRecCap);
+    for (int i = tid >> 4; i + 1 < P.n_bands; i += nt >> 4) {
+        const int X = (i + 1) * P.band_w;
+        const BandRec *A = W.recs + (size_t)i * kBandRecCap, *B = W.recs + (size_t)(i + 1) * kBandRecCap;
+        const int na = min((int)W.rec_count[i], kBandRecCap), nb = min((int)W.rec_count[i + 1], kBandRecCap);
         const int nmax = max(na, nb);
         for (int k = gl; k < nmax; k += 16) {
             // (both bands' loads of a stride are in flight together)
@@ -170,27 +167,31 @@ __device__ void boundaries_agree_lds(const BandParams &P, const BandWork &W, uin
         }
     }
     __syncthreads();
-    if (!on) return;
-    const int ca = (int)zc[2 * i], cb = (int)zc[2 * i + 1];
     int bad = 0;
-    if (ca != cb) {
-        bad = 1;
-    } else if (ca > kZoneCap) {
-        for (int a = gl; a < na; a += 16) {
-            if (A[a].cb < X - P.hw || A[a].cb >= X + P.hw) continue;
-            bool found = false;
-            for (int b = 0; b < nb && !found; b++) found = B[b].cb == A[a].cb && band_rec_same(A[a], B[b]);
-            if (!found) bad = 1;
-        }
-    } else {
-        for (int k = gl; k < ca; k += 16) {
-            const BandRec ra = A[za[i * kZoneCap + k]];
-            bool found = false;
-            for (int j = 0; j < cb && !found; j++) {
-                const ZoneEnt e = zb[i * kZoneCap + j];
-                if (e.cb == (uint32_t)ra.cb && e.start_lo == (uint32_t)ra.start) found = band_rec_same(ra, B[e.idx]);
+    for (int i = tid >> 4; i + 1 < P.n_bands; i += nt >> 4) {
+        const int X = (i + 1) * P.band_w;
+        const BandRec *A = W.recs + (size_t)i * kBandRecCap, *B = W.recs + (size_t)(i + 1) * kBandRecCap;
+        const int na = min((int)W.rec_count[i], kBandRecCap), nb = min((int)W.rec_count[i + 1], kBandRecCap);
+        const int ca = (int)zc[2 * i], cb = (int)zc[2 * i + 1];
+        if (ca != cb) {
+            bad = 1;
+        } else if (ca > kZoneCap) {
+            for (int a = gl; a < na; a += 16) {
+                if (A[a].cb < X - P.hw || A[a].cb >= X + P.hw) continue;
+                bool found = false;
+                for (int b = 0; b < nb && !found; b++) found = B[b].cb == A[a].cb && band_rec_same(A[a], B[b]);
+                if (!found) bad = 1;
             }
-            if (!found) bad = 1;
+        } else {
+            for (int k = gl; k < ca; k += 16) {
+                const BandRec ra = A[za[i * kZoneCap + k]];
+                bool found = false;
+                for (int j = 0; j < cb && !found; j++) {
+                    const ZoneEnt e = zb[i * kZoneCap + j];
+                    if (e.cb == (uint32_t)ra.cb && e.start_lo == (uint32_t)ra.start) found = band_rec_same(ra, B[e.idx]);
+                }
+                if (!found) bad = 1;
+            }
         }
     }
     if (bad) atomicOr(s_fail, 1);
@@ -347,8 +348,8 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             }
             __syncthreads();
         }
-        if (lds != nullptr && NT >= 16 * 64) {
-            boundaries_agree_lds(P, W, lds, &s_agree_fail);
+        if (lds != nullptr) {
+            boundaries_agree_lds(P, W, lds, &s_agree_fail, NT);
             if (P.selfcheck & 1) {
                 // (test hook) the wavefront form must give the same answer
                 __shared__ int s_other;
@@ -583,14 +584,15 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
     }
 }
 
-__global__ __launch_bounds__(kPlanThreads) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
-                                                                 DetState *__restrict__ st, int round)
+template <int NT>
+__global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
+                                                       DetState *__restrict__ st, int round)
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * round);
     __shared__ PlanShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
-    band_plan_body<kPlanThreads>(P, W, counts, st, round, sh, g_plan_lds_on ? plan_lds : nullptr);
+    band_plan_body<NT>(P, W, counts, st, round, sh, (P.selfcheck & 16) ? nullptr : plan_lds);
 }
 
 // ---- sums: one lane per bin along the planned update steps ----
@@ -1212,6 +1214,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_plan_threads = 1024;   // threads of the plan pass's workgroup (256 / 512 / 1024)
 int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment (band_wave.hpp); 0: a lane per band (band_core.hpp)
 int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
 int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
@@ -1355,7 +1358,9 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     (void)hipFuncSetAttribute((const void *)band_walk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     (void)hipFuncSetAttribute((const void *)band_walk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     (void)hipFuncSetAttribute((const void *)band_commit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)commit_lds);
-    (void)hipFuncSetAttribute((const void *)band_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
+    (void)hipFuncSetAttribute((const void *)band_plan_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
+    (void)hipFuncSetAttribute((const void *)band_plan_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
+    (void)hipFuncSetAttribute((const void *)band_plan_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
     if (g_band_coop) {
         // every round up to the verdict in one launch (the kernel leaves as soon as a round is accepted or declined)
         (void)round_end;
@@ -1372,7 +1377,15 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     for (int round = round_begin; round <= round_end; round++) {
         // (a continuation starts behind the plan its predecessor's verdict pass already made)
         if (round > round_begin || round_begin == 0)
-            hipLaunchKernelGGL(band_plan_kernel, dim3(1), dim3(kPlanThreads), kPlanLdsBytes, stream, P, W, counts, st, round);
+        {
+            const size_t plan_lds = (P.selfcheck & 16) ? 0 : kPlanLdsBytes;
+            if (g_band_plan_threads == 256)
+                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, stream, P, W, counts, st, round);
+            else if (g_band_plan_threads == 512)
+                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, stream, P, W, counts, st, round);
+            else
+                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, stream, P, W, counts, st, round);
+        }
         if (round == round_end) break;
         if (g_band_sum_bins == 32)
             hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);

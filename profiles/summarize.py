@@ -93,6 +93,25 @@ if sq:
 for name in ("b", "b0", "d2", "d40", "cfg5_12mhz_d40", "lds_fir", "cfg4_n1"):
     if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
         shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_bench_{name}.json")
+# the scan's device timeline: per pass [us from the first workgroup's start to the last one's end, idle us in front of it,
+# launches per chunk], the plan pass's phase stamps and the walk's event counts (bench.py config.*)
+tl = {}
+for name, label in (("tl", "cfg3_in_run"), ("tl_depth0", "cfg3_alone"), ("tl_cfg5", "cfg5_12mhz_d40_in_run"),
+                    ("tl_cfg5_depth0", "cfg5_12mhz_d40_alone")):
+    path = f"{src}/{name}.json"
+    if os.path.exists(path) and os.path.getsize(path) > 10:
+        e = json.load(open(path))
+        c = e["config"]
+        tl[label] = {"Msamples_per_s": e["value"], "ms_per_step": e["ms_per_step"], "scan_stage_ms": e["roofline"]["stage_ms"]["scan"],
+                     "passes_us_dur_gap_launches": c.get("scan_timeline_us"), "walk_events": c.get("walk_events"),
+                     "plan_phase_us": c.get("plan_phase_us"), "scan": c.get("scan")}
+if tl:
+    json.dump(tl, open(f"profiles/{tag}_scan_timeline.json", "w"), indent=1)
+    for k, v in tl.items():
+        p = v["passes_us_dur_gap_launches"] or {}
+        print(k, v["Msamples_per_s"], "scan", v["scan_stage_ms"], "dur", round(sum(x[0] for x in p.values())), "gap",
+              round(sum(x[1] for x in p.values())))
+
 for f in (f"profiles/{tag}_kernel_stats.csv", f"profiles/{tag}_kernel_stats_depth0.csv",
           f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40.csv", f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40_depth0.csv"):
     if os.path.exists(f):

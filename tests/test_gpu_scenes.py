@@ -223,3 +223,16 @@ def test_lane_per_band_walk_still_agrees(case):
         p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
         p.set_option("band_walk_wave", 1)
         p.close()
+
+
+@pytest.mark.parametrize("case", ["too_long", "strong_simultaneous", "many_active_10m"])
+def test_wave_walk_without_look_ahead_agrees(case):
+    """option band_selfcheck 8: the wavefront walk event by event (band_wave.hpp without skim()) -- the records must not
+    depend on the 64-frame look-ahead"""
+    fs, iq = scenes.ALL[case]()
+    ref = orc.run_stream(iq, fs)
+    try:
+        got = parity.run_gpu(iq, fs, options={"band_selfcheck": 8})
+        parity.compare(got, ref)
+    finally:
+        _restore_selfcheck()

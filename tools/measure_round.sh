@@ -15,6 +15,12 @@ timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 40 2>/dev/null | t
 timeout 120 python bench.py --steps 10 --warmup 3 $Q --alone-steps 3 $D12 2>/dev/null | tail -1 > "$OUT/cfg5_12mhz_d40.json"
 timeout 90 python bench.py --steps 6 --warmup 2 $Q --opt fir_layout=2 2>/dev/null | tail -1 > "$OUT/lds_fir.json"
 timeout 120 python bench.py --shard time --steps 6 --warmup 2 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
+# the detector scan's own device timeline (option band_timeline: first workgroup's start / last one's end per pass), in
+# run and alone, both scenes
+timeout 90 python bench.py $Q --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/tl.json"
+timeout 90 python bench.py --depth 0 $Q --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/tl_depth0.json"
+timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/tl_cfg5.json"
+timeout 120 python bench.py --steps 6 --warmup 2 --depth 0 $Q $D12 --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/tl_cfg5_depth0.json"
 cd /tmp && export TMPDIR=/tmp
 B="$GRAFT_REPO_ROOT/bench.py"
 timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT" -o r1 --output-format csv -- python $B --steps 20 --warmup 5 $Q > "$OUT/kt.log" 2>&1
