@@ -69,6 +69,7 @@ struct BandWork {                        // device workspace, carved out of one 
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
+extern int g_band_fuse_commit;           // 1 (default): the accepting plan pass runs the commit itself
 extern int g_band_plan_threads;          // threads of the plan pass's one workgroup: 256, 512 or 1024 (default)
 extern int g_band_walk_wave;             // 1 (default): the walk pass with a wavefront per band and segment; 0: a lane per band
 extern int g_band_timeline;              // 1: the band scan's passes record a device timeline (read back by the pipeline per chunk)

@@ -2693,6 +2693,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_timeline")) { irdm::g_band_timeline = value; return 0; }
     if (!strcmp(key, "band_walk_wave")) { irdm::g_band_walk_wave = value; return 0; }
     if (!strcmp(key, "band_plan_threads")) { irdm::g_band_plan_threads = value; return 0; }
+    if (!strcmp(key, "band_fuse_commit")) { irdm::g_band_fuse_commit = value; return 0; }
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }

@@ -584,15 +584,27 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
     }
 }
 
+__device__ void band_commit_body(const BandParams &P, const BandWork &W, DetState *__restrict__ st,
+                                 float *__restrict__ sum, GoneBurst *__restrict__ gone, int gone_cap,
+                                 unsigned char *smem_raw);
+
+// fuse != 0: a verdict "accepted" is followed by the commit in the same workgroup (the commit pass enqueued behind the
+// rounds then finds its work done) -- one launch and its wait less on the scan's critical path
 template <int NT>
 __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
-                                                       DetState *__restrict__ st, int round)
+                                                       DetState *__restrict__ st, int round, float *__restrict__ sum,
+                                                       GoneBurst *__restrict__ gone, int gone_cap, int fuse)
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * round);
     __shared__ PlanShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
+    static_assert(kPlanLdsBytes >= (size_t)kBandMaxTotal * 10, "the fused commit sorts in the plan pass's LDS");
     band_plan_body<NT>(P, W, counts, st, round, sh, (P.selfcheck & 16) ? nullptr : plan_lds);
+    if (fuse && round >= 1 && !(P.selfcheck & 16)) {
+        __syncthreads();
+        if (!band_void(P, W) && W.ctl->status == 1) band_commit_body(P, W, st, sum, gone, gone_cap, plan_lds);
+    }
 }
 
 // ---- sums: one lane per bin along the planned update steps ----
@@ -1053,19 +1065,18 @@ __device__ void lds_bitonic_sort(uint64_t *key, uint16_t *val, int np)
     }
 }
 
-__global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P, BandWork W, DetState *__restrict__ st,
-                                                                   float *__restrict__ sum, GoneBurst *__restrict__ gone,
-                                                                   int gone_cap)
+// (one workgroup of blockDim.x threads; smem_raw: kBandMaxTotal * 10 bytes of LDS)
+__device__ void band_commit_body(const BandParams &P, const BandWork &W, DetState *__restrict__ st,
+                                 float *__restrict__ sum, GoneBurst *__restrict__ gone, int gone_cap,
+                                 unsigned char *smem_raw)
 {
-    IRDM_DETECTOR_PRIO();
-    TlScope tl(P, W, 24);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int kPlanThreads = (int)blockDim.x;      // (shadows the launch constant: every stride below is the workgroup's size)
     uint64_t *s_key = reinterpret_cast<uint64_t *>(smem_raw);                    // kBandMaxTotal
     uint16_t *s_val = reinterpret_cast<uint16_t *>(s_key + kBandMaxTotal);       // kBandMaxTotal
     uint32_t *rank_of = W.rank;                                                  // record -> place in creation order
     __shared__ unsigned s_n, s_carried, s_gone;
     BandCtl *ctl = W.ctl;
-    if (band_void(P, W) || ctl->status != 1) return;
+    if (band_void(P, W) || ctl->status != 1 || ctl->committed) return;
     const int tid = threadIdx.x;
     if (tid == 0) {
         s_n = 0;
@@ -1174,6 +1185,16 @@ __global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P,
     }
 }
 
+__global__ __launch_bounds__(kPlanThreads) void band_commit_kernel(BandParams P, BandWork W, DetState *__restrict__ st,
+                                                                   float *__restrict__ sum, GoneBurst *__restrict__ gone,
+                                                                   int gone_cap)
+{
+    IRDM_DETECTOR_PRIO();
+    TlScope tl(P, W, 24);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    band_commit_body(P, W, st, sum, gone, gone_cap, smem_raw);
+}
+
 constexpr int kExportBlocks = 32;
 
 __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
@@ -1214,6 +1235,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_fuse_commit = 1;       // 1: the plan pass that accepts a round commits it in the same launch
 int g_band_plan_threads = 1024;   // threads of the plan pass's workgroup (256 / 512 / 1024)
 int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment (band_wave.hpp); 0: a lane per band (band_core.hpp)
 int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
@@ -1380,11 +1402,11 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         {
             const size_t plan_lds = (P.selfcheck & 16) ? 0 : kPlanLdsBytes;
             if (g_band_plan_threads == 256)
-                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, stream, P, W, counts, st, round);
+                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, stream, P, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit);
             else if (g_band_plan_threads == 512)
-                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, stream, P, W, counts, st, round);
+                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, stream, P, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit);
             else
-                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, stream, P, W, counts, st, round);
+                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, stream, P, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit);
         }
         if (round == round_end) break;
         if (g_band_sum_bins == 32)
@@ -1407,7 +1429,9 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         else
             hipLaunchKernelGGL((band_walk_kernel<8>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
     }
-    hipLaunchKernelGGL(band_commit_kernel, dim3(1), dim3(kPlanThreads), commit_lds, stream, P, W, st, sum, gone, gone_cap);
+    // (with the commit fused into the accepting plan pass there is nothing left for a commit launch to do)
+    if (g_band_coop || !g_band_fuse_commit || (P.selfcheck & 16))
+        hipLaunchKernelGGL(band_commit_kernel, dim3(1), dim3(kPlanThreads), commit_lds, stream, P, W, st, sum, gone, gone_cap);
     static_assert(kHistory >= kExportBlocks, "the export rides on the history pass's first workgroups");
     hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist, st,
                        reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap,

@@ -236,3 +236,20 @@ def test_wave_walk_without_look_ahead_agrees(case):
         parity.compare(got, ref)
     finally:
         _restore_selfcheck()
+
+
+@pytest.mark.parametrize("case", ["too_long", "strong_simultaneous"])
+def test_commit_as_a_launch_of_its_own_agrees(case):
+    """option band_fuse_commit 0: the commit pass as its own launch behind the rounds instead of inside the plan pass that
+    accepts the round -- same records"""
+    fs, iq = scenes.ALL[case]()
+    ref = orc.run_stream(iq, fs)
+    try:
+        got = parity.run_gpu(iq, fs, options={"band_fuse_commit": 0})
+        parity.compare(got, ref)
+        chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, options={"band_fuse_commit": 0})
+        parity.compare(chunked, ref)
+    finally:
+        p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        p.set_option("band_fuse_commit", 1)
+        p.close()
