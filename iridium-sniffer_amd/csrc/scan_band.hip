@@ -12,7 +12,8 @@
 //                          planned steps, loads software-pipelined; writes the needed snapshots
 //   cross   (1 WG / frame) relative magnitude = mag / sum > threshold (simd_relative_mag, exact division) for the
 //                          bins the prefilter listed -> crossing bits, relative magnitudes, band occupancy
-//   walk    (1 lane / band x 64-frame block) the state machine per band and activity segment (band_core.hpp)
+//   walk    (1 wavefront / band and activity segment) the state machine per band (band_wave.hpp; band_core.hpp is the
+//                          same machine with a lane per band: the CPU test's and option band_walk_wave 0's form)
 //   (verify: the next round's plan checks that neighbouring bands agree on every burst within burst_width/2 of
 //            their common boundary, one wavefront per boundary)
 //
@@ -26,7 +27,7 @@
 // point within kBandRounds, a capacity, a stale prefilter reference, a possible squelch -- leaves the carried state
 // untouched (nothing is written before `commit`) and the caller falls back to the sequential kernels.
 //
-//   commit  (1 workgroup)  ids by a global sort of the creation events (frame, descending relative magnitude,
+//   commit  (1 workgroup; inside the plan pass that accepts the round)  ids by a global sort of the creation events (frame, descending relative magnitude,
 //                          ascending bin -- the order of :551/:569), finished bursts in emission order, the bursts
 //                          carried to the next chunk, DetState, the new sums
 //   history (512 WGs)      the last <= 512 update frames' magnitude rows become the history ring
