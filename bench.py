@@ -309,8 +309,8 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=int, default=64 * 1024 * 1024, help="samples per chunk per GPU")
     ap.add_argument("--density", type=float, default=10.0, help="bursts per Msample")
     ap.add_argument("--sample-rate", type=int, default=10_000_000)
