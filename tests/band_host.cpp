@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "../iridium-sniffer_amd/csrc/band_core.hpp"
+// the walk pass as the device runs it (a wavefront per band and segment, csrc/band_wave.hpp) on an emulated wavefront
+#include "wave_emul.hpp"
+#include "../iridium-sniffer_amd/csrc/band_wave.hpp"
 
 using namespace irdm;
 
@@ -20,6 +23,36 @@ struct Host {
     int rounds_total = 0, chunks = 0;
     uint32_t last_flags = 0;
 };
+
+int g_walker = 0;        // 0: BandWalker (a lane per band), 1: WaveWalker on the emulated wavefront, 2: the same without skim()
+
+// band_walk_wave_kernel's treatment of one (band, block) pair, all 64 lanes in lock step
+template <int NW>
+void walk_all_wave(const BandParams &P, BandIO &io)
+{
+    for (int blk = 0; blk < P.occ_words; blk++) {
+        for (int band = 0; band < P.n_bands; band++) {
+            if (blk != 0 && band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, false) == 0) continue;
+            wave_emul::run([&](int lane) {
+                bool carried = false;
+                if (blk == 0) {
+                    WaveWalker<NW> w(P, io, band, lane);
+                    if (w.load_carried() > 0) {
+                        carried = true;
+                        w.run(0, true);
+                    }
+                }
+                uint64_t starts = wv_first64(band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, carried));
+                while (starts) {
+                    const int q = __builtin_ctzll(starts);
+                    starts &= starts - 1;
+                    WaveWalker<NW> w(P, io, band, lane);
+                    w.run(64 * blk + q, false);
+                }
+            });
+        }
+    }
+}
 
 template <int NW>
 void walk_all(const BandParams &P, BandIO &io)
@@ -56,6 +89,7 @@ int band_chunk(Host &H, const float *mag, int n_frames, std::vector<GoneBurst> &
     const DetParams &D = H.D;
     const int N = D.n, F = n_frames;
     BandParams P;
+    P.selfcheck = g_walker == 2 ? 8 : 0;
     P.n = N; P.log_n = 31 - __builtin_clz((unsigned)N); P.nw64 = N / 64; P.n_frames = F; P.occ_words = (F + 63) / 64; P.hw = D.width / 2;
     P.pre_len = D.pre_len; P.post_len = D.post_len; P.max_len = D.max_len; P.max_bursts = D.max_bursts;
     P.band_w = band_w_override ? band_w_override : (P.hw <= 20 ? 128 : 256);
@@ -197,7 +231,9 @@ int band_chunk(Host &H, const float *mag, int n_frames, std::vector<GoneBurst> &
         io.slot_post = slot_post.data(); io.act_in = H.st.act; io.n_act_in = H.st.n_act;
         io.recs = recs.data(); io.rec_count = rec_count.data(); io.busy = busy.data(); io.forced = forced.data();
         io.conc = conc.data(); io.flags = &flags;
-        if (P.band_w == 128) walk_all<4>(P, io);
+        if (g_walker && P.band_w == 128) walk_all_wave<4>(P, io);
+        else if (g_walker && P.band_w == 256) walk_all_wave<8>(P, io);
+        else if (P.band_w == 128) walk_all<4>(P, io);
         else if (P.band_w == 256) walk_all<8>(P, io);
         else return -1;
     }
@@ -254,6 +290,9 @@ int band_chunk(Host &H, const float *mag, int n_frames, std::vector<GoneBurst> &
 }  // namespace
 
 extern "C" {
+
+// which form of the walk the next scans use (g_walker)
+void band_host_set_walker(int w) { g_walker = w; }
 
 // mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
 // (burst_detect.c:427-428, :448-452); the rest is scanned in chunks of chunk_frames.  Returns the number of finished

@@ -30,10 +30,12 @@ def bandlib():
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libbandhost.so")
     src = os.path.join(ROOT, "tests", "band_host.cpp")
-    hdr = os.path.join(ROOT, "iridium-sniffer_amd", "csrc", "band_core.hpp")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [src, os.path.join(ROOT, "tests", "wave_emul.hpp")] + [os.path.join(ROOT, "iridium-sniffer_amd", "csrc", h)
+                                                                   for h in ("band_core.hpp", "band_wave.hpp", "types.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     L = C.CDLL(so)
+    L.band_host_set_walker.argtypes = [C.c_int]
     L.band_host_scan.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(Gone), C.c_int,
                                  C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -181,3 +183,55 @@ def test_band_scan_12mhz(bandlib):
               for s in starts]
     iq, _ = siggen.make_stream(fs, n, bursts, seed=6)
     check(bandlib, iq, fs, chunks=(1 << 20, 64))
+
+
+WALKERS = {1: "a wavefront per band and segment (csrc/band_wave.hpp) on the emulated wavefront of tests/wave_emul.hpp",
+           2: "the same without its 64-frame look-ahead (skim)"}
+
+
+@pytest.mark.parametrize("walker", sorted(WALKERS))
+@pytest.mark.parametrize("name", ["too_long", "dc_and_edges", "strong_simultaneous", "cfo_spread"])
+def test_wavefront_walk_scene_zoo(bandlib, name, walker):
+    """The walk pass in the form the GPU runs -- lane = burst slot, ballots, readlanes, DPP reductions, the look-ahead over
+    64 frames -- executed lane by lane on the CPU (64 user-space contexts in lock step) inside the same sequential
+    restatement of the other passes: records and final sums must equal the oracle's, whole stream and cut into chunks
+    that split bursts (burst_detect.c:426-632)."""
+    fs, iq = scenes.ALL[name]()
+    bandlib.band_host_set_walker(walker)
+    try:
+        check(bandlib, iq, fs, chunks=(1 << 20, 37))
+    finally:
+        bandlib.band_host_set_walker(0)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_wavefront_walk_random_scenes(bandlib, seed):
+    fs, iq = scenes.random_scene(seed)
+    mag, ref, ref_sums = oracle_detect(iq, fs)
+    bandlib.band_host_set_walker(1)
+    try:
+        rc, got, sums, stats = band_scan(bandlib, mag, fs, 1 << 20)
+    finally:
+        bandlib.band_host_set_walker(0)
+    if rc < 0:
+        assert (-rc - 1000) & 16, "flags 0x%x" % (-rc - 1000)
+        return
+    assert got == ref
+    assert np.array_equal(sums.view(np.uint32), ref_sums.view(np.uint32))
+
+
+def test_wavefront_walk_12mhz_dense(bandlib):
+    """16384-point frames, bands of 256 bins (eight crossing words per band), a dense scene"""
+    fs = 12_000_000
+    n = (520 * 16384 + 2 * 1024 * 1024) // 32768 * 32768
+    rng = np.random.default_rng(12)
+    first = 520 * 16384
+    starts = np.sort(rng.integers(first, n - int(0.03 * fs), 70))
+    bursts = [dict(start=int(s), freq_hz=siggen.channel_freq(int(rng.integers(-110, 111)) or 1),
+                   payload=rng.integers(0, 4, int(rng.integers(119, 180))).tolist()) for s in starts]
+    iq, _ = siggen.make_stream(fs, n, bursts, seed=12)
+    bandlib.band_host_set_walker(1)
+    try:
+        check(bandlib, iq, fs, chunks=(1 << 20, 50))
+    finally:
+        bandlib.band_host_set_walker(0)
