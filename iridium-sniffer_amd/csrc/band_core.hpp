@@ -67,6 +67,8 @@ struct BandParams {
                                  // bit 1 spoil band i+1's copy of every record in a boundary zone first (both must object),
                                  // bit 3 the wavefront walk without its 64-frame look-ahead (band_wave.hpp: skim),
                                  // bit 4 the plan pass without its LDS (through the workspace arrays, wavefront boundary test)
+    int32_t ahead = 0;           // 1: the plan passes of this launch are launched ahead on a second stream and wait for
+                                 // the walk pass's workgroups to count themselves done (BandWork::bar[8])
     int32_t tl_sel = -1;         // >= 0: the passes stamp their first workgroup's start and last one's end into half tl_sel of
                                  // BandWork::tl (diagnostic, option band_timeline)
     int32_t chained = 0;         // 1: enqueued behind a band scan whose verdict the host had not seen: valid only if that

@@ -65,10 +65,12 @@ struct BandWork {                        // device workspace, carved out of one 
     uint32_t *flags;
     uint32_t *rank;                      // commit: record -> place in creation order
     unsigned long long *tl;              // [2 halves][2][32] pass timeline (BandParams::tl_sel): per slot earliest start | latest end, 10 ns ticks
-    unsigned *bar;                       // [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
+    unsigned *walk_host;                 // HOST counter: walk workgroups launched with BandParams::ahead so far (what bar[8] will reach)
+    unsigned *bar;                       // [8] walk workgroups done (never reset; BandParams::ahead); [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
+extern int g_band_plan_ahead;            // 1: plan passes launched ahead on the side stream (default 0, or IRDM_PLAN_AHEAD=1)
 extern int g_band_fuse_commit;           // 1 (default): the accepting plan pass runs the commit itself
 extern int g_band_plan_threads;          // threads of the plan pass's one workgroup: 256, 512 or 1024 (default)
 extern int g_band_walk_wave;             // 1 (default): the walk pass with a wavefront per band and segment; 0: a lane per band
@@ -83,7 +85,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream);
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream,
+                     hipStream_t side = nullptr, hipEvent_t *plan_ev = nullptr);
 constexpr int kBandTlSlots = 32;         // plan / sums / cross / walk of round r: 4 r + 0..3; commit 24; history 25
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,

@@ -233,6 +233,9 @@ struct irdm_pipeline {
     hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream with CUs of its own (CU mask), so that the
                              // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
     hipEvent_t ev_scan_in, ev_scan_out;
+    hipStream_t stream_side = nullptr;      // plan passes launched ahead (option band_plan_ahead)
+    hipEvent_t ev_plan_set[2][kBandRounds + 2] = {};
+    unsigned walk_launched = 0;             // BandWork::walk_host
     int scan_events = 1;     // 0: no timing events around the band scan (stage time of the scan reads -1)
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
     hipEvent_t ev[10];   // 0 start,1 fft,2 scan,3 pre-fir,4 fir,5 post,6 demod,7 end,8 caller sync
@@ -490,6 +493,10 @@ static void pipeline_free(irdm_pipeline *p)
         if (f.ev_copy) (void)hipEventDestroy(f.ev_copy);
     }
     rot_table_release(p->d_rot_table);       // (ev_rot belongs to the shared table)
+    if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
+    for (auto &set : p->ev_plan_set)
+        for (auto &e : set)
+            if (e) (void)hipEventDestroy(e);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
@@ -788,6 +795,12 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_smin, float, (size_t)P.n);
         if (ok) ok = hipMalloc(&p->d_band, band_work_bytes(P.n, p->max_chunk)) == hipSuccess;
         if (ok) band_work_carve(&p->band, p->d_band, P.n, p->max_chunk);
+        if (ok) {
+            p->band.walk_host = &p->walk_launched;
+            ok = hipStreamCreateWithPriority(&p->stream_side, hipStreamNonBlocking, prio_hi) == hipSuccess;
+            for (auto &set : p->ev_plan_set)
+                for (auto &e : set) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        }
         if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // the cooperative kernel's grid barrier starts idle
     }
     mark("band scan workspace");
@@ -1566,7 +1579,8 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
         // the first rounds left the verdict open: the remaining rounds, on the same lists and workspace
         return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
                                 p->d_smin, p->d_gone, p->gone_cap, first, kBandRounds, hpg,
-                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, sel, p->stream);
+                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, sel, p->stream, p->stream_side,
+                                p->ev_plan_set[sel]);
     }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
@@ -1578,7 +1592,8 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
     if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
                          entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, first, hpg,
-                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream) != 0)
+                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream, p->stream_side,
+                         p->ev_plan_set[sel]) != 0)
         return -1;
     if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
@@ -2694,6 +2709,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_walk_wave")) { irdm::g_band_walk_wave = value; return 0; }
     if (!strcmp(key, "band_plan_threads")) { irdm::g_band_plan_threads = value; return 0; }
     if (!strcmp(key, "band_fuse_commit")) { irdm::g_band_fuse_commit = value; return 0; }
+    if (!strcmp(key, "band_plan_ahead")) { irdm::g_band_plan_ahead = value != 0; return 0; }
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }

@@ -47,6 +47,25 @@ __device__ __forceinline__ bool band_void(const BandParams &P, const BandWork &W
     return __hip_atomic_load(W.bar + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)P.serial;
 }
 
+// BandParams::ahead: every workgroup of a walk pass counts itself done when it leaves (BandWork::bar[8], monotonic) -- what
+// a plan pass that was launched ahead of the walk it depends on waits for (tools/ubench/launch_ahead.hip measures why:
+// behind a many-workgroup pass a 1024-thread workgroup starts 6 us late alone and 28 us late beside a chip-filling
+// kernel; resident and waiting on the counter it sees the pass end after 6 us either way)
+struct WalkDone {
+    unsigned *c;
+    __device__ __forceinline__ WalkDone(const BandParams &P, const BandWork &W) : c(P.ahead ? W.bar + 8 : nullptr) {}
+    __device__ __forceinline__ ~WalkDone()
+    {
+        if (c) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
+
 // diagnostic timeline (BandParams::tl_sel >= 0): earliest start and latest end over the workgroups of a pass
 struct TlScope {
     unsigned long long *lo, *hi;
@@ -594,9 +613,30 @@ __device__ void band_commit_body(const BandParams &P, const BandWork &W, DetStat
 template <int NT>
 __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                        DetState *__restrict__ st, int round, float *__restrict__ sum,
-                                                       GoneBurst *__restrict__ gone, int gone_cap, int fuse)
+                                                       GoneBurst *__restrict__ gone, int gone_cap, int fuse,
+                                                       unsigned wait_target)
 {
     IRDM_DETECTOR_PRIO();
+    if (P.ahead && round >= 1) {
+        // launched ahead of the walk pass whose results it judges (on a second stream): resident, waiting for that pass's
+        // workgroups to have counted themselves done.  Bounded: 200 ms.
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            bool ok = true;
+            while ((int)(__hip_atomic_load(W.bar + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_target) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 20000000ull) {
+                    ok = false;
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // (timed out: the launch voids itself like a chained launch whose predecessor did not commit -- every later
+            // pass returns at once, nothing of the carried state is written, the host runs the chunk again)
+            if (!ok) __hip_atomic_store(W.bar + 5, (unsigned)P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
     TlScope tl(P, W, 4 * round);
     __shared__ PlanShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
@@ -791,6 +831,7 @@ __global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W,
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 3);
+    WalkDone done(P, W);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     if (band_void(P, W) || W.ctl->status != 0) return;
     unsigned long long *tl_stat = nullptr;
@@ -812,6 +853,7 @@ __global__ __launch_bounds__(256) void band_walk_wave_kernel(BandParams P, BandW
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 3);
+    WalkDone done(P, W);
     if (band_void(P, W) || W.ctl->status != 0) return;
     io.act_in = st->act;
     io.n_act_in = (int32_t)wv_first((uint32_t)st->n_act);
@@ -1236,6 +1278,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_plan_ahead = -1;       // 1: plan passes launched ahead on the side stream; -1: IRDM_PLAN_AHEAD in the environment, else 0
 int g_band_fuse_commit = 1;       // 1: the plan pass that accepts a round commits it in the same launch
 int g_band_plan_threads = 1024;   // threads of the plan pass's workgroup (256 / 512 / 1024)
 int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment (band_wave.hpp); 0: a lane per band (band_core.hpp)
@@ -1332,6 +1375,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->flags = static_cast<uint32_t *>(take(256));
     W->bar = static_cast<unsigned *>(take(256));
     W->rank = static_cast<uint32_t *>(take(4 * kBandMaxTotal));
+    W->walk_host = nullptr;
     W->tl = static_cast<unsigned long long *>(take(8 * 4 * kBandTlSlots));
     return 0;
 }
@@ -1341,12 +1385,17 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream)
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream, hipStream_t side,
+                     hipEvent_t *plan_ev)
 {
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
     // verdict is still open (status 0, no flags), the rest up to kBandRounds with round_begin = kBandFirst: everything a
     // round needs from the one before lives in the workspace.
+    if (g_band_plan_ahead < 0) {
+        const char *e = getenv("IRDM_PLAN_AHEAD");
+        g_band_plan_ahead = e && atoi(e) ? 1 : 0;
+    }
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
     static unsigned launch_serial = 0;
@@ -1354,6 +1403,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     P.serial = (int32_t)launch_serial;
     P.chained = chained;
     P.selfcheck = g_band_selfcheck;
+    P.ahead = (g_band_plan_ahead && !g_band_coop && side && plan_ev && W.walk_host) ? 1 : 0;
     P.tl_sel = g_band_timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;
     if (P.tl_sel >= 0 && round_begin == 0) {
         unsigned long long *half = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots;
@@ -1402,12 +1452,23 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         if (round > round_begin || round_begin == 0)
         {
             const size_t plan_lds = (P.selfcheck & 16) ? 0 : kPlanLdsBytes;
+            // (ahead: the walk pass this plan judges was enqueued just above; its workgroups bring bar[8] to *walk_host)
+            const bool ahead = P.ahead && round > round_begin && round >= 1;
+            hipStream_t ps = ahead ? side : stream;
+            BandParams Pp = P;
+            Pp.ahead = ahead ? 1 : 0;
+            const unsigned target = ahead ? *W.walk_host : 0u;
             if (g_band_plan_threads == 256)
-                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, stream, P, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit);
+                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target);
             else if (g_band_plan_threads == 512)
-                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, stream, P, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit);
+                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target);
             else
-                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, stream, P, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit);
+                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target);
+            if (ahead) {
+                // what follows on the scan's own stream waits for this plan
+                (void)hipEventRecord(plan_ev[round], side);
+                (void)hipStreamWaitEvent(stream, plan_ev[round], 0);
+            }
         }
         if (round == round_end) break;
         if (g_band_sum_bins == 32)
@@ -1420,6 +1481,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
         else
             hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
+        if (P.ahead) *W.walk_host += (unsigned)(g_band_walk_wave ? kWalkWaveGroups : P.occ_words);
         if (g_band_walk_wave) {
             if (P.band_w == 128)
                 hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
