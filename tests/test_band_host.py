@@ -190,7 +190,8 @@ WALKERS = {1: "a wavefront per band and segment (csrc/band_wave.hpp) on the emul
 
 
 @pytest.mark.parametrize("walker", sorted(WALKERS))
-@pytest.mark.parametrize("name", ["too_long", "dc_and_edges", "strong_simultaneous", "cfo_spread"])
+@pytest.mark.parametrize("name", ["too_long", "dc_and_edges", "strong_simultaneous", "cfo_spread", "many_active_10m", "junk",
+                                  "frame_lengths"])
 def test_wavefront_walk_scene_zoo(bandlib, name, walker):
     """The walk pass in the form the GPU runs -- lane = burst slot, ballots, readlanes, DPP reductions, the look-ahead over
     64 frames -- executed lane by lane on the CPU (64 user-space contexts in lock step) inside the same sequential
