@@ -1,0 +1,346 @@
+// hip/hip_runtime.h -- TEST INFRASTRUCTURE, not HIP: just enough of the HIP device language, emulated on the CPU, to run
+// iridium-sniffer_amd/csrc/scan_band.hip (the band scan's kernels exactly as the gfx950 build compiles them) inside a host
+// test without a GPU (tests/scan_emul.cpp, tests/test_scan_emul.py).
+//
+// A workgroup is a set of user-space contexts (ucontext), one per thread, resumed round robin.  __syncthreads() and the
+// wavefront-level operations (ballot, readlane, shuffles, DPP row shifts, wave barrier) are rendezvous points: a thread
+// deposits its value, waits until every live thread of the workgroup / wavefront has arrived, reads what it needs and
+// waits again before the slot is reused.  Threads that have returned no longer count (as exited wavefronts do not on
+// the hardware).  Workgroups of a launch run one after the other; a launch returns when its last workgroup is done, so
+// streams, events and memory fences are no-ops and atomics are plain operations.  __shared__ variables are statics
+// (one workgroup at a time); dynamic LDS is one 160 KB buffer (hip_emul::dyn_lds()).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+#include <algorithm>
+#include <functional>
+#include <vector>
+
+#define __HIPCC__ 1
+#define __HIP_DEVICE_COMPILE__ 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 1
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct short2 { short x, y; };
+struct char2 { signed char x, y; };
+inline float2 make_float2(float x, float y) { return float2{ x, y }; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{ x, y, z, w }; }
+inline int2 make_int2(int x, int y) { return int2{ x, y }; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{ x, y, z, w }; }
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void *hipStream_t;
+typedef void *hipEvent_t;
+enum hipError_t { hipSuccess = 0, hipErrorUnknown = 1 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+template <typename... A> inline hipError_t hipFuncSetAttribute(A...) { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+using std::max;
+using std::min;
+
+namespace hip_emul {
+
+struct Idx3 { unsigned x, y, z; };
+
+struct Machine {
+    ucontext_t main_ctx;
+    std::vector<ucontext_t> ctx;
+    std::vector<std::vector<char>> stacks;
+    std::vector<char> done;
+    std::vector<uint64_t> box;
+    int n = 0, cur = 0, live = 0;
+    int wg_count = 0;
+    unsigned wg_gen = 0;
+    std::vector<int> wave_live, wave_count;
+    std::vector<unsigned> wave_gen;
+    Idx3 block{ 0, 0, 0 }, bdim{ 1, 1, 1 }, gdim{ 1, 1, 1 };
+    std::function<void()> body;
+    unsigned long long clock = 0;
+    std::vector<unsigned char> lds;
+};
+
+inline Machine &M()
+{
+    static Machine m;
+    return m;
+}
+
+inline unsigned char *dyn_lds()
+{
+    Machine &m = M();
+    if (m.lds.empty()) m.lds.resize(160 * 1024 + 64);
+    return reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(m.lds.data()) + 63) & ~(uintptr_t)63);
+}
+
+inline Idx3 thread_idx() { return Idx3{ (unsigned)M().cur, 0, 0 }; }
+inline Idx3 block_idx() { return M().block; }
+inline Idx3 block_dim() { return M().bdim; }
+inline Idx3 grid_dim() { return M().gdim; }
+
+inline void yield()
+{
+    Machine &m = M();
+    const int me = m.cur;
+    int nxt = me;
+    do nxt = nxt + 1 == m.n ? 0 : nxt + 1;
+    while (m.done[nxt] && nxt != me);
+    if (nxt == me) return;
+    m.cur = nxt;
+    swapcontext(&m.ctx[me], &m.ctx[nxt]);
+}
+
+inline void wg_barrier()
+{
+    Machine &m = M();
+    const unsigned g = m.wg_gen;
+    if (++m.wg_count >= m.live) {
+        m.wg_count = 0;
+        m.wg_gen++;
+    }
+    while (m.wg_gen == g) yield();
+}
+
+inline void wave_barrier()
+{
+    Machine &m = M();
+    const int w = m.cur >> 6;
+    const unsigned g = m.wave_gen[w];
+    if (++m.wave_count[w] >= m.wave_live[w]) {
+        m.wave_count[w] = 0;
+        m.wave_gen[w]++;
+    }
+    while (m.wave_gen[w] == g) yield();
+}
+
+inline void thread_exit()
+{
+    Machine &m = M();
+    const int me = m.cur, w = me >> 6;
+    m.done[me] = 1;
+    m.live--;
+    m.wave_live[w]--;
+    // threads waiting at a rendezvous that only this one had not reached may go on
+    if (m.live > 0 && m.wg_count >= m.live) {
+        m.wg_count = 0;
+        m.wg_gen++;
+    }
+    if (m.wave_live[w] > 0 && m.wave_count[w] >= m.wave_live[w]) {
+        m.wave_count[w] = 0;
+        m.wave_gen[w]++;
+    }
+    for (int k = 1; k <= m.n; k++) {
+        const int nxt = (me + k) % m.n;
+        if (!m.done[nxt]) {
+            m.cur = nxt;
+            setcontext(&m.ctx[nxt]);
+        }
+    }
+    setcontext(&m.main_ctx);
+}
+
+inline void thread_entry()
+{
+    M().body();
+    thread_exit();
+}
+
+inline void run_workgroup(int n_threads, const std::function<void()> &body)
+{
+    Machine &m = M();
+    m.n = n_threads;
+    m.live = n_threads;
+    m.wg_count = 0;
+    m.body = body;
+    if ((int)m.ctx.size() < n_threads) {
+        m.ctx.resize(n_threads);
+        m.stacks.resize(n_threads);
+    }
+    m.done.assign(n_threads, 0);
+    m.box.assign(n_threads, 0);
+    const int n_waves = (n_threads + 63) / 64;
+    m.wave_live.assign(n_waves, 0);
+    m.wave_count.assign(n_waves, 0);
+    m.wave_gen.assign(n_waves, 0);
+    for (int t = 0; t < n_threads; t++) {
+        m.wave_live[t >> 6]++;
+        if (m.stacks[t].empty()) m.stacks[t].resize(192 * 1024);
+        getcontext(&m.ctx[t]);
+        m.ctx[t].uc_stack.ss_sp = m.stacks[t].data();
+        m.ctx[t].uc_stack.ss_size = m.stacks[t].size();
+        m.ctx[t].uc_link = nullptr;
+        makecontext(&m.ctx[t], reinterpret_cast<void (*)()>(thread_entry), 0);
+    }
+    m.cur = 0;
+    swapcontext(&m.main_ctx, &m.ctx[0]);
+}
+
+template <typename K, typename... A>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... args)
+{
+    Machine &m = M();
+    m.gdim = Idx3{ grid.x, grid.y, grid.z };
+    m.bdim = Idx3{ block.x, block.y, block.z };
+    for (unsigned bx = 0; bx < grid.x; bx++) {
+        m.block = Idx3{ bx, 0, 0 };
+        run_workgroup((int)block.x, [&]() { kernel(args...); });
+    }
+}
+
+// ---- wavefront-level exchanges (lanes of the calling thread's wavefront) ----
+inline uint64_t wave_exchange(uint64_t v, int from_lane)
+{
+    Machine &m = M();
+    const int base = m.cur & ~63;
+    m.box[m.cur] = v;
+    wave_barrier();
+    const uint64_t r = m.box[base + (from_lane & 63)];
+    wave_barrier();
+    return r;
+}
+
+inline uint64_t ballot(bool p)
+{
+    Machine &m = M();
+    const int base = m.cur & ~63;
+    m.box[m.cur] = p ? 1 : 0;
+    wave_barrier();
+    uint64_t r = 0;
+    for (int i = 0; i < 64 && base + i < m.n; i++)
+        if (!m.done[base + i]) r |= (m.box[base + i] & 1) << i;
+    wave_barrier();
+    return r;
+}
+
+inline int first_live_lane()
+{
+    Machine &m = M();
+    const int base = m.cur & ~63;
+    for (int i = 0; i < 64 && base + i < m.n; i++)
+        if (!m.done[base + i]) return i;
+    return 0;
+}
+
+template <typename X>
+inline X shfl(X v, int src_lane)
+{
+    static_assert(sizeof(X) == 4, "32-bit values");
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    u = (uint32_t)wave_exchange(u, src_lane);
+    X r;
+    memcpy(&r, &u, 4);
+    return r;
+}
+
+inline int update_dpp(int old, int src, int ctrl, int, int, bool)
+{
+    Machine &m = M();
+    const int l = m.cur & 63, base = m.cur & ~63;
+    m.box[m.cur] = (uint32_t)src;
+    wave_barrier();
+    int r = old;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {                 // row_shr:n
+        const int n = ctrl - 0x110;
+        if ((l & 15) >= n) r = (int)(uint32_t)m.box[base + l - n];
+    } else if (ctrl == 0x138) {                           // wave_shr:1
+        if (l >= 1) r = (int)(uint32_t)m.box[base + l - 1];
+    } else {
+        fprintf(stderr, "hip_emul: DPP control 0x%x is not emulated\n", ctrl);
+        abort();
+    }
+    wave_barrier();
+    return r;
+}
+
+struct BufferRsrc {
+    char *base;
+    uint32_t num;
+};
+
+}  // namespace hip_emul
+
+#define threadIdx (hip_emul::thread_idx())
+#define blockIdx (hip_emul::block_idx())
+#define blockDim (hip_emul::block_dim())
+#define gridDim (hip_emul::grid_dim())
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) hip_emul::launch(kernel, grid, block, lds, stream, __VA_ARGS__)
+
+inline void __syncthreads() { hip_emul::wg_barrier(); }
+inline void __threadfence() {}
+inline void __threadfence_system() {}
+inline unsigned long long wall_clock64() { return hip_emul::M().clock += 7; }
+
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() hip_emul::wave_barrier()
+#define __builtin_amdgcn_ballot_w64(p) hip_emul::ballot((p))
+#define __builtin_amdgcn_readlane(v, l) hip_emul::shfl<int>((v), (l))
+#define __builtin_amdgcn_readfirstlane(v) hip_emul::shfl<int>((v), hip_emul::first_live_lane())
+#define __builtin_amdgcn_update_dpp(o, s, c, rm, bm, bc) hip_emul::update_dpp((o), (s), (c), (rm), (bm), (bc))
+template <typename X> inline X __shfl_xor(X v, int d) { return hip_emul::shfl<X>(v, (hip_emul::M().cur & 63) ^ d); }
+template <typename X> inline X __shfl_up(X v, int d)
+{
+    const int l = hip_emul::M().cur & 63;
+    return hip_emul::shfl<X>(v, l >= d ? l - d : l);
+}
+
+template <typename T, typename V> inline T atomicAdd(T *p, V v) { const T o = *p; *p = (T)(o + (T)v); return o; }
+template <typename T, typename V> inline T atomicOr(T *p, V v) { const T o = *p; *p = (T)(o | (T)v); return o; }
+template <typename T, typename V> inline T atomicMin(T *p, V v) { const T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <typename T, typename V> inline T atomicMax(T *p, V v) { const T o = *p; if ((T)v > o) *p = (T)v; return o; }
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+template <typename T, typename V> inline T hip_emul_fetch_add(T *p, V v) { const T o = *p; *p = (T)(o + (T)v); return o; }
+#define __hip_atomic_fetch_add(p, v, order, scope) hip_emul_fetch_add((p), (v))
+
+typedef hip_emul::BufferRsrc __amdgpu_buffer_rsrc_t;
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short, int num, int)
+{
+    return __amdgpu_buffer_rsrc_t{ static_cast<char *>(p), (uint32_t)num };
+}
+// raw buffer access: the range check is on the vector offset (the scalar offset is not part of it on gfx9)
+inline int __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    if ((uint32_t)voff + 4u > r.num) return 0;
+    int v;
+    memcpy(&v, r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, 4);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b32(int v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    if ((uint32_t)voff + 4u > r.num) return;
+    memcpy(r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, &v, 4);
+}
+
+inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __brev(unsigned v)
+{
+    unsigned r = 0;
+    for (int b = 0; b < 32; b++)
+        if (v & (1u << b)) r |= 1u << (31 - b);
+    return r;
+}

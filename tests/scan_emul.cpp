@@ -1,0 +1,129 @@
+// scan_emul.cpp -- TEST INFRASTRUCTURE: the band scan exactly as the GPU build compiles it (csrc/scan_band.hip: plan with
+// its LDS path and the boundary test, sums with buffer loads, frame-walking crossing pass, wavefront walk with the
+// look-ahead, commit fused into the accepting plan pass, history) executed on the CPU by the HIP emulation of
+// tests/hip_emul/hip/hip_runtime.h, chunk by chunk through launch_band_scan() as csrc/pipeline.cpp drives it (rounds
+// enqueued up front, continuation if the verdict is open, the stale-list retry), so that the whole speculative scan can
+// be compared with the oracle's sequential detector without a GPU (tests/test_scan_emul.py).
+//
+// The test builds scan_band_emul.inc from csrc/scan_band.hip; the only change is the declaration of the dynamic LDS
+// arrays (`extern __shared__ ... name[]` becomes a pointer to the emulation's LDS buffer).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <vector>
+
+#include "scan_band_emul.inc"
+
+using namespace irdm;
+
+extern "C" {
+
+// test hooks of the scan (csrc/kernels.hpp: g_band_*)
+void scan_emul_option(const char *key, int value)
+{
+    if (!strcmp(key, "band_walk_wave")) g_band_walk_wave = value;
+    else if (!strcmp(key, "band_selfcheck")) g_band_selfcheck = value;
+    else if (!strcmp(key, "band_fuse_commit")) g_band_fuse_commit = value;
+    else if (!strcmp(key, "band_plan_threads")) g_band_plan_threads = value;
+    else if (!strcmp(key, "band_plan_ahead")) g_band_plan_ahead = value;
+    else if (!strcmp(key, "band_sum_bins")) g_band_sum_bins = value;
+    else if (!strcmp(key, "band_cross_wave")) g_band_cross_wave = value;
+    else if (!strcmp(key, "band_timeline")) g_band_timeline = value;
+}
+
+// mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
+// (burst_detect.c:427-428, :448-452); the rest is scanned in chunks of chunk_frames.  Returns the number of finished
+// bursts written to out (emission order), or -(flags) - 1000 if a chunk was declined.  stats: [0] rounds, [1] chunks,
+// [2] bursts still active, [3] stale-list retries, [4] continuation launches.
+int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_len, int width, int max_bursts, int max_len,
+                  float threshold, int chunk_frames, int first_rounds, GoneBurst *out, int out_cap, float *sum_out, int *stats)
+{
+    DetParams D;
+    D.n = n;
+    D.log_n = 31 - __builtin_clz((unsigned)n);
+    D.pre_len = pre_len;
+    D.post_len = post_len;
+    D.width = width;
+    D.max_bursts = max_bursts;
+    D.max_len = max_len;
+    D.threshold = threshold;
+    if (n_frames < kHistory) return -1;
+    std::vector<DetState> st_store(1);
+    DetState *st = st_store.data();
+    memset(st, 0, sizeof(DetState));
+    std::vector<float> sum(n, 0.0f), hist((size_t)kHistory * n, 0.0f), pre(n), smin(n, 0.0f);
+    for (int f = 0; f < kHistory; f++) {
+        const float *m = mag + (size_t)f * n;
+        for (int b = 0; b < n; b++) {
+            const float d = sum[b] - 0.0f;
+            sum[b] = d + m[b];
+        }
+        memcpy(&hist[(size_t)f * n], m, sizeof(float) * n);
+    }
+    st->index = (uint64_t)kHistory * n;
+    st->primed = 1;
+    const int F_cap = std::min(chunk_frames, n_frames - kHistory);
+    if (F_cap < 1) return 0;
+    const size_t max_chunk = (size_t)F_cap * n;
+    std::vector<unsigned char> ws(band_work_bytes(n, max_chunk) + 256);
+    BandWork W;
+    band_work_carve(&W, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(ws.data()) + 255) & ~(uintptr_t)255), n, max_chunk);
+    memset(W.bar, 0, 256);
+    unsigned walk_host = 0;
+    W.walk_host = &walk_host;
+    const int cap = band_list_cap(n);
+    std::vector<unsigned> counts(F_cap);
+    std::vector<ListEntry> entries((size_t)F_cap * cap);
+    const int gone_cap = 8192;
+    std::vector<GoneBurst> gone(gone_cap), all;
+    memset(stats, 0, sizeof(int) * 5);
+    hipEvent_t plan_ev[kBandRounds + 2] = {};
+    for (int f0 = kHistory; f0 < n_frames; f0 += chunk_frames) {
+        const int F = std::min(chunk_frames, n_frames - f0);
+        const float *m0 = mag + (size_t)f0 * n;
+        for (int b = 0; b < n; b++) pre[b] = 0.5f * threshold * sum[b];
+        int tries = 0;
+        for (;;) {
+            // the candidate lists as K1 / the prefilter pass write them: unordered, the count may exceed the capacity
+            for (int f = 0; f < F; f++) {
+                unsigned c = 0;
+                for (int b = 0; b < n; b++) {
+                    const float v = m0[(size_t)f * n + b];
+                    if (v > pre[b]) {
+                        if (c < (unsigned)cap) entries[(size_t)f * cap + c] = ListEntry{ b, v };
+                        c++;
+                    }
+                }
+                counts[f] = c;
+            }
+            const int first = first_rounds > 0 ? first_rounds : kBandFirst;
+            if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(), pre.data(),
+                                 smin.data(), gone.data(), gone_cap, 0, first, nullptr, nullptr, nullptr, gone_cap, 0, 0,
+                                 nullptr, reinterpret_cast<hipStream_t>(1), plan_ev) != 0)
+                return -3;
+            if (W.ctl->status == 0 && W.ctl->flags == 0) {
+                // verdict still open after the rounds enqueued up front: the rest (csrc/pipeline.cpp: more_rounds)
+                stats[4]++;
+                if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(),
+                                     pre.data(), smin.data(), gone.data(), gone_cap, first, kBandRounds, nullptr, nullptr,
+                                     nullptr, gone_cap, 0, 0, nullptr, reinterpret_cast<hipStream_t>(1), plan_ev) != 0)
+                    return -3;
+            }
+            if (W.ctl->status == 1 || W.ctl->flags != BAND_F_STALE || tries >= 2) break;
+            // a bin's running sum fell below what the lists assumed: lower the list threshold where it did and redo
+            tries++;
+            stats[3]++;
+            for (int b = 0; b < n; b++) pre[b] = std::min(pre[b], 0.45f * threshold * smin[b]);
+        }
+        stats[0] += W.ctl->rounds;
+        stats[1]++;
+        if (W.ctl->status != 1 || !W.ctl->committed) return -(int)W.ctl->flags - 1000;
+        for (uint32_t i = 0; i < st->n_gone; i++) all.push_back(gone[i]);
+    }
+    if ((int)all.size() > out_cap) return -2;
+    for (size_t i = 0; i < all.size(); i++) out[i] = all[i];
+    memcpy(sum_out, sum.data(), sizeof(float) * n);
+    stats[2] = st->n_act;
+    return (int)all.size();
+}
+
+}

@@ -1,0 +1,141 @@
+"""The band scan's GPU code on the CPU: iridium-sniffer_amd/csrc/scan_band.hip -- every kernel as the gfx950 build compiles
+it (plan pass with its LDS path and the all-boundaries test, sums pass with buffer loads, frame-walking crossing pass,
+wavefront walk with the 64-frame look-ahead, commit fused into the accepting plan pass, history) -- compiled with g++
+against the HIP emulation of tests/hip_emul/hip/hip_runtime.h (a workgroup = user-space contexts in lock step, a launch
+= its workgroups one after the other) and driven chunk by chunk through launch_band_scan() the way csrc/pipeline.cpp does
+(tests/scan_emul.cpp), against the oracle's sequential detector (burst_detect.c:426-632, :689-698): burst records in
+emission order, ids, and the final baseline sums, bit for bit.  No GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+import scenes
+import siggen
+from test_band_host import Gone, det_params, oracle_detect
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "iridium-sniffer_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libscanemul.so")
+    inc = os.path.join(out_dir, "scan_band_emul.inc")
+    src = os.path.join(ROOT, "tests", "scan_emul.cpp")
+    deps = [src, os.path.join(ROOT, "tests", "hip_emul", "hip", "hip_runtime.h")] + [
+        os.path.join(CSRC, h) for h in ("scan_band.hip", "band_core.hpp", "band_wave.hpp", "types.hpp", "kernels.hpp", "common.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        text = open(os.path.join(CSRC, "scan_band.hip")).read()
+        # the one change: dynamic LDS arrays become pointers into the emulation's LDS buffer
+        text, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) unsigned char (\w+)\[\];",
+                          r"unsigned char *\1 = hip_emul::dyn_lds();", text)
+        assert n >= 3
+        open(inc, "w").write(text)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-I" + os.path.join(ROOT, "tests", "hip_emul"), "-I" + out_dir, "-I" + CSRC, "-o", so, src])
+    L = C.CDLL(so)
+    L.scan_emul_option.argtypes = [C.c_char_p, C.c_int]
+    L.scan_emul_run.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_float, C.c_int, C.c_int, C.POINTER(Gone), C.c_int, C.POINTER(C.c_float),
+                                C.POINTER(C.c_int)]
+    return L
+
+
+def run(L, mag, fs, chunk_frames, first_rounds=0):
+    p = det_params(fs)
+    out = (Gone * 8192)()
+    sums = np.zeros(p["n"], np.float32)
+    stats = (C.c_int * 8)()
+    rc = L.scan_emul_run(orc.fptr(mag), mag.shape[0], p["n"], p["pre"], p["post"], p["width"], p["max_bursts"],
+                         p["max_len"], p["thr"], chunk_frames, first_rounds, out, 8192, orc.fptr(sums), stats)
+    recs = [(g.id, g.start, g.stop, g.last_active, g.center_bin, g.peak_rel, g.base_sum) for g in out[:max(rc, 0)]]
+    return rc, recs, sums, list(stats)
+
+
+def check(L, iq, fs, chunks, **kw):
+    mag, ref, ref_sums = oracle_detect(iq, fs)
+    assert len(ref) > 0
+    stats = None
+    for cf in chunks:
+        rc, got, sums, stats = run(L, mag, fs, cf, **kw)
+        assert rc >= 0, "the scan declined a chunk: flags 0x%x" % (-rc - 1000)
+        assert got == ref, "chunk_frames %d: records differ" % cf
+        assert np.array_equal(sums.view(np.uint32), ref_sums.view(np.uint32)), "chunk_frames %d: sums differ" % cf
+    return stats
+
+
+@pytest.mark.parametrize("name", ["too_long", "dc_and_edges", "strong_simultaneous", "cfo_spread", "junk"])
+def test_scan_kernels_scene_zoo(emul, name):
+    """whole stream in one chunk and cut into chunks that split bursts (carried bursts, history ring across chunks)"""
+    fs, iq = scenes.ALL[name]()
+    stats = check(emul, iq, fs, chunks=(1 << 20, 97))
+    assert stats[1] >= 1
+
+
+def test_scan_kernels_continuation_and_options(emul):
+    """two rounds enqueued up front where the scene needs more (the continuation launch), the lane-per-band walk, the
+    commit as a launch of its own, the walk without look-ahead, both forms of the boundary test compared on the fly"""
+    fs, iq = scenes.ALL["too_long"]()
+    stats = check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
+    assert stats[4] >= 1, "no continuation launch was needed: %r" % stats
+    try:
+        for key, value in ((b"band_walk_wave", 0), (b"band_fuse_commit", 0), (b"band_selfcheck", 8), (b"band_selfcheck", 1),
+                           (b"band_plan_threads", 256), (b"band_plan_ahead", 1)):
+            emul.scan_emul_option(key, value)
+            check(emul, iq, fs, chunks=(131,))
+            emul.scan_emul_option(key, {b"band_walk_wave": 1, b"band_fuse_commit": 1, b"band_selfcheck": 0,
+                                        b"band_plan_threads": 1024, b"band_plan_ahead": 0}[key])
+    finally:
+        for key, value in ((b"band_walk_wave", 1), (b"band_fuse_commit", 1), (b"band_selfcheck", 0),
+                           (b"band_plan_threads", 1024), (b"band_plan_ahead", 0)):
+            emul.scan_emul_option(key, value)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_scan_kernels_random_scenes(emul, seed):
+    fs, iq = scenes.random_scene(seed)
+    mag, ref, ref_sums = oracle_detect(iq, fs)
+    rc, got, sums, stats = run(emul, mag, fs, 1 << 20)
+    if rc < 0:
+        assert (-rc - 1000) & 16, "flags 0x%x" % (-rc - 1000)       # only a possible squelch may make it decline
+        return
+    assert got == ref
+    assert np.array_equal(sums.view(np.uint32), ref_sums.view(np.uint32))
+
+
+def test_scan_kernels_decline_squelch(emul):
+    fs, iq = scenes.squelch()
+    mag, ref, _ = oracle_detect(iq, fs)
+    rc, _, _, _ = run(emul, mag, fs, 1 << 20)
+    assert rc < 0 and ((-rc - 1000) & (16 | 4))
+
+
+def _dense(fs, n_fft, samples, nb, seed):
+    n = (520 * n_fft + samples) // 32768 * 32768
+    rng = np.random.default_rng(seed)
+    first = 520 * n_fft
+    starts = np.sort(rng.integers(first, n - int(0.03 * fs), nb))
+    bursts = [dict(start=int(s), freq_hz=siggen.channel_freq(int(rng.integers(-110, 111)) or 1),
+                   payload=rng.integers(0, 4, int(rng.integers(119, 180))).tolist()) for s in starts]
+    iq, _ = siggen.make_stream(fs, n, bursts, seed=seed)
+    return iq
+
+
+def test_scan_kernels_10mhz_dense(emul):
+    """8192-point frames, 40 bursts per Msample (BASELINE config 5's density) over 4 Mi samples after priming: 64 bands of
+    128 bins, four crossing words per band, the plan's LDS path at its frame capacity class"""
+    fs = 10_000_000
+    check(emul, _dense(fs, 8192, 4 * 1024 * 1024, 160, 5), fs, chunks=(1 << 20, 128))
+
+
+def test_scan_kernels_12mhz(emul):
+    """16384-point frames: 64 bands of 256 bins, eight crossing words per band (the <8> instantiations)"""
+    fs = 12_000_000
+    check(emul, _dense(fs, 16384, 2 * 1024 * 1024, 70, 12), fs, chunks=(1 << 20, 50))
