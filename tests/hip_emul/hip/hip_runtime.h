@@ -344,3 +344,10 @@ inline unsigned __brev(unsigned v)
         if (v & (1u << b)) r |= 1u << (31 - b);
     return r;
 }
+
+// (detect.hip)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) ((void)(*(p) = (v)))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+inline int __any(int p) { return hip_emul::ballot(p != 0) != 0; }
+inline int __all(int p) { return hip_emul::ballot(p == 0) == 0; }

@@ -139,3 +139,95 @@ def test_scan_kernels_12mhz(emul):
     """16384-point frames: 64 bands of 256 bins, eight crossing words per band (the <8> instantiations)"""
     fs = 12_000_000
     check(emul, _dense(fs, 16384, 2 * 1024 * 1024, 70, 12), fs, chunks=(1 << 20, 50))
+
+
+# ---- csrc/detect.hip on the same emulation: K1 and the dense sequential scan ----
+
+class Entry(C.Structure):
+    _fields_ = [("bin", C.c_int32), ("mag", C.c_float)]
+
+
+@pytest.fixture(scope="module")
+def detect_emul():
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "libdetectemul.so")
+    inc = os.path.join(out_dir, "detect_emul.inc")
+    src = os.path.join(ROOT, "tests", "detect_emul.cpp")
+    deps = [src, os.path.join(ROOT, "tests", "hip_emul", "hip", "hip_runtime.h")] + [
+        os.path.join(CSRC, h) for h in ("detect.hip", "host_design.cpp", "types.hpp", "kernels.hpp", "common.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        text = open(os.path.join(CSRC, "detect.hip")).read()
+        text, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) unsigned char (\w+)\[\];",
+                          r"unsigned char *\1 = hip_emul::dyn_lds();", text)
+        assert n >= 2
+        open(inc, "w").write(text)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-I" + os.path.join(ROOT, "tests", "hip_emul"), "-I" + out_dir, "-I" + CSRC, "-o", so, src])
+    L = C.CDLL(so)
+    L.detect_emul_k1.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_uint), C.POINTER(Entry), C.c_int]
+    L.detect_emul_scan.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_float, C.c_int, C.POINTER(Gone), C.c_int, C.POINTER(C.c_float)]
+    return L
+
+
+def _k1(L, x, fmt, n, frames, variant, pre=None, cap=4096):
+    mag = np.zeros((frames, n), np.float32)
+    counts = np.zeros(frames, np.uint32)
+    entries = (Entry * (frames * cap))()
+    rc = L.detect_emul_k1(x.ctypes.data_as(C.c_void_p), fmt, n, frames, variant, orc.fptr(mag),
+                          orc.fptr(pre) if pre is not None else None, counts.ctypes.data_as(C.POINTER(C.c_uint)), entries, cap)
+    return rc, mag, counts, entries
+
+
+@pytest.mark.parametrize("fs", [2_000_000, 10_000_000, 12_000_000])
+def test_k1_kernels_match_the_oracle_fft(detect_emul, fs):
+    """window . N-point FFT . fftshift . |.|^2 (burst_detect.c:679-687) by the radix-16 register kernel, the same kernel
+    writing the band scan's candidate lists, and the radix-2 LDS kernel, for cf32 / ci16 / ci8 input: magnitudes bit for
+    bit those of the oracle's pinned FFT; the lists hold exactly the bins above the prefilter level"""
+    n = det_params(fs)["n"]
+    frames = 24 if n > 2048 else 64
+    iq, _ = siggen.standard_scene(fs, (frames + 4) * n // 32768 * 32768 + 32768, 3, seed=fs // 1_000_000)
+    for fmt in (2, 1, 0):
+        if fmt == 2:
+            x, as_cf = iq, iq
+        elif fmt == 1:
+            x = siggen.to_ci16(iq)
+            as_cf = ((x.astype(np.int16) >> 8).astype(np.float32) / np.float32(128.0)).view(np.complex64)
+        else:
+            x = siggen.to_ci8(iq)
+            as_cf = (x.astype(np.float32) / np.float32(128.0)).view(np.complex64)
+        ref_mag, _, _ = oracle_detect(np.ascontiguousarray(as_cf), fs)
+        assert ref_mag.shape[0] >= frames
+        ref_mag = ref_mag[:frames]
+        for variant in (0, 2):
+            rc, mag, _, _ = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, variant)
+            assert rc == 0
+            assert np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32)), (fs, fmt, variant)
+        if n >= 4096 and fmt == 2:
+            pre = (np.float32(0.5) * np.percentile(ref_mag, 99.0, axis=0)).astype(np.float32)
+            rc, mag, counts, entries = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, 1, pre=pre)
+            assert rc == 0 and np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32))
+            for f in range(frames):
+                want = {(int(b), float(ref_mag[f, b])) for b in np.nonzero(ref_mag[f] > pre)[0]}
+                got = {(entries[f * 4096 + i].bin, entries[f * 4096 + i].mag) for i in range(int(counts[f]))}
+                assert got == want, (fs, f)
+
+
+@pytest.mark.parametrize("name", ["too_long", "squelch", "dc_and_edges", "strong_simultaneous"])
+def test_dense_scan_kernel_matches_the_oracle(detect_emul, name):
+    """detect_scan_kernel (one workgroup walking the frames: the exact fallback of every faster scan, squelch included)
+    from the first frame of the stream, whole and in chunks"""
+    fs, iq = scenes.ALL[name]()
+    mag, ref, ref_sums = oracle_detect(iq, fs)
+    p = det_params(fs)
+    for cf in (1 << 20, 61):
+        out = (Gone * 8192)()
+        sums = np.zeros(p["n"], np.float32)
+        rc = detect_emul.detect_emul_scan(orc.fptr(mag), mag.shape[0], p["n"], p["pre"], p["post"], p["width"], p["max_bursts"],
+                                          p["max_len"], p["thr"], cf, out, 8192, orc.fptr(sums))
+        assert rc >= 0, rc
+        got = [(g.id, g.start, g.stop, g.last_active, g.center_bin, g.peak_rel, g.base_sum) for g in out[:rc]]
+        assert got == ref, "chunk_frames %d" % cf
+        assert np.array_equal(sums.view(np.uint32), ref_sums.view(np.uint32))
