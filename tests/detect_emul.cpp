@@ -1,7 +1,7 @@
 // detect_emul.cpp -- TEST INFRASTRUCTURE: csrc/detect.hip as the GPU build compiles it -- K1 (window, N-point FFT in
 // registers and LDS, fftshift, |.|^2, the candidate lists written in its store stage), the radix-2 LDS form of K1, and
 // the dense sequential detector scan -- on the CPU emulation of tests/hip_emul/hip/hip_runtime.h, with the product's own
-// window and twiddle designs (csrc/host_design.cpp), against the oracle (tests/test_scan_emul.py).
+// window and twiddle designs (csrc/host_design.cpp), against the oracle (tests/test_kernels_emul.py).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <vector>

@@ -1,6 +1,6 @@
 // hip/hip_runtime.h -- TEST INFRASTRUCTURE, not HIP: just enough of the HIP device language, emulated on the CPU, to run
 // iridium-sniffer_amd/csrc/scan_band.hip (the band scan's kernels exactly as the gfx950 build compiles them) inside a host
-// test without a GPU (tests/scan_emul.cpp, tests/test_scan_emul.py).
+// test without a GPU (tests/scan_emul.cpp, tests/test_kernels_emul.py).
 //
 // A workgroup is a set of user-space contexts (ucontext), one per thread, resumed round robin.  __syncthreads() and the
 // wavefront-level operations (ballot, readlane, shuffles, DPP row shifts, wave barrier) are rendezvous points: a thread
@@ -351,3 +351,9 @@ inline unsigned __brev(unsigned v)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 inline int __any(int p) { return hip_emul::ballot(p != 0) != 0; }
 inline int __all(int p) { return hip_emul::ballot(p == 0) == 0; }
+// (bitlayer.hip)
+#define __constant__ static
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __ffs(int v) { return __builtin_ffs(v); }

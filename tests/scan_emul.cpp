@@ -3,7 +3,7 @@
 // look-ahead, commit fused into the accepting plan pass, history) executed on the CPU by the HIP emulation of
 // tests/hip_emul/hip/hip_runtime.h, chunk by chunk through launch_band_scan() as csrc/pipeline.cpp drives it (rounds
 // enqueued up front, continuation if the verdict is open, the stale-list retry), so that the whole speculative scan can
-// be compared with the oracle's sequential detector without a GPU (tests/test_scan_emul.py).
+// be compared with the oracle's sequential detector without a GPU (tests/test_kernels_emul.py).
 //
 // The test builds scan_band_emul.inc from csrc/scan_band.hip; the only change is the declaration of the dynamic LDS
 // arrays (`extern __shared__ ... name[]` becomes a pointer to the emulation's LDS buffer).
