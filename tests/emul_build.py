@@ -1,0 +1,71 @@
+"""TEST INFRASTRUCTURE: builds tests/_build/libirdm_emul.so -- the product's sources (every kernel file, csrc/pipeline.cpp,
+csrc/host_design.cpp, csrc/compat.cpp: the whole C-ABI of include/irdm_hip.h) compiled with g++ against the HIP emulation
+of tests/hip_emul/hip/hip_runtime.h, so that the `-m "not gpu"` tests can drive the product end to end without a GPU
+(tests/test_pipeline_emul.py).  Never loaded by the product: iridium-sniffer_amd/irdm.py loads libirdm_hip.so unless a
+test points IRDM_LIB elsewhere.
+
+Source changes made on the way (text substitutions on copies under tests/_build/emul/):
+  * `extern __shared__ ... name[];` (dynamic LDS) -> a pointer to the emulation's LDS buffer
+  * scan_fast.hip: `s_waitcnt` / `s_barrier` inline asm -> nothing / __syncthreads()
+  * fir_reg.hip: the one `v_writelane_b32` inline asm -> hip_emul::writelane0
+  * csrc/fir_mac.inc (generated gfx950 assembly) is replaced by tests/hip_emul/fir_mac.inc: the same multiply-add chains in
+    plain C++, products and sums rounded separately, same order."""
+import concurrent.futures
+import os
+import re
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "iridium-sniffer_amd", "csrc")
+EMUL = os.path.join(ROOT, "tests", "hip_emul")
+OUT = os.path.join(ROOT, "tests", "_build", "emul")
+SO = os.path.join(ROOT, "tests", "_build", "libirdm_emul.so")
+SOURCES = ["detect.hip", "scan_fast.hip", "scan_band.hip", "downmix.hip", "fir_reg.hip", "demod.hip", "bitlayer.hip",
+           "pipeline.cpp", "host_design.cpp", "compat.cpp"]
+
+
+def transform(name, text):
+    text = re.sub(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) unsigned char (\w+)\[\];",
+                  r"unsigned char *\1 = hip_emul::dyn_lds();", text)
+    if name == "scan_fast.hip":
+        text = text.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
+        text = text.replace('asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory")', "__syncthreads()")
+    if name == "fir_reg.hip":
+        text = text.replace('asm("v_writelane_b32 %0, %1, 0" : "=v"(r) : "s"(s), "0"(v));', "r = hip_emul::writelane0(v, s);")
+    if name == "host_design.cpp":
+        # (hipcc = clang has __builtin_complex in C++; g++ spells it with __real__ / __imag__)
+        text = ("#define __builtin_complex(re, im) ({ float _Complex z_; __real__ z_ = (re); __imag__ z_ = (im); z_; })\n" + text)
+    assert "asm(" not in text.replace('asm volatile("" ::: "memory")', "") or name == "pipeline.cpp", name
+    return text
+
+
+def newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False):
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(EMUL, "hip", "hip_runtime.h"),
+                                                                os.path.join(EMUL, "fir_mac.inc"), os.path.abspath(__file__)]
+    deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest(deps):
+        return SO
+    os.makedirs(OUT, exist_ok=True)
+    shutil.copy(os.path.join(EMUL, "fir_mac.inc"), os.path.join(OUT, "fir_mac.inc"))
+    jobs = []
+    for name in SOURCES:
+        dst = os.path.join(OUT, name.replace(".hip", "_hip") .replace(".cpp", "_cpp") + ".cpp")
+        open(dst, "w").write(transform(name, open(os.path.join(CSRC, name)).read()))
+        obj = dst[:-4] + ".o"
+        jobs.append((obj, ["g++", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-w", "-I" + EMUL, "-I" + OUT,
+                           "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-c", dst, "-o", obj]))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+        for rc in ex.map(lambda j: subprocess.run(j[1], capture_output=True, text=True), jobs):
+            if rc.returncode != 0:
+                raise RuntimeError("emulated build failed:\n" + rc.stderr[-4000:])
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", SO] + [j[0] for j in jobs])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE: runs the product end to end on the CPU emulation (tests/_build/libirdm_emul.so, built by
+tests/emul_build.py from the product's own sources) and compares every record with the oracle, exactly as the -m gpu
+parity tests do on the real library (tests/parity.py).  Started by tests/test_pipeline_emul.py in a process of its own with
+IRDM_LIB pointing at the emulated build.  Usage: python emul_pipeline_run.py <case>"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "iridium-sniffer_amd"))
+
+import numpy as np      # noqa: E402
+
+import irdm             # noqa: E402
+import orc              # noqa: E402
+import parity           # noqa: E402
+import scenes           # noqa: E402
+import siggen           # noqa: E402
+
+
+def scene(fs, secs, nb, seed):
+    n = int(secs * fs) // 32768 * 32768
+    iq, _ = siggen.standard_scene(fs, n, nb, seed=seed)
+    return iq
+
+
+def chunks_of(n, parts):
+    blocks = n // 32768
+    cuts = [blocks * (i + 1) // parts for i in range(parts)]
+    out, prev = [], 0
+    for c in cuts:
+        if c > prev:
+            out.append((c - prev) * 32768)
+            prev = c
+    if n % 32768:
+        out[-1] += n % 32768
+    return out
+
+
+def main():
+    case = sys.argv[1]
+    assert "libirdm_emul" in irdm.LIB_PATH, irdm.LIB_PATH
+    res = {}
+    if case == "2mhz":
+        fs = 2_000_000
+        iq = scene(fs, 1.3, 7, 3)
+        ref = orc.run_stream(iq, fs)
+        res["whole"] = parity.compare(parity.run_gpu(iq, fs), ref)
+        res["chunked_depth1"] = parity.compare(parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 4), depth=1), ref)
+        res["chunked_depth2_in_place_lookahead"] = parity.compare(
+            parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead"), ref)
+        x = siggen.to_ci8(iq)
+        ref8 = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
+        res["ci8"] = parity.compare(parity.run_gpu(x, fs, fmt=irdm.FMT_CI8), ref8)
+        res["sequential_scan"] = parity.compare(parity.run_gpu(iq, fs, scan_mode=1), ref)
+    elif case == "scene_zoo":
+        for name in ("too_long", "squelch", "dc_and_edges"):
+            fs, iq = scenes.ALL[name]()
+            ref = orc.run_stream(iq, fs)
+            res[name] = parity.compare(parity.run_gpu(iq, fs), ref)
+    elif case == "10mhz":
+        # 8192-point frames, decimation by 40: K1's radix-16 kernel and the register-resident decimator (fir_reg.hip:
+        # columns in registers, DPP shifts, travelling accumulators) -- and the LDS decimator it replaced
+        fs = 10_000_000
+        iq = scene(fs, 0.62, 2, 31)
+        ref = orc.run_stream(iq, fs)
+        res["default"] = parity.compare(parity.run_gpu(iq, fs), ref)
+        if os.environ.get("IRDM_EMUL_FULL"):
+            res["lds_decimator"] = parity.compare(parity.run_gpu(iq, fs, options={"fir_layout": 2}), ref)
+    else:
+        raise SystemExit("unknown case")
+    print("RESULT " + json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -357,3 +357,79 @@ inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __ffs(int v) { return __builtin_ffs(v); }
+// (downmix.hip, libm_port.hpp)
+struct uint4 { unsigned x, y, z, w; };
+struct uint2 { unsigned x, y; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{ x, y, z, w }; }
+inline double __fma_rn(double a, double b, double c) { return __builtin_fma(a, b, c); }
+inline double __dmul_rn(double a, double b) { volatile double p = a * b; return p; }
+inline double __dadd_rn(double a, double b) { volatile double s = a + b; return s; }
+inline unsigned long long __builtin_amdgcn_s_memtime_emul() { return hip_emul::M().clock += 3; }
+#define __builtin_amdgcn_s_memtime() __builtin_amdgcn_s_memtime_emul()
+#define HIP_SYMBOL(x) (&(x))
+struct hipDeviceProp_t { int multiProcessorCount; };
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 1; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(0x20); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+template <typename S> inline hipError_t hipMemcpyFromSymbol(void *dst, S *sym, size_t n, size_t off = 0, int = 0)
+{
+    memcpy(dst, reinterpret_cast<const char *>(sym) + off, n);
+    return hipSuccess;
+}
+template <typename S> inline hipError_t hipMemcpyToSymbol(S *sym, const void *src, size_t n, size_t off = 0, int = 0)
+{
+    memcpy(reinterpret_cast<char *>(sym) + off, src, n);
+    return hipSuccess;
+}
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+template <typename X> inline X __shfl_down(X v, int d)
+{
+    const int l = hip_emul::M().cur & 63;
+    return hip_emul::shfl<X>(v, l + d < 64 ? l + d : l);
+}
+template <typename X> inline X __shfl(X v, int src) { return hip_emul::shfl<X>(v, src); }
+
+// ---- the host runtime API as far as csrc/pipeline.cpp and csrc/compat.cpp use it: device memory is host memory, streams
+// and events are tokens, everything has completed when the call returns ----
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocMapped = 2,
+       hipHostMallocCoherent = 0x40000000 };
+inline hipError_t hipMalloc(void **p, size_t n)
+{
+    *p = nullptr;
+    if (posix_memalign(p, 256, n ? n : 256) != 0) return hipErrorUnknown;
+    return hipSuccess;
+}
+template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc(reinterpret_cast<void **>(p), n); }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <typename T> inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc(reinterpret_cast<void **>(p), n, f); }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { *dev = host; return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = reinterpret_cast<hipStream_t>(0x10); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = reinterpret_cast<hipEvent_t>(0x20); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 1; *hi = -1; return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = (size_t)64 << 30; *tot = (size_t)64 << 30; return hipSuccess; }
+
+namespace hip_emul {
+// v_writelane_b32 v, s, 0 (fir_reg.hip: lane 0 of v <- the wavefront-uniform s)
+inline float writelane0(float v, float s) { return (M().cur & 63) == 0 ? s : v; }
+}
+template <typename T, typename V> inline T atomicAnd(T *p, V v) { const T o = *p; *p = (T)(o & (T)v); return o; }
+template <typename T, typename V> inline T atomicExch(T *p, V v) { const T o = *p; *p = (T)v; return o; }
+template <typename T> inline T atomicCAS(T *p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }
+inline unsigned long long __ballot(int p) { return hip_emul::ballot(p != 0); }

@@ -1,0 +1,54 @@
+"""The product end to end without a GPU: every source of iridium-sniffer_amd/csrc (all kernel files as the gfx950 build
+compiles them, pipeline.cpp, compat.cpp, host_design.cpp: the C-ABI of include/irdm_hip.h) is compiled with g++ against the
+HIP emulation of tests/hip_emul (tests/emul_build.py says which lines are substituted: the dynamic-LDS declarations, six
+inline-assembly statements, and the generated assembly of fir_mac.inc, restated in C++) and driven through irdm.py exactly
+like the real library; every burst, downmixed frame (samples bit for bit), hard bit and LLR is compared with the oracle by
+the same code as the -m gpu parity tests (tests/parity.py).  This is test infrastructure: the product never loads it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import emul_build
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emul_lib():
+    return emul_build.build()
+
+
+def run_case(lib, case, timeout=900):
+    env = dict(os.environ, IRDM_LIB=lib)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "emul_pipeline_run.py"), case], env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_whole_path_2mhz(emul_lib):
+    """2 MHz: whole stream, chunked at pipeline_depth 1, chunked at depth 2 fed in place with look-ahead (chained scans),
+    ci8 input, and the sequential scan instead of the band scan"""
+    res = run_case(emul_lib, "2mhz")
+    assert set(res) == {"whole", "chunked_depth1", "chunked_depth2_in_place_lookahead", "ci8", "sequential_scan"}
+    for name, s in res.items():
+        assert s["bursts"] >= 5 and s["demods"] >= 3, (name, s)
+
+
+def test_whole_path_scene_zoo(emul_lib):
+    res = run_case(emul_lib, "scene_zoo")
+    assert res["too_long"]["bursts"] >= 2 and res["squelch"]["bursts"] >= 1 and res["dc_and_edges"]["bursts"] >= 1, res
+
+
+def test_whole_path_10mhz_register_resident_decimator(emul_lib):
+    """10 MHz: 8192-point frames through K1's radix-16 kernel, decimation by 40 through fir_reg.hip -- columns of rotated
+    samples in registers, accumulators travelling from lane to lane by DPP shifts -- (IRDM_EMUL_FULL=1 adds the LDS
+    decimator it replaced, another minute)"""
+    res = run_case(emul_lib, "10mhz", timeout=1500)
+    for name in res:
+        assert res[name]["bursts"] >= 2 and res[name]["frames"] >= 1, res
+    assert "default" in res
