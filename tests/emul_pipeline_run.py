@@ -68,6 +68,16 @@ def main():
         res["default"] = parity.compare(parity.run_gpu(iq, fs), ref)
         if os.environ.get("IRDM_EMUL_FULL"):
             res["lds_decimator"] = parity.compare(parity.run_gpu(iq, fs, options={"fir_layout": 2}), ref)
+    elif case == "12mhz":
+        # 16384-point frames (K1 <14>), decimation by 48 (the decimator's second instantiation), ci16 in two chunks
+        fs = 12_000_000
+        iq = scene(fs, 0.78, 3, 12)
+        ref = orc.run_stream(iq, fs)
+        res["default"] = parity.compare(parity.run_gpu(iq, fs), ref)
+        x = siggen.to_ci16(iq)
+        ref16 = orc.run_stream(x, fs, fmt=irdm.FMT_CI16)
+        res["ci16_chunked_depth1"] = parity.compare(
+            parity.run_gpu(x, fs, fmt=irdm.FMT_CI16, chunks=chunks_of(len(iq), 2), depth=1), ref16)
     else:
         raise SystemExit("unknown case")
     print("RESULT " + json.dumps(res))

@@ -52,3 +52,11 @@ def test_whole_path_10mhz_register_resident_decimator(emul_lib):
     for name in res:
         assert res[name]["bursts"] >= 2 and res[name]["frames"] >= 1, res
     assert "default" in res
+
+
+@pytest.mark.skipif(not os.environ.get("IRDM_EMUL_FULL"), reason="four minutes of emulation: set IRDM_EMUL_FULL=1")
+def test_whole_path_12mhz(emul_lib):
+    """12 MHz: 16384-point frames, decimation by 48, cf32 whole and ci16 in two chunks at pipeline_depth 1"""
+    res = run_case(emul_lib, "12mhz", timeout=2400)
+    for name in ("default", "ci16_chunked_depth1"):
+        assert res[name]["bursts"] >= 3 and res[name]["frames"] >= 2, res
