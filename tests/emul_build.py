@@ -57,7 +57,7 @@ def build(force=False):
         dst = os.path.join(OUT, name.replace(".hip", "_hip") .replace(".cpp", "_cpp") + ".cpp")
         open(dst, "w").write(transform(name, open(os.path.join(CSRC, name)).read()))
         obj = dst[:-4] + ".o"
-        jobs.append((obj, ["g++", "-O1", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-w", "-I" + EMUL, "-I" + OUT,
+        jobs.append((obj, ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-w", "-I" + EMUL, "-I" + OUT,
                            "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-c", dst, "-o", obj]))
     with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
         for rc in ex.map(lambda j: subprocess.run(j[1], capture_output=True, text=True), jobs):

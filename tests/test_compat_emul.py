@@ -24,8 +24,7 @@ def compat_exe_emul(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("fmt", ["cf32", pytest.param("ci8", marks=pytest.mark.skipif(
-    not os.environ.get("IRDM_EMUL_FULL"), reason="another 50 s of emulation: set IRDM_EMUL_FULL=1"))])
+@pytest.mark.parametrize("fmt", ["cf32", "ci8"])
 def test_reference_stage_api_on_the_emulation(compat_exe_emul, tmp_path, fmt):
     G.test_reference_stage_api_matches_the_oracle(compat_exe_emul, tmp_path, fmt)
 
