@@ -245,8 +245,20 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... ar
     Machine &m = M();
     m.gdim = Idx3{ grid.x, grid.y, grid.z };
     m.bdim = Idx3{ block.x, block.y, block.z };
-    for (unsigned bx = 0; bx < grid.x; bx++) {
-        m.block = Idx3{ bx, 0, 0 };
+    // The hardware promises no order among the workgroups of a launch: HIP_EMUL_ORDER=reverse runs them last to first,
+    // HIP_EMUL_ORDER=shuffle in a pseudo-random order that changes from launch to launch (results must not depend on it)
+    static const char *order = getenv("HIP_EMUL_ORDER");
+    static unsigned long long lcg = 88172645463325252ull;
+    std::vector<unsigned> seq(grid.x);
+    for (unsigned i = 0; i < grid.x; i++) seq[i] = i;
+    if (order && order[0] == 'r') std::reverse(seq.begin(), seq.end());
+    if (order && order[0] == 's')
+        for (unsigned i = grid.x; i > 1; i--) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            std::swap(seq[i - 1], seq[(unsigned)((lcg >> 33) % i)]);
+        }
+    for (unsigned k = 0; k < grid.x; k++) {
+        m.block = Idx3{ seq[k], 0, 0 };
         run_workgroup((int)block.x, [&]() { kernel(args...); });
     }
 }

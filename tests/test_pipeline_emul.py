@@ -21,8 +21,10 @@ def emul_lib():
     return emul_build.build()
 
 
-def run_case(lib, case, timeout=900):
+def run_case(lib, case, timeout=900, order=None):
     env = dict(os.environ, IRDM_LIB=lib)
+    if order:
+        env["HIP_EMUL_ORDER"] = order
     p = subprocess.run([sys.executable, os.path.join(HERE, "emul_pipeline_run.py"), case], env=env, capture_output=True,
                        text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -35,6 +37,15 @@ def test_whole_path_2mhz(emul_lib):
     ci8 input, and the sequential scan instead of the band scan"""
     res = run_case(emul_lib, "2mhz")
     assert set(res) == {"whole", "chunked_depth1", "chunked_depth2_in_place_lookahead", "ci8", "sequential_scan"}
+    for name, s in res.items():
+        assert s["bursts"] >= 5 and s["demods"] >= 3, (name, s)
+
+
+@pytest.mark.parametrize("order", ["reverse", "shuffle"])
+def test_workgroup_order_does_not_matter(emul_lib, order):
+    """the hardware promises no order among the workgroups of a launch: the emulation runs them last to first / in a
+    pseudo-random order that changes from launch to launch (HIP_EMUL_ORDER) -- same records"""
+    res = run_case(emul_lib, "2mhz", order=order)
     for name, s in res.items():
         assert s["bursts"] >= 5 and s["demods"] >= 3, (name, s)
 
