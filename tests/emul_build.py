@@ -44,7 +44,14 @@ def newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False):
+def build(force=False, sanitize=False):
+    """sanitize: an AddressSanitizer build (tests/_build/libirdm_emul_asan.so; ucontext switches, which the sanitizer
+    follows): out-of-bounds accesses of kernels to "device" memory, which a GPU does not report, stop the run.  Load it
+    with LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0."""
+    global SO, OUT
+    if sanitize:
+        SO = os.path.join(ROOT, "tests", "_build", "libirdm_emul_asan.so")
+        OUT = os.path.join(ROOT, "tests", "_build", "emul_asan")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(EMUL, "hip", "hip_runtime.h"),
                                                                 os.path.join(EMUL, "fir_mac.inc"), os.path.abspath(__file__)]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
@@ -57,15 +64,17 @@ def build(force=False):
         dst = os.path.join(OUT, name.replace(".hip", "_hip") .replace(".cpp", "_cpp") + ".cpp")
         open(dst, "w").write(transform(name, open(os.path.join(CSRC, name)).read()))
         obj = dst[:-4] + ".o"
-        jobs.append((obj, ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-w", "-I" + EMUL, "-I" + OUT,
+        extra = ["-fsanitize=address", "-fno-omit-frame-pointer", "-DHIP_EMUL_UCONTEXT", "-g"] if sanitize else []
+        jobs.append((obj, ["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread", "-w"] + extra + ["-I" + EMUL, "-I" + OUT,
                            "-I" + CSRC, "-I" + os.path.join(ROOT, "include"), "-c", dst, "-o", obj]))
     with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
         for rc in ex.map(lambda j: subprocess.run(j[1], capture_output=True, text=True), jobs):
             if rc.returncode != 0:
                 raise RuntimeError("emulated build failed:\n" + rc.stderr[-4000:])
-    subprocess.check_call(["g++", "-shared", "-pthread", "-o", SO] + [j[0] for j in jobs])
+    subprocess.check_call(["g++", "-shared", "-pthread"] + (["-fsanitize=address"] if sanitize else []) + ["-o", SO] + [j[0] for j in jobs])
     return SO
 
 
 if __name__ == "__main__":
-    print(build(force=True))
+    import sys
+    print(build(force=True, sanitize="asan" in sys.argv[1:]))

@@ -65,7 +65,7 @@ struct Idx3 { unsigned x, y, z; };
 // Switching between the threads of a workgroup: on x86-64 a dozen instructions (callee-saved registers and the stack
 // pointer; ucontext's swapcontext makes two signal-mask system calls per switch, which made the emulated tests ten times
 // slower), elsewhere ucontext.
-#if defined(__x86_64__)
+#if defined(__x86_64__) && !defined(HIP_EMUL_UCONTEXT)
 #define HIP_EMUL_FAST_SWITCH 1
 static __attribute__((naked, noinline)) void fiber_switch(void **save_sp, void *load_sp)
 {
