@@ -60,12 +60,17 @@ def main():
             ref = orc.run_stream(iq, fs)
             res[name] = parity.compare(parity.run_gpu(iq, fs), ref)
     elif case == "10mhz":
-        # 8192-point frames, decimation by 40: K1's radix-16 kernel and the register-resident decimator (fir_reg.hip:
-        # columns in registers, DPP shifts, travelling accumulators) -- and the LDS decimator it replaced
+        # 8192-point frames, decimation by 40: K1's radix-16 kernel (writing the band scan's candidate lists once the
+        # detector is primed) and the register-resident decimator (fir_reg.hip: columns in registers, DPP shifts,
+        # travelling accumulators); a priming chunk and three more at pipeline_depth 2, fed in place with look-ahead
         fs = 10_000_000
-        iq = scene(fs, 0.62, 2, 31)
+        iq = scene(fs, 0.95, 8, 77)
         ref = orc.run_stream(iq, fs)
-        res["default"] = parity.compare(parity.run_gpu(iq, fs), ref)
+        first = 512 * 8192
+        c = ((len(iq) - first) // 3) // 32768 * 32768
+        got = parity.run_gpu(iq, fs, chunks=[first, c, c, len(iq) - first - 2 * c], depth=2, feed="ingest_lookahead")
+        res["default"] = parity.compare(got, ref)
+        res["default"]["k1_lists"] = got["stats"]["k1_lists"]
         if os.environ.get("IRDM_EMUL_FULL"):
             res["lds_decimator"] = parity.compare(parity.run_gpu(iq, fs, options={"fir_layout": 2}), ref)
     elif case == "12mhz":
