@@ -65,7 +65,8 @@ def _worker(rank, world, port, depth, case, q):
     try:
         FS, NFFT, STEPS, _ = CASES[case]
         iq, chunk, ov = _stream(case)
-        dev = torch.device("cuda", 0)
+        # (IRDM_TEST_DEVICE=cpu: tests/test_timeshard_emul.py runs these workers on the emulated build of the product)
+        dev = torch.device(os.environ.get("IRDM_TEST_DEVICE", "cuda:0"))
         pipe = irdm.Pipeline(FS, max_chunk_samples=chunk, max_bursts_per_chunk=1024, pipeline_depth=depth)
         ts = sharding.TimeShard(dist, pipe, torch, dev, chunk, 8, ov)
         out = []
@@ -97,11 +98,24 @@ def test_two_rank_time_shard_equals_the_oracle(case, depth):
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, depth, case, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get() for _ in range(world)]
+    # (a worker that dies must fail the test, not leave it waiting for a result that never comes)
+    import queue
+    import time
+    res, deadline = [], time.time() + 900
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2.0))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("time-shard worker failed (exit codes %r)" % [p.exitcode for p in procs])
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
