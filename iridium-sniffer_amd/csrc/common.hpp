@@ -62,6 +62,23 @@ __host__ __device__ __forceinline__ float cabs_f(float2 v)
     return (float)sqrt(x * x + y * y);
 }
 
+// ---- kernel clock (option "kernel_clock"): first wavefront in / last wavefront out of a launch ----
+// A record is kKClkWords 64-bit words in device memory: [0..63] earliest entry per slot, [64..127] latest exit per slot
+// (10 ns ticks of the 100 MHz wall clock, s_memrealtime; slot = workgroup index mod 64 so that the atomics of a
+// chip-filling grid do not queue on one address), [128] sum of the launches' spans, [129] launches, [130] last span.
+// kclk_fold_kernel (downmix.hip), enqueued behind the kernel on its stream, folds the slots into the sums and re-arms
+// them.  What bench.py's roofline divides the algorithmic bytes by: the kernel's own span on the device, free of the
+// dispatch wait a host-side event bracket includes.
+constexpr int kKClkWords = 136;
+__device__ __forceinline__ void kclk_enter(unsigned long long *k)
+{
+    if (k && (threadIdx.x & 63) == 0) atomicMin(&k[blockIdx.x & 63], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void kclk_leave(unsigned long long *k)
+{
+    if (k && (threadIdx.x & 63) == 0) atomicMax(&k[64 + (blockIdx.x & 63)], (unsigned long long)wall_clock64());
+}
+
 // ---- pinned FFT: radix-2 decimation in time (DESIGN.md "Pinned FFT") ----
 // The data sits in LDS in bit-reversed order on entry and natural order on exit.
 // tw[k] = (float)cos(2 pi k/N), (float)(-sin(2 pi k/N)), k < N/2, tw[0]=(1,0),

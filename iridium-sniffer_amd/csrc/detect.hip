@@ -213,15 +213,326 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
     }
 }
 
+// ---------------------------------------------------------------------------
+// K1, streaming form (N = 8192 / 16384): "p32" -- 32 points per lane, N/32 lanes per frame (256 / 512).
+//
+// A lane loads SIXTEEN BYTES at a time: the adjacent samples n = 2 pi and 2 pi + 1 (pi = t + T r, r < 16; cf32; ci16 /
+// ci8 pairs are 8 / 4 bytes), so a wavefront's load covers 1 KB of the stream.  Bit reversal sends the lowest index bit
+// to the highest position bit: the even samples are the upper operand E and the odd samples the lower operand O of the
+// LAST stage (X[k] = E[k] + W.O[k]), each of them a 4096-point transform of its own -- the same pinned radix-2 DIT
+// flow graph, regrouped.  A lane therefore carries two (N = 16384: two of four) independent 4096-point sub-transforms
+// side by side through three radix-16 register passes:
+//
+//   pass A  stages 1-4    sub-position p = 16 rev8(t') + q     twiddles are compile-time indices -> SGPR operands
+//   pass B  stages 5-8    p = hi 256 + q 16 + lo               per-lane twiddles, SHARED by the lane's two sub-transforms
+//   pass C  stages 9-12   p = q 256 + lo3
+//   last    stage 13 [and 14] join the sub-transforms of a lane [and, N = 16384, of the lane 32 further on: the two
+//           halves of a wavefront swap registers with v_permlane32_swap, no LDS], then fftshift + |.|^2
+//
+// Two exchanges through the LDS instead of three, and ONE sub-transform at a time: 34 KB per 256 lanes (68 KB per 512 at
+// N = 16384) instead of 66 / 133 KB, so four workgroups of four wavefronts (two of eight) share a CU, and a workgroup
+// needs ONE free wavefront slot per SIMD to start -- it fits beside the register-filling decimator (fir_reg.hip), where
+// the radix-16 kernel above (8 / 16 wavefronts and 66 / 133 KB per frame) waits for a whole CU to drain.
+// Exchange layouts (8-byte slots; conflict-free for ds_write_b64's 16-lane and ds_read_b64's 32-lane groups, all
+// addresses base + immediate):
+//   A -> B   slot = (alpha & 15) 256 + e 16 + (alpha >> 4),  alpha = p >> 4, e = p & 15       (32 KB, no padding)
+//   B -> C   slot = mid 272 + low 17 + top,  p = top 256 + mid 16 + low                       (34 KB)
+// The magnitudes leave through the same buffer, transposed so that a lane stores (and tests against `pre`) four
+// consecutive bins with one 16-byte access.
+// The butterflies are csrc/fft_bfly.inc: five packed instructions each, no moves.  Arithmetic: every butterfly is
+// a' = a + W.b, b' = a - W.b with the table twiddle of the radix-2 flow graph and W.b in four-product form -- bit for
+// bit fft_lds_radix2 (in passes B.. the exact twiddles (1,0), (0,-1) are multiplied rather than copied / swapped, which
+// changes the sign of zeros only; |.|^2 cannot see it).
+// ---------------------------------------------------------------------------
+#include "fft_bfly.inc"
+
+// Buffer accesses: the address of every global access of the kernel is  resource (SGPRs) + lane offset (one VGPR that never
+// changes) + scalar / immediate offset (the compile-time part), so that no vector instruction is spent on addresses.
+// aux 2 = non-temporal: the chunk and its magnitudes are streamed once and are far larger than L2 / MALL.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t k1_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)(bytes > 0x7fffffffu ? 0x7fffffffu : bytes), 0x00020000);
+}
+__device__ __forceinline__ v2f k1_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff)
+{
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+// sample pair (2 lane + {0, 1}) of the 2 T samples behind soff: converted exactly as load_iq does
+template <int FMT>
+__device__ __forceinline__ void load_pair(__amdgpu_buffer_rsrc_t r, int lane, int soff, v2f &x0, v2f &x1)
+{
+    if (FMT == 2) {
+        const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, soff, 2));
+        x0 = v2f{ v.x, v.y };
+        x1 = v2f{ v.z, v.w };
+    } else if (FMT == 1) {
+        const int2 v = __builtin_bit_cast(int2, __builtin_amdgcn_raw_buffer_load_b64(r, lane * 8, soff, 2));
+        const short r0 = (short)(v.x & 0xffff), i0 = (short)(v.x >> 16), r1 = (short)(v.y & 0xffff), i1 = (short)(v.y >> 16);
+        x0 = v2f{ (float)(r0 >> 8) / 128.0f, (float)(i0 >> 8) / 128.0f };     // load_iq<1>
+        x1 = v2f{ (float)(r1 >> 8) / 128.0f, (float)(i1 >> 8) / 128.0f };
+    } else {
+        const int v = __builtin_amdgcn_raw_buffer_load_b32(r, lane * 4, soff, 2);
+        const signed char r0 = (signed char)(v & 0xff), i0 = (signed char)((v >> 8) & 0xff);
+        const signed char r1 = (signed char)((v >> 16) & 0xff), i1 = (signed char)((v >> 24) & 0xff);
+        x0 = v2f{ (float)r0 / 128.0f, (float)i0 / 128.0f };                   // load_iq<0>
+        x1 = v2f{ (float)r1 / 128.0f, (float)i1 / 128.0f };
+    }
+}
+
+template <int LOGN>
+struct P32 {
+    static constexpr int N = 1 << LOGN, T = N / 32;
+    static constexpr int G = N / 8192;                       // groups of two sub-transforms (lanes of one group exchange)
+    static constexpr int REGION = 16 * 272 + (G > 1 ? 1 : 0);   // slots per group (+1: pass A's two groups write one
+                                                             // instruction's slots on different banks)
+    static constexpr size_t LDS = sizeof(float2) * (size_t)G * REGION;
+    static_assert(LOGN == 13 || LOGN == 14, "two or four 4096-point sub-transforms");
+    static_assert(LDS >= sizeof(float) * (size_t)N, "the magnitudes are staged in the exchange buffer");
+};
+
+// stages s0+1 .. s0+4 of both sub-transforms of a lane; c = the lane's position below 2^s0
+template <int LOGN>
+__device__ __forceinline__ void dit16_x2(v2f (&a)[16], v2f (&b)[16], int c, int s0, __amdgpu_buffer_rsrc_t r_tw)
+{
+#pragma unroll
+    for (int i = 1; i <= 4; i++) {
+        const int half = 1 << (i - 1);
+        // twiddle index (c + (jq << s0)) << (LOGN - s0 - i): the lane's part in the vector offset, jq's in the scalar offset
+        const int voff = c << (LOGN - s0 - i + 3);
+        v2f w[8];
+#pragma unroll
+        for (int jq = 0; jq < 8; jq++) {
+            if (jq >= half) continue;
+            w[jq] = k1_load2(r_tw, voff, jq << (LOGN - i + 3));
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0++) {
+            if (q0 & half) continue;
+            bfly2_v(a[q0], a[q0 + half], b[q0], b[q0 + half], w[q0 & (half - 1)]);
+        }
+        // keep each stage's twiddle loads inside the stage (hoisted together they cost the occupancy)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int LOGN, int FMT, bool LISTS>
+__global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const void *__restrict__ iq,
+                                                                          const float *__restrict__ window,
+                                                                          const float2 *__restrict__ tw,
+                                                                          float *__restrict__ mag, int n_frames,
+                                                                          const float *__restrict__ pre,
+                                                                          unsigned *__restrict__ counts,
+                                                                          ListEntry *__restrict__ entries, int cap,
+                                                                          unsigned long long *__restrict__ kclk)
+{
+    using G_ = P32<LOGN>;
+    constexpr int N = G_::N, T = G_::T, G = G_::G, REGION = G_::REGION;
+    constexpr int BPS = FMT == 2 ? 8 : (FMT == 1 ? 4 : 2);
+    __shared__ int s_cnt;
+    __builtin_amdgcn_s_setprio(2);      // the scan of this chunk waits for K1; it shares SIMDs with the per-burst chains
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f *const X = reinterpret_cast<v2f *>(smem_raw);
+    const int t = threadIdx.x;
+    const int frame = blockIdx.x;
+    if (frame >= n_frames) return;
+    kclk_enter(kclk);
+    if (LISTS && t == 0) s_cnt = 0;                 // (several barriers before the first candidate)
+    const __amdgpu_buffer_rsrc_t r_tw = k1_rsrc(tw, sizeof(float2) * (N / 2));
+
+    // ---- load, window, pass A ----
+    v2f a[16], b[16];                               // the lane's two sub-transforms: even samples (E), odd samples (O)
+    {
+        const __amdgpu_buffer_rsrc_t r_in = k1_rsrc(reinterpret_cast<const char *>(iq) + (size_t)frame * N * BPS, (size_t)N * BPS);
+        const __amdgpu_buffer_rsrc_t r_win = k1_rsrc(window, sizeof(float) * N);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            v2f x0, x1;
+            load_pair<FMT>(r_in, t, r * T * 2 * BPS, x0, x1);        // samples 2 (t + T r) + {0, 1}
+            const v2f w = k1_load2(r_win, t * 8, r * T * 8);
+            a[rev4c(r)] = x0 * w.x;                 // simd_window_cf: re * w, im * w
+            b[rev4c(r)] = x1 * w.y;
+        }
+        const uint64_t *const tw64 = reinterpret_cast<const uint64_t *>(tw);
+#pragma unroll
+        for (int i = 1; i <= 4; i++) {
+            const int half = 1 << (i - 1);
+#pragma unroll
+            for (int q0 = 0; q0 < 16; q0++) {
+                if (q0 & half) continue;
+                const int tix = (q0 & (half - 1)) << (LOGN - i);
+                if (tix == 0) bfly2_one(a[q0], a[q0 + half], b[q0], b[q0 + half]);
+                else if (tix == N / 4) bfly2_mi(a[q0], a[q0 + half], b[q0], b[q0 + half]);
+                else bfly2_s(a[q0], a[q0 + half], b[q0], b[q0 + half], tw64[tix]);
+            }
+        }
+    }
+    // ---- A -> B ----
+    {
+        const int ga = G > 1 ? (t & 1) : 0, tp = G > 1 ? (t >> 1) : t;
+        const int al_lo = (int)bitrev((unsigned)(tp >> 4), 4), al_hi = (int)bitrev((unsigned)(tp & 15), 4);   // alpha = rev8(t')
+        v2f *const Xw = X + ga * REGION + al_lo * 256 + al_hi;
+        const int gb = G > 1 ? (t >> 8) : 0;
+        const v2f *const Xr = X + gb * REGION + (t & 255);
+#pragma unroll
+        for (int e = 0; e < 16; e++) Xw[e * 16] = a[e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) a[q] = Xr[q * 256];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; e++) Xw[e * 16] = b[e];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) b[q] = Xr[q * 256];
+    }
+    // ---- pass B: lane = (hi, lo), p = hi 256 + q 16 + lo ----
+    const int hi = t & 15, lo = (t >> 4) & 15;
+    dit16_x2<LOGN>(a, b, lo, 4, r_tw);
+    __syncthreads();
+    // ---- B -> C ----
+    const int gc = G > 1 ? ((t >> 5) & 1) : 0;
+    const int lo3 = G > 1 ? (((t >> 6) << 5) | (t & 31)) : t;
+    {
+        const int gb = G > 1 ? (t >> 8) : 0;
+        v2f *const Xw = X + gb * REGION + lo * 17 + hi;
+        const v2f *const Xr = X + gc * REGION + (lo3 >> 4) * 272 + (lo3 & 15) * 17;
+#pragma unroll
+        for (int q = 0; q < 16; q++) Xw[q * 272] = a[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) a[q] = Xr[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) Xw[q * 272] = b[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; q++) b[q] = Xr[q];
+    }
+    // ---- pass C: p = q 256 + lo3 ----
+    dit16_x2<LOGN>(a, b, lo3, 8, r_tw);
+    __syncthreads();                                // every lane has read its points: the buffer takes the magnitudes
+    // ---- last stage(s), fftshift, |.|^2 -> LDS ----
+    float *const M = reinterpret_cast<float *>(smem_raw);
+    if (G == 1) {
+        // stage 13: X[p] = E[p] + W^p O[p], X[p + 4096] = E[p] - W^p O[p],  p = q 256 + lo3
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+            const v2f w0 = k1_load2(r_tw, lo3 * 8, q * 2048), w1 = k1_load2(r_tw, lo3 * 8, (q + 1) * 2048);
+            bfly2_vv(a[q], b[q], w0, a[q + 1], b[q + 1], w1);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int p = q * 256 + lo3;
+            M[p + N / 2] = mag2(make_float2(a[q].x, a[q].y));       // bin k = p       -> (k + N/2) mod N
+            M[p] = mag2(make_float2(b[q].x, b[q].y));               // bin k = p + N/2 -> p
+        }
+    } else {
+        // the sub-transforms of a lane are (b0 = 0 | 1, b1 = gc); stage 13 joins b1 = 0 with b1 = 1 (twiddle W^2p), stage 14
+        // b0 = 0 with b0 = 1.  The wavefront's lower half (b1 = 0) takes q < 8, the upper half q >= 8: after the swap
+        // a[j] / b[j] hold the b1 = 0 operands and a[j + 8] / b[j + 8] the b1 = 1 operands of p = (j + 8 gc) 256 + lo3.
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            swap32(a[j], a[j + 8]);
+            swap32(b[j], b[j + 8]);
+        }
+        const int pl = gc * 2048 + lo3;             // p = j 256 + pl
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const v2f w = k1_load2(r_tw, pl * 16, j * 4096);                                    // W^(2p)
+            const v2f w0 = k1_load2(r_tw, pl * 8, j * 2048), w1 = k1_load2(r_tw, pl * 8, j * 2048 + 32768);   // W^p, W^(p + 4096)
+            bfly2_v(a[j], a[j + 8], b[j], b[j + 8], w);               // -> U0[p], U0[p + 4096], U1[p], U1[p + 4096]
+            bfly2_vv(a[j], b[j], w0, a[j + 8], b[j + 8], w1);
+            // a[j] = X[p], b[j] = X[p + 8192], a[j + 8] = X[p + 4096], b[j + 8] = X[p + 12288]
+            const int p = j * 256 + pl;
+            M[p + 8192] = mag2(make_float2(a[j].x, a[j].y));
+            M[p] = mag2(make_float2(b[j].x, b[j].y));
+            M[p + 12288] = mag2(make_float2(a[j + 8].x, a[j + 8].y));
+            M[p + 4096] = mag2(make_float2(b[j + 8].x, b[j + 8].y));
+        }
+    }
+    __syncthreads();
+    // ---- store: four consecutive bins per lane and access; the band scan's candidate test on the way ----
+    {
+        const __amdgpu_buffer_rsrc_t r_out = k1_rsrc(mag + (size_t)frame * N, sizeof(float) * N);
+        const __amdgpu_buffer_rsrc_t r_pre = k1_rsrc(pre, sizeof(float) * N);
+        ListEntry *const list = LISTS ? entries + (size_t)frame * cap : nullptr;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int k = 4 * (t + T * i);
+            const v4f m = *reinterpret_cast<const v4f *>(M + k);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k1_u32x4, m), r_out, t * 16, i * T * 16, 2);
+            if (LISTS) {
+                const v4f pr = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r_pre, t * 16, i * T * 16, 0));
+                const bool h0 = m.x > pr.x, h1 = m.y > pr.y, h2 = m.z > pr.z, h3 = m.w > pr.w;
+                if (__builtin_amdgcn_ballot_w64(h0 || h1 || h2 || h3) != 0) {      // (wavefront-uniform branch)
+                    // one LDS atomic per wavefront and access for all of its candidates; a lane's slot is the base the
+                    // atomic returned + the candidates of the components before + its rank among the component's lanes
+                    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
+                    const unsigned long long b2 = __builtin_amdgcn_ballot_w64(h2), b3 = __builtin_amdgcn_ballot_w64(h3);
+                    const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+                    int base = 0;
+                    if ((t & 63) == 0) base = atomicAdd(&s_cnt, n0 + n1 + n2 + n3);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const unsigned long long below = (1ull << (t & 63)) - 1ull;
+                    const float mv[4] = { m.x, m.y, m.z, m.w };
+                    const bool hv[4] = { h0, h1, h2, h3 };
+                    const unsigned long long bv[4] = { b0, b1, b2, b3 };
+                    const int ov[4] = { 0, n0, n0 + n1, n0 + n1 + n2 };
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int slot = base + ov[c] + __popcll(bv[c] & below);
+                        if (hv[c] && slot < cap) {
+                            list[slot].bin = k + c;
+                            list[slot].mag = mv[c];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (LISTS) {
+        __syncthreads();
+        if (t == 0) counts[frame] = (unsigned)s_cnt;
+    }
+    kclk_leave(kclk);
+}
+
+int g_fft_kernel = 1;         // 1 (default): the 32-points-per-lane streaming kernel where it applies (N = 8192, 16384); 0: radix-16 kernel
 int g_fft_force_radix2 = 0;   // test hook: 1 = always use the radix-2 LDS kernel
+
+template <int LOGN, bool LISTS>
+static int launch_p32(int fmt, const void *iq, const float *window, const float2 *tw, float *mag, int n_frames,
+                      const float *pre, unsigned *counts, ListEntry *entries, int cap, unsigned long long *kclk,
+                      hipStream_t stream)
+{
+    const size_t lds = P32<LOGN>::LDS;
+    const dim3 grid(n_frames), block(P32<LOGN>::T);
+#define IRDM_LAUNCH_P32(F)                                                                               \
+    do {                                                                                                 \
+        (void)hipFuncSetAttribute((const void *)fft_mag_p32_kernel<LOGN, F, LISTS>,                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+        hipLaunchKernelGGL((fft_mag_p32_kernel<LOGN, F, LISTS>), grid, block, lds, stream, iq, window, tw, mag, \
+                           n_frames, pre, counts, entries, cap, kclk);                                   \
+    } while (0)
+    if (fmt == 2) IRDM_LAUNCH_P32(2);
+    else if (fmt == 1) IRDM_LAUNCH_P32(1);
+    else IRDM_LAUNCH_P32(0);
+#undef IRDM_LAUNCH_P32
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 // K1 with the candidate lists of the band scan (see fft_mag_r16_kernel); 1 if this FFT size has no such kernel
 int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window, const float2 *tw, float *mag,
                          int n_frames, const float *pre, unsigned *counts, ListEntry *entries, int cap,
-                         hipStream_t stream)
+                         hipStream_t stream, unsigned long long *kclk)
 {
     if (n_frames <= 0) return 0;
     if (fmt < 0 || fmt > 2 || log_n < 12 || log_n > 14 || g_fft_force_radix2) return 1;
+    if (g_fft_kernel == 1 && log_n == 13)
+        return launch_p32<13, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, kclk, stream);
+    if (g_fft_kernel == 1 && log_n == 14)
+        return launch_p32<14, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, kclk, stream);
 #define IRDM_LAUNCH_R16L_F(LOGN, F)                                                            \
     do {                                                                                       \
         constexpr int NB_ = 1 << (LOGN - 8);                                                   \
@@ -249,12 +560,16 @@ int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window
 }
 
 int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
-                   float *mag, int n_frames, hipStream_t stream)
+                   float *mag, int n_frames, hipStream_t stream, unsigned long long *kclk)
 {
     if (n_frames <= 0) return 0;
     int grid = n_frames < 4096 ? n_frames : 4096;
     const int f = fmt;
     if (f < 0 || f > 2) return -1;
+    if (g_fft_kernel == 1 && !g_fft_force_radix2 && log_n == 13)
+        return launch_p32<13, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, kclk, stream);
+    if (g_fft_kernel == 1 && !g_fft_force_radix2 && log_n == 14)
+        return launch_p32<14, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, kclk, stream);
 #define IRDM_LAUNCH_FFT_F(LOGN, NT, F)                                                         \
     do {                                                                                       \
         size_t lds = sizeof(float2) << LOGN;                                                   \

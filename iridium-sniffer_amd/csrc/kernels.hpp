@@ -6,12 +6,13 @@
 namespace irdm {
 
 // detect.hip
+// kclk (here and below): the kernel's clock record (common.hpp, KClk), or nullptr
 int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window, const float2 *tw, float *mag,
                          int n_frames, const float *pre, unsigned *counts, ListEntry *entries, int cap,
-                         hipStream_t stream);
+                         hipStream_t stream, unsigned long long *kclk = nullptr);
 int launch_prefilter_threshold(const float *sum, float thr, float *pre, int n, hipStream_t stream);
 int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
-                   float *mag, int n_frames, hipStream_t stream);
+                   float *mag, int n_frames, hipStream_t stream, unsigned long long *kclk = nullptr);
 int launch_detect_scan(const DetParams &P, DetState *st, float *sum, float *hist, const float *mag,
                        int n_frames, GoneBurst *gone, int gone_cap, PeakCand *cand_a,
                        PeakCand *cand_b, hipStream_t stream);
@@ -121,6 +122,7 @@ int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, in
 int fir_tile_out(int decim, int aligned);   // outputs per FirTile of the kernel launch_fir_decimate() picks (aligned:
                                   // ring_len and ref_ring are multiples of 8 samples)
 extern int g_fft_force_radix2;    // 1: always the radix-2 LDS FFT kernel
+extern int g_fft_kernel;          // 1 (default): K1 = fft_mag_p32_kernel at N = 8192 / 16384; 0: fft_mag_r16_kernel
 int fir_needs_tile_list(int decim, int aligned);
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,

@@ -2714,6 +2714,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
+    if (!strcmp(key, "k1_kernel")) { irdm::g_fft_kernel = value; return 0; }
     return -1;
 }
 

@@ -17,7 +17,7 @@ extern "C" {
 
 // K1 over n_frames frames of `iq` (fmt 2 cf32, 1 ci16, 0 ci8): mag [n_frames][n]; variant 0: radix-16 kernel, 1: the same
 // with candidate lists (pre [n] given; counts [n_frames], entries [n_frames][cap]), 2: radix-2 LDS kernel.  Returns 0, or
-// 1 if this FFT size has no such kernel.
+// 1 if this FFT size has no such kernel.  variant + 4: the radix-16 kernel where the 32-points-per-lane kernel is the default.
 int detect_emul_k1(const void *iq, int fmt, int n, int n_frames, int variant, float *mag, const float *pre,
                    unsigned *counts, ListEntry *entries, int cap)
 {
@@ -26,6 +26,8 @@ int detect_emul_k1(const void *iq, int fmt, int n, int n_frames, int variant, fl
     for (int i = 0; i < n; i++) window[i] /= 0.42f;               // burst_detect.c:249-250, as csrc/pipeline.cpp prepares it
     std::vector<cfloat> tw = design_twiddles(n);
     const float2 *tw2 = reinterpret_cast<const float2 *>(tw.data());
+    g_fft_kernel = variant >= 4 ? 0 : 1;
+    variant &= 3;
     g_fft_force_radix2 = variant == 2;
     int rc;
     if (variant == 1) {
@@ -35,6 +37,7 @@ int detect_emul_k1(const void *iq, int fmt, int n, int n_frames, int variant, fl
         rc = launch_fft_mag(log_n, fmt, iq, window.data(), tw2, mag, n_frames, nullptr);
     }
     g_fft_force_radix2 = 0;
+    g_fft_kernel = 1;
     return rc;
 }
 

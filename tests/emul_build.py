@@ -9,7 +9,8 @@ Source changes made on the way (text substitutions on copies under tests/_build/
   * scan_fast.hip: `s_waitcnt` / `s_barrier` inline asm -> nothing / __syncthreads()
   * fir_reg.hip: the one `v_writelane_b32` inline asm -> hip_emul::writelane0
   * csrc/fir_mac.inc (generated gfx950 assembly) is replaced by tests/hip_emul/fir_mac.inc: the same multiply-add chains in
-    plain C++, products and sums rounded separately, same order."""
+    plain C++, products and sums rounded separately, same order.
+  * csrc/fft_bfly.inc (K1's butterflies: inline gfx950 assembly) likewise by tests/hip_emul/fft_bfly.inc."""
 import concurrent.futures
 import os
 import re
@@ -53,12 +54,14 @@ def build(force=False, sanitize=False):
         SO = os.path.join(ROOT, "tests", "_build", "libirdm_emul_asan.so")
         OUT = os.path.join(ROOT, "tests", "_build", "emul_asan")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(EMUL, "hip", "hip_runtime.h"),
-                                                                os.path.join(EMUL, "fir_mac.inc"), os.path.abspath(__file__)]
+                                                                os.path.join(EMUL, "fir_mac.inc"), os.path.join(EMUL, "fft_bfly.inc"),
+                                                                os.path.abspath(__file__)]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest(deps):
         return SO
     os.makedirs(OUT, exist_ok=True)
     shutil.copy(os.path.join(EMUL, "fir_mac.inc"), os.path.join(OUT, "fir_mac.inc"))
+    shutil.copy(os.path.join(EMUL, "fft_bfly.inc"), os.path.join(OUT, "fft_bfly.inc"))
     jobs = []
     for name in SOURCES:
         dst = os.path.join(OUT, name.replace(".hip", "_hip") .replace(".cpp", "_cpp") + ".cpp")

@@ -389,6 +389,29 @@ inline void __builtin_amdgcn_raw_buffer_store_b32(int v, __amdgpu_buffer_rsrc_t 
     if ((uint32_t)voff + 4u > r.num) return;
     memcpy(r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, &v, 4);
 }
+namespace hip_emul {
+struct u32x2 { uint32_t v[2]; };
+struct u32x4 { uint32_t v[4]; };
+}
+inline hip_emul::u32x2 __builtin_amdgcn_raw_buffer_load_b64(__amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    hip_emul::u32x2 v{};
+    if ((uint32_t)voff + 8u > r.num) return v;
+    memcpy(&v, r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, 8);
+    return v;
+}
+inline hip_emul::u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    hip_emul::u32x4 v{};
+    if ((uint32_t)voff + 16u > r.num) return v;
+    memcpy(&v, r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, 16);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(hip_emul::u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+    if ((uint32_t)voff + 16u > r.num) return;
+    memcpy(r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, &v, 16);
+}
 
 inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

@@ -8,6 +8,7 @@ emission order, ids, and the final baseline sums, bit for bit.  No GPU."""
 import ctypes as C
 import os
 import re
+import shutil
 import subprocess
 
 import numpy as np
@@ -155,13 +156,16 @@ def detect_emul():
     inc = os.path.join(out_dir, "detect_emul.inc")
     src = os.path.join(ROOT, "tests", "detect_emul.cpp")
     deps = [src, os.path.join(ROOT, "tests", "hip_emul", "hip", "hip_runtime.h")] + [
-        os.path.join(CSRC, h) for h in ("detect.hip", "host_design.cpp", "types.hpp", "kernels.hpp", "common.hpp")]
+        os.path.join(CSRC, h) for h in ("detect.hip", "host_design.cpp", "types.hpp", "kernels.hpp", "common.hpp")] + [
+        os.path.join(ROOT, "tests", "hip_emul", "fft_bfly.inc")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         text = open(os.path.join(CSRC, "detect.hip")).read()
         text, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) unsigned char (\w+)\[\];",
                           r"unsigned char *\1 = hip_emul::dyn_lds();", text)
         assert n >= 2
         open(inc, "w").write(text)
+        # (csrc/fft_bfly.inc is inline gfx950 assembly; tests/hip_emul/fft_bfly.inc restates it in C++)
+        shutil.copy(os.path.join(ROOT, "tests", "hip_emul", "fft_bfly.inc"), os.path.join(out_dir, "fft_bfly.inc"))
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-I" + os.path.join(ROOT, "tests", "hip_emul"), "-I" + out_dir, "-I" + CSRC, "-o", so, src])
     L = C.CDLL(so)
@@ -201,18 +205,21 @@ def test_k1_kernels_match_the_oracle_fft(detect_emul, fs):
         ref_mag, _, _ = oracle_detect(np.ascontiguousarray(as_cf), fs)
         assert ref_mag.shape[0] >= frames
         ref_mag = ref_mag[:frames]
-        for variant in (0, 2):
+        # variants 0 / 1 / 2: the default register kernel (32 points per lane at 8192 / 16384 points), the same with the
+        # candidate lists, the radix-2 LDS kernel; 4 / 5: the radix-16 kernel where it is no longer the default
+        for variant in (0, 2) + ((4,) if n >= 8192 else ()):
             rc, mag, _, _ = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, variant)
             assert rc == 0
             assert np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32)), (fs, fmt, variant)
-        if n >= 4096 and fmt == 2:
+        if n >= 4096:
             pre = (np.float32(0.5) * np.percentile(ref_mag, 99.0, axis=0)).astype(np.float32)
-            rc, mag, counts, entries = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, 1, pre=pre)
-            assert rc == 0 and np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32))
-            for f in range(frames):
-                want = {(int(b), float(ref_mag[f, b])) for b in np.nonzero(ref_mag[f] > pre)[0]}
-                got = {(entries[f * 4096 + i].bin, entries[f * 4096 + i].mag) for i in range(int(counts[f]))}
-                assert got == want, (fs, f)
+            for variant in (1,) + ((5,) if n >= 8192 and fmt == 2 else ()):
+                rc, mag, counts, entries = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, variant, pre=pre)
+                assert rc == 0 and np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32))
+                for f in range(frames):
+                    want = sorted((int(b), float(ref_mag[f, b])) for b in np.nonzero(ref_mag[f] > pre)[0])
+                    got = sorted((entries[f * 4096 + i].bin, entries[f * 4096 + i].mag) for i in range(int(counts[f])))
+                    assert got == want, (fs, fmt, variant, f)
 
 
 @pytest.mark.parametrize("name", ["too_long", "squelch", "dc_and_edges", "strong_simultaneous"])
