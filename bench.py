@@ -306,6 +306,34 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
     pipe.close()
 
 
+def rocprof_avg_ms(kernel, fs, density):
+    """average duration of `kernel` in the newest committed rocprofv3 --kernel-trace --stats summary of THIS configuration
+    (profiles/r<round>_kernel_stats.csv: 10 MHz, 10 bursts per Msample; ..._cfg5_12mhz_d40.csv: 12 MHz, 40), or None"""
+    import glob
+    import re
+    if fs == 10_000_000 and density == 10:
+        pat = r"r(\d+)_kernel_stats\.csv$"
+    elif fs == 12_000_000 and density == 40:
+        pat = r"r(\d+)_kernel_stats_cfg5_12mhz_d40\.csv$"
+    else:
+        return None
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats*.csv")):
+        m = re.search(pat, os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None
+    try:
+        for line in open(best[1]).read().splitlines()[1:]:
+            name, calls, total_ms, avg_us = line.rsplit(",", 4)[:4]
+            if kernel in name:
+                return {"avg_ms": round(float(avg_us) / 1e3, 4), "calls": int(calls), "file": os.path.basename(best[1])}
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,6 +426,7 @@ def main():
     packed = bool(args.packed)
     if packed:
         pipe.set_option("packed_records", 1)
+    pipe.set_option("kernel_clock", 1)      # the chip-filling kernels' own device spans (irdm_kernel_clock): roofline below
     poll_demods = pipe.poll_demods_packed_raw if packed else pipe.poll_demods_raw
     stream = None        # the chunk is complete in HBM before the timed region: nothing to order against
     # record gather to rank 0 (RCCL over xGMI): what frame_output_print needs of a demodulated frame (frame_output.c:
@@ -518,6 +547,8 @@ def main():
         gathered.zero_()
         dist.barrier()
     torch.cuda.synchronize()
+    pipe.kernel_clock(0, reset=True)            # (waits for the device: outside the timed region)
+    pipe.kernel_clock(1, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -570,8 +601,21 @@ def main():
     # what they wait for each other), so it is reported in stage_ms / stage_GBps but not as "the" kernel
     # (the decimator does 57 % of the step's algorithmic bytes and all of its arithmetic; K1 only where bursts are so few
     # that the decimator's launch is less than half of K1's)
-    dom = "fir" if ms["fir"] >= 0.5 * ms["fft_mag"] else "fft_mag"
-    ach = alg_bytes[dom] / (ms[dom] * 1e-3) / 1e9 if ms[dom] > 0 else 0.0
+    # ms_per_launch = the kernel's own span on the device, first wavefront in to last wavefront out (s_memrealtime stamps
+    # inside the kernel, irdm_kernel_clock), averaged over the launches of the timed region -- not the HIP-event bracket
+    # (stage_ms), which also holds the strip-geometry kernel and whatever the launch waited for in the queue.  The
+    # dominant kernel is the one of the two chip-filling kernels with the longer span per launch.
+    kclk = {}
+    for which, key in ((0, "fir"), (1, "fft_mag")):
+        sm, nl, _ = pipe.kernel_clock(which)
+        kclk[key] = {"ms": sm / nl if nl else 0.0, "launches": nl}
+    has_clock = kernels["fir"] == "fir_decimate_kernel_r" and kclk["fir"]["launches"] > 0
+    if has_clock:
+        dom = "fir" if kclk["fir"]["ms"] >= kclk["fft_mag"]["ms"] else "fft_mag"
+    else:
+        dom = "fir" if ms["fir"] >= 0.5 * ms["fft_mag"] else "fft_mag"
+    dom_ms = kclk[dom]["ms"] if kclk[dom]["launches"] > 0 else ms[dom]
+    ach = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # HBM traffic per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs and
     # corrected as MI355X_MICROARCH.md prescribes; profiles/summarize.py -> profiles/<round>_pmc.json)
     traffic = None
@@ -588,7 +632,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": kernels[dom], "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes": round(alg_bytes[dom]),
-                "ms_per_launch": round(ms[dom], 4),
+                "ms_per_launch": round(dom_ms, 4),
+                "ms_per_launch_source": ("device clock inside the kernel: first wavefront in .. last wavefront out, mean of %d launches"
+                                         % kclk[dom]["launches"]) if kclk[dom]["launches"] > 0 else "HIP-event bracket (no kernel clock in this kernel)",
+                "dominant_rule": "longer device span per launch of {decimator, K1}",
+                "kernel_clock_ms": {k: round(v["ms"], 4) for k, v in kclk.items()},
+                "kernel_ms_rocprof": rocprof_avg_ms(kernels[dom], fs, args.density),
                 "stage_ms": {k: round(v, 4) for k, v in ms.items()},
                 "stage_ms_alone": None,
                 "host_ms": {k: round(v / K, 3) for k, v in host.items()},
@@ -627,12 +676,14 @@ def main():
     # ---- the same stages with one kernel on the chip at a time (pipeline_depth 0), and the chunk's records for the
     #      parity check below ----
     alone = None
+    alone_clock = {}
     gpu_recs = None
     if rank == 0 and world == 1 and args.alone_steps > 0:
         p0 = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=n, max_bursts_per_chunk=8192, device=local, pipeline_depth=0)
         for kv in args.opt:
             key, val = kv.split("=")
             p0.set_option(key, int(val))
+        p0.set_option("kernel_clock", 1)
         acc = {k: 0.0 for k in stage}
         for i in range(args.alone_steps):
             p0.feed_device(x.data_ptr(), n, None)
@@ -647,6 +698,10 @@ def main():
                     acc[kk] += t[kk]
         d = max(args.alone_steps - 1, 1)
         alone = {k: round(v / d, 4) for k, v in acc.items()}
+        alone_clock = {}
+        for which, key in ((0, "fir"), (1, "fft_mag")):
+            sm, nl, last = p0.kernel_clock(which)
+            alone_clock[key] = round(last, 4)           # (the last launch: the first ones include module loading)
         p0.close()
 
     # ---- BASELINE config 2: detect-only (K1 + scan, burst records) on the same chunk ----
@@ -817,9 +872,12 @@ def main():
 
     if rank == 0:
         roofline["stage_ms_alone"] = alone
-        if alone and alone.get(dom, 0) > 0:
-            roofline["achieved_alone"] = round(alg_bytes[dom] / (alone[dom] * 1e-3) / 1e9, 2)
-            roofline["frac_alone"] = round(roofline["achieved_alone"] / HBM_PEAK_GBS, 5)
+        if alone:
+            roofline["kernel_clock_ms_alone"] = alone_clock
+            a_ms = alone_clock.get(dom, 0) or alone.get(dom, 0)
+            if a_ms > 0:
+                roofline["achieved_alone"] = round(alg_bytes[dom] / (a_ms * 1e-3) / 1e9, 2)
+                roofline["frac_alone"] = round(roofline["achieved_alone"] / HBM_PEAK_GBS, 5)
         out = {
             "metric": "IQ Msamples/s end-to-end (detect->demod), %d MHz %s" % (fs // 1_000_000, args.format),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -832,6 +890,7 @@ def main():
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
                        "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": look,
+                       "packed_records": packed,      # the timed context returns 176-byte frame records (what frame_output_print reads: no LLRs)
                        "records": ({"produced": int(counts[1].item()), "sent": int(counts[2].item()),
                                     "gathered_on_rank0": int(gathered.item())} if world > 1 else None),
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",

@@ -356,11 +356,13 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  * "scan_mode" (0 = band-parallel speculative scan (scan_band.hip) where the FFT size supports it, with the sequential
  *   scans as its exact fallback -- default; 1 = dense sequential scan only; 2 / 3 = round 1's sparse leader scan on one
  *   CU / with "scan_updaters" baseline-update workgroups, dense fallback; 4 = band scan with the dense scan as fallback),
+ * "kernel_clock" (default 0; see irdm_kernel_clock), "k1_kernel" (default 1: K1 = the 32-points-per-lane streaming kernel
+ *   at 8192 / 16384 points; 0 = the radix-16 kernel of rounds 1-3),
  * "scan_updaters" (1..32, default 7: updater workgroups of the multi-CU sparse scan),
  * "k1_lists" (default 1: the FFT kernel writes the band scan's candidate lists; 0 = a prefilter pass does),
  * "k1_first" (default 1: a per-burst chain is enqueued behind the FFT of the newest chunk),
  * "band_first" (default 0 = as many band-scan rounds up front as the previous chunk needed; n = always n; test hook),
- * kernel-variant switches for A/B runs and tests: "fir_layout" (2 persistent decimator -- default, 1 / 0 one tile per
+ * kernel-variant switches for A/B runs and tests: "fir_layout" (3 register-resident decimator -- default at M = 40 / 48; 2 persistent LDS decimator, 1 / 0 one tile per
  *   workgroup, column-major / polyphase rows), "fir_budget" (tiles per workgroup of the persistent decimator, default 4),
  *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof".
  * Stats (irdm_get_stat): "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks", "band_rounds",
@@ -371,6 +373,12 @@ int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);
 /* per-stage device time of the last chunk in milliseconds (hipEvent):
  * [0] fft+mag  [1] detector scan  [2] rotate+FIR decimate  [3] downmix post  [4] demod  [5] total */
 int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n);
+/* Option "kernel_clock" 1: the chip-filling kernels stamp the 100 MHz device clock when their first wavefront starts and
+ * when their last one ends (s_memrealtime, per launch); this returns the spans summed over the launches since the last
+ * reset -- the kernel's own duration on the device, free of the dispatch wait a host-side event bracket includes (what
+ * bench.py's roofline divides the algorithmic bytes by).  which: 0 = the register-resident decimator
+ * (fir_decimate_kernel_r), 1 = K1 (fft_mag_p32_kernel / fft_mag_r16_kernel).  Waits for the device.  0 ok, -1 error. */
+int irdm_kernel_clock(irdm_pipeline_t *p, int which, double *sum_ms, uint64_t *launches, double *last_ms, int reset);
 
 /* ------------------------------------------------------------------ */
 /* 3. RAW line (frame_output.c:160-199)                                 */

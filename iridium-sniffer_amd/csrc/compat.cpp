@@ -91,10 +91,27 @@ struct _burst_detector {
     uint64_t total;
     burst_callback_t last_cb;           // the callback of the last feed: the tail of the stream is delivered through it
     void *last_user;
-    // what main.c's stats thread reads while the detector thread feeds (main.c:455-456): refreshed after every feed
-    std::atomic<int> active;
-    std::atomic<float> noise_floor, peak_signal;
+    // what main.c's stats thread reads while the detector thread feeds (main.c:455-456).  The reference's getters are free
+    // (plain reads of the detector's fields); here the figures live on the device, so they are fetched when a getter asks
+    // and a feed has run since the last fetch -- not after every 32768-sample block (a device-wide wait and three
+    // copies 305 times a second at 10 MHz).  `mu` keeps the getter's fetch and the detector thread's feed apart.
+    std::recursive_mutex mu;        // (recursive: a burst callback may ask the getters)
+    bool stats_dirty;
+    int active;
+    float noise_floor, peak_signal;
 };
+
+static void detector_refresh(_burst_detector *d)
+{
+    if (!d->p || !d->stats_dirty) return;
+    irdm_detector_stats_t st;
+    if (irdm_detector_stats(d->p, &st) == 0) {
+        d->active = st.active_bursts;
+        d->noise_floor = st.noise_floor_dbfs_hz;
+        d->peak_signal = st.peak_signal_db;
+    }
+    d->stats_dirty = false;
+}
 
 extern "C" _burst_detector *burst_detector_create(burst_config_t *config)
 {
@@ -118,6 +135,7 @@ extern "C" _burst_detector *burst_detector_create(burst_config_t *config)
     d->total = 0;
     d->last_cb = nullptr;
     d->last_user = nullptr;
+    d->stats_dirty = false;
     d->active = 0;
     d->noise_floor = 0.0f;             // burst_detect.c:364-365: no baseline yet
     d->peak_signal = 0.0f;
@@ -171,17 +189,13 @@ static void detector_emit(_burst_detector *d, int emitted, burst_callback_t cb, 
         if (cb) cb(b, user);                   // ownership of b and b->samples passes to the callee
         else { free(s); free(b); }
     }
-    irdm_detector_stats_t st;
-    if (irdm_detector_stats(d->p, &st) == 0) {
-        d->active = st.active_bursts;
-        d->noise_floor = st.noise_floor_dbfs_hz;
-        d->peak_signal = st.peak_signal_db;
-    }
+    d->stats_dirty = true;
 }
 
 static void detector_feed(_burst_detector *d, const void *iq, size_t num_samples, int fmt, burst_callback_t cb, void *user)
 {
     if (!d || !iq || !num_samples) return;
+    std::lock_guard<std::recursive_mutex> lk(d->mu);
     if (!d->p && detector_open(d, fmt) != 0) {
         fprintf(stderr, "irdm_hip: burst_detector_feed: no device context\n");
         return;
@@ -224,13 +238,32 @@ extern "C" void burst_detector_feed_cf32(_burst_detector *det, const float *iq, 
 extern "C" uint64_t burst_detector_total_count(_burst_detector *det) { return det ? det->total : 0; }
 
 // burst_detect.c:355-395, as main.c's stats thread calls them (any thread; values as of the end of the last feed)
-extern "C" int burst_detector_active_count(_burst_detector *det) { return det ? det->active.load() : 0; }
-extern "C" float burst_detector_noise_floor(_burst_detector *det) { return det ? det->noise_floor.load() : 0.0f; }
-extern "C" float burst_detector_peak_signal(_burst_detector *det) { return det ? det->peak_signal.load() : 0.0f; }
+extern "C" int burst_detector_active_count(_burst_detector *det)
+{
+    if (!det) return 0;
+    std::lock_guard<std::recursive_mutex> lk(det->mu);
+    detector_refresh(det);
+    return det->active;
+}
+extern "C" float burst_detector_noise_floor(_burst_detector *det)
+{
+    if (!det) return 0.0f;
+    std::lock_guard<std::recursive_mutex> lk(det->mu);
+    detector_refresh(det);
+    return det->noise_floor;
+}
+extern "C" float burst_detector_peak_signal(_burst_detector *det)
+{
+    if (!det) return 0.0f;
+    std::lock_guard<std::recursive_mutex> lk(det->mu);
+    detector_refresh(det);
+    return det->peak_signal;
+}
 
 extern "C" void burst_detector_destroy(_burst_detector *det)
 {
     if (!det) return;
+    det->mu.lock();
     if (det->p && !det->stage.empty()) {
         // The end of the stream: the samples that never made up a whole 32768-sample block.  The reference's reader
         // feeds its short last read like any other (main.c:223-271) and the detector processes every whole frame of it
@@ -247,6 +280,7 @@ extern "C" void burst_detector_destroy(_burst_detector *det)
         fprintf(stderr, "burst_detect: tagged %llu bursts total\n", (unsigned long long)irdm_tagged_bursts(det->p));
         irdm_destroy(det->p);
     }
+    det->mu.unlock();
     delete det;
 }
 

@@ -457,34 +457,49 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
         const __amdgpu_buffer_rsrc_t r_out = k1_rsrc(mag + (size_t)frame * N, sizeof(float) * N);
         const __amdgpu_buffer_rsrc_t r_pre = k1_rsrc(pre, sizeof(float) * N);
         ListEntry *const list = LISTS ? entries + (size_t)frame * cap : nullptr;
+        // The candidate tests leave wavefront masks in scalar registers (a v_cmp each, nothing else on the vector unit);
+        // a wavefront with candidates in a half of its accesses takes ONE slot range for all of them from the frame's
+        // counter (one LDS atomic) and every candidate's lane writes its entry at  base + the candidates of the tests
+        // before + its rank among the test's lanes.
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int k = 4 * (t + T * i);
-            const v4f m = *reinterpret_cast<const v4f *>(M + k);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k1_u32x4, m), r_out, t * 16, i * T * 16, 2);
+        for (int h = 0; h < 2; h++) {
+            v4f m[4];
+            unsigned long long hit[16];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; i4++) {
+                const int i = 4 * h + i4;
+                m[i4] = *reinterpret_cast<const v4f *>(M + 4 * (t + T * i));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k1_u32x4, m[i4]), r_out, t * 16, i * T * 16, 2);
+                if (LISTS) {
+                    const v4f pr = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r_pre, t * 16, i * T * 16, 0));
+                    hit[4 * i4 + 0] = __builtin_amdgcn_ballot_w64(m[i4].x > pr.x);
+                    hit[4 * i4 + 1] = __builtin_amdgcn_ballot_w64(m[i4].y > pr.y);
+                    hit[4 * i4 + 2] = __builtin_amdgcn_ballot_w64(m[i4].z > pr.z);
+                    hit[4 * i4 + 3] = __builtin_amdgcn_ballot_w64(m[i4].w > pr.w);
+                }
+            }
             if (LISTS) {
-                const v4f pr = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r_pre, t * 16, i * T * 16, 0));
-                const bool h0 = m.x > pr.x, h1 = m.y > pr.y, h2 = m.z > pr.z, h3 = m.w > pr.w;
-                if (__builtin_amdgcn_ballot_w64(h0 || h1 || h2 || h3) != 0) {      // (wavefront-uniform branch)
-                    // one LDS atomic per wavefront and access for all of its candidates; a lane's slot is the base the
-                    // atomic returned + the candidates of the components before + its rank among the component's lanes
-                    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
-                    const unsigned long long b2 = __builtin_amdgcn_ballot_w64(h2), b3 = __builtin_amdgcn_ballot_w64(h3);
-                    const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
-                    int base = 0;
-                    if ((t & 63) == 0) base = atomicAdd(&s_cnt, n0 + n1 + n2 + n3);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    const unsigned long long below = (1ull << (t & 63)) - 1ull;
-                    const float mv[4] = { m.x, m.y, m.z, m.w };
-                    const bool hv[4] = { h0, h1, h2, h3 };
-                    const unsigned long long bv[4] = { b0, b1, b2, b3 };
-                    const int ov[4] = { 0, n0, n0 + n1, n0 + n1 + n2 };
+                unsigned long long any = 0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const int slot = base + ov[c] + __popcll(bv[c] & below);
-                        if (hv[c] && slot < cap) {
-                            list[slot].bin = k + c;
-                            list[slot].mag = mv[c];
+                for (int j = 0; j < 16; j++) any |= hit[j];
+                if (any != 0) {                                              // (wavefront-uniform)
+                    int total = 0;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) total += __popcll(hit[j]);
+                    int base = 0;
+                    if ((t & 63) == 0) base = atomicAdd(&s_cnt, total);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    const unsigned long long below = (1ull << (t & 63)) - 1ull, me = 1ull << (t & 63);
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        if (hit[j] != 0) {                                   // (wavefront-uniform)
+                            const int slot = base + __popcll(hit[j] & below);
+                            if ((hit[j] & me) && slot < cap) {
+                                const int i4 = j >> 2, c = j & 3;
+                                list[slot].bin = 4 * (t + T * (4 * h + i4)) + c;
+                                list[slot].mag = c == 0 ? m[i4].x : (c == 1 ? m[i4].y : (c == 2 ? m[i4].z : m[i4].w));
+                            }
+                            base += __popcll(hit[j]);
                         }
                     }
                 }

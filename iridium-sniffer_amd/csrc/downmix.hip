@@ -774,7 +774,7 @@ static int launch_fir_w_fmt(const SampleSource &src, const FirGeom *geom, unsign
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
-                        hipStream_t stream)
+                        hipStream_t stream, unsigned long long *kclk)
 {
     if (n_tiles <= 0) return 0;
 #define IRDM_LAUNCH_FIR_M(MM)                                                                                  \
@@ -794,13 +794,13 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
                            work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
-    const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0;
+    const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
     if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
                            fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
-        return launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream) == 0 ? 0 : -1;
+        return launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
     }
     if (fir_wide_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
@@ -886,6 +886,35 @@ int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneB
 }
 
 int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream);
+
+// kernel clock (common.hpp): fold the per-slot entry / exit stamps of the launch that has just ended into the record's
+// sums and re-arm the slots
+__global__ __launch_bounds__(64) void kclk_fold_kernel(unsigned long long *__restrict__ k)
+{
+    const int l = threadIdx.x;
+    unsigned long long lo = k[l], hi = k[64 + l];
+    k[l] = ~0ull;
+    k[64 + l] = 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long lo2 = ((unsigned long long)__shfl_xor((unsigned)(lo >> 32), d) << 32) | __shfl_xor((unsigned)lo, d);
+        const unsigned long long hi2 = ((unsigned long long)__shfl_xor((unsigned)(hi >> 32), d) << 32) | __shfl_xor((unsigned)hi, d);
+        lo = lo2 < lo ? lo2 : lo;
+        hi = hi2 > hi ? hi2 : hi;
+    }
+    if (l == 0 && lo != ~0ull && hi >= lo) {
+        k[128] += hi - lo;
+        k[129] += 1ull;
+        k[130] = hi - lo;
+    }
+}
+
+int launch_kclk_fold(unsigned long long *kclk, hipStream_t stream)
+{
+    if (!kclk) return 0;
+    hipLaunchKernelGGL(kclk_fold_kernel, dim3(1), dim3(64), 0, stream, kclk);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t stream);
 
 // Device memory -> pinned host memory, 16 bytes per lane, when the stream gets there.  (Results of the per-burst chain:

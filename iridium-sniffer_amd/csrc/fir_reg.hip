@@ -30,12 +30,18 @@
 #include "kernels.hpp"
 #include "burst_src.hpp"
 
+// (A/B builds only: -DIRDM_FIR_KCLK=0 compiles the kernel-clock stamps out of the decimator)
+#ifndef IRDM_FIR_KCLK
+#define IRDM_FIR_KCLK 1
+#endif
+
 namespace irdm {
 
 #include "fir_mac.inc"
 
 int g_fir_strip = 3;           // double blocks (128 columns) per strip: a strip yields 128*g_fir_strip - NR outputs
 int g_fir_grid = 0;            // > 0: at most this many single-wavefront workgroups in flight, each walking strips (0: one per strip)
+int g_fir_slice = 0;           // > 0: strips per launch (the chunk's strips as several launches); 0: one launch
 
 template <int M>
 struct FirR {
@@ -119,11 +125,12 @@ __device__ __forceinline__ float lane_shr1(float v)
 template <int M, int FMT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_r(
     SampleSource src, const FirGeom *__restrict__ geom, const float *__restrict__ taps,
-    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles)
+    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk)
 {
     using R = FirR<M>;
     constexpr int NR = R::NR, REM = R::REM;
     const int lane = threadIdx.x;
+    if (IRDM_FIR_KCLK) kclk_enter(kclk);
     // (a grid smaller than the strip count -- option fir_grid -- walks the strips with the grid's stride)
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -292,21 +299,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
     }
+    if (IRDM_FIR_KCLK) kclk_leave(kclk);
 }
 
 template <int M>
 static int launch_fir_r_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
-                            const float2 *rot_table, float2 *dec, hipStream_t stream)
+                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
 {
-    const int grid = g_fir_grid > 0 && g_fir_grid < n_tiles ? g_fir_grid : n_tiles;
-    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles);
-    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles);
-    else hipLaunchKernelGGL((fir_decimate_kernel_r<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles);
+    // Slices (option fir_slice): the strips of a chunk as several launches of `g_fir_slice` strips each.  A wavefront of
+    // this kernel owns half a SIMD's registers for its whole life and the dispatcher refills a freed slot from the SAME
+    // launch: next to one launch of 12 000 strips a pass of the detector scan (another stream, higher priority) that
+    // arrives after the first generation of wavefronts waits until the launch has drained (measured: passes of 60-90 us
+    // stretched to 350-390 us).  The strips of a generation end together anyway (equal lengths), so a launch boundary per
+    // generation costs a dispatch (~2 us) and lets everything that is waiting in.
+    const int slice = g_fir_slice > 0 && g_fir_grid <= 0 ? g_fir_slice : n_tiles;
+    for (int t0 = 0; t0 < n_tiles; t0 += slice) {
+        const int cnt = n_tiles - t0 < slice ? n_tiles - t0 : slice;
+        const int grid = g_fir_grid > 0 && g_fir_grid < cnt ? g_fir_grid : cnt;
+        if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom + t0, taps, rot_table, dec, cnt, kclk);
+        else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom + t0, taps, rot_table, dec, cnt, kclk);
+        else hipLaunchKernelGGL((fir_decimate_kernel_r<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom + t0, taps, rot_table, dec, cnt, kclk);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
-                   const float2 *rot_table, float2 *dec, hipStream_t stream)
+                   const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
 {
     // every boundary a column can meet must be a multiple of 8 samples (see the fetch); chunks start at multiples of the
     // feed block, which is a multiple of the FFT size
@@ -317,8 +335,8 @@ int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, in
         return 1;
     }
     switch (decim) {
-    case 40: return launch_fir_r_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream);
-    case 48: return launch_fir_r_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream);
+    case 40: return launch_fir_r_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
+    case 48: return launch_fir_r_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
     default: return 1;
     }
 }

@@ -71,7 +71,9 @@ struct BandWork {                        // device workspace, carved out of one 
                                          // when idle); [4] the last scan committed; [5] serial number of a void launch
 };
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
-extern int g_band_plan_ahead;            // 1: plan passes launched ahead on the side stream (default 0, or IRDM_PLAN_AHEAD=1)
+extern int g_band_plan_ahead;            // 1: plan passes launched ahead on the side stream (-1 until band_resolve_env(): IRDM_PLAN_AHEAD or the default)
+constexpr int kBandPlanAheadDefault = 0;
+void band_resolve_env();
 extern int g_band_fuse_commit;           // 1 (default): the accepting plan pass runs the commit itself
 extern int g_band_plan_threads;          // threads of the plan pass's one workgroup: 256, 512 or 1024 (default)
 extern int g_band_walk_wave;             // 1 (default): the walk pass with a wavefront per band and segment; 0: a lane per band
@@ -115,10 +117,12 @@ extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the ot
 // fir_reg.hip: the register-resident decimator (M = 40, 48)
 extern int g_fir_strip;           // double blocks of 128 columns per strip
 extern int g_fir_grid;            // workgroups of the register-resident decimator (0: one per strip)
+extern int g_fir_slice;           // strips per launch of the register-resident decimator (0: all in one launch)
 int fir_reg_supported(int decim);
 int fir_reg_tile_out(int decim);
 int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
-                   const float2 *rot_table, float2 *dec, hipStream_t stream);   // 0 ok, -1 error, 1 not applicable
+                   const float2 *rot_table, float2 *dec, hipStream_t stream,
+                   unsigned long long *kclk = nullptr);   // 0 ok, -1 error, 1 not applicable
 int fir_tile_out(int decim, int aligned);   // outputs per FirTile of the kernel launch_fir_decimate() picks (aligned:
                                   // ring_len and ref_ring are multiples of 8 samples)
 extern int g_fft_force_radix2;    // 1: always the radix-2 LDS FFT kernel
@@ -127,7 +131,9 @@ int fir_needs_tile_list(int decim, int aligned);
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
-                        hipStream_t stream);
+                        hipStream_t stream, unsigned long long *kclk = nullptr);   // kclk: the register-resident kernel's clock record
+// folds a kernel-clock record's slots into its sums and re-arms them (common.hpp); enqueue behind the kernel
+int launch_kclk_fold(unsigned long long *kclk, hipStream_t stream);
 int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneBurst *hp_gone, uint32_t *hp_hdr,
                        const void *ctl, void *hp_ctl, int ctl_bytes, hipStream_t stream);
 int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t stream);

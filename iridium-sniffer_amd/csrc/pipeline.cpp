@@ -218,6 +218,7 @@ struct irdm_pipeline {
     int feed_block, decim, out_rate;
     float peak_signal_db;    // burst_detector_peak_signal over the finished bursts (starts at 0 like the reference's calloc)
     bool dev_cfo;            // the fine-CFO libm step runs on the device (the port reproduces this host's cexpf)
+    bool dev_cfo_ok;         // irdm_create's self-check: libm_port.hpp reproduces THIS host's cexpf (option host_cfo cannot override a failed check)
     float sps;
     uint64_t ref_ring, ring_len;
     size_t l_cap;
@@ -382,6 +383,10 @@ struct irdm_pipeline {
     std::vector<irdm_burst_t> last_bursts;
     float last_ms[6];
     int keep_frame_samples;
+    // kernel clock (option "kernel_clock", common.hpp): records 0..2 the decimator of bc[0..2], 3..5 K1 of feed slot 0..2
+    unsigned long long *d_kclk = nullptr;
+    int kernel_clock = 0;
+    unsigned long long *kclk_rec(int i) const { return kernel_clock && d_kclk ? d_kclk + (size_t)i * kKClkWords : nullptr; }
 };
 
 // The rotator checkpoint table (4.5 GB at 10 MHz, 10.9 GB at 12 MHz) is a function of the FFT size and the longest burst
@@ -449,7 +454,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_fir_off, p->d_mag2, p->d_mag3, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
                      p->k1_pre[0] != p->d_pre ? p->k1_pre[0] : nullptr, p->k1_counts[0] != p->d_counts ? p->k1_counts[0] : nullptr,
                      p->k1_entries[0] != p->d_entries ? p->k1_entries[0] : nullptr, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
-                     p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin };
+                     p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin, p->d_kclk };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (int s = 0; s < 2; s++) {
@@ -520,6 +525,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         fprintf(stderr, "irdm_hip: no HIP device -- there is no CPU fallback in this library\n");
         return nullptr;
     }
+    irdm::band_resolve_env();
     if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
     // IRDM_CREATE_DEBUG: where the time and the device memory of a context go (stderr)
     const bool dbg = getenv("IRDM_CREATE_DEBUG") != nullptr;
@@ -790,6 +796,13 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_mc_done, unsigned, 32 * 16);
     }
     mark("per-burst scratch, lists");
+    AL(p->d_kclk, unsigned long long, (size_t)6 * kKClkWords);
+    if (ok) {
+        std::vector<unsigned long long> init((size_t)6 * kKClkWords, 0ull);
+        for (int r = 0; r < 6; r++)
+            for (int i = 0; i < 64; i++) init[(size_t)r * kKClkWords + i] = ~0ull;
+        ok = hipMemcpy(p->d_kclk, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     p->band_ok = band_scan_supported(P, nullptr, 1, 0) != 0;
     if (p->band_ok) {
         AL(p->d_smin, float, (size_t)P.n);
@@ -926,6 +939,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             p->dev_cfo = false;
         }
     }
+    p->dev_cfo_ok = p->dev_cfo;
     mark("libm self-check");
     p->cfo_thread = std::thread(cfo_helper_main, p);
     mark("done");
@@ -1182,7 +1196,9 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     b.n = nb;
     b.recs.assign(nb, irdm_burst_t());
     size_t n_tiles = 0;
-    const int fir_aligned = p->ring_len % 8 == 0 && p->ref_ring % 8 == 0;
+    // (the register-resident decimator also needs the chunk to start at a multiple of 8 samples: a caller's burst window
+    // presented as a chunk -- irdm_downmix_burst -- may not; such sources take the LDS kernel)
+    const int fir_aligned = p->ring_len % 8 == 0 && p->ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
     const int tile_out = fir_tile_out(p->decim, fir_aligned);
     for (int i = 0; i < nb; i++) {
         const GoneBurst &g = gone_list[i];
@@ -1253,7 +1269,8 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     if (tile_list && n_tiles && launch_copy_words(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
-                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st) != 0)
+                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st,
+                            p->kclk_rec((int)(&b - p->bc))) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
     if (launch_downmix_post1(b.d_work, nb, b.d_dec, p->dec_stride, b.d_lpf, p->d_noise_taps,
@@ -1309,12 +1326,12 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_packed, b.d_packed,
                                  sizeof(DemodPacked) * nb, st) != 0)
             return -1;
-        return 0;
+        return launch_kclk_fold(p->kclk_rec((int)(&b - p->bc)), st);
     }
     if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_demod, b.d_demod, sizeof(DemodOut) * nb,
                              st) != 0)
         return -1;
-    return 0;
+    return launch_kclk_fold(p->kclk_rec((int)(&b - p->bc)), st);
 }
 
 // returns the number of bursts whose records were emitted, -1 on error
@@ -2056,13 +2073,16 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
     if (p->k1_lists && p->host_primed && scan_pick(p) == 2 && p->k1_pre[ls] && n_frames > 0) {
         if (launch_prefilter_threshold(p->d_sum, P.threshold, p->k1_pre[ls], P.n, p->fstream) != 0) return -1;
         const int rc = launch_fft_mag_lists(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->k1_pre[ls],
-                                            p->k1_counts[ls], p->k1_entries[ls], band_list_cap(P.n), p->fstream);
+                                            p->k1_counts[ls], p->k1_entries[ls], band_list_cap(P.n), p->fstream,
+                                            p->kclk_rec(3 + ls));
         if (rc < 0) return -1;
         f.lists = rc == 0;
     }
-    if (!f.lists && launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream) != 0)
+    if (!f.lists && launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream,
+                                   p->kclk_rec(3 + ls)) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(f.ev_k1, p->fstream));
+    if (n_frames > 0 && launch_kclk_fold(p->kclk_rec(3 + ls), p->fstream) != 0) return -1;   // (behind the event the scan waits for)
     // this chunk into the history ring, behind K1 on its stream (the ring keeps the chunks the per-burst chains in
     // flight still read: the copy never overwrites them)
     if (p->depth && !in_ring && ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
@@ -2684,7 +2704,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "packed_records")) { p->packed_records = value; return 0; }
-    if (!strcmp(key, "host_cfo")) { p->dev_cfo = value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
+    if (!strcmp(key, "host_cfo")) { p->dev_cfo = p->dev_cfo_ok && value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
     if (!strcmp(key, "scan_updaters")) { if (value < 1 || value > 32) return -1; p->mc_updaters = value; return 0; }
     if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
@@ -2701,6 +2721,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
+    if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
     if (!strcmp(key, "band_sum_bins")) { irdm::g_band_sum_bins = value; return 0; }
@@ -2711,6 +2732,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_fuse_commit")) { irdm::g_band_fuse_commit = value; return 0; }
     if (!strcmp(key, "band_plan_ahead")) { irdm::g_band_plan_ahead = value != 0; return 0; }
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
+    if (!strcmp(key, "kernel_clock")) { p->kernel_clock = value != 0; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
@@ -2742,6 +2764,33 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
     return -1;
+}
+
+// Kernel clock (option "kernel_clock" 1): the device's own record of a kernel's launches -- first wavefront in to last
+// wavefront out, s_memrealtime -- summed since the last reset.  which: 0 the register-resident decimator, 1 K1.
+extern "C" int irdm_kernel_clock(irdm_pipeline_t *p, int which, double *sum_ms, uint64_t *launches, double *last_ms, int reset)
+{
+    if (!p || !p->d_kclk || which < 0 || which > 1) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    std::vector<unsigned long long> h((size_t)6 * kKClkWords);
+    if (hipMemcpy(h.data(), p->d_kclk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    unsigned long long ticks = 0, n = 0, last = 0;
+    for (int r = 3 * which; r < 3 * which + 3; r++) {
+        ticks += h[(size_t)r * kKClkWords + 128];
+        n += h[(size_t)r * kKClkWords + 129];
+        if (h[(size_t)r * kKClkWords + 130] > last) last = h[(size_t)r * kKClkWords + 130];
+    }
+    if (sum_ms) *sum_ms = (double)ticks * 1e-5;          // 10 ns ticks
+    if (launches) *launches = n;
+    if (last_ms) *last_ms = (double)last * 1e-5;
+    if (reset) {
+        for (int r = 3 * which; r < 3 * which + 3; r++) {
+            unsigned long long z[3] = { 0, 0, 0 };
+            if (hipMemcpy(p->d_kclk + (size_t)r * kKClkWords + 128, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        }
+    }
+    return 0;
 }
 
 extern "C" int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n)

@@ -31,6 +31,8 @@
 //                          ascending bin -- the order of :551/:569), finished bursts in emission order, the bursts
 //                          carried to the next chunk, DetState, the new sums
 //   history (512 WGs)      the last <= 512 update frames' magnitude rows become the history ring
+#include <atomic>
+#include <mutex>
 #include "common.hpp"
 #include "types.hpp"
 #include "kernels.hpp"
@@ -1382,6 +1384,16 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
 
 // Enqueue the whole band scan of one chunk on `stream`.  Nothing of the carried state (st, sum, hist) is written
 // unless BandCtl::status ends as 1 (accepted); the caller reads the control block afterwards.
+// IRDM_PLAN_AHEAD in the environment overrides the default of "band_plan_ahead"; resolved once per process (irdm_create)
+void band_resolve_env()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("IRDM_PLAN_AHEAD");
+        if (g_band_plan_ahead < 0) g_band_plan_ahead = e ? (atoi(e) ? 1 : 0) : kBandPlanAheadDefault;
+    });
+}
+
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
@@ -1392,15 +1404,14 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
     // verdict is still open (status 0, no flags), the rest up to kBandRounds with round_begin = kBandFirst: everything a
     // round needs from the one before lives in the workspace.
-    if (g_band_plan_ahead < 0) {
-        const char *e = getenv("IRDM_PLAN_AHEAD");
-        g_band_plan_ahead = e && atoi(e) ? 1 : 0;
-    }
+    if (g_band_plan_ahead < 0) band_resolve_env();
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
-    static unsigned launch_serial = 0;
-    launch_serial = launch_serial + 1 ? launch_serial + 1 : 1;      // (never 0: the idle value of bar[5])
-    P.serial = (int32_t)launch_serial;
+    // (one counter for all contexts of the process, fed from any thread: two launches never share a serial number)
+    static std::atomic<unsigned> launch_serial{ 0 };
+    unsigned serial = launch_serial.fetch_add(1) + 1;
+    if (serial == 0) serial = launch_serial.fetch_add(1) + 1;       // (never 0: the idle value of bar[5])
+    P.serial = (int32_t)serial;
     P.chained = chained;
     P.selfcheck = g_band_selfcheck;
     P.ahead = (g_band_plan_ahead && !g_band_coop && side && plan_ev && W.walk_host) ? 1 : 0;

@@ -164,6 +164,7 @@ def lib():
         L.irdm_get_stat.argtypes = [C.c_void_p, C.c_char_p]
         L.irdm_get_stat.restype = C.c_int64
         L.irdm_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+        L.irdm_kernel_clock.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int]
         L.irdm_format_raw.argtypes = [C.POINTER(Demod), C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         L.irdm_version.restype = C.c_char_p
         _lib = L
@@ -484,6 +485,14 @@ class Pipeline:
         if got < 0:
             raise RuntimeError("irdm_burst_samples failed")
         return out[:2 * got].view(np.complex64)
+
+    def kernel_clock(self, which, reset=False):
+        """(sum of the launches' device spans in ms, launches, last span in ms) of the decimator (0) / K1 (1); option
+        kernel_clock must be on"""
+        sm, n, last = C.c_double(0), C.c_uint64(0), C.c_double(0)
+        if self.L.irdm_kernel_clock(self.h, which, C.byref(sm), C.byref(n), C.byref(last), 1 if reset else 0) != 0:
+            raise RuntimeError("irdm_kernel_clock failed")
+        return sm.value, int(n.value), last.value
 
     def timings(self):
         t = (C.c_float * 6)()
