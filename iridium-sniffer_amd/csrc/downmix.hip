@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     int decim, int row, const float *__restrict__ taps, const int *__restrict__ tap_off,
     const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride)
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride, int order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
@@ -160,7 +160,31 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     }
     __syncthreads();
 
-    if (tid < n_out) {
+    if (tid < n_out && order == 1) {
+        // the order of the reference's AVX2 kernel (simd_avx2.c:62-108, option fir_order 1; see fir_reg.hip,
+        // fir_decimate_kernel_f): tap k into accumulator k % 4 with a fused multiply-add, horizontal sum, then the one
+        // tap the vector loop leaves over with a separately rounded product and sum
+        float ar[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, ai[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        const unsigned char *col = reinterpret_cast<const unsigned char *>(s + tid);
+        static_assert((kFirTaps - 1) % 4 == 0, "the vector loop takes all taps but the last");
+        for (int k0 = 0; k0 < kFirTaps - 1; k0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float2 v = *reinterpret_cast<const float2 *>(col + tap_off[k0 + u]);
+                const float t = taps[k0 + u];
+                ar[u] = __builtin_fmaf(t, v.x, ar[u]);
+                ai[u] = __builtin_fmaf(t, v.y, ai[u]);
+            }
+        }
+        float sr = (ar[0] + ar[2]) + (ar[1] + ar[3]), si = (ai[0] + ai[2]) + (ai[1] + ai[3]);
+        {
+            const float2 v = *reinterpret_cast<const float2 *>(col + tap_off[kFirTaps - 1]);
+            const float t = taps[kFirTaps - 1];
+            sr += t * v.x;
+            si += t * v.y;
+        }
+        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(sr, si);
+    } else if (tid < n_out) {
         // 801 taps, k ascending, two independent mul+add chains (simd_generic.c:86-96).  Eight LDS reads
         // are issued ahead of the eight dependent accumulations; (p, q) walk the polyphase tile in
         // scalar registers.
@@ -694,15 +718,27 @@ int fir_tile_row(int decim)
 int g_fir_reserve_cus = 0;     // persistent kernel: CUs left to the other streams' kernels
 int g_fir_budget = 4;          // persistent kernel: tiles per workgroup before it retires (0: one resident grid)
 
+// Which of the reference's two forms of the decimating FIR the kernels follow (DESIGN.md "Arithmetic contract"):
+//   1 (default)  avx2_fir_ccf_dec, simd_avx2.c:62-108 -- what the reference runs on x86 unless --no-simd is given: four
+//                accumulators, fused multiply-adds (fir_decimate_kernel_f at M = 40 / 48; the runtime-M kernel otherwise)
+//   0            generic_fir_ccf_dec, simd_generic.c:86-96 (--no-simd): one accumulator, every product and sum rounded
+//                (fir_decimate_kernel_r / _w / _c / _m)
+int g_fir_order = 1;
+
 // `aligned`: the pipeline's ring lengths are multiples of 8 samples (fir_reg.hip fetches columns in pieces of 8)
+static bool fir_fma_ok(int decim, int aligned)
+{
+    return !g_fir_force_generic && g_fir_order == 1 && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
+}
+
 static bool fir_reg_ok(int decim, int aligned)
 {
-    return !g_fir_force_generic && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
+    return !g_fir_force_generic && g_fir_order == 0 && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
 }
 
 static bool fir_wide_ok(int decim, int aligned)
 {
-    return !g_fir_force_generic && (g_fir_layout == 2 || (g_fir_layout == 3 && !fir_reg_ok(decim, aligned))) &&
+    return !g_fir_force_generic && g_fir_order == 0 && (g_fir_layout == 2 || (g_fir_layout == 3 && !fir_reg_ok(decim, aligned))) &&
            (decim == 8 || decim == 16 || decim == 40 || decim == 48);
 }
 
@@ -714,11 +750,12 @@ static int fir_wide_tile(int)
 }
 
 // 1: launch_fir_decimate() reads the FirTile list (the one-tile-per-workgroup kernels); 0: only BurstWork::tile_base
-int fir_needs_tile_list(int decim, int aligned) { return fir_wide_ok(decim, aligned) || fir_reg_ok(decim, aligned) ? 0 : 1; }
+int fir_needs_tile_list(int decim, int aligned) { return fir_wide_ok(decim, aligned) || fir_reg_ok(decim, aligned) || fir_fma_ok(decim, aligned) ? 0 : 1; }
 
 // outputs per FirTile for the kernel launch_fir_decimate() will pick
 int fir_tile_out(int decim, int aligned)
 {
+    if (fir_fma_ok(decim, aligned)) return fir_fma_tile_out(decim);
     if (fir_reg_ok(decim, aligned)) return fir_reg_tile_out(decim);
     return fir_wide_ok(decim, aligned) ? fir_wide_tile(decim) : kFirTileOut;
 }
@@ -795,6 +832,13 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
     const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
+    if (fir_fma_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
+        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
+        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
+        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
+                           fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+        return launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
+    }
     if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
@@ -823,7 +867,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         default: break;
         }
     }
-    if (!g_fir_force_generic && g_fir_layout == 1) {
+    if (!g_fir_force_generic && g_fir_order == 0 && g_fir_layout == 1) {
         switch (decim) {
         case 8: IRDM_LAUNCH_FIR_C(8);
         case 16: IRDM_LAUNCH_FIR_C(16);
@@ -833,7 +877,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         }
     }
 #undef IRDM_LAUNCH_FIR_C
-    if (!g_fir_force_generic) {
+    if (!g_fir_force_generic && g_fir_order == 0) {
         switch (decim) {
         case 8: IRDM_LAUNCH_FIR_M(8);
         case 16: IRDM_LAUNCH_FIR_M(16);
@@ -849,7 +893,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
     (void)hipFuncSetAttribute((const void *)fir_decimate_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
-                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride);
+                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride, g_fir_order);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

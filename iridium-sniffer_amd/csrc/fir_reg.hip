@@ -302,6 +302,226 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (IRDM_FIR_KCLK) kclk_leave(kclk);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The decimator in the order of the reference's AVX2 kernel (option fir_order 1): simd_avx2.c:62-108, avx2_fir_ccf_dec
+// -- what simd_init() selects on every x86 host with AVX2 + FMA unless --no-simd is given (simd_generic.c:33-57).
+//
+//   acc_j = fma(t[4m + j], y[qM + 4m + j], acc_j)   j = 0..3, m = 0..199      (four accumulators, FUSED multiply-adds)
+//   out   = ((acc_0 + acc_2) + (acc_1 + acc_3)) + t[800] * y[qM + 800]        (horizontal sum; the one tap left over
+//                                                                               by the vector loop: product and sum
+//                                                                               rounded on their own, -std=c99)
+//
+// One v_pk_fma_f32 per tap and output instead of v_pk_mul_f32 + v_pk_add_f32, and four independent chains per output
+// instead of one: half the arithmetic instructions of fir_decimate_kernel_r, whose 801 separately rounded multiply-adds
+// on ONE accumulator are what kept it at the packed-fp32 issue limit.  Same idea as above -- a lane keeps
+// its columns of M rotated samples in VGPRs, the accumulators travel -- laid out for four accumulators per output:
+//
+//   lane l holds columns 2l (A) and 2l + 1 (B) of the strip: 2M consecutive samples, rotated by ONE run of the phase
+//   recurrence;  in row r column c works on output q = c - r;  between rows an output's accumulators move from column c
+//   to c + 1:  A -> B is the SAME lane (no instruction: the two accumulator sets swap names, rows are unrolled in
+//   pairs), B -> A of the next lane is one DPP shift per register -- 8 shifts per row for the 2 x 4 accumulators of a
+//   lane, no lane-63 hand-offs and no delay line: a strip is ONE block of 128 columns (128 - NR outputs) and the strips
+//   of a burst overlap by NR columns (16 - 19 % of the samples read twice; the kernel it replaces carried accumulators
+//   from block to block through a delay line, 18 instructions per row).
+//   Per row and lane: 2M fused multiply-adds + 8 shifts (M = 40: 88 instructions; fir_decimate_kernel_r: 338).
+// The taps are wavefront-uniform SGPR operands as above (csrc/fir_fma.inc, generated).
+// ---------------------------------------------------------------------------------------------------------------
+#include "fir_fma.inc"
+
+int fir_fma_tile_out(int decim) { return 128 - kFirTaps / decim; }
+
+// column `cr` of the strip -> y[0..M-1] (ringbuf_extract semantics as in fir_decimate_kernel_r: a sample at or past
+// avail_end reads the ring slot as the reference found it, one reference ring length earlier, or zero)
+template <int M, int FMT>
+__device__ __forceinline__ void fir_fetch_column(const SampleSource &src, const FirGeom &g, int cr, int n_cols, v2f *y)
+{
+    const bool needed = cr < n_cols;
+    const int k0 = needed ? cr * M : 0;                  // sample offset from the strip's first sample
+    const uint64_t a0 = g.a_tile + (uint64_t)k0;
+    uint64_t rp = g.ring_pos + (uint64_t)k0;             // a0 mod ring_len
+    if (rp >= src.ring_len) rp -= src.ring_len;
+    const bool in_chunk = a0 >= src.chunk_start;
+    // simple column: all M samples written, on one side of the chunk start, no wrap of the ring inside
+    const bool simple = a0 + M <= g.avail_end && (in_chunk || (a0 + M <= src.chunk_start && rp + M <= src.ring_len));
+    if (__builtin_amdgcn_ballot_w64(needed && !simple) == 0) {
+        const void *base = in_chunk ? src.chunk : src.ring;
+        const size_t idx = !needed ? 0 : in_chunk ? (size_t)(a0 - src.chunk_start) : (size_t)rp;
+#pragma unroll
+        for (int i = 0; i < M / 8; i++) load_piece<FMT>(base, idx + 8 * i, &y[8 * i]);
+    } else {
+        uint64_t rs = g.stale_pos + (uint64_t)k0;        // (a0 - ref_ring) mod ring_len
+        if (rs >= src.ring_len) rs -= src.ring_len;
+#pragma unroll
+        for (int i = 0; i < M / 8; i++) {
+            const uint64_t a = a0 + 8 * i;
+            v2f xn[8], xs[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) xn[u] = xs[u] = v2f{ 0.0f, 0.0f };
+            if (needed && a < g.avail_end) {
+                uint64_t p = rp + 8 * i;
+                if (p >= src.ring_len) p -= src.ring_len;
+                if (a >= src.chunk_start) load_piece<FMT>(src.chunk, (size_t)(a - src.chunk_start), xn);
+                else load_piece<FMT>(src.ring, (size_t)p, xn);
+            }
+            if (needed && a + 8 > g.avail_end && a >= src.ref_ring) {
+                const uint64_t as = a - src.ref_ring;
+                uint64_t p = rs + 8 * i;
+                if (p >= src.ring_len) p -= src.ring_len;
+                if (as >= src.chunk_start) load_piece<FMT>(src.chunk, (size_t)(as - src.chunk_start), xs);
+                else load_piece<FMT>(src.ring, (size_t)p, xs);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) y[8 * i + u] = (a + u < g.avail_end) ? xn[u] : xs[u];
+        }
+    }
+}
+
+template <int M, int FMT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_f(
+    SampleSource src, const FirGeom *__restrict__ geom, const float *__restrict__ taps,
+    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk)
+{
+    using R = FirR<M>;
+    constexpr int NR = R::NR, REM = R::REM;
+    constexpr int VT = REM - 1;                              // taps of the partial row the vector loop takes
+    static_assert(NR % 2 == 0, "rows are unrolled in pairs (the accumulator sets swap names)");
+    static_assert(M % 4 == 0 && VT % 8 == 0 && (kFirTaps - 1) % 4 == 0, "tap k -> accumulator k % 4 = (k % M) % 4; one tap left over");
+    const int lane = threadIdx.x;
+    kclk_enter(kclk);
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const FirGeom g = geom[tile];
+        const int n_cols = g.n_out + NR;                     // columns that feed a stored output (<= 128)
+        const v2f inc = { g.inc_re, g.inc_im };
+        const uint64_t *taps64 = reinterpret_cast<const uint64_t *>(taps);
+        v2f y[2][M];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fir_fetch_column<M, FMT>(src, g, 2 * lane + j, n_cols, y[j]);
+        // ---- rotate in place (rotator.h:38-39): the phase restored from the checkpoint table (every kRotSeg samples);
+        // column 2l starts on a checkpoint, column 2l + 1 on one too (M % 16 == 0) or 8 samples behind one ----
+        {
+            v2f ph[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int cr = 2 * lane + j;
+                const int k0 = cr < n_cols ? cr * M : 0;
+                const float2 c = rot_table[g.ck_index + (uint64_t)(k0 / kRotSeg)];
+                ph[j] = v2f{ c.x, c.y };
+            }
+            if (M % kRotSeg != 0) {
+                static_assert(M % kRotSeg == 0 || M % kRotSeg == 8, "a column starts on a checkpoint or 8 samples behind one");
+                // (2l M is a multiple of 16; (2l + 1) M = 8 mod 16 -- unless the column is not needed: then k0 = 0 and the
+                // phase is not used)
+                v2f pw = ph[1];
+#pragma unroll
+                for (int u = 0; u < 8; u++) pw = cmul_pk(pw, inc);
+                if (2 * lane + 1 < n_cols) ph[1] = pw;
+            }
+#pragma unroll
+            for (int p = 0; p < M; p++) {
+                v2f r0, r1, n0, n1;
+                cmul_pk2(r0, y[0][p], ph[0], r1, y[1][p], ph[1]);       // out[i] = in[i] * phase (rotator.h:38)
+                cmul_pk2(n0, ph[0], inc, n1, ph[1], inc);               // phase *= incr          (rotator.h:39)
+                y[0][p] = r0;
+                y[1][p] = r1;
+                ph[0] = n0;
+                ph[1] = n1;
+            }
+        }
+        // ---- the taps ----
+        const v2f zero = { 0.0f, 0.0f };
+        v2f X[4] = { zero, zero, zero, zero }, Y[4] = { zero, zero, zero, zero };
+        constexpr int H = M / 2;                             // taps per half row (20 / 24)
+        static_assert(H == 20 || H == 24, "half rows of 8 + 8 + 4 or 8 + 8 + 8 taps");
+        uint64_t ta[H / 2], tb[H / 2];
+        auto request = [&](uint64_t (&t)[H / 2], int tap0) {
+#pragma unroll
+            for (int i = 0; i < H / 2; i++) t[i] = taps64[tap0 / 2 + i];
+        };
+        // one row: xa = the accumulators that are with column A in this row, xb = with column B; the next half row's taps
+        // are requested behind the first group of the half before it (scalar loads return out of order)
+        auto half_rest = [&](v2f (&xa)[4], v2f (&xb)[4], const uint64_t *t, int p0) {
+            fir_fma2x8(xa, xb, &y[0][p0 + 8], &y[1][p0 + 8], t + 4);
+            if constexpr (H == 24) fir_fma2x8(xa, xb, &y[0][p0 + 16], &y[1][p0 + 16], t + 8);
+            else fir_fma2x4(xa, xb, &y[0][p0 + 16], &y[1][p0 + 16], t + 8);
+        };
+        auto row = [&](v2f (&xa)[4], v2f (&xb)[4], int r, int next_tap0) {
+            fir_fma2x8(xa, xb, &y[0][0], &y[1][0], ta);
+            __builtin_amdgcn_sched_barrier(0);
+            request(tb, r * M + H);
+            __builtin_amdgcn_sched_barrier(0);
+            half_rest(xa, xb, ta, 0);
+            fir_fma2x8(xa, xb, &y[0][H], &y[1][H], tb);
+            __builtin_amdgcn_sched_barrier(0);
+            request(ta, next_tap0);
+            __builtin_amdgcn_sched_barrier(0);
+            half_rest(xa, xb, tb, H);
+        };
+        auto shift = [&](v2f (&x)[4]) {                      // the B accumulators of lane l - 1 become the A accumulators of lane l
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                x[j].x = lane_shr1(x[j].x);
+                x[j].y = lane_shr1(x[j].y);
+            }
+        };
+        request(ta, 0);
+#pragma unroll 1
+        for (int rp = 0; rp < NR / 2; rp++) {
+            row(X, Y, 2 * rp, (2 * rp + 1) * M);             // X with column A, Y with column B
+            shift(Y);                                        // -> Y with column A, X with column B
+            // (behind the last full row: the partial row's first taps, if the vector loop takes any of it)
+            row(Y, X, 2 * rp + 1, (2 * rp + 2 < NR || VT >= H) ? (2 * rp + 2) * M : 0);
+            shift(X);                                        // -> X with column A, Y with column B
+        }
+        if constexpr (VT > 0) {
+            // the partial row's taps NR M .. NR M + VT - 1 (M = 48: 32 of its 33)
+            static_assert(VT < H || VT == H + 8, "VT = 32 at M = 48");
+            if constexpr (VT >= H) {
+                fir_fma2x8(X, Y, &y[0][0], &y[1][0], ta);
+                half_rest(X, Y, ta, 0);
+                const uint64_t *t = taps64 + (NR * M + H) / 2;
+                fir_fma2x8(X, Y, &y[0][H], &y[1][H], t);
+            } else {
+                const uint64_t *t = taps64 + (NR * M) / 2;
+#pragma unroll
+                for (int gq = 0; gq < VT / 8; gq++) fir_fma2x8(X, Y, &y[0][8 * gq], &y[1][8 * gq], t + 4 * gq);
+            }
+        }
+        // ---- horizontal sum (simd_avx2.c:89-96) and the tap the vector loop leaves over (:102-105) ----
+        {
+            const float tq = taps[kFirTaps - 1];
+            const v2f sa = (X[0] + X[2]) + (X[1] + X[3]), sb = (Y[0] + Y[2]) + (Y[1] + Y[3]);
+            const v2f oa = sa + y[0][VT] * tq, ob = sb + y[1][VT] * tq;
+            const int qa = 2 * lane - NR, qb = qa + 1;
+            if (qa >= 0 && qa < g.n_out) dec[g.out_base + qa] = make_float2(oa.x, oa.y);
+            if (qb >= 0 && qb < g.n_out) dec[g.out_base + qb] = make_float2(ob.x, ob.y);
+        }
+    }
+    kclk_leave(kclk);
+}
+
+template <int M>
+static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
+                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
+{
+    const int grid = g_fir_grid > 0 && g_fir_grid < n_tiles ? g_fir_grid : n_tiles;
+    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
+                   const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
+{
+    if (src.ring_len % 8 != 0 || src.ref_ring % 8 != 0 || (src.chunk_start != ~0ull && src.chunk_start % 8 != 0)) return 1;
+    switch (decim) {
+    case 40: return launch_fir_f_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
+    case 48: return launch_fir_f_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
+    default: return 1;
+    }
+}
+
 template <int M>
 static int launch_fir_r_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
                             const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)

@@ -118,6 +118,12 @@ extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the ot
 extern int g_fir_strip;           // double blocks of 128 columns per strip
 extern int g_fir_grid;            // workgroups of the register-resident decimator (0: one per strip)
 extern int g_fir_slice;           // strips per launch of the register-resident decimator (0: all in one launch)
+extern int g_fir_order;           // 1 (default): the decimating FIR in the order of the reference's AVX2 kernel (simd_avx2.c:62-108),
+                                  // 0: of its scalar kernel (simd_generic.c:86-96, --no-simd)
+int fir_fma_tile_out(int decim);
+int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
+                   const float2 *rot_table, float2 *dec, hipStream_t stream,
+                   unsigned long long *kclk = nullptr);   // fir_decimate_kernel_f; 0 ok, -1 error, 1 not applicable
 int fir_reg_supported(int decim);
 int fir_reg_tile_out(int decim);
 int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,

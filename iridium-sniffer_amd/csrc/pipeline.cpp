@@ -2721,6 +2721,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
+    if (!strcmp(key, "fir_order")) { irdm::g_fir_order = value ? 1 : 0; return 0; }
     if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }

@@ -170,6 +170,44 @@ void orc_fir_ccf_dec(const float *taps, int ntaps, const float *in, float *out,
     }
 }
 
+/* simd_avx2.c:62-108 (avx2_fir_ccf_dec) -- the decimating FIR the reference runs on an x86 host with AVX2 + FMA unless
+ * --no-simd is given (simd_init, simd_generic.c:33-57; main.c:567): the taps four at a time into FOUR accumulators
+ * with fused multiply-adds (_mm256_fmadd_ps: acc_j = fma(t[4m+j], x[4m+j], acc_j), m ascending), the horizontal sum
+ * (a0 + a2) + (a1 + a3) (:89-96), then the remaining ntaps % 4 taps one by one with a separately rounded product and
+ * sum (:102-105; the file is compiled -std=c99, CMakeLists.txt:6, so GCC does not contract the scalar tail --
+ * oracle/Makefile compiles the reference file with those flags and tests/test_oracle_vs_ref.py pins this function to
+ * it bit for bit).  This translation unit is compiled -ffp-contract=off -mfma: fmaf() is the fused instruction, nothing
+ * else is fused. */
+void orc_fir_ccf_dec_avx2(const float *taps, int ntaps, const float *in, float *out,
+                          int n_out, int decimation)
+{
+    for (int i = 0; i < n_out; i++) {
+        const float *p = in + 2 * (size_t)i * (size_t)decimation;
+        float re[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, im[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        int k = 0;
+        for (; k + 3 < ntaps; k += 4)
+            for (int j = 0; j < 4; j++) {
+                re[j] = fmaf(taps[k + j], p[2 * (k + j)], re[j]);
+                im[j] = fmaf(taps[k + j], p[2 * (k + j) + 1], im[j]);
+            }
+        float ar = (re[0] + re[2]) + (re[1] + re[3]);
+        float ai = (im[0] + im[2]) + (im[1] + im[3]);
+        for (; k < ntaps; k++) {
+            ar += taps[k] * p[2 * k];
+            ai += taps[k] * p[2 * k + 1];
+        }
+        out[2 * (size_t)i] = ar;
+        out[2 * (size_t)i + 1] = ai;
+    }
+}
+
+/* Which form of the decimating FIR stage B uses (orc_downmix_*, orc_run_stream): 0 = simd_generic.c (what --no-simd
+ * selects), 1 = simd_avx2.c (the reference's default on x86).  Both are the reference's arithmetic; the product has
+ * the matching option "fir_order".  Set before any stream is run (read-only afterwards). */
+static int g_orc_fir_order = 0;
+void orc_set_fir_order(int order) { g_orc_fir_order = order ? 1 : 0; }
+int orc_get_fir_order(void) { return g_orc_fir_order; }
+
 /* simd_generic.c:98-106 */
 void orc_fir_fff(const float *taps, int ntaps, const float *in, float *out, int n)
 {
@@ -1078,7 +1116,7 @@ int orc_downmix_process(orc_downmix_t *dm, const orc_burst_rec_t *rec, const flo
     if (dec_len <= 0) dec_len = 0;
     if (dec_len > DM_WORK) dec_len = DM_WORK;
     if (dec_len > 0) {
-        orc_fir_ccf_dec(dm->in_taps, dm->in_ntaps, (const float *)dm->wa, (float *)dm->wb,
+(g_orc_fir_order ? orc_fir_ccf_dec_avx2 : orc_fir_ccf_dec)(dm->in_taps, dm->in_ntaps, (const float *)dm->wa, (float *)dm->wb,
                         dec_len, decim);
         timestamp += (uint64_t)((dm->in_ntaps / 2) * 1000000000ULL / sample_rate);
     }

@@ -10,7 +10,8 @@ Source changes made on the way (text substitutions on copies under tests/_build/
   * fir_reg.hip: the one `v_writelane_b32` inline asm -> hip_emul::writelane0
   * csrc/fir_mac.inc (generated gfx950 assembly) is replaced by tests/hip_emul/fir_mac.inc: the same multiply-add chains in
     plain C++, products and sums rounded separately, same order.
-  * csrc/fft_bfly.inc (K1's butterflies: inline gfx950 assembly) likewise by tests/hip_emul/fft_bfly.inc."""
+  * csrc/fft_bfly.inc (K1's butterflies: inline gfx950 assembly) likewise by tests/hip_emul/fft_bfly.inc, and
+    csrc/fir_fma.inc (the AVX2-order decimator's fused multiply-adds and packed complex products) by tests/hip_emul/fir_fma.inc."""
 import concurrent.futures
 import os
 import re
@@ -55,6 +56,7 @@ def build(force=False, sanitize=False):
         OUT = os.path.join(ROOT, "tests", "_build", "emul_asan")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(EMUL, "hip", "hip_runtime.h"),
                                                                 os.path.join(EMUL, "fir_mac.inc"), os.path.join(EMUL, "fft_bfly.inc"),
+                                                                os.path.join(EMUL, "fir_fma.inc"),
                                                                 os.path.abspath(__file__)]
     deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest(deps):
@@ -62,6 +64,7 @@ def build(force=False, sanitize=False):
     os.makedirs(OUT, exist_ok=True)
     shutil.copy(os.path.join(EMUL, "fir_mac.inc"), os.path.join(OUT, "fir_mac.inc"))
     shutil.copy(os.path.join(EMUL, "fft_bfly.inc"), os.path.join(OUT, "fft_bfly.inc"))
+    shutil.copy(os.path.join(EMUL, "fir_fma.inc"), os.path.join(OUT, "fir_fma.inc"))
     jobs = []
     for name in SOURCES:
         dst = os.path.join(OUT, name.replace(".hip", "_hip") .replace(".cpp", "_cpp") + ".cpp")

@@ -71,8 +71,14 @@ def main():
         got = parity.run_gpu(iq, fs, chunks=[first, c, c, len(iq) - first - 2 * c], depth=2, feed="ingest_lookahead")
         res["default"] = parity.compare(got, ref)
         res["default"]["k1_lists"] = got["stats"]["k1_lists"]
+        # the same stream with the decimating FIR in the reference's scalar order (--no-simd: fir_decimate_kernel_r, one
+        # accumulator per output travelling from lane to lane) against the oracle in that order
+        orc.set_fir_order(0)
+        ref0 = orc.run_stream(iq, fs)
+        res["scalar_fir_order"] = parity.compare(parity.run_gpu(iq, fs, options={"fir_order": 0}), ref0)
         if os.environ.get("IRDM_EMUL_FULL"):
-            res["lds_decimator"] = parity.compare(parity.run_gpu(iq, fs, options={"fir_layout": 2}), ref)
+            res["lds_decimator"] = parity.compare(parity.run_gpu(iq, fs, options={"fir_order": 0, "fir_layout": 2}), ref0)
+        orc.set_fir_order(1)
     elif case == "12mhz":
         # 16384-point frames (K1 <14>), decimation by 48 (the decimator's second instantiation), ci16 in two chunks
         fs = 12_000_000

@@ -71,6 +71,11 @@ def fptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def set_fir_order(order):
+    """0: stage B's decimating FIR as simd_generic.c (--no-simd), 1: as simd_avx2.c (default)"""
+    lib().orc_set_fir_order(int(order))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -79,6 +84,11 @@ def lib():
             build()
         L = C.CDLL(path)
         L.orc_fft.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int]
+        L.orc_fir_ccf_dec_avx2.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]
+        L.orc_set_fir_order.argtypes = [C.c_int]
+        # the decimating FIR of stage B in the order of the reference's AVX2 kernel (simd_avx2.c:62-108: the reference's
+        # default on x86, and the product's default "fir_order" 1); tests of the scalar order call set_fir_order(0)
+        L.orc_set_fir_order(1)
         L.orc_max_float.restype = C.c_float
         L.orc_detector_create.restype = C.c_void_p
         L.orc_detector_create.argtypes = [C.c_double, C.c_int, C.c_float, C.c_int]

@@ -1,6 +1,7 @@
-"""-m gpu: the register-resident decimator (csrc/fir_reg.hip, `fir_layout` 3: columns of M samples in VGPRs, travelling
-accumulators) against the oracle and against the LDS kernel it replaces (burst_downmix.c:663-672, :417-437;
-rotator.h:36-46; simd_generic.c:86-96).
+"""-m gpu: the register-resident decimators (csrc/fir_reg.hip, `fir_layout` 3: columns of M samples in VGPRs, travelling
+accumulators) -- fir_decimate_kernel_f in the order of the reference's AVX2 kernel (simd_avx2.c:62-108, the default) and
+fir_decimate_kernel_r in its scalar order (simd_generic.c:86-96, option fir_order 0) -- against the oracle in the same
+order and against the LDS kernel (burst_downmix.c:663-672, :417-437; rotator.h:36-46).
 
 Everything downstream of the decimator is compared bit for bit (downmixed frame samples, start index, CFO, correlation
 peaks, hard bits), so one wrong rounding in any of the 801 multiply-adds of any output shows.  Cases chosen for the
@@ -27,18 +28,42 @@ def _scene(fs, secs, nb, seed):
 
 @pytest.fixture(scope="module")
 def scene10():
+    """the scene, the oracle's records with the decimating FIR in the order of the reference's AVX2 kernel (the default:
+    fir_decimate_kernel_f) and in its scalar order (option fir_order 0: fir_decimate_kernel_r and the LDS kernels)"""
     iq = _scene(10_000_000, 0.9, 7, seed=31)
-    return iq, orc.run_stream(iq, 10_000_000)
+    ref = orc.run_stream(iq, 10_000_000)
+    try:
+        orc.set_fir_order(0)
+        ref0 = orc.run_stream(iq, 10_000_000)
+    finally:
+        orc.set_fir_order(1)
+    return iq, ref, ref0
+
+
+def test_fused_four_accumulator_kernel_10mhz(scene10):
+    """the default decimator (fir_decimate_kernel_f: four fused accumulators per output, simd_avx2.c:62-108) whole, in
+    chunks (strips in the chunk, in the ring, across the boundary) and with a capped grid (workgroups walking the strips)"""
+    iq, ref, ref0 = scene10
+    assert any(a.center_offset != b.center_offset for a, b in zip(ref.frames, ref0.frames)), "the two orders should differ in rounding"
+    s = parity.compare(parity.run_gpu(iq, 10_000_000), ref)
+    assert s["demods"] >= 4, s
+    n = len(iq)
+    c = (n // 3) // 32768 * 32768
+    parity.compare(parity.run_gpu(iq, 10_000_000, chunks=[c, c, n - 2 * c], depth=1), ref)
+    try:
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 300}), ref)
+    finally:
+        _restore()
 
 
 @pytest.mark.parametrize("strip", [1, 2, 3, 7])
 def test_strip_lengths_10mhz(scene10, strip):
-    iq, ref = scene10
+    iq, _, ref0 = scene10
     try:
-        got = parity.run_gpu(iq, 10_000_000, options={"fir_layout": 3, "fir_strip": strip})
+        got = parity.run_gpu(iq, 10_000_000, options={"fir_order": 0, "fir_layout": 3, "fir_strip": strip})
     finally:
         _restore()
-    s = parity.compare(got, ref)
+    s = parity.compare(got, ref0)
     assert s["demods"] >= 4, s
 
 
@@ -46,16 +71,31 @@ def _restore():
     p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
     p.set_option("fir_layout", 3)
     p.set_option("fir_strip", 3)
+    p.set_option("fir_grid", 0)
+    p.set_option("fir_order", 1)
     p.close()
 
 
 def test_lds_kernel_still_agrees_10mhz(scene10):
-    iq, ref = scene10
+    iq, _, ref0 = scene10
     try:
-        got = parity.run_gpu(iq, 10_000_000, options={"fir_layout": 2})
+        got = parity.run_gpu(iq, 10_000_000, options={"fir_order": 0, "fir_layout": 2})
     finally:
         _restore()
-    parity.compare(got, ref)
+    parity.compare(got, ref0)
+
+
+def test_runtime_m_kernel_in_both_orders_10mhz(scene10):
+    """the runtime-M kernel (what 2 / 4 MHz and unaligned sources take in the AVX2 order; option fir_generic)"""
+    iq, ref, ref0 = scene10
+    try:
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_generic": 1}), ref)
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_generic": 1, "fir_order": 0}), ref0)
+    finally:
+        p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        p.set_option("fir_generic", 0)
+        p.close()
+        _restore()
 
 
 @pytest.mark.parametrize("fs,fmt", [(10_000_000, irdm.FMT_CI16), (10_000_000, irdm.FMT_CI8),

@@ -188,9 +188,15 @@ def test_kernel_variants_agree():
     grid / the smallest tile budget give the same records as the default kernels and the oracle."""
     fs, iq = _scene_2m(seed=19, n_bursts=6, secs=2.0)
     ref = orc.run_stream(iq, fs)
-    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0}
-    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"fir_layout": 0}, {"fir_layout": 1}, {"fir_layout": 2}, {"fir_budget": 0}, {"fir_budget": 2},
-                 {"post_generic": 1}):
+    try:
+        orc.set_fir_order(0)                   # the decimating FIR in the reference's scalar order: the LDS decimators' order
+        ref0 = orc.run_stream(iq, fs)
+    finally:
+        orc.set_fir_order(1)
+    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0, "fir_order": 1}
+    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"post_generic": 1}, {"fir_order": 0},
+                 {"fir_order": 0, "fir_generic": 1}, {"fir_order": 0, "fir_layout": 0}, {"fir_order": 0, "fir_layout": 1},
+                 {"fir_order": 0, "fir_layout": 2}, {"fir_order": 0, "fir_budget": 0}, {"fir_order": 0, "fir_budget": 2}):
         p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)
         p.set_option("keep_frame_samples", 1)
         try:
@@ -203,7 +209,7 @@ def test_kernel_variants_agree():
             for k in opts:
                 p.set_option(k, defaults[k])
             p.close()
-        parity.compare(got, ref)
+        parity.compare(got, ref if opts.get("fir_order", 1) else ref0)
 
 
 def test_known_answer_bits_from_reference_docs():

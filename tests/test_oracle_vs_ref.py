@@ -192,9 +192,30 @@ def test_stage_c_matches_reference(oracle, reflib, gardner):
     assert n_ok >= 8
 
 
+def test_fir_ccf_dec_avx2_order(oracle, reflib):
+    """orc_fir_ccf_dec_avx2 == the reference's avx2_fir_ccf_dec (simd_avx2.c:62-108, compiled in place with the
+    reference's own flags: -std=c99 -O3 -mavx2 -mfma), bit for bit: four fused accumulators, horizontal sum, scalar tail.
+    This is the decimating FIR the reference runs by default on x86 (simd_init) and the order the product's decimator
+    follows with option fir_order 1."""
+    rng = np.random.default_rng(11)
+    for ntaps in (801, 800, 803, 25):
+        taps = np.zeros(ntaps + 8, np.float32)          # (the AVX2 kernel loads taps four at a time)
+        taps[:ntaps] = rng.standard_normal(ntaps).astype(np.float32)
+        for dec, n_out in ((8, 300), (40, 300), (48, 250), (1, 100)):
+            x = crand(rng, ntaps + dec * n_out + 8, scale=float(rng.uniform(0.01, 10.0)))
+            a = np.zeros(n_out, np.complex64)
+            b = np.zeros(n_out, np.complex64)
+            oracle.orc_fir_ccf_dec_avx2(fp(taps), ntaps, fp(x), fp(a), n_out, dec)
+            reflib.avx2_fir_ccf_dec(fp(taps), ntaps, fp(x), fp(b), n_out, dec)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (ntaps, dec)
+            c = np.zeros(n_out, np.complex64)
+            oracle.orc_fir_ccf_dec(fp(taps), ntaps, fp(x), fp(c), n_out, dec)
+            assert not np.array_equal(a.view(np.uint32), c.view(np.uint32)) or ntaps < 100      # the two orders differ in rounding
+
+
 def test_avx2_variant_differs_only_in_float_rounding(reflib):
-    """The reference's AVX2 path is NOT bit-identical to its scalar path:
-    documents why the scalar path is the canonical oracle."""
+    """The reference's AVX2 path is NOT bit-identical to its scalar path: the oracle restates both forms of
+    the decimating FIR (orc_fir_ccf_dec / orc_fir_ccf_dec_avx2) and pins each to its reference kernel."""
     rng = np.random.default_rng(4)
     taps = rng.standard_normal(801).astype(np.float32)
     pad = np.zeros(808, np.float32); pad[:801] = taps

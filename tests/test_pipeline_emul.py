@@ -56,10 +56,11 @@ def test_whole_path_scene_zoo(emul_lib):
 
 
 def test_whole_path_10mhz_register_resident_decimator(emul_lib):
-    """10 MHz in four chunks at pipeline_depth 2, fed in place with look-ahead: 8192-point frames through K1's radix-16
-    kernel (with the candidate lists once the detector is primed), decimation by 40 through fir_reg.hip -- columns of
-    rotated samples in registers, accumulators travelling from lane to lane by DPP shifts -- (IRDM_EMUL_FULL=1 adds the
-    LDS decimator it replaced, another minute)"""
+    """10 MHz in four chunks at pipeline_depth 2, fed in place with look-ahead: 8192-point frames through K1's
+    32-points-per-lane kernel (with the candidate lists once the detector is primed), decimation by 40 through fir_reg.hip
+    -- columns of rotated samples in registers, accumulators travelling from lane to lane by DPP shifts: the fused
+    four-accumulator form of the reference's AVX2 kernel (default) and, in a second run, the scalar-order form
+    (IRDM_EMUL_FULL=1 adds the LDS decimator, another minute)"""
     res = run_case(emul_lib, "10mhz", timeout=1500)
     for name in res:
         assert res[name]["bursts"] >= 6 and res[name]["frames"] >= 4, res

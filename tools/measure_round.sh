@@ -13,7 +13,7 @@ timeout 90 python bench.py --depth 0 $Q 2>/dev/null | tail -1 > "$OUT/b0.json"
 timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 2 2>/dev/null | tail -1 > "$OUT/d2.json"
 timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 40 2>/dev/null | tail -1 > "$OUT/d40.json"
 timeout 120 python bench.py --steps 10 --warmup 3 $Q --alone-steps 3 $D12 2>/dev/null | tail -1 > "$OUT/cfg5_12mhz_d40.json"
-timeout 90 python bench.py --steps 6 --warmup 2 $Q --opt fir_layout=2 2>/dev/null | tail -1 > "$OUT/lds_fir.json"
+timeout 90 python bench.py --steps 20 --warmup 5 $Q --alone-steps 3 --opt fir_order=0 2>/dev/null | tail -1 > "$OUT/scalar_fir.json"
 timeout 120 python bench.py --shard time --steps 6 --warmup 2 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
 # the detector scan's own device timeline (option band_timeline: first workgroup's start / last one's end per pass), in
 # run and alone, both scenes
