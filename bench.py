@@ -218,12 +218,26 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
         del x, flat
     buf = torch.empty((ov + chunk) * bps, dtype=torch.uint8, device=device)
     stage = None if nccl else torch.empty((ov + chunk) * bps, dtype=torch.uint8)
+    # (several ranks: a rank works on one chunk per super-step, its per-burst chain overlaps the other ranks' scans --
+    # pipeline_depth 1; one rank: the ordinary chained feed, chunk k + 1 begun before chunk k ends)
     pipe = irdm.Pipeline(fs, fmt=irdm.FMT_CF32, max_chunk_samples=chunk, max_bursts_per_chunk=8192, device=local,
-                         pipeline_depth=min(args.depth, 1))
+                         pipeline_depth=min(args.depth, 1) if world > 1 else args.depth)
     for kv in args.opt:
         key, val = kv.split("=")
         pipe.set_option(key, int(val))
     ts = sharding.TimeShard(dist, pipe, torch, device, chunk, bps, ov) if world > 1 else None
+    ingest = world == 1 and args.depth >= 1
+    if ingest:
+        # one rank: the producer writes every chunk where the context keeps it (irdm_ingest_ptr), as in the stream mode --
+        # every chunk-sized slot of the history ring holds the chunk before the timed region
+        ring_ptr, ring_len = pipe.ring()
+        if ring_len % chunk == 0:
+            for k in range(ring_len // chunk):
+                rc = irdm.lib().irdm_device_copy(C.c_void_p(ring_ptr + k * chunk * bps), C.c_void_p(parts[0].data_ptr() + ov * bps), chunk * bps)
+                assert rc == 0, rc
+            torch.cuda.synchronize()
+        else:
+            ingest = False
     cap = 8192                           # = max_bursts_per_chunk above: more frames in one chunk are an error, not truncated
     msg = record_msg_bytes(irdm, cap)
     ghost = torch.zeros((msg,), dtype=torch.uint8).pin_memory() if world > 1 else None
@@ -239,9 +253,12 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                 buf.copy_(stage)
             torch.cuda.synchronize()
             ts.step(buf, first_of_stream=True)
-        else:
+        elif not args.depth:
             pipe.feed_device(parts[0].data_ptr() + ov * bps, chunk, None)
-            pipe.flush()
+        else:
+            pipe.feed_begin(pipe.ingest_ptr(chunk) if ingest else parts[0].data_ptr() + ov * bps, chunk, None)
+            if step_no[0] > 0:
+                pipe.feed_end()
         step_no[0] += 1
         nbst = len(pipe.poll_bursts_raw())
         pipe.drop_frames()
@@ -266,6 +283,14 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
     t0 = time.perf_counter()
     for _ in range(args.steps):
         super_step(True)
+    if world == 1 and args.depth:
+        # drain: the last chunk's scan and the chains in flight belong to the timed work
+        pipe.feed_end()
+        step_no[0] = 0
+        pipe.flush()
+        counts[0] += len(pipe.poll_bursts_raw())
+        pipe.drop_frames()
+        counts[1] += len(pipe.poll_demods_raw())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

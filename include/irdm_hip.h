@@ -346,6 +346,18 @@ int irdm_seed_history(irdm_pipeline_t *p, const void *h_iq, size_t n_samples, ui
  * no host bounce, and only the detector is waited for -- K1 of the next chunk and per-burst work in flight go on */
 long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, size_t cap);
 int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, size_t n);
+/* The same hand-off in two parts, so that the history (512 x N floats: 16-32 MiB) can FOLLOW the part a scan needs first:
+ * head = the first irdm_state_head_bytes() bytes of the blob (header, detector state, baseline sums), history = the rest.
+ * Round 0 of the band scan reads no history; a rank imports the head, asks irdm_expect_history(p, buf) -- 1: the scan
+ * that the next irdm_feed_end enqueues waits ON THE DEVICE (a one-lane kernel polling a word the host writes) until
+ * irdm_import_state_history_device(p, buf, n) says the history has arrived in buf, copies it in and goes on; the caller
+ * must make that call before it settles the scan (irdm_export_state_device, irdm_flush, the next irdm_feed_end); 0: this
+ * scan cannot wait (pipeline_depth 0, an unprimed detector, a sequential scan mode): import the history first -- calls
+ * irdm_feed_end, receives the history while K1 and round 0 run, and imports it.  0 ok, -1 error. */
+size_t irdm_state_head_bytes(const irdm_pipeline_t *p);
+int irdm_import_state_head_device(irdm_pipeline_t *p, const void *d_buf, size_t n);
+int irdm_expect_history(irdm_pipeline_t *p, const void *d_hist_buf);   /* d_hist_buf: where the history will arrive (device memory) */
+int irdm_import_state_history_device(irdm_pipeline_t *p, const void *d_hist_buf, size_t n);
 int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, uint64_t abs_start);
 
 /* Options: "decode_frames" / "decode_ida" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded /

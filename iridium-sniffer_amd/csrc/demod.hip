@@ -68,8 +68,38 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
     float2 *dec = ws + (size_t)b * 2 * kMaxSymbols;
     float2 *po = dec + kMaxSymbols;
 
-    // step 1: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141)
+    // Steps 1 and 2 in ONE loop: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141) produces symbol n,
+    // qpsk_pll (:145-195, alpha = 0.2) consumes it in the same iteration.  The two recurrences -- the timing loop's
+    // position and the PLL's phase -- do not feed each other (the reference runs them one after the other over the
+    // whole frame), so in one instruction stream the scheduler interleaves symbol n's PLL chain (cabsf, atan2f,
+    // sincosf, cabsf: ~100 dependent instructions) with symbol n + 1's interpolation: the kernel is pure dependent-chain
+    // latency (a dependent instruction issues ~20 cycles after its producer at this occupancy), and two independent
+    // chains cost little more than the longer one.  Same operations on the same operands in the same order per chain.
     int n = 0;
+    float2 phi = make_float2(1.0f, 0.0f);
+    float total_phase = 0.0f;
+    auto pll = [&](int i, float2 sym) {
+        const float2 v = cmul(sym, phi);
+        po[i] = v;
+        float2 xh;
+        if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
+        else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
+        else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
+        else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
+        const float2 er = cmul(make_float2(xh.x, -xh.y), v);
+        const float em = cabs_f(er);
+        if (em < 1e-10f) return;
+        const float2 unit = make_float2(er.x / em, er.y / em);
+        const float ang = atan2f(unit.y, unit.x);
+        const float sa = 0.2f * ang;
+        float sn, cs;
+        sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
+        const float2 corr = make_float2(cs, sn);
+        total_phase += sa;
+        phi = cmul(make_float2(corr.x, -corr.y), phi);
+        const float pm = cabs_f(phi);
+        if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
+    };
     if (use_gardner) {
         float pos = 0.0f, toff = 0.0f;
         float2 prev = make_float2(0.0f, 0.0f);
@@ -93,40 +123,19 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
                 pos += adj;
             }
             prev = on;
-            n++;
             pos += sps;
+            pll(n, on);
+            n++;
         }
     } else {
         const int step = (int)sps;
         n = (n_samples + step - 1) / step;
         if (n > kMaxSymbols) n = kMaxSymbols;
-        for (int i = 0; i < n; i++) dec[i] = fr[i * step];
-    }
-
-    // step 2: qpsk_pll (qpsk_demod.c:145-195), alpha = 0.2
-    float2 phi = make_float2(1.0f, 0.0f);
-    float total_phase = 0.0f;
-    for (int i = 0; i < n; i++) {
-        const float2 v = cmul(dec[i], phi);
-        po[i] = v;
-        float2 xh;
-        if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
-        else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
-        else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
-        else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
-        const float2 er = cmul(make_float2(xh.x, -xh.y), v);
-        const float em = cabs_f(er);
-        if (em < 1e-10f) continue;
-        const float2 unit = make_float2(er.x / em, er.y / em);
-        const float ang = atan2f(unit.y, unit.x);
-        const float sa = 0.2f * ang;
-        float sn, cs;
-        sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
-        const float2 corr = make_float2(cs, sn);
-        total_phase += sa;
-        phi = cmul(make_float2(corr.x, -corr.y), phi);
-        const float pm = cabs_f(phi);
-        if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
+        for (int i = 0; i < n; i++) {
+            const float2 sym = fr[i * step];
+            dec[i] = sym;
+            pll(i, sym);
+        }
     }
     out[b].n_symbols = n;               // (demod_par_kernel replaces it by the frame's symbol count)
     out[b].total_phase = total_phase;

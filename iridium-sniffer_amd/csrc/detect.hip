@@ -291,28 +291,36 @@ struct P32 {
     static_assert(LDS >= sizeof(float) * (size_t)N, "the magnitudes are staged in the exchange buffer");
 };
 
-// stages s0+1 .. s0+4 of both sub-transforms of a lane; c = the lane's position below 2^s0
+// The fifteen twiddles of stages s0+1 .. s0+4 (1 + 2 + 4 + 8) for the lane whose position below 2^s0 is c.  Requested
+// BEFORE the exchange that precedes the pass: they do not depend on the data, and the exchange's barriers cover their
+// latency (fetched inside the pass, every stage began with a wait for its own loads).
 template <int LOGN>
-__device__ __forceinline__ void dit16_x2(v2f (&a)[16], v2f (&b)[16], int c, int s0, __amdgpu_buffer_rsrc_t r_tw)
+__device__ __forceinline__ void dit16_twiddles(v2f (&w)[15], int c, int s0, __amdgpu_buffer_rsrc_t r_tw)
 {
 #pragma unroll
     for (int i = 1; i <= 4; i++) {
         const int half = 1 << (i - 1);
         // twiddle index (c + (jq << s0)) << (LOGN - s0 - i): the lane's part in the vector offset, jq's in the scalar offset
         const int voff = c << (LOGN - s0 - i + 3);
-        v2f w[8];
 #pragma unroll
         for (int jq = 0; jq < 8; jq++) {
             if (jq >= half) continue;
-            w[jq] = k1_load2(r_tw, voff, jq << (LOGN - i + 3));
+            w[half - 1 + jq] = k1_load2(r_tw, voff, jq << (LOGN - i + 3));
         }
+    }
+}
+
+// stages s0+1 .. s0+4 of both sub-transforms of a lane
+__device__ __forceinline__ void dit16_x2(v2f (&a)[16], v2f (&b)[16], const v2f (&w)[15])
+{
+#pragma unroll
+    for (int i = 1; i <= 4; i++) {
+        const int half = 1 << (i - 1);
 #pragma unroll
         for (int q0 = 0; q0 < 16; q0++) {
             if (q0 & half) continue;
-            bfly2_v(a[q0], a[q0 + half], b[q0], b[q0 + half], w[q0 & (half - 1)]);
+            bfly2_v(a[q0], a[q0 + half], b[q0], b[q0 + half], w[half - 1 + (q0 & (half - 1))]);
         }
-        // keep each stage's twiddle loads inside the stage (hoisted together they cost the occupancy)
-        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -368,6 +376,10 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
         }
     }
     // ---- A -> B ----
+    const int hi = t & 15, lo = (t >> 4) & 15;      // pass B: lane = (hi, lo), p = hi 256 + q 16 + lo
+    v2f w[15];
+    dit16_twiddles<LOGN>(w, lo, 4, r_tw);
+    __builtin_amdgcn_sched_barrier(0);
     {
         const int ga = G > 1 ? (t & 1) : 0, tp = G > 1 ? (t >> 1) : t;
         const int al_lo = (int)bitrev((unsigned)(tp >> 4), 4), al_hi = (int)bitrev((unsigned)(tp & 15), 4);   // alpha = rev8(t')
@@ -386,13 +398,14 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
 #pragma unroll
         for (int q = 0; q < 16; q++) b[q] = Xr[q * 256];
     }
-    // ---- pass B: lane = (hi, lo), p = hi 256 + q 16 + lo ----
-    const int hi = t & 15, lo = (t >> 4) & 15;
-    dit16_x2<LOGN>(a, b, lo, 4, r_tw);
+    // ---- pass B ----
+    dit16_x2(a, b, w);
     __syncthreads();
     // ---- B -> C ----
     const int gc = G > 1 ? ((t >> 5) & 1) : 0;
     const int lo3 = G > 1 ? (((t >> 6) << 5) | (t & 31)) : t;
+    dit16_twiddles<LOGN>(w, lo3, 8, r_tw);          // pass C: p = q 256 + lo3
+    __builtin_amdgcn_sched_barrier(0);
     {
         const int gb = G > 1 ? (t >> 8) : 0;
         v2f *const Xw = X + gb * REGION + lo * 17 + hi;
@@ -409,8 +422,8 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
 #pragma unroll
         for (int q = 0; q < 16; q++) b[q] = Xr[q];
     }
-    // ---- pass C: p = q 256 + lo3 ----
-    dit16_x2<LOGN>(a, b, lo3, 8, r_tw);
+    // ---- pass C ----
+    dit16_x2(a, b, w);
     __syncthreads();                                // every lane has read its points: the buffer takes the magnitudes
     // ---- last stage(s), fftshift, |.|^2 -> LDS ----
     float *const M = reinterpret_cast<float *>(smem_raw);

@@ -40,7 +40,8 @@ namespace irdm {
 #include "fir_mac.inc"
 
 int g_fir_strip = 3;           // double blocks (128 columns) per strip: a strip yields 128*g_fir_strip - NR outputs
-int g_fir_grid = 0;            // > 0: at most this many single-wavefront workgroups in flight, each walking strips (0: one per strip)
+int g_fir_grid = -1;           // > 0: at most this many single-wavefront workgroups in flight, each walking strips; 0: one per
+                               // strip; -1 (default): fir_decimate_kernel_f seven per CU, fir_decimate_kernel_r one per strip
 int g_fir_slice = 0;           // > 0: strips per launch (the chunk's strips as several launches); 0: one launch
 
 template <int M>
@@ -504,7 +505,24 @@ template <int M>
 static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
                             const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
 {
-    const int grid = g_fir_grid > 0 && g_fir_grid < n_tiles ? g_fir_grid : n_tiles;
+    // Workgroups: by default a resident grid of seven single-wavefront workgroups per CU that walk the strips, i.e. seven
+    // of a CU's eight 256-register slots (two per SIMD) -- the eighth is where the waves of K1, the scan's passes and
+    // the per-burst filters of the other streams live while this kernel runs.  Measured (10 MHz, in run, six / seven per
+    // CU): the decimator's own span 0.55 -> 0.41 / 0.40 ms, the step 1.09 -> 1.06-1.09 / 1.08 ms against one workgroup
+    // per strip, whose short-lived waves (40 000 per chunk) lose every freed slot to the higher-priority streams (12 MHz
+    // dense, six: 2.7 -> 2.2 ms, step 3.13 -> 2.96 ms).  Option fir_grid: n > 0 workgroups, 0 one per strip.
+    int grid = n_tiles;
+    if (g_fir_grid > 0) grid = g_fir_grid < n_tiles ? g_fir_grid : n_tiles;
+    else if (g_fir_grid < 0) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        if (7 * n_cu < n_tiles) grid = 7 * n_cu;
+    }
     if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
     else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
     else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);

@@ -89,7 +89,9 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
                      uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream,
-                     hipStream_t side = nullptr, hipEvent_t *plan_ev = nullptr);
+                     hipStream_t side = nullptr, hipEvent_t *plan_ev = nullptr, const uint32_t *gate_flag = nullptr,
+                     uint32_t gate_seq = 0, uint32_t *gate_err = nullptr, const void *gate_src = nullptr,
+                     size_t gate_bytes = 0);                                  // gate: see irdm_expect_history
 constexpr int kBandTlSlots = 32;         // plan / sums / cross / walk of round r: 4 r + 0..3; commit 24; history 25
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,

@@ -383,6 +383,14 @@ struct irdm_pipeline {
     std::vector<irdm_burst_t> last_bursts;
     float last_ms[6];
     int keep_frame_samples;
+    // time-chunk sharding: the previous chunk's 512-frame history may arrive AFTER this chunk's scan has been enqueued
+    // (irdm_expect_history / irdm_import_state_history_device): [0] sequence number the import publishes, [1] time-out
+    // flag of the waiting kernel, in mapped pinned memory; the import's copies run on gstream
+    uint32_t *hp_gate = nullptr, *hp_gate_dev = nullptr;
+    uint32_t gate_seq = 0;
+    bool gate_armed = false;        // the next band scan enqueued from frame 0 waits for gate_seq before its first history read
+    bool gate_open_pending = false; // a scan in flight waits for the history to arrive in gate_src
+    const void *gate_src = nullptr; // the caller's receive buffer (device memory) the scan copies the history from
     // kernel clock (option "kernel_clock", common.hpp): records 0..2 the decimator of bc[0..2], 3..5 K1 of feed slot 0..2
     unsigned long long *d_kclk = nullptr;
     int kernel_clock = 0;
@@ -497,6 +505,7 @@ static void pipeline_free(irdm_pipeline *p)
         if (f.ev_k1) (void)hipEventDestroy(f.ev_k1);
         if (f.ev_copy) (void)hipEventDestroy(f.ev_copy);
     }
+    if (p->hp_gate) (void)hipHostFree(p->hp_gate);
     rot_table_release(p->d_rot_table);       // (ev_rot belongs to the shared table)
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
     for (auto &set : p->ev_plan_set)
@@ -796,6 +805,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_mc_done, unsigned, 32 * 16);
     }
     mark("per-burst scratch, lists");
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->hp_gate), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+         hipHostGetDevicePointer(reinterpret_cast<void **>(&p->hp_gate_dev), p->hp_gate, 0) == hipSuccess;
+    if (ok) memset(p->hp_gate, 0, 64);
     AL(p->d_kclk, unsigned long long, (size_t)6 * kKClkWords);
     if (ok) {
         std::vector<unsigned long long> init((size_t)6 * kKClkWords, 0ull);
@@ -1607,10 +1619,16 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
         p->stat_k1_lists++;
     }
     if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
+    const bool gate = p->gate_armed && !retry && p->hp_gate_dev;
+    if (gate) {
+        p->gate_armed = false;
+        p->gate_open_pending = true;
+    }
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
                          entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, first, hpg,
                          reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream, p->stream_side,
-                         p->ev_plan_set[sel]) != 0)
+                         p->ev_plan_set[sel], gate ? p->hp_gate_dev : nullptr, p->gate_seq, gate ? p->hp_gate_dev + 1 : nullptr,
+                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n) != 0)
         return -1;
     if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
@@ -1779,6 +1797,16 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     double tq0 = now_us(), tq1;
     // (the scan's own end, not the stream's: the next chunk's scan may be enqueued behind it already)
     IRDM_HIP_CHECK(hipEventSynchronize(p->ev_end));
+    if (p->gate_open_pending) {
+        // the scan waited for the previous chunk's history (irdm_expect_history): whatever runs from here on -- more
+        // rounds, a retry, a sequential fallback -- reads it too
+        p->gate_open_pending = false;
+        if (p->hp_gate[1]) {
+            fprintf(stderr, "irdm_hip: the detector scan waited for a history import that never came (irdm_expect_history)\n");
+            p->hp_gate[1] = 0;
+            return -1;
+        }
+    }
     tq1 = now_us(); p->host_us[6] += tq1 - tq0; tq0 = tq1;          // [6] waiting for the scan itself
     int redo_from = p->fl_done;       // where a dense redo restarts (the priming frames are never redone)
     bool redone = false;              // something ran after the export the launch enqueued
@@ -2484,6 +2512,76 @@ extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, s
     p->start_time_ns = h.start_time_ns;
     p->host_primed = h.host_primed;
     p->host_hist_idx = h.host_hist_idx;
+    return 0;
+}
+
+// ---- the same hand-off in two parts, so that the 16-32 MiB history can FOLLOW the detector's head ----
+// head = header + DetState + sums (65 KB at 12 MHz): everything round 0 of the band scan reads.  The history (512 x N
+// floats) is first read by round 1's sums pass: a rank takes the head, enqueues its scan and imports the history when it
+// arrives; the scan waits for it on the device (launch_band_scan's gate).
+extern "C" size_t irdm_state_head_bytes(const irdm_pipeline_t *p)
+{
+    if (!p) return 0;
+    return sizeof(StateHeader) + sizeof(DetState) + sizeof(float) * (size_t)p->P.n;
+}
+
+extern "C" int irdm_import_state_head_device(irdm_pipeline_t *p, const void *d_buf, size_t n)
+{
+    if (!p || !d_buf || n < irdm_state_head_bytes(p)) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (settle(p) != 0) return -1;
+    const char *i = static_cast<const char *>(d_buf);
+    StateHeader h;
+    IRDM_HIP_CHECK(hipMemcpyAsync(&h, i, sizeof(h), hipMemcpyDeviceToHost, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (h.magic != 0x4952444d53544154ull || h.n != (uint64_t)p->P.n || h.hist != (uint64_t)kHistory) return -1;
+    i += sizeof(h);
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_state, i, sizeof(DetState), hipMemcpyDeviceToDevice, p->stream));
+    i += sizeof(DetState);
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, i, sizeof(float) * p->P.n, hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
+    if (p->begin_no == p->end_no) p->total_samples = p->begun_samples = h.total_samples;
+    p->tagged = h.tagged;
+    p->start_time_ns = h.start_time_ns;
+    p->host_primed = h.host_primed;
+    p->host_hist_idx = h.host_hist_idx;
+    return 0;
+}
+
+// Call between irdm_import_state_head_device and irdm_feed_end.  d_hist_buf: device memory (irdm_state_bytes() -
+// irdm_state_head_bytes() bytes) the history WILL be in.  1 = the scan that irdm_feed_end enqueues waits on the device --
+// behind its round 0 -- until irdm_import_state_history_device(p, d_hist_buf, n) says the history has arrived there, and
+// copies it into the context itself; the caller MUST make that call before anything settles the scan
+// (irdm_export_state_device, irdm_flush, the next irdm_feed_end).  0 = this scan cannot wait (pipeline_depth 0, a
+// detector that is not primed, a scan other than the band scan): import the history before irdm_feed_end.
+extern "C" int irdm_expect_history(irdm_pipeline_t *p, const void *d_hist_buf)
+{
+    if (!p || !d_hist_buf || !p->hp_gate_dev || !p->depth || !p->host_primed || scan_pick(p) != 2 || p->begin_no == p->end_no)
+        return 0;
+    p->gate_seq++;
+    p->gate_src = d_hist_buf;
+    p->gate_armed = true;
+    return 1;
+}
+
+// d_hist_buf: the history part of the blob (behind irdm_state_head_bytes()), device memory, complete and visible to the
+// device when this is called
+extern "C" int irdm_import_state_history_device(irdm_pipeline_t *p, const void *d_hist_buf, size_t n)
+{
+    const size_t bytes = p ? sizeof(float) * (size_t)kHistory * p->P.n : 0;
+    if (!p || !d_hist_buf || n < bytes) return -1;
+    (void)hipSetDevice(p->cfg.device);
+    if (p->gate_open_pending) {
+        // a scan is waiting for it: the word it polls is written by the HOST (no GPU work of ours that could queue up
+        // behind the waiting kernel); the scan's stream copies the history in and goes on
+        if (d_hist_buf != p->gate_src) return -1;
+        __atomic_store_n(&p->hp_gate[0], p->gate_seq, __ATOMIC_RELEASE);
+        return 0;
+    }
+    p->gate_armed = false;               // (announced, but the scan was never enqueued: the ordinary import)
+    if (settle(p) != 0) return -1;
+    IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, d_hist_buf, bytes, hipMemcpyDeviceToDevice, p->stream));
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
     return 0;
 }
 

@@ -1398,7 +1398,8 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
                      uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream, hipStream_t side,
-                     hipEvent_t *plan_ev)
+                     hipEvent_t *plan_ev, const uint32_t *gate_flag, uint32_t gate_seq, uint32_t *gate_err, const void *gate_src,
+                     size_t gate_bytes)
 {
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
@@ -1482,6 +1483,15 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             }
         }
         if (round == round_end) break;
+        // Gate (time-chunk sharding, irdm_expect_history): the 512-frame history of the previous chunk is still on its way
+        // from the previous rank.  Round 0 speculates "no update" and reads none of it; the first sums pass that does
+        // (round 1) starts behind a one-lane kernel that waits until the HOST has published `gate_seq` (the history has
+        // arrived in the caller's receive buffer) and the copy of it into the ring, both on this stream: nothing the
+        // waiting kernel depends on needs another queue of the GPU.
+        if (gate_flag && round == (round_begin > 1 ? round_begin : 1)) {
+            if (launch_wait_host_flag(gate_flag, gate_seq, gate_err, stream) != 0) return -1;
+            if (hipMemcpyAsync(hist, gate_src, gate_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+        }
         if (g_band_sum_bins == 32)
             hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         else if (g_band_sum_bins == 16)

@@ -127,6 +127,11 @@ def lib():
         L.irdm_export_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_export_state_device.restype = C.c_longlong
         L.irdm_import_state_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_state_head_bytes.argtypes = [C.c_void_p]
+        L.irdm_state_head_bytes.restype = C.c_size_t
+        L.irdm_import_state_head_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_expect_history.argtypes = [C.c_void_p, C.c_void_p]
+        L.irdm_import_state_history_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_seed_history_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
         L.irdm_device_alloc.argtypes = [C.c_int, C.c_size_t]
         L.irdm_device_alloc.restype = C.c_void_p
@@ -339,6 +344,22 @@ class Pipeline:
     def export_state_device(self, dptr, cap):
         if self.L.irdm_export_state_device(self.h, C.c_void_p(dptr), cap) < 0:
             raise RuntimeError("irdm_export_state_device failed")
+
+    def state_head_bytes(self):
+        return int(self.L.irdm_state_head_bytes(self.h))
+
+    def import_state_head_device(self, dptr, n):
+        if self.L.irdm_import_state_head_device(self.h, C.c_void_p(dptr), n) != 0:
+            raise RuntimeError("irdm_import_state_head_device failed")
+
+    def expect_history(self, dptr):
+        """True: the scan the next feed_end enqueues waits on the device until import_state_history_device(dptr, n) says
+        the history has arrived at dptr"""
+        return bool(self.L.irdm_expect_history(self.h, C.c_void_p(dptr)))
+
+    def import_state_history_device(self, dptr, n):
+        if self.L.irdm_import_state_history_device(self.h, C.c_void_p(dptr), n) != 0:
+            raise RuntimeError("irdm_import_state_history_device failed")
 
     def import_state_device(self, dptr, n):
         if self.L.irdm_import_state_device(self.h, C.c_void_p(dptr), n) != 0:

@@ -127,11 +127,13 @@ class TimeShard:
 
         seed_history_device   the `overlap` samples in front of the chunk (arrive with the chunk)
         feed_begin            K1 + history-ring copy: no detector state needed, runs while the state is on its way
-        recv + import         the detector state of the previous chunk (rank k-1; rank 0: rank world-1's of the
-                              previous super-step) -- DetState + sums + 512-frame history, 16-32 MiB, GPU to GPU
-        feed_end              prefilter + scan (+ per-burst chain enqueued)
-        export + send         the state moves on as soon as the scan has settled; only this recv -> scan -> send
-                              stretch is sequential across the ranks (burst_detect.c:438-454, :594-631)
+        recv + import head    of the previous chunk's detector state (rank k-1; rank 0: rank world-1's of the previous
+                              super-step): header + DetState + baseline sums, 65 KB at 12 MHz, GPU to GPU
+        feed_end              scan enqueued (+ per-burst chain of the chunk before); round 0 reads no history
+        recv + import history the 512-frame history (16-32 MiB) arrives while K1 and round 0 run; round 1's sums pass
+                              waits for it on the device (irdm_expect_history)
+        export + send         head, then history, as soon as the scan has settled; only recv head -> scan -> send head
+                              is sequential across the ranks (burst_detect.c:438-454, :594-631)
         flush                 the chunk's per-burst stages, overlapping the next ranks' scans
 
     With "nccl" the blob is a device tensor (RCCL send/recv over xGMI); with "gloo" (CPU tests, or several ranks
@@ -145,25 +147,31 @@ class TimeShard:
         self.chunk, self.bps, self.overlap = chunk_samples, bps, overlap
         self.nccl = dist.get_backend() == "nccl"
         self.nbytes = pipe.state_bytes()
+        # the blob travels in two messages: the head (header, detector state, baseline sums: what round 0 of the scan
+        # reads; 65 KB at 12 MHz) and the 512-frame history behind it (first read by round 1's sums pass)
+        self.head = pipe.state_head_bytes()
         self.state = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
         self.host_state = None if self.nccl else torch.empty(self.nbytes, dtype=torch.uint8)
         self.step_no = 0
+        self.have_head = self.have_hist = False       # rank 0: parts of the last rank's state already received
 
-    def _recv_state(self, src):
+    def _recv_part(self, src, lo, hi):
         if self.nccl:
-            self.dist.recv(self.state, src=src)
+            self.dist.recv(self.state[lo:hi], src=src)
         else:
-            self.dist.recv(self.host_state, src=src)
-            self.state.copy_(self.host_state)
+            self.dist.recv(self.host_state[lo:hi], src=src)
+            self.state[lo:hi].copy_(self.host_state[lo:hi])
         if self.device.type == "cuda":          # (a CPU device only in the emulated tests: nothing is in flight there)
-            self.torch.cuda.synchronize(self.device)
+            # the stream the part arrived on, NOT the device: this rank's scan may be on the GPU waiting for exactly this
+            # part (irdm_expect_history), and a device-wide wait would wait for the scan
+            self.torch.cuda.current_stream(self.device).synchronize()
 
-    def _send_state(self, dst):
+    def _send_part(self, dst, lo, hi):
         if self.nccl:
-            self.dist.send(self.state, dst=dst)
+            self.dist.send(self.state[lo:hi], dst=dst)
         else:
-            self.host_state.copy_(self.state)
-            self.dist.send(self.host_state, dst=dst)
+            self.host_state[lo:hi].copy_(self.state[lo:hi])
+            self.dist.send(self.host_state[lo:hi], dst=dst)
 
     def step(self, buf, first_of_stream):
         """buf: device uint8 tensor holding [overlap samples | chunk samples] for this rank's chunk of the current
@@ -181,20 +189,39 @@ class TimeShard:
             self.step_no += 1
             return
         first = first_of_stream and self.step_no == 0 and rank == 0
+        head, nbytes, sp = self.head, self.nbytes, self.state.data_ptr()
         if not first:
             pipe.seed_history_device(base, self.overlap, abs_start)
         pipe.feed_begin(base + self.overlap * self.bps, self.chunk, None)
+        late_history = False
         if not first:
-            if rank != 0:
-                self._recv_state(rank - 1)
-            # (rank 0 already holds the state: received at the end of its previous step)
-            pipe.import_state_device(self.state.data_ptr(), self.nbytes)
+            prev = (rank - 1) % world
+            if not self.have_head:
+                self._recv_part(prev, 0, head)
+            # (rank 0 received what had arrived of the last rank's state at the end of its previous step)
+            pipe.import_state_head_device(sp, head)
+            # the history follows while K1 and round 0 of the scan run -- if this scan can wait for it on the device
+            # (a primed detector, the band scan, pipeline_depth >= 1, a real GPU: the emulated device runs a launch to
+            # its end when it is enqueued)
+            late_history = (not self.have_hist) and self.device.type == "cuda" and pipe.expect_history(sp + head)
+            if not late_history:
+                if not self.have_hist:
+                    self._recv_part(prev, head, nbytes)
+                pipe.import_state_history_device(sp + head, nbytes - head)
         pipe.feed_end()
-        pipe.export_state_device(self.state.data_ptr(), self.nbytes)
-        self._send_state((rank + 1) % world)
+        if late_history:
+            self._recv_part((rank - 1) % world, head, nbytes)
+            pipe.import_state_history_device(sp + head, nbytes - head)
+        self.have_head = self.have_hist = False
+        pipe.export_state_device(sp, nbytes)             # (waits for this chunk's scan)
+        nxt = (rank + 1) % world
+        self._send_part(nxt, 0, head)                    # the next rank's scan can start: head first ...
+        self._send_part(nxt, head, nbytes)               # ... the history behind it
         pipe.flush()
         if rank == 0:
-            self._recv_state(world - 1)
+            self._recv_part(world - 1, 0, head)
+            self._recv_part(world - 1, head, nbytes)
+            self.have_head = self.have_hist = True
         self.step_no += 1
 
     def drain(self):

@@ -52,6 +52,7 @@ def test_fused_four_accumulator_kernel_10mhz(scene10):
     parity.compare(parity.run_gpu(iq, 10_000_000, chunks=[c, c, n - 2 * c], depth=1), ref)
     try:
         parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 300}), ref)
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 0}), ref)      # one workgroup per strip
     finally:
         _restore()
 
@@ -71,7 +72,7 @@ def _restore():
     p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
     p.set_option("fir_layout", 3)
     p.set_option("fir_strip", 3)
-    p.set_option("fir_grid", 0)
+    p.set_option("fir_grid", -1)
     p.set_option("fir_order", 1)
     p.close()
 
