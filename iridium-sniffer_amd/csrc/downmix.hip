@@ -84,6 +84,34 @@ int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ck
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// The same rows ON DEMAND: the table is a pool of rows, a row is given to a centre bin when the first burst on that bin
+// reaches the decimator (pipeline.cpp, rot_rows_prepare).  news[i] = (bin, row); the lane that has written a row publishes
+// it in slot[bin] (read by the decimator's geometry pass and the LDS decimators of the SAME stream, launched behind this
+// kernel; later chains wait for the event recorded behind it).
+__global__ void rotator_rows_kernel(const float2 *__restrict__ incr, float2 *__restrict__ table, int n_ckpt,
+                                    const int2 *__restrict__ news, int n_new, int *__restrict__ slot)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_new) return;
+    const int bin = news[i].x, row_no = news[i].y;
+    const float2 inc = incr[bin];
+    float2 ph = make_float2(1.0f, 0.0f);
+    float2 *row = table + (size_t)row_no * n_ckpt;
+    for (int c = 0; c < n_ckpt; c++) {
+        row[c] = ph;
+#pragma unroll
+        for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
+    }
+    slot[bin] = row_no;
+}
+
+int launch_rotator_rows(const float2 *incr, float2 *table, int n_ckpt, const int2 *news, int n_new, int *slot, hipStream_t stream)
+{
+    if (n_new <= 0) return 0;
+    hipLaunchKernelGGL(rotator_rows_kernel, dim3((n_new + 63) / 64), dim3(64), 0, stream, incr, table, n_ckpt, news, n_new, slot);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // ---------------------------------------------------------------------------
 // Rotate + decimate.  One workgroup = kFirTileOut outputs of one burst.
 //   staging : samples [o0*M, o0*M + (nout-1)*M + 801) of the burst window are read
@@ -100,7 +128,8 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     int decim, int row, const float *__restrict__ taps, const int *__restrict__ tap_off,
     const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride, int order)
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride, int order,
+    const int *__restrict__ rot_slot)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2 *s = reinterpret_cast<float2 *>(smem_raw);
@@ -113,7 +142,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     const int span = (n_out - 1) * decim + kFirTaps;
     const int s0 = o0 * decim;                       // multiple of kRotSeg
     const float2 inc = rot_incr[w.center_bin];
-    const float2 *ck = rot_table + (size_t)w.center_bin * n_ckpt + s0 / kRotSeg;
+    const float2 *ck = rot_table + (size_t)rot_slot[w.center_bin] * n_ckpt + s0 / kRotSeg;
     const int n_seg = (span + kRotSeg - 1) / kRotSeg;
 
     for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
@@ -242,7 +271,8 @@ template <int M>
 __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride)
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride,
+    const int *__restrict__ rot_slot)
 {
     constexpr int ROW = fir_tile_row_c(M);
     constexpr int NR = kFirTaps / M;               // full rows of M taps
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
     const int span = (n_out - 1) * M + kFirTaps;
     const int s0 = o0 * M;                           // multiple of kRotSeg
     const float2 inc = rot_incr[w.center_bin];
-    const float2 *ck = rot_table + (size_t)w.center_bin * n_ckpt + s0 / kRotSeg;
+    const float2 *ck = rot_table + (size_t)rot_slot[w.center_bin] * n_ckpt + s0 / kRotSeg;
     const int n_seg = (span + kRotSeg - 1) / kRotSeg;
 
     for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
@@ -355,7 +385,8 @@ template <int M>
 __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride)
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride,
+    const int *__restrict__ rot_slot)
 {
     using C = FirCol<M>;
     constexpr int NR = C::NR, REM = C::REM, CS = C::CS;
@@ -371,7 +402,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
     const int span = (n_out - 1) * M + kFirTaps;
     const int s0 = o0 * M;                           // multiple of kRotSeg
     const float2 inc = rot_incr[w.center_bin];
-    const float2 *ck = rot_table + (size_t)w.center_bin * n_ckpt + s0 / kRotSeg;
+    const float2 *ck = rot_table + (size_t)rot_slot[w.center_bin] * n_ckpt + s0 / kRotSeg;
     const int n_seg = (span + kRotSeg - 1) / kRotSeg;
 
     for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
@@ -490,7 +521,8 @@ struct FirW {
 // one lane per tile: everything the decimator's workgroups need, in one record
 __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts, int n_tiles, int M,
                                 int tile_out, uint64_t ring_len, uint64_t ref_ring, const float2 *__restrict__ rot_incr, int n_ckpt,
-                                int dec_stride, FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile)
+                                int dec_stride, FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile,
+                                const int *__restrict__ rot_slot)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) *next_tile = 0;
@@ -522,7 +554,7 @@ __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts
     const float2 inc = rot_incr[cb];
     g.inc_re = inc.x;
     g.inc_im = inc.y;
-    g.ck_index = (uint64_t)cb * (uint64_t)n_ckpt + (uint64_t)(g.s0 / kRotSeg);
+    g.ck_index = (uint64_t)rot_slot[cb] * (uint64_t)n_ckpt + (uint64_t)(g.s0 / kRotSeg);      // (the bin's row of the checkpoint pool)
     g.out_base = (int64_t)tile.burst * dec_stride + o0;
     g.stale_pos = (g.ring_pos + ring_len - ref_ring % ring_len) % ring_len;
     for (int i = 0; i < 4; i++) g.pad[i] = 0;
@@ -811,7 +843,7 @@ static int launch_fir_w_fmt(const SampleSource &src, const FirGeom *geom, unsign
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
-                        hipStream_t stream, unsigned long long *kclk)
+                        hipStream_t stream, unsigned long long *kclk, const int *rot_slot)
 {
     if (n_tiles <= 0) return 0;
 #define IRDM_LAUNCH_FIR_M(MM)                                                                                  \
@@ -820,7 +852,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_m<MM>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);                     \
         hipLaunchKernelGGL(fir_decimate_kernel_m<MM>, dim3(n_tiles), dim3(kFirTileOut), lds_m, stream, src,    \
-                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);                   \
+                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride, rot_slot);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
 #define IRDM_LAUNCH_FIR_C(MM)                                                                                  \
@@ -828,7 +860,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_c<MM>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FirCol<MM>::LDS);           \
         hipLaunchKernelGGL(fir_decimate_kernel_c<MM>, dim3(n_tiles), dim3(kFirTileOut), FirCol<MM>::LDS, stream, src, \
-                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride);                   \
+                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride, rot_slot);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
     const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
@@ -836,14 +868,14 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+                           fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile, rot_slot);
         return launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
     }
     if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+                           fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile, rot_slot);
         return launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
     }
     if (fir_wide_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
@@ -851,7 +883,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);      // (one spare record behind the last)
         const int to = fir_wide_tile(decim);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           to, src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile);
+                           to, src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile, rot_slot);
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -893,7 +925,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
     (void)hipFuncSetAttribute((const void *)fir_decimate_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
-                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride, g_fir_order);
+                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride, g_fir_order, rot_slot);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

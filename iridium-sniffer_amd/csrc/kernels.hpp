@@ -79,6 +79,7 @@ extern int g_band_plan_threads;          // threads of the plan pass's one workg
 extern int g_band_walk_wave;             // 1 (default): the walk pass with a wavefront per band and segment; 0: a lane per band
 extern int g_band_timeline;              // 1: the band scan's passes record a device timeline (read back by the pipeline per chunk)
 extern int g_band_selfcheck;             // test hook: BandParams::selfcheck of the launches that follow
+extern int g_band_cross_groups;          // workgroups of the crossing pass (default 256 = 1024 wavefronts)
 extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass
 int band_list_cap(int n);                // entries per frame the band scan's lists hold
@@ -110,6 +111,8 @@ struct SampleSource {
 
 // downmix.hip
 int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream);
+// rows of the checkpoint pool for centre bins that have none yet: news[i] = (bin, row), slot[bin] = row when done
+int launch_rotator_rows(const float2 *incr, float2 *table, int n_ckpt, const int2 *news, int n_new, int *slot, hipStream_t stream);
 int fir_tile_row(int decim);
 extern int g_fir_force_generic;   // 1: always the runtime-M decimator kernel
 extern int g_fir_layout;          // 2 (default): persistent column-major kernel, 1: column-major tile, 0: polyphase rows
@@ -139,7 +142,8 @@ int fir_needs_tile_list(int decim, int aligned);
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
-                        hipStream_t stream, unsigned long long *kclk = nullptr);   // kclk: the register-resident kernel's clock record
+                        hipStream_t stream, unsigned long long *kclk = nullptr,    // kclk: the register-resident kernel's clock record
+                        const int *rot_slot = nullptr);                            // rot_slot[bin] = the bin's row in rot_table
 // folds a kernel-clock record's slots into its sums and re-arms them (common.hpp); enqueue behind the kernel
 int launch_kclk_fold(unsigned long long *kclk, hipStream_t stream);
 int launch_gone_export(const DetState *st, const GoneBurst *gone, int cap, GoneBurst *hp_gone, uint32_t *hp_hdr,

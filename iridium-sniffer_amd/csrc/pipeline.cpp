@@ -198,6 +198,7 @@ struct BatchCtx {
     DemodOut *hp_demod;
     DemodPacked *d_packed, *hp_packed;      // packed_records: the demodulator's result without LLRs, bits 8 per byte
     uint32_t *hp_flag, *hp_flag_dev;    // [0] sequence number the helper publishes, [1] time-out flag of the waiting kernel
+    int2 *hp_rot_new, *hp_rot_new_dev, *d_rot_new;   // (bin, row) of the checkpoint rows this batch has to build: mapped pinned / device
     uint32_t cfo_seq;
     bool packed;                 // this batch came back as DemodPacked records
     bool cfo_on_device;          // this batch's libm step ran on the device: h_cfreq is filled from the returned records
@@ -383,6 +384,12 @@ struct irdm_pipeline {
     std::vector<irdm_burst_t> last_bursts;
     float last_ms[6];
     int keep_frame_samples;
+    // rotator checkpoint rows on demand (rot_rows_prepare)
+    int *d_rot_slot = nullptr;              // [n] centre bin -> row of d_rot_table, -1: none yet (written by the kernel that builds the row)
+    std::vector<int> rot_slot_h;            // the host's view: rows handed out (their kernels may still be in flight)
+    int rot_rows_used = 0, rot_rows_cap = 0;
+    std::vector<float2 *> rot_retired;      // outgrown pools
+    uint64_t stat_rot_builds = 0, stat_rot_rows = 0;
     // time-chunk sharding: the previous chunk's 512-frame history may arrive AFTER this chunk's scan has been enqueued
     // (irdm_expect_history / irdm_import_state_history_device): [0] sequence number the import publishes, [1] time-out
     // flag of the waiting kernel, in mapped pinned memory; the import's copies run on gstream
@@ -397,58 +404,14 @@ struct irdm_pipeline {
     unsigned long long *kclk_rec(int i) const { return kernel_clock && d_kclk ? d_kclk + (size_t)i * kKClkWords : nullptr; }
 };
 
-// The rotator checkpoint table (4.5 GB at 10 MHz, 10.9 GB at 12 MHz) is a function of the FFT size and the longest burst
-// only: contexts of one sample rate on one device share it (several streams per GPU, the reference-API layer's
-// workers).  The entry owns the table and the event that says it is complete; the last user frees both.
-struct RotTableEntry {
-    int device, n, n_ckpt, refs;
-    float2 *table;
-    hipEvent_t ready;
-};
-static std::mutex g_rot_mu;
-static std::vector<RotTableEntry> g_rot_tables;
-
-static bool rot_table_acquire(int device, int n, int n_ckpt, const float2 *d_incr, hipStream_t st, float2 **table,
-                              hipEvent_t *ready)
-{
-    std::lock_guard<std::mutex> lk(g_rot_mu);
-    for (auto &e : g_rot_tables)
-        if (e.device == device && e.n == n && e.n_ckpt == n_ckpt) {
-            e.refs++;
-            *table = e.table;
-            *ready = e.ready;
-            return true;
-        }
-    RotTableEntry e{ device, n, n_ckpt, 1, nullptr, nullptr };
-    if (hipMalloc(reinterpret_cast<void **>(&e.table), sizeof(float2) * (size_t)n * n_ckpt) != hipSuccess) return false;
-    // (not needed before the first burst reaches the decimator: built asynchronously on the caller's per-burst stream)
-    if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess ||
-        launch_rotator_table(d_incr, e.table, n, n_ckpt, st) != 0 || hipEventRecord(e.ready, st) != hipSuccess) {
-        if (e.ready) (void)hipEventDestroy(e.ready);
-        (void)hipFree(e.table);
-        return false;
-    }
-    g_rot_tables.push_back(e);
-    *table = e.table;
-    *ready = e.ready;
-    return true;
-}
-
-static void rot_table_release(const float2 *table)
-{
-    if (!table) return;
-    std::lock_guard<std::mutex> lk(g_rot_mu);
-    for (size_t i = 0; i < g_rot_tables.size(); i++)
-        if (g_rot_tables[i].table == table) {
-            if (--g_rot_tables[i].refs == 0) {
-                (void)hipEventSynchronize(g_rot_tables[i].ready);
-                (void)hipEventDestroy(g_rot_tables[i].ready);
-                (void)hipFree(g_rot_tables[i].table);
-                g_rot_tables.erase(g_rot_tables.begin() + (long)i);
-            }
-            return;
-        }
-}
+// The rotator checkpoints (rotator.h:36-46 restated: the phase of the float recurrence every 16 samples, a row of
+// l_cap / 16 of them per centre bin -- 0.55 MB at 10 MHz) are kept for the centre bins bursts have actually appeared on: a
+// pool of rows handed out on first use, rows built by one lane each (the recurrence is sequential: 12 ms for any number of
+// new bins, on the chain that needs them; the bins of a band repeat, so this happens in a stream's first chunks).  The
+// whole table -- a row for every FFT bin, 4.5 GB at 10 MHz and 10.9 GB at 12 MHz, built at create in rounds 1-3 -- is the
+// pool's upper bound: it grows by doubling; a pool that has been outgrown stays allocated until the context is closed
+// (chains in flight still read it).
+static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st);
 
 static void pipeline_free(irdm_pipeline *p)
 {
@@ -486,6 +449,8 @@ static void pipeline_free(irdm_pipeline *p)
         for (auto &e : b.ev)
             if (e) (void)hipEventDestroy(e);
         if (b.hp_flag) (void)hipHostFree(b.hp_flag);
+        if (b.hp_rot_new) (void)hipHostFree(b.hp_rot_new);
+        if (b.d_rot_new) (void)hipFree(b.d_rot_new);
         if (b.hp_work) (void)hipHostFree(b.hp_work);
         if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
         if (b.hp_demod) (void)hipHostFree(b.hp_demod);
@@ -506,7 +471,10 @@ static void pipeline_free(irdm_pipeline *p)
         if (f.ev_copy) (void)hipEventDestroy(f.ev_copy);
     }
     if (p->hp_gate) (void)hipHostFree(p->hp_gate);
-    rot_table_release(p->d_rot_table);       // (ev_rot belongs to the shared table)
+    if (p->d_rot_table) (void)hipFree(p->d_rot_table);
+    for (float2 *q : p->rot_retired) (void)hipFree(q);
+    if (p->d_rot_slot) (void)hipFree(p->d_rot_slot);
+    if (p->ev_rot) (void)hipEventDestroy(p->ev_rot);
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
     for (auto &set : p->ev_plan_set)
         for (auto &e : set)
@@ -869,6 +837,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_flag), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_flag_dev), b.hp_flag, 0) == hipSuccess;
         if (ok) memset(b.hp_flag, 0, 64);
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_rot_new), sizeof(int2) * (size_t)p->burst_cap, hipHostMallocMapped) == hipSuccess &&
+             hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_rot_new_dev), b.hp_rot_new, 0) == hipSuccess;
+        AL(b.d_rot_new, int2, (size_t)p->burst_cap);
         ok = ok && hipEventCreateWithFlags(&b.ev_cfo, hipEventDisableTiming) == hipSuccess;
         for (auto &e : b.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         b.h_cfreq.assign((size_t)p->burst_cap, 0.0);
@@ -899,8 +870,16 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     // The rotator checkpoint table (one sequential float recurrence per FFT bin, 12.5 ms of one-lane-per-bin work at
     // 10 MHz) is not needed before the first burst reaches the decimator -- at the earliest 512 priming frames into
     // the stream -- so irdm_create does not wait for it: it runs on a per-burst stream, the chains wait for ev_rot.
-    ok = ok && rot_table_acquire(cfg->device, P.n, p->n_ckpt, p->d_rot_incr, p->bc[0].stream, &p->d_rot_table, &p->ev_rot);
-    mark("rotator table");
+    // rotator checkpoint rows: a pool, rows on first use of a centre bin (rot_rows_prepare); nothing is built here
+    p->rot_rows_cap = std::min(P.n, 1024);
+    p->rot_rows_used = 0;
+    p->rot_slot_h.assign((size_t)P.n, -1);
+    ok = ok && (p->d_rot_table = dev_alloc<float2>((size_t)p->rot_rows_cap * p->n_ckpt)) != nullptr;
+    ok = ok && (p->d_rot_slot = dev_alloc<int>((size_t)P.n)) != nullptr;
+    ok = ok && hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)P.n) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->ev_rot, hipEventDisableTiming) == hipSuccess &&
+         hipEventRecord(p->ev_rot, p->bc[0].stream) == hipSuccess;
+    mark("rotator row pool");
     if (!ok) {
         fprintf(stderr, "irdm_hip: device initialisation failed\n");
         pipeline_free(p);
@@ -1201,6 +1180,45 @@ static void cfo_helper_main(irdm_pipeline *p)
     }
 }
 
+static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st)
+{
+    int n_new = 0;
+    for (int i = 0; i < nb; i++) {
+        const BurstWork &w = b.hp_work[i];
+        if (w.drop_reason) continue;
+        const int bin = w.center_bin;
+        if (bin < 0 || bin >= p->P.n || p->rot_slot_h[(size_t)bin] >= 0) continue;
+        if (p->rot_rows_used == p->rot_rows_cap) {
+            // the pool is full: twice the rows (at most one per FFT bin), the rows built so far copied over on this
+            // chain's stream -- every build so far is complete there (ev_rot) -- and the old pool kept for the chains in
+            // flight that were launched with its address
+            const int cap2 = std::min(p->P.n, 2 * p->rot_rows_cap);
+            float2 *pool2 = nullptr;
+            if (cap2 <= p->rot_rows_cap || hipMalloc(reinterpret_cast<void **>(&pool2), sizeof(float2) * (size_t)cap2 * p->n_ckpt) != hipSuccess) {
+                fprintf(stderr, "irdm_hip: no memory for %d rotator checkpoint rows\n", cap2);
+                return -1;
+            }
+            // (the rows of this batch's list so far are not built yet: they will be built in the new pool)
+            IRDM_HIP_CHECK(hipMemcpyAsync(pool2, p->d_rot_table, sizeof(float2) * (size_t)p->rot_rows_cap * p->n_ckpt,
+                                          hipMemcpyDeviceToDevice, st));
+            p->rot_retired.push_back(p->d_rot_table);
+            p->d_rot_table = pool2;
+            p->rot_rows_cap = cap2;
+        }
+        const int row = p->rot_rows_used++;
+        p->rot_slot_h[(size_t)bin] = row;
+        b.hp_rot_new[n_new++] = int2{ bin, row };
+    }
+    if (!n_new) return 0;
+    p->stat_rot_builds++;
+    p->stat_rot_rows += (uint64_t)n_new;
+    // (the list by copy kernel: a kernel's plain loads of mapped host memory may be served from stale L2 lines)
+    if (launch_copy_words(b.d_rot_new, b.hp_rot_new_dev, sizeof(int2) * (size_t)n_new, st) != 0) return -1;
+    if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_rot_new, n_new, p->d_rot_slot, st) != 0) return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_rot, st));                  // later chains wait for these rows
+    return 0;
+}
+
 static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src, const GoneBurst *gone_list, int nb)
 {
     const DetParams &P = p->P;
@@ -1274,7 +1292,8 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         }
     }
     hipStream_t st = b.stream;
-    IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));
+    IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));           // rows an earlier chain is still building
+    if (rot_rows_prepare(p, b, nb, st) != 0) return -1;
     // (copies by kernel, here and at the end of the chain: the runtime's copy path answers late next to the chains'
     // kernels, and an H2D from pinned memory may block the enqueueing thread)
     if (launch_copy_words(b.d_work, b.hp_work_dev, sizeof(BurstWork) * nb, st) != 0) return -1;
@@ -1282,7 +1301,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
                             p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st,
-                            p->kclk_rec((int)(&b - p->bc))) != 0)
+                            p->kclk_rec((int)(&b - p->bc)), p->d_rot_slot) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
     if (launch_downmix_post1(b.d_work, nb, b.d_dec, p->dec_stride, b.d_lpf, p->d_noise_taps,
@@ -2820,6 +2839,16 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
     if (!strcmp(key, "fir_order")) { irdm::g_fir_order = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "rot_pool_rows")) {
+        // (test hook) the rotator checkpoint pool with `value` rows to begin with; only before the first burst
+        if (p->rot_rows_used != 0 || value < 1 || value > p->P.n) return -1;
+        float2 *pool = dev_alloc<float2>((size_t)value * p->n_ckpt);
+        if (!pool) return -1;
+        (void)hipFree(p->d_rot_table);
+        p->d_rot_table = pool;
+        p->rot_rows_cap = value;
+        return 0;
+    }
     if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
@@ -2829,6 +2858,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_walk_wave")) { irdm::g_band_walk_wave = value; return 0; }
     if (!strcmp(key, "band_plan_threads")) { irdm::g_band_plan_threads = value; return 0; }
     if (!strcmp(key, "band_fuse_commit")) { irdm::g_band_fuse_commit = value; return 0; }
+    if (!strcmp(key, "band_cross_groups")) { irdm::g_band_cross_groups = value; return 0; }
     if (!strcmp(key, "band_plan_ahead")) { irdm::g_band_plan_ahead = value != 0; return 0; }
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
     if (!strcmp(key, "kernel_clock")) { p->kernel_clock = value != 0; return 0; }
@@ -2860,6 +2890,9 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
         const int i = atoi(key + 8);
         return i >= 0 && i < 16 ? (int64_t)p->stat_plan_tp[i] : -1;
     }
+    if (!strcmp(key, "rot_rows")) return (int64_t)p->rot_rows_used;
+    if (!strcmp(key, "rot_rows_cap")) return (int64_t)p->rot_rows_cap;
+    if (!strcmp(key, "rot_builds")) return (int64_t)p->stat_rot_builds;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
     return -1;

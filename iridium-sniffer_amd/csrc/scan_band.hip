@@ -1280,6 +1280,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_cross_groups = 256;     // workgroups (of four wavefronts) of the crossing pass: option band_cross_groups
 int g_band_plan_ahead = -1;       // 1: plan passes launched ahead on the side stream; -1: IRDM_PLAN_AHEAD in the environment, else 0
 int g_band_fuse_commit = 1;       // 1: the plan pass that accepts a round commits it in the same launch
 int g_band_plan_threads = 1024;   // threads of the plan pass's workgroup (256 / 512 / 1024)
@@ -1499,7 +1500,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         else
             hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         if (g_band_cross_wave)
-            hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
+            hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
         else
             hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
         if (P.ahead) *W.walk_host += (unsigned)(g_band_walk_wave ? kWalkWaveGroups : P.occ_words);

@@ -1,0 +1,28 @@
+#!/bin/bash
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r4_run12}
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+show() { python - "$1" <<'P'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); r=d["roofline"]
+    tl = d["config"].get("scan_timeline_us") or {}
+    print(sys.argv[1].split('/')[-1], d["value"], d["ms_per_step"], "clk", r.get("kernel_clock_ms"), "stage", r["stage_ms"])
+    if tl: print("   " + "  ".join("%s %.0f/%.0f" % (k, v[0], v[1]) for k, v in tl.items() if v[2] > 0.5))
+except Exception as e: print(sys.argv[1], "ERR", e)
+P
+}
+run() { name=$1; shift; timeout 120 python bench.py --steps 20 --warmup 5 $Q "$@" 2>/dev/null | tail -1 > "$OUT/$name.json"; show "$OUT/$name.json"; }
+for g in 256 512 1024 2048; do
+run tl_cg$g --opt band_timeline=1 --opt band_cross_groups=$g
+done
+for g in 256 1024; do
+run cg${g}_a --opt band_cross_groups=$g
+run cg${g}_b --opt band_cross_groups=$g
+done
+run c5_cg256 --steps 10 --warmup 3 --density 40 --sample-rate 12000000 --opt band_timeline=1
+run c5_cg1024 --steps 10 --warmup 3 --density 40 --sample-rate 12000000 --opt band_timeline=1 --opt band_cross_groups=1024
+run d2_cg256 --steps 10 --warmup 3 --density 2 --opt band_timeline=1
+run d2_cg1024 --steps 10 --warmup 3 --density 2 --opt band_timeline=1 --opt band_cross_groups=1024
