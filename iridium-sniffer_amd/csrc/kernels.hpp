@@ -79,6 +79,7 @@ extern int g_band_plan_threads;          // threads of the plan pass's one workg
 extern int g_band_walk_wave;             // 1 (default): the walk pass with a wavefront per band and segment; 0: a lane per band
 extern int g_band_timeline;              // 1: the band scan's passes record a device timeline (read back by the pipeline per chunk)
 extern int g_band_selfcheck;             // test hook: BandParams::selfcheck of the launches that follow
+extern int g_band_fold_sums0;            // 1 (default): round 0's sums pass inside its plan pass
 extern int g_band_cross_groups;          // workgroups of the crossing pass (default 256 = 1024 wavefronts)
 extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed grid of frame-walking wavefronts; 0: a workgroup per frame
 extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass

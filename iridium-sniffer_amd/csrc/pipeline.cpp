@@ -2858,6 +2858,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_walk_wave")) { irdm::g_band_walk_wave = value; return 0; }
     if (!strcmp(key, "band_plan_threads")) { irdm::g_band_plan_threads = value; return 0; }
     if (!strcmp(key, "band_fuse_commit")) { irdm::g_band_fuse_commit = value; return 0; }
+    if (!strcmp(key, "band_fold_sums0")) { irdm::g_band_fold_sums0 = value != 0; return 0; }
     if (!strcmp(key, "band_cross_groups")) { irdm::g_band_cross_groups = value; return 0; }
     if (!strcmp(key, "band_plan_ahead")) { irdm::g_band_plan_ahead = value != 0; return 0; }
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }

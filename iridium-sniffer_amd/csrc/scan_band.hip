@@ -616,7 +616,8 @@ template <int NT>
 __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                        DetState *__restrict__ st, int round, float *__restrict__ sum,
                                                        GoneBurst *__restrict__ gone, int gone_cap, int fuse,
-                                                       unsigned wait_target)
+                                                       unsigned wait_target, const float *__restrict__ pre,
+                                                       float *__restrict__ smin_out)
 {
     IRDM_DETECTOR_PRIO();
     if (P.ahead && round >= 1) {
@@ -644,6 +645,22 @@ __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W,
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
     static_assert(kPlanLdsBytes >= (size_t)kBandMaxTotal * 10, "the fused commit sorts in the plan pass's LDS");
     band_plan_body<NT>(P, W, counts, st, round, sh, (P.selfcheck & 16) ? nullptr : plan_lds);
+    if (round == 0 && pre != nullptr) {
+        // Round 0 has no update steps: its sums pass would copy the carried sums into snapshot 0 and check the lists'
+        // levels against them (band_sum_body with n_upd = 0) -- N loads and stores, done here by the workgroup that is
+        // resident anyway instead of a launch of its own (3 us alone, 20 us + 17 us of waiting in front of it in run).
+        __syncthreads();
+        if (!band_void(P, W) && W.ctl->status == 0) {
+            const int slot0 = W.snap_slot[0];
+            for (int b = (int)threadIdx.x; b < P.n; b += NT) {
+                const float sv = sum[b];
+                if (slot0 >= 0) W.snap[(size_t)slot0 * P.n + b] = sv;
+                W.sum_new[b] = sv;
+                smin_out[b] = sv;
+                if (!(pre[b] <= 0.9f * P.thr * sv)) atomicOr(W.flags, BAND_F_STALE);
+            }
+        }
+    }
     if (fuse && round >= 1 && !(P.selfcheck & 16)) {
         __syncthreads();
         if (!band_void(P, W) && W.ctl->status == 1) band_commit_body(P, W, st, sum, gone, gone_cap, plan_lds);
@@ -1280,6 +1297,7 @@ int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan
                             // lose their scalar loads, 11 grid barriers; kept as an option and tested)
 
 int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
+int g_band_fold_sums0 = 1;         // 1 (default): round 0's sums pass (no update steps) runs inside its plan pass
 int g_band_cross_groups = 256;     // workgroups (of four wavefronts) of the crossing pass: option band_cross_groups
 int g_band_plan_ahead = -1;       // 1: plan passes launched ahead on the side stream; -1: IRDM_PLAN_AHEAD in the environment, else 0
 int g_band_fuse_commit = 1;       // 1: the plan pass that accepts a round commits it in the same launch
@@ -1471,12 +1489,13 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             BandParams Pp = P;
             Pp.ahead = ahead ? 1 : 0;
             const unsigned target = ahead ? *W.walk_host : 0u;
+            const float *pre0 = (round == 0 && g_band_fold_sums0) ? pre : nullptr;      // round 0's sums pass inside its plan pass
             if (g_band_plan_threads == 256)
-                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target);
+                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin);
             else if (g_band_plan_threads == 512)
-                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target);
+                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin);
             else
-                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target);
+                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin);
             if (ahead) {
                 // what follows on the scan's own stream waits for this plan
                 (void)hipEventRecord(plan_ev[round], side);
@@ -1493,7 +1512,9 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             if (launch_wait_host_flag(gate_flag, gate_seq, gate_err, stream) != 0) return -1;
             if (hipMemcpyAsync(hist, gate_src, gate_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
         }
-        if (g_band_sum_bins == 32)
+        if (round == 0 && g_band_fold_sums0) {
+            // (done by the plan pass above)
+        } else if (g_band_sum_bins == 32)
             hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         else if (g_band_sum_bins == 16)
             hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);

@@ -34,6 +34,7 @@ void scan_emul_option(const char *key, int value)
     else if (!strcmp(key, "band_sum_bins")) g_band_sum_bins = value;
     else if (!strcmp(key, "band_cross_wave")) g_band_cross_wave = value;
     else if (!strcmp(key, "band_timeline")) g_band_timeline = value;
+    else if (!strcmp(key, "band_fold_sums0")) g_band_fold_sums0 = value;
 }
 
 // mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
