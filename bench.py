@@ -15,14 +15,19 @@ frame records are gathered to rank 0 over RCCL.  `value` = samples all ranks pro
 / max-over-ranks wall time.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline       dominant KERNEL (the decimator, or K1 on scenes with few bursts; the detector scan is a
-                 chain of ~11 short launches and is reported under stage_ms only) by mean HIP-event time
-                 per step on its own stream, measured inside the timed region, i.e. with the other
-                 stages of neighbouring chunks running beside it:
-                 achieved = algorithmic bytes per launch / mean launch duration, vs the 8 TB/s HBM peak.
-                 stage_ms_alone = the same stages from a few extra steps at pipeline_depth 0 (one
-                 kernel on the chip at a time).
-  cpu_baseline   the CPU oracle (scalar C port of the reference) in the reference's thread layout
+  roofline       dominant KERNEL (the decimator, or K1 on scenes with few bursts: the longer device span per
+                 launch of the two; the detector scan is a chain of ~10 short launches and is reported under
+                 stage_ms only).  ms_per_launch = the kernel's OWN clock: its wavefronts stamp the device's
+                 100 MHz clock when they start and end (irdm_kernel_clock), first wavefront in to last
+                 wavefront out, averaged over the launches of the timed region -- i.e. in run, with the other
+                 stages of neighbouring chunks beside it.  achieved = algorithmic bytes per launch /
+                 ms_per_launch, vs the 8 TB/s HBM peak; kernel_ms_rocprof = the same kernel's average in the
+                 newest committed rocprofv3 summary of this configuration (profiles/); stage_ms = HIP-event
+                 brackets of the stages on their streams (they include what a launch waits in its queue);
+                 stage_ms_alone / kernel_clock_ms_alone = the same from a few extra steps at pipeline_depth 0
+                 (one kernel on the chip at a time).
+  cpu_baseline   the CPU oracle (C port of the reference, the decimating FIR in the order of the reference's
+                 AVX2 kernel like the product's default) in the reference's thread layout
                  (1 detector + 4 downmix + 1 demod thread, main.c:175) on a bounded prefix of the
                  same stream, N=1 / rank 0 only; cpu_baseline_1core: the same oracle on one core.
   parity_checked the records of one chunk through the HIP path compared field by field with the
@@ -362,7 +367,7 @@ def rocprof_avg_ms(kernel, fs, density):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--samples", type=int, default=64 * 1024 * 1024, help="samples per chunk per GPU")
     ap.add_argument("--density", type=float, default=10.0, help="bursts per Msample")

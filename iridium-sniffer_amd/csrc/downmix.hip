@@ -1157,13 +1157,18 @@ __device__ __forceinline__ float parabolic(float alpha, float beta, float gamma)
 constexpr int kPostThreads = 256;
 
 // ---------------------------------------------------------------------------
-// post1: one workgroup per burst.  Steps 2b and 3 walk the burst in tiles of kPostThreads outputs staged in LDS: the
+// post1: one workgroup per burst.  Steps 2b and 3 walk the burst in tiles of kPostTile outputs staged in LDS (four per
+// thread: a burst of 6000 decimated samples is six rounds of load - barrier - filter - barrier - box filter - barrier
+// instead of twenty-four; each round is mostly the latency of its loads): the
 // noise filter reads its 25 neighbours and the start filter its 20 from LDS with unrolled loops (the first version read
 // them from HBM/L2 one dependent load per tap: 0.5 ms for 667 bursts).  The start filter's outputs are kept in the
 // burst's row of `dec` (as floats, behind the part of the row the tiles still read) for the threshold pass.
 // NT / SN: compile-time tap counts (25 / 20 at every supported rate), 0 = the runtime values.
 // ---------------------------------------------------------------------------
 constexpr int kPostMaxTaps = 64;
+constexpr int kPostTile = 4 * kPostThreads;
+static_assert(sizeof(float2) * (kPostTile + 2 * kPostMaxTaps) + sizeof(float) * (kPostTile + kPostMaxTaps) <= sizeof(float2) * kCfoTotal,
+              "the tile buffers live in the CFO transform's LDS");
 
 // what the host's fine-CFO step reads, stored straight into the burst's record in mapped pinned memory (system scope):
 // the helper thread is released by an event behind this kernel, no copy pass in between
@@ -1205,14 +1210,14 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     if (flen > search) flen = search;
 
     // the tile buffers live in the FFT's LDS (not in use yet)
-    float2 *xs = s;                                          // kPostThreads + 2 * kPostMaxTaps samples
-    float *m2 = reinterpret_cast<float *>(s + kPostThreads + 2 * kPostMaxTaps);      // kPostThreads + kPostMaxTaps
+    float2 *xs = s;                                          // kPostTile + 2 * kPostMaxTaps samples
+    float *m2 = reinterpret_cast<float *>(s + kPostTile + 2 * kPostMaxTaps);         // kPostTile + kPostMaxTaps
     const bool do_lpf = dec_len - noise_ntaps + 1 > 0;       // burst_downmix.c:683-698
     const int half = (noise_ntaps - 1) / 2;
-    const int span_y = kPostThreads + start_ntaps - 1;       // LPF outputs a tile's start filter needs
+    const int span_y = kPostTile + start_ntaps - 1;          // LPF outputs a tile's start filter needs
     const int span_x = span_y + noise_ntaps - 1;
     float mx = -1e30f;
-    for (int B = 0; B < dec_len; B += kPostThreads) {
+    for (int B = 0; B < dec_len; B += kPostTile) {
         for (int q = tid; q < span_x; q += kPostThreads) {
             const int j = B - half + q;
             xs[q] = (j >= 0 && j < dec_len) ? x[j] : make_float2(0.0f, 0.0f);
@@ -1245,19 +1250,19 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
             } else {
                 v = xs[p + half];
             }
-            if (p < kPostThreads) y[B + p] = v;
+            if (p < kPostTile) y[B + p] = v;
             m2[p] = mag2(v);
         }
         __syncthreads();
         // step 3, first half: the box filter over |y|^2
-        if (B + tid < flen) {
+        for (int o = tid; o < kPostTile && B + o < flen; o += kPostThreads) {
             float acc = 0.0f;
 #pragma unroll
             for (int k = 0; k < (SN ? SN : 1); k++)
-                if (SN) acc += start_taps[k] * m2[tid + k];
+                if (SN) acc += start_taps[k] * m2[o + k];
             if (!SN)
-                for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[tid + k];
-            fscr[B + tid] = acc;
+                for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[o + k];
+            fscr[B + o] = acc;
             mx = acc > mx ? acc : mx;
         }
         __syncthreads();

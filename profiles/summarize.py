@@ -90,9 +90,32 @@ if sq:
     json.dump(sq, open(f"profiles/{tag}_fir_pmc.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(sq, indent=1))
 
-for name in ("b", "b0", "d2", "d40", "cfg5_12mhz_d40", "lds_fir", "cfg4_n1"):
+for name in ("b", "b0", "d2", "d40", "cfg5_12mhz_d40", "lds_fir", "scalar_fir", "cfg4_n1"):
     if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
         shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_bench_{name}.json")
+for name in ("k1_bench.txt", "hop_timing.txt"):
+    if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 10:
+        shutil.copy(f"{src}/{name}", f"profiles/{tag}_{name}")
+# K1 alone: SQ counters per launch (tools/ubench/k1_bench under rocprofv3 --pmc)
+k1 = {}
+for i in (1, 2):
+    path = f"{src}/k1sq{i}/pmc_counter_collection.csv"
+    if not os.path.exists(path):
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        acc[(short(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k, c), v in acc.items():
+        k1.setdefault(k, {})[c] = sum(v) / len(v)
+for k, d in k1.items():
+    if all(c in d for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")):
+        tot = d["SQ_WAIT_ANY"] + d["SQ_WAIT_INST_ANY"] + d["SQ_ACTIVE_INST_ANY"]
+        d["wave_time_split"] = {"issuing": round(d["SQ_ACTIVE_INST_ANY"] / tot, 3), "waiting_for_issue": round(d["SQ_WAIT_INST_ANY"] / tot, 3),
+                                "parked_waitcnt_barrier": round(d["SQ_WAIT_ANY"] / tot, 3)}
+    if "SQ_WAVES" in d:
+        d["per_wave"] = {c: round(v / d["SQ_WAVES"], 1) for c, v in d.items() if c.startswith("SQ_INSTS")}
+if k1:
+    json.dump(k1, open(f"profiles/{tag}_k1_pmc_final.json", "w"), indent=1, sort_keys=True)
 # the scan's device timeline: per pass [us from the first workgroup's start to the last one's end, idle us in front of it,
 # launches per chunk], the plan pass's phase stamps and the walk's event counts (bench.py config.*)
 tl = {}

@@ -8,8 +8,8 @@ mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
 Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
 D12="--density 40 --sample-rate 12000000"
-timeout 600 python bench.py 2>"$OUT/b.err" | tail -1 > "$OUT/b.json"
-timeout 90 python bench.py --depth 0 $Q 2>/dev/null | tail -1 > "$OUT/b0.json"
+timeout 600 python bench.py --steps 20 --warmup 5 2>"$OUT/b.err" | tail -1 > "$OUT/b.json"
+timeout 90 python bench.py --steps 20 --warmup 5 --depth 0 $Q 2>/dev/null | tail -1 > "$OUT/b0.json"
 timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 2 2>/dev/null | tail -1 > "$OUT/d2.json"
 timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 40 2>/dev/null | tail -1 > "$OUT/d40.json"
 timeout 120 python bench.py --steps 10 --warmup 3 $Q --alone-steps 3 $D12 2>/dev/null | tail -1 > "$OUT/cfg5_12mhz_d40.json"
@@ -41,4 +41,15 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
   timeout 200 rocprofv3 --pmc $pass --kernel-include-regex "fir_decimate" -d "$OUT/c5_sq$i" -o pmc --output-format csv -- \
       python $B --steps 2 --warmup 1 --depth 0 $Q $D12 > "$OUT/c5_sq$i.log" 2>&1
 done
+# SQ counters of K1 alone (tools/ubench/k1_bench: the kernel on a random chunk, nothing beside it), two passes
+i=0
+for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  timeout 120 rocprofv3 --pmc $pass --kernel-include-regex "fft_mag_p32" -d "$OUT/k1sq$i" -o pmc --output-format csv -- \
+      $GRAFT_REPO_ROOT/tools/ubench/k1_bench 13 8192 3 2 200 > "$OUT/k1sq$i.log" 2>&1
+done
+cd "$GRAFT_REPO_ROOT"
+{ timeout 120 tools/ubench/k1_bench 13 8192 20 2 200; timeout 120 tools/ubench/k1_bench 14 4096 20 2 400; } > "$OUT/k1_bench.txt" 2>&1
+timeout 200 python tools/hop_timing.py > "$OUT/hop_timing.txt" 2>/dev/null
 ls "$OUT"
