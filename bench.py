@@ -325,7 +325,7 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                                     "gathered_on_rank0": int(counts[3].item())} if world > 1 else None),
                        "pipeline_depth": args.depth, "backend": backend,
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
-            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_r", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_f", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
             "cpu_baseline": None,
         }
@@ -625,8 +625,13 @@ def main():
         "scan": 8.0 * n,                          # history row read + write per bin-frame (B_det = 16 B/sample with K1)
         "fir": float(bps) * lb + 8.0 * lb / decim,   # burst-window re-read + decimated (cf32) write
     }
-    kernels = {"fft_mag": "fft_mag_r16_kernel", "scan": "band_* (scan_band.hip passes)",
-               "fir": "fir_decimate_kernel_r" if decim in (40, 48) else "fir_decimate_kernel_w"}
+    opts = dict((kv.split("=", 1)[0], int(kv.split("=", 1)[1])) for kv in args.opt)
+    # (the kernels the library picks for this configuration: DESIGN.md section 5; options fir_order / k1_kernel)
+    fir_name = "fir_decimate_kernel_w"
+    if decim in (40, 48):
+        fir_name = "fir_decimate_kernel_f" if opts.get("fir_order", 1) else "fir_decimate_kernel_r"
+    k1_name = "fft_mag_p32_kernel" if opts.get("k1_kernel", 1) and pipe.fft_size >= 8192 else "fft_mag_r16_kernel"
+    kernels = {"fft_mag": k1_name, "scan": "band_* (scan_band.hip passes)", "fir": fir_name}
     # the dominant KERNEL: the scan is a chain of ~25 short launches of six kernels (its stage time is their sum plus
     # what they wait for each other), so it is reported in stage_ms / stage_GBps but not as "the" kernel
     # (the decimator does 57 % of the step's algorithmic bytes and all of its arithmetic; K1 only where bursts are so few
@@ -639,7 +644,7 @@ def main():
     for which, key in ((0, "fir"), (1, "fft_mag")):
         sm, nl, _ = pipe.kernel_clock(which)
         kclk[key] = {"ms": sm / nl if nl else 0.0, "launches": nl}
-    has_clock = kernels["fir"] == "fir_decimate_kernel_r" and kclk["fir"]["launches"] > 0
+    has_clock = kernels["fir"] != "fir_decimate_kernel_w" and kclk["fir"]["launches"] > 0
     if has_clock:
         dom = "fir" if kclk["fir"]["ms"] >= kclk["fft_mag"]["ms"] else "fft_mag"
     else:

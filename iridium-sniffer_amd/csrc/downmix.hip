@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     int decim, int row, const float *__restrict__ taps, const int *__restrict__ tap_off,
     const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride, int order,
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int order,
     const int *__restrict__ rot_slot)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
             sr += t * v.x;
             si += t * v.y;
         }
-        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(sr, si);
+        dec[(size_t)w.dec_off + o0 + tid] = make_float2(sr, si);
     } else if (tid < n_out) {
         // 801 taps, k ascending, two independent mul+add chains (simd_generic.c:86-96).  Eight LDS reads
         // are issued ahead of the eight dependent accumulations; (p, q) walk the polyphase tile in
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
             ar += t * v.x;
             ai += t * v.y;
         }
-        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(ar, ai);
+        dec[(size_t)w.dec_off + o0 + tid] = make_float2(ar, ai);
     }
 }
 
@@ -271,7 +271,7 @@ template <int M>
 __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride,
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec,
     const int *__restrict__ rot_slot)
 {
     constexpr int ROW = fir_tile_row_c(M);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
             ar += t * v.x;
             ai += t * v.y;
         }
-        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(ar, ai);
+        dec[(size_t)w.dec_off + o0 + tid] = make_float2(ar, ai);
     }
 }
 
@@ -385,7 +385,7 @@ template <int M>
 __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
     SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
     const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec, int dec_stride,
+    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec,
     const int *__restrict__ rot_slot)
 {
     using C = FirCol<M>;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
                 ai += t * v.y;
             }
         }
-        dec[(size_t)tile.burst * dec_stride + o0 + tid] = make_float2(ar, ai);
+        dec[(size_t)w.dec_off + o0 + tid] = make_float2(ar, ai);
     }
 }
 
@@ -521,7 +521,7 @@ struct FirW {
 // one lane per tile: everything the decimator's workgroups need, in one record
 __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts, int n_tiles, int M,
                                 int tile_out, uint64_t ring_len, uint64_t ref_ring, const float2 *__restrict__ rot_incr, int n_ckpt,
-                                int dec_stride, FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile,
+                                FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile,
                                 const int *__restrict__ rot_slot)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,7 +555,7 @@ __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts
     g.inc_re = inc.x;
     g.inc_im = inc.y;
     g.ck_index = (uint64_t)rot_slot[cb] * (uint64_t)n_ckpt + (uint64_t)(g.s0 / kRotSeg);      // (the bin's row of the checkpoint pool)
-    g.out_base = (int64_t)tile.burst * dec_stride + o0;
+    g.out_base = (int64_t)w->dec_off + o0;
     g.stale_pos = (g.ring_pos + ring_len - ref_ring % ring_len) % ring_len;
     for (int i = 0; i < 4; i++) g.pad[i] = 0;
     geom[t] = g;
@@ -842,7 +842,7 @@ static int launch_fir_w_fmt(const SampleSource &src, const FirGeom *geom, unsign
 
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
-                        const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
+                        const float2 *rot_table, int n_ckpt, float2 *dec,
                         hipStream_t stream, unsigned long long *kclk, const int *rot_slot)
 {
     if (n_tiles <= 0) return 0;
@@ -852,7 +852,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_m<MM>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);                     \
         hipLaunchKernelGGL(fir_decimate_kernel_m<MM>, dim3(n_tiles), dim3(kFirTileOut), lds_m, stream, src,    \
-                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride, rot_slot);                   \
+                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, rot_slot);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
 #define IRDM_LAUNCH_FIR_C(MM)                                                                                  \
@@ -860,7 +860,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_c<MM>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)FirCol<MM>::LDS);           \
         hipLaunchKernelGGL(fir_decimate_kernel_c<MM>, dim3(n_tiles), dim3(kFirTileOut), FirCol<MM>::LDS, stream, src, \
-                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, dec_stride, rot_slot);                   \
+                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, rot_slot);                   \
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
     const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
@@ -868,14 +868,14 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile, rot_slot);
+                           fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
         return launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
     }
     if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile, rot_slot);
+                           fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
         return launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
     }
     if (fir_wide_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
@@ -883,7 +883,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);      // (one spare record behind the last)
         const int to = fir_wide_tile(decim);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           to, src.ring_len, src.ref_ring, rot_incr, n_ckpt, dec_stride, geom, next_tile, rot_slot);
+                           to, src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
         static int n_cu = 0;
         if (!n_cu) {
             int dev = 0;
@@ -925,7 +925,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
     (void)hipFuncSetAttribute((const void *)fir_decimate_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
-                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, dec_stride, g_fir_order, rot_slot);
+                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, g_fir_order, rot_slot);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void post1_publish(BurstWork &hp, const BurstWork &w)
 
 template <int NT, int SN>
 __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
-    BurstWork *__restrict__ work, float2 *__restrict__ dec, int dec_stride,
+    BurstWork *__restrict__ work, float2 *__restrict__ dec,
     float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps_rt,
     const float *__restrict__ start_taps, int start_ntaps_rt, int search_depth, int pre_start,
     const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096, BurstWork *__restrict__ hp_work)
@@ -1198,9 +1198,9 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     const int noise_ntaps = NT ? NT : noise_ntaps_rt;
     const int start_ntaps = SN ? SN : start_ntaps_rt;
     const int dec_len = w.dec_len;
-    float2 *x = dec + (size_t)blockIdx.x * dec_stride;
+    float2 *x = dec + (size_t)w.dec_off;
     float *fscr = reinterpret_cast<float *>(x);         // start-filter outputs: float i aliases x[i / 2], read long before
-    float2 *y = lpf + (size_t)blockIdx.x * dec_stride;
+    float2 *y = lpf + (size_t)w.dec_off;
 
     // step 3 geometry (burst_downmix.c:441-478)
     int search = search_depth < dec_len ? search_depth : dec_len;
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
 
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
 
-int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_stride,
+int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
                          const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream)
@@ -1338,11 +1338,11 @@ int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_str
     if (noise_ntaps > kPostMaxTaps || start_ntaps > kPostMaxTaps) return -1;
     if (noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic)
         hipLaunchKernelGGL((downmix_post1_kernel<25, 20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
-                           dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
+                           lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
                            pre_start, cfo_window, tw4096, hp_work);
     else
         hipLaunchKernelGGL((downmix_post1_kernel<0, 0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
-                           dec_stride, lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
+                           lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
                            pre_start, cfo_window, tw4096, hp_work);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ w
 // ---------------------------------------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
-    BurstWork *__restrict__ work, const float2 *__restrict__ lpf, int dec_stride,
+    BurstWork *__restrict__ work, const float2 *__restrict__ lpf,
     const float *__restrict__ rrc_taps, int rrc_ntaps_rt, const float2 *__restrict__ tw2048,
     const float2 *__restrict__ dl_fft, const float2 *__restrict__ ul_fft, int dl_len, int ul_len,
     float sps, float2 *__restrict__ rrc_ws, float2 *__restrict__ frames)
@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     const int start = w.start_idx;
     const int frame_len = w.dec_len - start;
     const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
-    const float2 *x = lpf + (size_t)blockIdx.x * dec_stride + start;
+    const float2 *x = lpf + (size_t)w.dec_off + start;
     float2 *r = rrc_ws + (size_t)blockIdx.x * kFrameNeed;
 
     // step 5 (burst_downmix.c:713-720): the phase sequence comes from rot_phase_kernel (in r)
@@ -1559,7 +1559,7 @@ int launch_sincosf_probe(const float *x, size_t n, float *re, float *im, hipStre
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
+int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
                          float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, const CfoStep &cfo,
@@ -1572,13 +1572,13 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int d
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((downmix_post2_kernel<51>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
-                           dec_stride, rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
+                           rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
                            rrc_ws, frames);
     } else {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<0>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((downmix_post2_kernel<0>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
-                           dec_stride, rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
+                           rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
                            rrc_ws, frames);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

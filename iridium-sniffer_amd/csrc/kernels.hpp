@@ -142,7 +142,7 @@ extern int g_fft_kernel;          // 1 (default): K1 = fft_mag_p32_kernel at N =
 int fir_needs_tile_list(int decim, int aligned);
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
-                        const float2 *rot_table, int n_ckpt, float2 *dec, int dec_stride,
+                        const float2 *rot_table, int n_ckpt, float2 *dec,
                         hipStream_t stream, unsigned long long *kclk = nullptr,    // kclk: the register-resident kernel's clock record
                         const int *rot_slot = nullptr);                            // rot_slot[bin] = the bin's row in rot_table
 // folds a kernel-clock record's slots into its sums and re-arms them (common.hpp); enqueue behind the kernel
@@ -157,7 +157,7 @@ int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hip
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
                         float2 *out, hipStream_t stream);
 extern int g_post_generic;        // 1: runtime-tap-count instances of post1 / post2 (test hook)
-int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec, int dec_stride,
+int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
                          const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream);
@@ -167,7 +167,7 @@ struct CfoStep {
     int n_fft, sample_rate, out_rate;
     double center_frequency;
 };
-int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf, int dec_stride,
+int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
                          float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, const CfoStep &cfo,

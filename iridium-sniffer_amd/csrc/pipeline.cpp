@@ -190,6 +190,7 @@ struct BatchCtx {
     FirTile *d_tiles;
     size_t tiles_cap;
     float2 *d_dec, *d_lpf, *d_rrc_ws, *d_frames, *d_demod_ws;
+    size_t dec_cap;              // outputs (float2) d_dec and d_lpf hold each: a batch's rows lie end to end by actual length
     DemodOut *d_demod;
     DecodedOut *d_decoded;
     IdaOut *d_ida;
@@ -390,6 +391,9 @@ struct irdm_pipeline {
     int rot_rows_used = 0, rot_rows_cap = 0;
     std::vector<float2 *> rot_retired;      // outgrown pools
     uint64_t stat_rot_builds = 0, stat_rot_rows = 0;
+    size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
+    std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
+    uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0;
     // time-chunk sharding: the previous chunk's 512-frame history may arrive AFTER this chunk's scan has been enqueued
     // (irdm_expect_history / irdm_import_state_history_device): [0] sequence number the import publishes, [1] time-out
     // flag of the waiting kernel, in mapped pinned memory; the import's copies run on gstream
@@ -473,6 +477,7 @@ static void pipeline_free(irdm_pipeline *p)
     if (p->hp_gate) (void)hipHostFree(p->hp_gate);
     if (p->d_rot_table) (void)hipFree(p->d_rot_table);
     for (float2 *q : p->rot_retired) (void)hipFree(q);
+    for (float2 *q : p->scratch_retired) (void)hipFree(q);
     if (p->d_rot_slot) (void)hipFree(p->d_rot_slot);
     if (p->ev_rot) (void)hipEventDestroy(p->ev_rot);
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
@@ -702,8 +707,12 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->tiles_cap = (size_t)p->burst_cap * 64;
     AL(p->d_tiles, FirTile, (p->tiles_cap + 1) * kFirTileUnits);
     p->cfo_quit = false;
-    AL(p->d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
-    AL(p->d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
+    // decimated and low-passed bursts: rows end to end by their actual length (BurstWork::dec_off), room for 1/16 of
+    // burst_cap full-length windows to begin with (4096 bursts of 7 ms at 10 MHz; 0.12 GB per context instead of 1.8),
+    // grown by doubling when a batch needs more (bursts_enqueue)
+    p->scratch_init = std::max<size_t>((size_t)p->burst_cap * p->dec_stride / 16, (size_t)4 * p->dec_stride);
+    AL(p->d_dec, float2, p->scratch_init);
+    AL(p->d_lpf, float2, p->scratch_init);
     AL(p->d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
     AL(p->d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
     AL(p->d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
@@ -809,6 +818,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         b.cfo_seq = 0;
         b.owns_buffers = i > 0;
         b.tiles_cap = p->tiles_cap;
+        b.dec_cap = p->scratch_init;
         if (i == 0) {
             b.stream = p->bstream;
             b.d_work = p->d_work; b.d_tiles = p->d_tiles; b.d_dec = p->d_dec; b.d_lpf = p->d_lpf;
@@ -818,8 +828,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             ok = ok && hipStreamCreateWithPriority(&b.stream, hipStreamNonBlocking, p->bstream_prio) == hipSuccess;
             AL(b.d_work, BurstWork, (size_t)p->burst_cap);
             AL(b.d_tiles, FirTile, (b.tiles_cap + 1) * kFirTileUnits);
-            AL(b.d_dec, float2, (size_t)p->burst_cap * p->dec_stride);
-            AL(b.d_lpf, float2, (size_t)p->burst_cap * p->dec_stride);
+            AL(b.d_dec, float2, p->scratch_init);
+            AL(b.d_lpf, float2, p->scratch_init);
             AL(b.d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
             AL(b.d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
             AL(b.d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
@@ -1225,7 +1235,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     const int fs = p->cfg.sample_rate;
     b.n = nb;
     b.recs.assign(nb, irdm_burst_t());
-    size_t n_tiles = 0;
+    size_t n_tiles = 0, dec_need = 0;
     // (the register-resident decimator also needs the chunk to start at a multiple of 8 samples: a caller's burst window
     // presented as a chunk -- irdm_downmix_burst -- may not; such sources take the LDS kernel)
     const int fir_aligned = p->ring_len % 8 == 0 && p->ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
@@ -1268,9 +1278,38 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             if (n_out < 100) w.drop_reason = 2;                          // burst_downmix.c:677
         }
         w.tile_base = (int32_t)n_tiles;
-        if (!w.drop_reason) n_tiles += (size_t)(w.dec_len + tile_out - 1) / tile_out;
+        w.dec_off = (int32_t)dec_need;
+        if (!w.drop_reason) {
+            n_tiles += (size_t)(w.dec_len + tile_out - 1) / tile_out;
+            dec_need += ((size_t)w.dec_len + 15) & ~(size_t)15;           // rows start on 128-byte lines
+        }
     }
     if (p->detect_only || nb == 0) return 0;      // stage A alone: burst records, no downmix / demod
+    if (dec_need > p->stat_scratch_peak) p->stat_scratch_peak = dec_need;
+    if (dec_need > b.dec_cap) {
+        // more outputs than this context's scratch holds: twice as much (the context is idle -- its last batch has been
+        // collected -- but a free would wait for the whole device, which a gated scan may keep busy until this thread
+        // opens the gate; the outgrown buffers stay until the context is closed)
+        const size_t cap2 = std::max(dec_need, 2 * b.dec_cap);
+        if (cap2 > (size_t)0x7fffffff) {
+            fprintf(stderr, "irdm_hip: %zu decimated samples in a batch of %d bursts\n", dec_need, nb);
+            return -1;
+        }
+        float2 *d2 = dev_alloc<float2>(cap2), *l2 = dev_alloc<float2>(cap2);
+        if (!d2 || !l2) {
+            if (d2) (void)hipFree(d2);
+            if (l2) (void)hipFree(l2);
+            fprintf(stderr, "irdm_hip: no memory for %zu decimated samples per batch\n", cap2);
+            return -1;
+        }
+        p->scratch_retired.push_back(b.d_dec);
+        p->scratch_retired.push_back(b.d_lpf);
+        b.d_dec = d2;
+        b.d_lpf = l2;
+        b.dec_cap = cap2;
+        if (!b.owns_buffers) { p->d_dec = d2; p->d_lpf = l2; }
+        p->stat_scratch_grows++;
+    }
     const bool tile_list = fir_needs_tile_list(p->decim, fir_aligned) != 0;
     if (n_tiles > b.tiles_cap) {
         (void)hipFree(b.d_tiles);
@@ -1300,11 +1339,11 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     if (tile_list && n_tiles && launch_copy_words(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
-                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, p->dec_stride, st,
+                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, st,
                             p->kclk_rec((int)(&b - p->bc)), p->d_rot_slot) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
-    if (launch_downmix_post1(b.d_work, nb, b.d_dec, p->dec_stride, b.d_lpf, p->d_noise_taps,
+    if (launch_downmix_post1(b.d_work, nb, b.d_dec, b.d_lpf, p->d_noise_taps,
                              p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
                              p->pre_start, p->d_cfo_window, p->d_tw4096, p->dev_cfo ? nullptr : b.hp_work_dev, st) != 0)
         return -1;
@@ -1330,7 +1369,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         p->cfo_cv.notify_one();
         if (launch_wait_host_flag(b.hp_flag_dev, b.cfo_seq, b.hp_flag_dev + 1, st) != 0) return -1;
     }
-    if (launch_downmix_post2(b.d_work, nb, b.d_lpf, p->dec_stride, p->d_rrc_taps, p->rrc_ntaps,
+    if (launch_downmix_post2(b.d_work, nb, b.d_lpf, p->d_rrc_taps, p->rrc_ntaps,
                              p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
                              b.d_rrc_ws, b.d_frames, p->dev_cfo ? nullptr : b.hp_work_dev, cfo, st) != 0)
         return -1;
@@ -2849,6 +2888,26 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
         p->rot_rows_cap = value;
         return 0;
     }
+    if (!strcmp(key, "scratch_outputs")) {
+        // (test hook) the decimated / low-passed scratch of every context with room for `value` outputs to begin with;
+        // only while no batch is in flight
+        if (value < 16) return -1;
+        for (int i = 0; i < p->n_bc; i++)
+            if (p->bc[i].n != 0) return -1;
+        IRDM_HIP_CHECK(hipDeviceSynchronize());
+        for (int i = 0; i < p->n_bc; i++) {
+            BatchCtx &b = p->bc[i];
+            float2 *d2 = dev_alloc<float2>((size_t)value), *l2 = dev_alloc<float2>((size_t)value);
+            if (!d2 || !l2) return -1;
+            (void)hipFree(b.d_dec);
+            (void)hipFree(b.d_lpf);
+            b.d_dec = d2;
+            b.d_lpf = l2;
+            b.dec_cap = (size_t)value;
+            if (!b.owns_buffers) { p->d_dec = d2; p->d_lpf = l2; }
+        }
+        return 0;
+    }
     if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
@@ -2894,6 +2953,9 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "rot_rows")) return (int64_t)p->rot_rows_used;
     if (!strcmp(key, "rot_rows_cap")) return (int64_t)p->rot_rows_cap;
     if (!strcmp(key, "rot_builds")) return (int64_t)p->stat_rot_builds;
+    if (!strcmp(key, "scratch_outputs")) return (int64_t)p->bc[0].dec_cap;
+    if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
+    if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
     return -1;

@@ -127,8 +127,10 @@ struct BurstWork {
     int32_t direction, uw_start, num_samples, drop_reason;
     float uw_corr, corr_re, corr_im;
     int32_t tile_base;       // index of the burst's first decimator tile (host; the persistent decimator's geometry pass)
+    int32_t dec_off;         // the burst's row in the decimated / low-passed scratch (float2 units; host: rows by actual length)
+    int32_t pad_;
 };
-static_assert(sizeof(BurstWork) == 80, "BurstWork is mirrored word by word between device and pinned host memory");
+static_assert(sizeof(BurstWork) == 88, "BurstWork is mirrored word by word between device and pinned host memory");
 
 struct DemodOut {
     int32_t ok, direction, confidence, n_symbols;

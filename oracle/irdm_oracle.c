@@ -201,12 +201,35 @@ void orc_fir_ccf_dec_avx2(const float *taps, int ntaps, const float *in, float *
     }
 }
 
-/* Which form of the decimating FIR stage B uses (orc_downmix_*, orc_run_stream): 0 = simd_generic.c (what --no-simd
- * selects), 1 = simd_avx2.c (the reference's default on x86).  Both are the reference's arithmetic; the product has
- * the matching option "fir_order".  Set before any stream is run (read-only afterwards). */
+/* Which form of the dispatched kernels (simd_kernels.h) stages A and B use (orc_detector_*, orc_downmix_*,
+ * orc_run_stream): 0 = simd_generic.c (what --no-simd selects, and every non-x86 host), 1 = simd_avx2.c (the reference's
+ * default on x86: simd_init, simd_generic.c:33-57).  The two differ in arithmetic in five kernels -- fir_ccf_dec (above),
+ * fir_ccf, fir_fff, fftshift_mag and mag_squared (below: fused multiply-adds in the vector body, the generic form in the
+ * scalar tail) -- and agree bit for bit in the rest (window_cf, baseline_update, relative_mag, convert_i8_cf, max_float:
+ * the same operations; csquare_window: a*b + b*a == 2*(a*b) exactly).  Both are the reference's arithmetic; the product
+ * has the matching option "fir_order" (alias "simd_order").  Set before any stream is run (read-only afterwards). */
 static int g_orc_fir_order = 0;
 void orc_set_fir_order(int order) { g_orc_fir_order = order ? 1 : 0; }
 int orc_get_fir_order(void) { return g_orc_fir_order; }
+
+/* simd_avx2.c:28-55 (avx2_fir_ccf): outputs four at a time, acc = fma(taps[k], in[i + k], acc) for k ascending (:36-40);
+ * the last n % 4 outputs in the generic form (:45-54, compiled -std=c99: not contracted) */
+void orc_fir_ccf_avx2(const float *taps, int ntaps, const float *in, float *out, int n)
+{
+    int i = 0;
+    for (; i + 3 < n; i += 4)
+        for (int j = 0; j < 4; j++) {
+            const float *p = in + 2 * (size_t)(i + j);
+            float ar = 0.0f, ai = 0.0f;
+            for (int k = 0; k < ntaps; k++) {
+                ar = fmaf(taps[k], p[2 * k], ar);
+                ai = fmaf(taps[k], p[2 * k + 1], ai);
+            }
+            out[2 * (size_t)(i + j)] = ar;
+            out[2 * (size_t)(i + j) + 1] = ai;
+        }
+    if (i < n) orc_fir_ccf(taps, ntaps, in + 2 * (size_t)i, out + 2 * (size_t)i, n - i);
+}
 
 /* simd_generic.c:98-106 */
 void orc_fir_fff(const float *taps, int ntaps, const float *in, float *out, int n)
@@ -217,6 +240,20 @@ void orc_fir_fff(const float *taps, int ntaps, const float *in, float *out, int 
             acc += taps[k] * in[i + k];
         out[i] = acc;
     }
+}
+
+/* simd_avx2.c:115-138 (avx2_fir_fff): outputs eight at a time with fused multiply-adds, the last n % 8 generic */
+void orc_fir_fff_avx2(const float *taps, int ntaps, const float *in, float *out, int n)
+{
+    int i = 0;
+    for (; i + 7 < n; i += 8)
+        for (int j = 0; j < 8; j++) {
+            float acc = 0.0f;
+            for (int k = 0; k < ntaps; k++)
+                acc = fmaf(taps[k], in[i + j + k], acc);
+            out[i + j] = acc;
+        }
+    if (i < n) orc_fir_fff(taps, ntaps, in + i, out + i, n - i);
 }
 
 /* simd_generic.c:108-112: complex x real = two real products */
@@ -237,6 +274,26 @@ void orc_fftshift_mag(const float *fft_out, float *mag_shifted, int fft_size)
         float re = fft_out[2 * src], im = fft_out[2 * src + 1];
         float a = re * re, b = im * im;
         mag_shifted[i] = a + b;
+    }
+}
+
+/* simd_avx2.c:177-221 (avx2_fftshift_mag): fma(re, re, im*im) -- the product im*im rounded, the sum fused (:196-197,
+ * :205-206); half is a multiple of four for every FFT size of the path, the generic tail (:210-220) for any other */
+void orc_fftshift_mag_avx2(const float *fft_out, float *mag_shifted, int fft_size)
+{
+    int half = fft_size / 2, vec = half & ~3;
+    for (int i = 0; i < half; i++) {
+        for (int side = 0; side < 2; side++) {
+            int src = side ? i : half + i, dst = side ? half + i : i;
+            float re = fft_out[2 * src], im = fft_out[2 * src + 1];
+            float b = im * im;
+            if (i < vec)
+                mag_shifted[dst] = fmaf(re, re, b);
+            else {
+                float a = re * re;
+                mag_shifted[dst] = a + b;
+            }
+        }
     }
 }
 
@@ -270,6 +327,15 @@ void orc_mag_squared(const float *in, float *out, int n)
         float a = in[2 * i] * in[2 * i], b = in[2 * i + 1] * in[2 * i + 1];
         out[i] = a + b;
     }
+}
+
+/* simd_avx2.c:304-323 (avx2_mag_squared): fma(re, re, im*im) four at a time, the last n % 4 generic */
+void orc_mag_squared_avx2(const float *in, float *out, int n)
+{
+    int vec = n & ~3;
+    for (int i = 0; i < vec; i++)
+        out[i] = fmaf(in[2 * i], in[2 * i], in[2 * i + 1] * in[2 * i + 1]);
+    if (vec < n) orc_mag_squared(in + 2 * (size_t)vec, out + vec, n - vec);
 }
 
 /* simd_generic.c:164-170 */
@@ -558,7 +624,7 @@ void orc_detector_magnitude_frame(orc_detector_t *d, const float *iq_frame, floa
     float *buf = (float *)d->fft_buf;
     orc_window_cf(iq_frame, d->window, buf, d->n);
     orc_fft(buf, d->n, -1);
-    orc_fftshift_mag(buf, mag_out, d->n);
+    (g_orc_fir_order ? orc_fftshift_mag_avx2 : orc_fftshift_mag)(buf, mag_out, d->n);
 }
 
 /* burst_detect.c:438-454 */
@@ -984,12 +1050,12 @@ static int dm_find_start(orc_downmix_t *dm, const cf *frame, int frame_len)
     if (search > frame_len) search = frame_len;
     int mag_len = search + dm->start_ntaps - 1;
     if (mag_len > frame_len) mag_len = frame_len;
-    orc_mag_squared((const float *)frame, dm->magf, mag_len);
+    (g_orc_fir_order ? orc_mag_squared_avx2 : orc_mag_squared)((const float *)frame, dm->magf, mag_len);
     int half = (dm->start_ntaps - 1) / 2;
     int flen = mag_len - dm->start_ntaps + 1;
     if (flen <= 0) return 0;
     if (flen > search) flen = search;
-    orc_fir_fff(dm->start_taps, dm->start_ntaps, dm->magf, dm->magfilt, flen);
+    (g_orc_fir_order ? orc_fir_fff_avx2 : orc_fir_fff)(dm->start_taps, dm->start_ntaps, dm->magf, dm->magfilt, flen);
     float mx = orc_max_float(dm->magfilt, flen);
     float thr = 0.45f * mx;
     int start = 0;
@@ -1132,7 +1198,7 @@ int orc_downmix_process(orc_downmix_t *dm, const orc_burst_rec_t *rec, const flo
             if (pad > DM_WORK) pad = DM_WORK;
             memset(dm->wa, 0, sizeof(cf) * (size_t)pad);
             memcpy(&dm->wa[half], dm->wb, sizeof(cf) * (size_t)dec_len);
-            orc_fir_ccf(dm->noise_taps, dm->noise_ntaps, (const float *)dm->wa,
+            (g_orc_fir_order ? orc_fir_ccf_avx2 : orc_fir_ccf)(dm->noise_taps, dm->noise_ntaps, (const float *)dm->wa,
                         (float *)dm->wb, dec_len);
         }
         memcpy(dm->wa, dm->wb, sizeof(cf) * (size_t)dec_len);
@@ -1165,7 +1231,7 @@ int orc_downmix_process(orc_downmix_t *dm, const orc_burst_rec_t *rec, const flo
         if (pad > DM_WORK) pad = DM_WORK;
         memset(dm->wa, 0, sizeof(cf) * (size_t)pad);
         memcpy(&dm->wa[half], dm->wb, sizeof(cf) * (size_t)frame_len);
-        orc_fir_ccf(dm->rrc_taps, dm->rrc_ntaps, (const float *)dm->wa, (float *)dm->wb,
+        (g_orc_fir_order ? orc_fir_ccf_avx2 : orc_fir_ccf)(dm->rrc_taps, dm->rrc_ntaps, (const float *)dm->wa, (float *)dm->wb,
                     frame_len);
     }
 

@@ -97,6 +97,10 @@ void orc_fir_ccf_dec(const float *taps, int ntaps, const float *in, float *out,
                      int n_out, int decimation);
 /* simd_avx2.c:62-108; selection of the form stage B uses (0 scalar = --no-simd, 1 AVX2 + FMA = the reference's default) */
 void orc_fir_ccf_dec_avx2(const float *taps, int ntaps, const float *in, float *out, int n_out, int decimation);
+void orc_fir_ccf_avx2(const float *taps, int ntaps, const float *in, float *out, int n);
+void orc_fir_fff_avx2(const float *taps, int ntaps, const float *in, float *out, int n);
+void orc_fftshift_mag_avx2(const float *fft_out, float *mag_shifted, int fft_size);
+void orc_mag_squared_avx2(const float *in, float *out, int n);
 void orc_set_fir_order(int order);
 int orc_get_fir_order(void);
 void orc_fir_fff(const float *taps, int ntaps, const float *in, float *out, int n);

@@ -54,6 +54,12 @@ def main():
         ref8 = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
         res["ci8"] = parity.compare(parity.run_gpu(x, fs, fmt=irdm.FMT_CI8), ref8)
         res["sequential_scan"] = parity.compare(parity.run_gpu(iq, fs, scan_mode=1), ref)
+        # the decimated / low-passed rows of a batch lie end to end by actual length: a scratch of 64 outputs to begin
+        # with grows by doubling, per context, while the other contexts' chains are in flight
+        got = parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead", options={"scratch_outputs": 64})
+        res["scratch_growth"] = parity.compare(got, ref)
+        res["scratch_growth"]["grows"] = got["stats"]["scratch_grows"]
+        assert got["stats"]["scratch_grows"] >= 1 and got["stats"]["scratch_outputs"] >= 64
     elif case == "scene_zoo":
         for name in ("too_long", "squelch", "dc_and_edges"):
             fs, iq = scenes.ALL[name]()

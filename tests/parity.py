@@ -77,7 +77,8 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
     res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, tagged=p.tagged,
                n_samples=p.sample_count, timings=p.timings(),
                stats={k: p.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
-                                             "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists", "band_extra")})
+                                             "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists", "band_extra",
+                                             "scratch_outputs", "scratch_grows", "scratch_peak")})
     p.close()
     return res
 

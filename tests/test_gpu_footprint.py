@@ -1,5 +1,6 @@
 """-m gpu: device memory of a context.  The rotator checkpoints (rotator.h:36-46 restated as checkpoints of the phase
-recurrence) are kept per centre bin that bursts have appeared on: a pool of rows handed out on first use."""
+recurrence) are kept per centre bin that bursts have appeared on: a pool of rows handed out on first use.  The decimated
+and low-passed bursts of a batch lie end to end by their actual length in a scratch that grows on demand."""
 import numpy as np
 import pytest
 import torch
@@ -57,12 +58,30 @@ def test_rotator_checkpoint_rows_on_demand_and_pool_growth():
     b.close()
 
 
+def test_burst_scratch_rows_by_length_and_growth():
+    """The per-burst scratch behind the decimator holds a batch's rows end to end (BurstWork::dec_off); one that starts
+    with room for 64 outputs doubles, context by context, while other chains are in flight; records are the oracle's."""
+    fs = 2_000_000
+    n = int(0.9 * fs) // 32768 * 32768
+    iq, _ = siggen.standard_scene(fs, n, 9, seed=5)
+    ref = orc.run_stream(iq, fs)
+    c = (n // 5) // 32768 * 32768
+    got = parity.run_gpu(iq, fs, chunks=[c, c, c, c, n - 4 * c], depth=2, feed="ingest_lookahead", options={"scratch_outputs": 64})
+    parity.compare(got, ref)
+    assert got["stats"]["scratch_grows"] >= 1 and got["stats"]["scratch_peak"] > 64
+    # the default scratch takes this stream without growing
+    got = parity.run_gpu(iq, fs, chunks=[c, c, c, c, n - 4 * c], depth=2, feed="ingest_lookahead")
+    parity.compare(got, ref)
+    assert got["stats"]["scratch_grows"] == 0 and got["stats"]["scratch_peak"] <= got["stats"]["scratch_outputs"]
+
+
 def test_context_footprint_10mhz():
     """a 10 MHz context for 16 Mi-sample chunks: no table of a row per FFT bin (4.5 GB in rounds 1-3), a pool of 1024
-    rows (0.57 GB) instead"""
+    rows (0.57 GB) instead; no decimated / low-passed scratch for 4096 bursts of the longest length per chain (3 x 1.8 GB
+    up to round 4), 1/16 of that to begin with"""
     u0 = _used()
     p = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=2)
     u1 = _used()
     p.close()
-    assert u1 - u0 < 9.5e9, u1 - u0        # (measured 8.8 GB: ring 3.2, per-burst scratch of three chains 6.6 -- sized for 4096 bursts of the longest length -- lists, band workspace, 0.57 GB of checkpoint rows; rounds 1-3: 6.1 GB + the 4.5 GB table)
+    assert u1 - u0 < 4.5e9, u1 - u0        # (8.8 GB with full-length scratch rows; rounds 1-3: 6.1 GB + the 4.5 GB table)
     print("10 MHz context, 16 Mi-sample chunks, depth 2: %.2f GB" % ((u1 - u0) / 1e9))

@@ -87,15 +87,17 @@ def test_scan_kernels_continuation_and_options(emul):
     stats = check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
     assert stats[4] >= 1, "no continuation launch was needed: %r" % stats
     try:
+        # (band_fold_sums0 0: round 0's sums pass as a launch of its own instead of inside its plan pass)
         for key, value in ((b"band_walk_wave", 0), (b"band_fuse_commit", 0), (b"band_selfcheck", 8), (b"band_selfcheck", 1),
-                           (b"band_plan_threads", 256), (b"band_plan_ahead", 1)):
+                           (b"band_plan_threads", 256), (b"band_plan_ahead", 1), (b"band_fold_sums0", 0)):
             emul.scan_emul_option(key, value)
             check(emul, iq, fs, chunks=(131,))
             emul.scan_emul_option(key, {b"band_walk_wave": 1, b"band_fuse_commit": 1, b"band_selfcheck": 0,
-                                        b"band_plan_threads": 1024, b"band_plan_ahead": 0}[key])
+                                        b"band_plan_threads": 1024, b"band_plan_ahead": 0,
+                                        b"band_fold_sums0": 1}[key])
     finally:
         for key, value in ((b"band_walk_wave", 1), (b"band_fuse_commit", 1), (b"band_selfcheck", 0),
-                           (b"band_plan_threads", 1024), (b"band_plan_ahead", 0)):
+                           (b"band_plan_threads", 1024), (b"band_plan_ahead", 0), (b"band_fold_sums0", 1)):
             emul.scan_emul_option(key, value)
 
 

@@ -34,9 +34,10 @@ def run_case(lib, case, timeout=900, order=None):
 
 def test_whole_path_2mhz(emul_lib):
     """2 MHz: whole stream, chunked at pipeline_depth 1, chunked at depth 2 fed in place with look-ahead (chained scans),
-    ci8 input, and the sequential scan instead of the band scan"""
+    ci8 input, the sequential scan instead of the band scan, and a per-burst scratch that has to grow"""
     res = run_case(emul_lib, "2mhz")
-    assert set(res) == {"whole", "chunked_depth1", "chunked_depth2_in_place_lookahead", "ci8", "sequential_scan"}
+    assert set(res) == {"whole", "chunked_depth1", "chunked_depth2_in_place_lookahead", "ci8", "sequential_scan", "scratch_growth"}
+    assert res["scratch_growth"]["grows"] >= 1
     for name, s in res.items():
         assert s["bursts"] >= 5 and s["demods"] >= 3, (name, s)
 
