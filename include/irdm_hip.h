@@ -368,6 +368,10 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  * "scan_mode" (0 = band-parallel speculative scan (scan_band.hip) where the FFT size supports it, with the sequential
  *   scans as its exact fallback -- default; 1 = dense sequential scan only; 2 / 3 = round 1's sparse leader scan on one
  *   CU / with "scan_updaters" baseline-update workgroups, dense fallback; 4 = band scan with the dense scan as fallback),
+ * "fir_order" (alias "simd_order"; PROCESS-WIDE; default 1 = the arithmetic of the reference's AVX2 kernels, simd_avx2.c --
+ *   what simd_init() (simd_generic.c:33-57) selects on x86: fir_ccf_dec :62-108, fir_ccf :28-55, fir_fff :115-138,
+ *   fftshift_mag :177-221, mag_squared :304-323; 0 = simd_generic.c, what --no-simd and every non-x86 build run.  The
+ *   other six dispatched kernels are the same operations in both files),
  * "kernel_clock" (default 0; see irdm_kernel_clock), "k1_kernel" (default 1: K1 = the 32-points-per-lane streaming kernel
  *   at 8192 / 16384 points; 0 = the radix-16 kernel of rounds 1-3),
  * "scan_updaters" (1..32, default 7: updater workgroups of the multi-CU sparse scan),
@@ -378,7 +382,9 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  *   workgroup, column-major / polyphase rows), "fir_budget" (tiles per workgroup of the persistent decimator, default 4),
  *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof".
  * Stats (irdm_get_stat): "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks", "band_rounds",
- * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "host_us_0".."host_us_9". */
+ * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "host_us_0".."host_us_9", "rot_rows",
+ * "rot_rows_cap", "rot_builds" (rotator checkpoint rows in use / allocated / build launches), "scratch_outputs",
+ * "scratch_grows", "scratch_peak" (decimated samples a batch context holds / times it doubled / most a batch needed). */
 int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);
 int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);
 
@@ -389,7 +395,7 @@ int irdm_last_timings(const irdm_pipeline_t *p, float *ms_out, int n);
  * when their last one ends (s_memrealtime, per launch); this returns the spans summed over the launches since the last
  * reset -- the kernel's own duration on the device, free of the dispatch wait a host-side event bracket includes (what
  * bench.py's roofline divides the algorithmic bytes by).  which: 0 = the register-resident decimator
- * (fir_decimate_kernel_r), 1 = K1 (fft_mag_p32_kernel / fft_mag_r16_kernel).  Waits for the device.  0 ok, -1 error. */
+ * (fir_decimate_kernel_f / _r), 1 = K1 (fft_mag_p32_kernel / fft_mag_r16_kernel).  Waits for the device.  0 ok, -1 error. */
 int irdm_kernel_clock(irdm_pipeline_t *p, int which, double *sum_ms, uint64_t *launches, double *last_ms, int reset);
 
 /* ------------------------------------------------------------------ */

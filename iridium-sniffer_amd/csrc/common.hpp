@@ -52,6 +52,15 @@ __host__ __device__ __forceinline__ float mag2(float2 v)
     return a + b;
 }
 
+// |v|^2 as the reference's AVX2 kernels round it (simd_avx2.c:196-197, :316: _mm_fmadd_ps(re, re, _mm_mul_ps(im, im))):
+// im*im rounded, the sum fused.  mag2_simd: the form option "fir_order" selects (0 generic, 1 AVX2).
+__host__ __device__ __forceinline__ float mag2_fma(float2 v)
+{
+    const float b = v.y * v.y;
+    return __builtin_fmaf(v.x, v.x, b);
+}
+__host__ __device__ __forceinline__ float mag2_simd(float2 v, int order) { return order ? mag2_fma(v) : mag2(v); }
+
 // glibc 2.35 cabsf/hypotf for finite inputs: sqrt in double of the exactly
 // representable double sum of squares, rounded once to float
 // (sysdeps/ieee754/flt-32/e_hypotf.c).  Exercised against the oracle (host libm cabsf) through every

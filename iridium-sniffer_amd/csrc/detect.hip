@@ -17,7 +17,7 @@ template <int LOGN, int NT, int FMT>
 __global__ __launch_bounds__(NT) void fft_mag_kernel(const void *__restrict__ iq,
                                                       const float *__restrict__ window,
                                                       const float2 *__restrict__ tw,
-                                                      float *__restrict__ mag, int n_frames)
+                                                      float *__restrict__ mag, int n_frames, int order)
 {
     constexpr int N = 1 << LOGN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NT) void fft_mag_kernel(const void *__restrict__ iq
         fft_lds_radix2<LOGN, NT, -1>(s, tw);
         for (int i = tid; i < N; i += NT) {
             const float2 v = s[(i + N / 2) & (N - 1)];
-            mag[base + i] = mag2(v);
+            mag[base + i] = mag2_simd(v, order);
         }
         __syncthreads();
     }
@@ -117,7 +117,8 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
                                                                        float *__restrict__ mag, int n_frames,
                                                                        const float *__restrict__ pre,
                                                                        unsigned *__restrict__ counts,
-                                                                       ListEntry *__restrict__ entries, int cap)
+                                                                       ListEntry *__restrict__ entries, int cap,
+                                                                       int order)
 {
     __shared__ int s_cnt;
     constexpr int N = 1 << LOGN, T = N / 16, LB = LOGN - 8, NB = 1 << LB, ROW = NB + 1, RD = LOGN - 12;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const int p = q * 256 + lo3;
-                put((p + N / 2) & (N - 1), mag2(v[q]));
+                put((p + N / 2) & (N - 1), mag2_simd(v[q], order));
             }
             __syncthreads();
         } else {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16) void fft_mag_r16_kernel(const voi
 #pragma unroll
                 for (int q = 0; q < RQ; q++) {
                     const int k = pp + q * 4096;
-                    put((k + N / 2) & (N - 1), mag2(d[q]));
+                    put((k + N / 2) & (N - 1), mag2_simd(d[q], order));
                 }
             }
             __syncthreads();
@@ -332,7 +333,7 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
                                                                           const float *__restrict__ pre,
                                                                           unsigned *__restrict__ counts,
                                                                           ListEntry *__restrict__ entries, int cap,
-                                                                          unsigned long long *__restrict__ kclk)
+                                                                          unsigned long long *__restrict__ kclk, int order)
 {
     using G_ = P32<LOGN>;
     constexpr int N = G_::N, T = G_::T, G = G_::G, REGION = G_::REGION;
@@ -437,8 +438,8 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int p = q * 256 + lo3;
-            M[p + N / 2] = mag2(make_float2(a[q].x, a[q].y));       // bin k = p       -> (k + N/2) mod N
-            M[p] = mag2(make_float2(b[q].x, b[q].y));               // bin k = p + N/2 -> p
+            M[p + N / 2] = mag2_simd(make_float2(a[q].x, a[q].y), order);       // bin k = p       -> (k + N/2) mod N
+            M[p] = mag2_simd(make_float2(b[q].x, b[q].y), order);               // bin k = p + N/2 -> p
         }
     } else {
         // the sub-transforms of a lane are (b0 = 0 | 1, b1 = gc); stage 13 joins b1 = 0 with b1 = 1 (twiddle W^2p), stage 14
@@ -458,10 +459,10 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
             bfly2_vv(a[j], b[j], w0, a[j + 8], b[j + 8], w1);
             // a[j] = X[p], b[j] = X[p + 8192], a[j + 8] = X[p + 4096], b[j + 8] = X[p + 12288]
             const int p = j * 256 + pl;
-            M[p + 8192] = mag2(make_float2(a[j].x, a[j].y));
-            M[p] = mag2(make_float2(b[j].x, b[j].y));
-            M[p + 12288] = mag2(make_float2(a[j + 8].x, a[j + 8].y));
-            M[p + 4096] = mag2(make_float2(b[j + 8].x, b[j + 8].y));
+            M[p + 8192] = mag2_simd(make_float2(a[j].x, a[j].y), order);
+            M[p] = mag2_simd(make_float2(b[j].x, b[j].y), order);
+            M[p + 12288] = mag2_simd(make_float2(a[j + 8].x, a[j + 8].y), order);
+            M[p + 4096] = mag2_simd(make_float2(b[j + 8].x, b[j + 8].y), order);
         }
     }
     __syncthreads();
@@ -526,6 +527,7 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
     kclk_leave(kclk);
 }
 
+int g_fir_order = 1;          // the form of the reference's dispatched kernels the product follows: 1 simd_avx2.c, 0 simd_generic.c (downmix.hip)
 int g_fft_kernel = 1;         // 1 (default): the 32-points-per-lane streaming kernel where it applies (N = 8192, 16384); 0: radix-16 kernel
 int g_fft_force_radix2 = 0;   // test hook: 1 = always use the radix-2 LDS kernel
 
@@ -541,7 +543,7 @@ static int launch_p32(int fmt, const void *iq, const float *window, const float2
         (void)hipFuncSetAttribute((const void *)fft_mag_p32_kernel<LOGN, F, LISTS>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
         hipLaunchKernelGGL((fft_mag_p32_kernel<LOGN, F, LISTS>), grid, block, lds, stream, iq, window, tw, mag, \
-                           n_frames, pre, counts, entries, cap, kclk);                                   \
+                           n_frames, pre, counts, entries, cap, kclk, g_fir_order);                                \
     } while (0)
     if (fmt == 2) IRDM_LAUNCH_P32(2);
     else if (fmt == 1) IRDM_LAUNCH_P32(1);
@@ -569,7 +571,7 @@ int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window
         (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F, true>,             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, true>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
-                           stream, iq, window, tw, mag, n_frames, pre, counts, entries, cap);  \
+                           stream, iq, window, tw, mag, n_frames, pre, counts, entries, cap, g_fir_order);  \
     } while (0)
 #define IRDM_LAUNCH_R16L(LOGN)                                                                 \
     do {                                                                                       \
@@ -604,7 +606,7 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
         (void)hipFuncSetAttribute((const void *)fft_mag_kernel<LOGN, NT, F>,                   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((fft_mag_kernel<LOGN, NT, F>), dim3(grid), dim3(NT), lds,           \
-                           stream, iq, window, tw, mag, n_frames);                             \
+                           stream, iq, window, tw, mag, n_frames, g_fir_order);                \
     } while (0)
 #define IRDM_LAUNCH_FFT(LOGN, NT)                                                              \
     do {                                                                                       \
@@ -621,7 +623,7 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, false>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
                            stream, iq, window, tw, mag, n_frames, (const float *)nullptr,      \
-                           (unsigned *)nullptr, (ListEntry *)nullptr, 0);                      \
+                           (unsigned *)nullptr, (ListEntry *)nullptr, 0, g_fir_order);         \
     } while (0)
 #define IRDM_LAUNCH_R16(LOGN)                                                                  \
     do {                                                                                       \

@@ -750,12 +750,16 @@ int fir_tile_row(int decim)
 int g_fir_reserve_cus = 0;     // persistent kernel: CUs left to the other streams' kernels
 int g_fir_budget = 4;          // persistent kernel: tiles per workgroup before it retires (0: one resident grid)
 
-// Which of the reference's two forms of the decimating FIR the kernels follow (DESIGN.md "Arithmetic contract"):
-//   1 (default)  avx2_fir_ccf_dec, simd_avx2.c:62-108 -- what the reference runs on x86 unless --no-simd is given: four
-//                accumulators, fused multiply-adds (fir_decimate_kernel_f at M = 40 / 48; the runtime-M kernel otherwise)
-//   0            generic_fir_ccf_dec, simd_generic.c:86-96 (--no-simd): one accumulator, every product and sum rounded
+// Which of the reference's two forms of its dispatched kernels (simd_kernels.h) the kernels follow (DESIGN.md "Arithmetic
+// contract"; option "fir_order", alias "simd_order"; defined in detect.hip):
+//   1 (default)  simd_avx2.c -- what the reference runs on x86 unless --no-simd is given.  avx2_fir_ccf_dec (:62-108): four
+//                accumulators, fused multiply-adds (fir_decimate_kernel_f at M = 40 / 48; the runtime-M kernel otherwise);
+//                avx2_fir_ccf (:28-55) / avx2_fir_fff (:115-138): a fused multiply-add per tap for the outputs of the vector
+//                body, the generic form for the last n % 4 / n % 8 outputs (post1's noise filter and start filter, post2's RRC
+//                filter); avx2_mag_squared (:304-323) / avx2_fftshift_mag (:177-221): fma(re, re, im*im) (post1, K1)
+//   0            simd_generic.c (--no-simd, every non-x86 host): one accumulator, every product and sum rounded
 //                (fir_decimate_kernel_r / _w / _c / _m)
-int g_fir_order = 1;
+// (the other dispatched kernels are the same operations in both forms: tests/test_oracle_vs_ref.py)
 
 // `aligned`: the pipeline's ring lengths are multiples of 8 samples (fir_reg.hip fetches columns in pieces of 8)
 static bool fir_fma_ok(int decim, int aligned)
@@ -1186,7 +1190,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     BurstWork *__restrict__ work, float2 *__restrict__ dec,
     float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps_rt,
     const float *__restrict__ start_taps, int start_ntaps_rt, int search_depth, int pre_start,
-    const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096, BurstWork *__restrict__ hp_work)
+    const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096, BurstWork *__restrict__ hp_work, int order)
 {
     __shared__ __attribute__((aligned(16))) float2 s[kCfoTotal];
     __shared__ float redf[4];
@@ -1216,6 +1220,11 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     const int half = (noise_ntaps - 1) / 2;
     const int span_y = kPostTile + start_ntaps - 1;          // LPF outputs a tile's start filter needs
     const int span_x = span_y + noise_ntaps - 1;
+    // option "fir_order" 1: the reference's AVX2 forms (simd_avx2.c) -- the outputs of a kernel's vector body take a fused
+    // multiply-add per tap, its last n % 4 (fir_ccf, mag_squared) / n % 8 (fir_fff) outputs the generic form
+    const int lpf_vec = order ? (dec_len & ~3) : 0;          // avx2_fir_ccf over dec_len outputs (burst_downmix.c:693)
+    const int mag_vec = order ? (mag_len & ~3) : 0;          // avx2_mag_squared over mag_len (burst_downmix.c:450)
+    const int box_vec = order ? (flen > 0 ? (flen & ~7) : 0) : 0;   // avx2_fir_fff over flen outputs (burst_downmix.c:458)
     float mx = -1e30f;
     for (int B = 0; B < dec_len; B += kPostTile) {
         for (int q = tid; q < span_x; q += kPostThreads) {
@@ -1229,21 +1238,41 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
             float2 v;
             if (do_lpf) {
                 float ar = 0.0f, ai = 0.0f;
+                if (B + p < lpf_vec) {
 #pragma unroll
-                for (int k = 0; k < (NT ? NT : 1); k++) {
-                    if (NT) {
-                        const float2 u = xs[p + k];
-                        const float t = noise_taps[k];
-                        ar += t * u.x;
-                        ai += t * u.y;
+                    for (int k = 0; k < (NT ? NT : 1); k++) {
+                        if (NT) {
+                            const float2 u = xs[p + k];
+                            const float t = noise_taps[k];
+                            ar = __builtin_fmaf(t, u.x, ar);
+                            ai = __builtin_fmaf(t, u.y, ai);
+                        }
                     }
-                }
-                if (!NT) {
-                    for (int k = 0; k < noise_ntaps; k++) {
-                        const float2 u = xs[p + k];
-                        const float t = noise_taps[k];
-                        ar += t * u.x;
-                        ai += t * u.y;
+                    if (!NT) {
+                        for (int k = 0; k < noise_ntaps; k++) {
+                            const float2 u = xs[p + k];
+                            const float t = noise_taps[k];
+                            ar = __builtin_fmaf(t, u.x, ar);
+                            ai = __builtin_fmaf(t, u.y, ai);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < (NT ? NT : 1); k++) {
+                        if (NT) {
+                            const float2 u = xs[p + k];
+                            const float t = noise_taps[k];
+                            ar += t * u.x;
+                            ai += t * u.y;
+                        }
+                    }
+                    if (!NT) {
+                        for (int k = 0; k < noise_ntaps; k++) {
+                            const float2 u = xs[p + k];
+                            const float t = noise_taps[k];
+                            ar += t * u.x;
+                            ai += t * u.y;
+                        }
                     }
                 }
                 v = make_float2(ar, ai);
@@ -1251,17 +1280,25 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
                 v = xs[p + half];
             }
             if (p < kPostTile) y[B + p] = v;
-            m2[p] = mag2(v);
+            m2[p] = B + p < mag_vec ? mag2_fma(v) : mag2(v);
         }
         __syncthreads();
         // step 3, first half: the box filter over |y|^2
         for (int o = tid; o < kPostTile && B + o < flen; o += kPostThreads) {
             float acc = 0.0f;
+            if (B + o < box_vec) {
 #pragma unroll
-            for (int k = 0; k < (SN ? SN : 1); k++)
-                if (SN) acc += start_taps[k] * m2[o + k];
-            if (!SN)
-                for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[o + k];
+                for (int k = 0; k < (SN ? SN : 1); k++)
+                    if (SN) acc = __builtin_fmaf(start_taps[k], m2[o + k], acc);
+                if (!SN)
+                    for (int k = 0; k < start_ntaps; k++) acc = __builtin_fmaf(start_taps[k], m2[o + k], acc);
+            } else {
+#pragma unroll
+                for (int k = 0; k < (SN ? SN : 1); k++)
+                    if (SN) acc += start_taps[k] * m2[o + k];
+                if (!SN)
+                    for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[o + k];
+            }
             fscr[B + o] = acc;
             mx = acc > mx ? acc : mx;
         }
@@ -1339,11 +1376,11 @@ int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
     if (noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic)
         hipLaunchKernelGGL((downmix_post1_kernel<25, 20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
                            lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                           pre_start, cfo_window, tw4096, hp_work);
+                           pre_start, cfo_window, tw4096, hp_work, g_fir_order);
     else
         hipLaunchKernelGGL((downmix_post1_kernel<0, 0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
                            lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                           pre_start, cfo_window, tw4096, hp_work);
+                           pre_start, cfo_window, tw4096, hp_work, g_fir_order);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1422,7 +1459,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     BurstWork *__restrict__ work, const float2 *__restrict__ lpf,
     const float *__restrict__ rrc_taps, int rrc_ntaps_rt, const float2 *__restrict__ tw2048,
     const float2 *__restrict__ dl_fft, const float2 *__restrict__ ul_fft, int dl_len, int ul_len,
-    float sps, float2 *__restrict__ rrc_ws, float2 *__restrict__ frames)
+    float sps, float2 *__restrict__ rrc_ws, float2 *__restrict__ frames, int order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // the rotated frame (steps 5-6) and the three correlation buffers (step 7) are never live together: they share the
@@ -1451,9 +1488,30 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
 
     // step 6 (burst_downmix.c:723-734): centred 51-tap RRC over the zero-padded frame
     const int half = (rrc_ntaps - 1) / 2;
+    // option "fir_order" 1: avx2_fir_ccf over frame_len outputs (burst_downmix.c:733) -- a fused multiply-add per tap but
+    // for the last frame_len % 4 outputs
+    const int rrc_vec = order ? (frame_len & ~3) : 0;
     for (int i = tid; i < L; i += kPostThreads) {
         float ar = 0.0f, ai = 0.0f;
-        if (RT && i >= half && i + (RT - 1 - half) < L) {
+        if (i < rrc_vec) {
+            if (RT && i >= half && i + (RT - 1 - half) < L) {
+#pragma unroll
+                for (int k = 0; k < (RT ? RT : 1); k++) {
+                    const float2 v = rot[i + k - half];
+                    const float t = rrc_taps[k];
+                    ar = __builtin_fmaf(t, v.x, ar);
+                    ai = __builtin_fmaf(t, v.y, ai);
+                }
+            } else {
+                for (int k = 0; k < rrc_ntaps; k++) {
+                    const int j = i + k - half;
+                    const float2 v = (j >= 0 && j < L) ? rot[j] : make_float2(0.0f, 0.0f);
+                    const float t = rrc_taps[k];
+                    ar = __builtin_fmaf(t, v.x, ar);
+                    ai = __builtin_fmaf(t, v.y, ai);
+                }
+            }
+        } else if (RT && i >= half && i + (RT - 1 - half) < L) {
             // every tap inside the frame: no bounds checks, unrolled
 #pragma unroll
             for (int k = 0; k < (RT ? RT : 1); k++) {
@@ -1573,13 +1631,13 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((downmix_post2_kernel<51>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
                            rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
-                           rrc_ws, frames);
+                           rrc_ws, frames, g_fir_order);
     } else {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<0>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((downmix_post2_kernel<0>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
                            rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
-                           rrc_ws, frames);
+                           rrc_ws, frames, g_fir_order);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -2877,7 +2877,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
-    if (!strcmp(key, "fir_order")) { irdm::g_fir_order = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "fir_order") || !strcmp(key, "simd_order")) { irdm::g_fir_order = value ? 1 : 0; return 0; }
     if (!strcmp(key, "rot_pool_rows")) {
         // (test hook) the rotator checkpoint pool with `value` rows to begin with; only before the first burst
         if (p->rot_rows_used != 0 || value < 1 || value > p->P.n) return -1;

@@ -213,6 +213,95 @@ def test_fir_ccf_dec_avx2_order(oracle, reflib):
             assert not np.array_equal(a.view(np.uint32), c.view(np.uint32)) or ntaps < 100      # the two orders differ in rounding
 
 
+def test_avx2_forms_of_the_small_kernels(oracle, reflib):
+    """The other dispatched kernels whose AVX2 form rounds differently (simd_avx2.c): fir_ccf (:28-55: outputs four at a
+    time with fused multiply-adds, the last n % 4 generic), fir_fff (:115-138: eight at a time, the last n % 8 generic),
+    fftshift_mag (:177-221) and mag_squared (:304-323): fma(re, re, im*im).  Each oracle restatement equals the
+    reference's kernel bit for bit at lengths with and without a tail; the kernels whose two forms are the same
+    operations agree with EACH OTHER bit for bit (window_cf, csquare_window, baseline_update, relative_mag, max_float)."""
+    rng = np.random.default_rng(23)
+    bits = lambda v: v.view(np.uint32)
+    for ntaps in (25, 51, 20, 7):
+        taps = rng.standard_normal(ntaps).astype(np.float32)
+        for n in (0, 1, 3, 4, 5, 64, 1023, 4002):
+            x = crand(rng, n + ntaps + 8, scale=float(rng.uniform(0.01, 10.0)))
+            a = np.zeros(max(n, 1), np.complex64); b = np.zeros(max(n, 1), np.complex64); c = np.zeros(max(n, 1), np.complex64)
+            oracle.orc_fir_ccf_avx2(fp(taps), ntaps, fp(x), fp(a), n)
+            reflib.avx2_fir_ccf(fp(taps), ntaps, fp(x), fp(b), n)
+            assert np.array_equal(bits(a), bits(b)), ("fir_ccf", ntaps, n)
+            oracle.orc_fir_ccf(fp(taps), ntaps, fp(x), fp(c), n)
+            if n % 4:                                   # the tail is the generic form
+                assert np.array_equal(bits(a)[-2 * (n % 4):], bits(c)[-2 * (n % 4):])
+            xr = rng.standard_normal(n + ntaps + 8).astype(np.float32)
+            ar = np.zeros(max(n, 1), np.float32); br = np.zeros(max(n, 1), np.float32)
+            oracle.orc_fir_fff_avx2(fp(taps), ntaps, fp(xr), fp(ar), n)
+            reflib.avx2_fir_fff(fp(taps), ntaps, fp(xr), fp(br), n)
+            assert np.array_equal(bits(ar), bits(br)), ("fir_fff", ntaps, n)
+    differs = 0
+    for n in (0, 1, 3, 4, 7, 8, 100, 4099):
+        x = crand(rng, n + 8, scale=3.0)
+        a = np.zeros(max(n, 1), np.float32); b = np.zeros(max(n, 1), np.float32); c = np.zeros(max(n, 1), np.float32)
+        oracle.orc_mag_squared_avx2(fp(x), fp(a), n)
+        reflib.avx2_mag_squared(fp(x), fp(b), n)
+        oracle.orc_mag_squared(fp(x), fp(c), n)
+        assert np.array_equal(bits(a), bits(b)), ("mag_squared", n)
+        differs += int(not np.array_equal(bits(a), bits(c)))
+    assert differs >= 2                                  # fused and separately rounded sums differ in the last bit
+    for n in (4, 8, 12, 4096, 8192, 16384):
+        x = crand(rng, n, scale=2.0)
+        a = np.zeros(n, np.float32); b = np.zeros(n, np.float32)
+        oracle.orc_fftshift_mag_avx2(fp(x), fp(a), n)
+        reflib.avx2_fftshift_mag(fp(x), fp(b), n)
+        assert np.array_equal(bits(a), bits(b)), ("fftshift_mag", n)
+    # the same operations in both forms
+    n = 1027
+    x = crand(rng, n + 8, scale=2.0)
+    w = rng.uniform(0.0, 1.0, n + 8).astype(np.float32)
+    for name in ("window_cf", "csquare_window"):
+        a = np.zeros(n, np.complex64); b = np.zeros(n, np.complex64)
+        getattr(reflib, "generic_" + name)(fp(x), fp(w), fp(a), n)
+        getattr(reflib, "avx2_" + name)(fp(x), fp(w), fp(b), n)
+        assert np.array_equal(bits(a), bits(b)), name
+    s0 = rng.uniform(0, 100, n).astype(np.float32); old = rng.uniform(0, 1, n).astype(np.float32); new = rng.uniform(0, 1, n).astype(np.float32)
+    sa, sb = s0.copy(), s0.copy()
+    reflib.generic_baseline_update(fp(sa), fp(old), fp(new), n)
+    reflib.avx2_baseline_update(fp(sb), fp(old), fp(new), n)
+    assert np.array_equal(bits(sa), bits(sb))
+    base = s0.copy(); base[::7] = 0.0
+    ra = np.zeros(n, np.float32); rb = np.zeros(n, np.float32)
+    reflib.generic_relative_mag(fp(new), fp(base), fp(ra), n)
+    reflib.avx2_relative_mag(fp(new), fp(base), fp(rb), n)
+    assert np.array_equal(bits(ra), bits(rb))
+    reflib.generic_max_float.restype = C.c_float
+    reflib.avx2_max_float.restype = C.c_float
+    assert reflib.generic_max_float(fp(new), n) == reflib.avx2_max_float(fp(new), n)
+
+
+def test_whole_stream_in_the_avx2_forms_differs_only_in_rounding(oracle):
+    """orc_run_stream with the AVX2 forms throughout (orc_set_fir_order 1: fftshift_mag, fir_ccf_dec, fir_ccf, mag_squared,
+    fir_fff) finds the same bursts and frames as with the generic forms, with the frame samples a rounding apart."""
+    import orc
+    import siggen
+    fs = 2_000_000
+    n = int(0.6 * fs) // 32768 * 32768
+    iq, _ = siggen.standard_scene(fs, n, 6, seed=2)
+    try:
+        orc.set_fir_order(0)
+        r0 = orc.run_stream(iq, fs)
+        orc.set_fir_order(1)
+        r1 = orc.run_stream(iq, fs)
+    finally:
+        orc.set_fir_order(1)
+    assert len(r0.bursts) == len(r1.bursts) >= 4 and len(r0.frames) == len(r1.frames) >= 3
+    assert [(b.start, b.stop, b.center_bin) for b in r0.bursts] == [(b.start, b.stop, b.center_bin) for b in r1.bursts]
+    same = 0
+    for f0, f1 in zip(r0.frames, r1.frames):
+        a, b = np.asarray(f0.samples), np.asarray(f1.samples)
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-3, atol=1e-4)
+        same += int(np.array_equal(a, b))
+    assert same < len(r0.frames)                          # ... but not the same bits
+
+
 def test_avx2_variant_differs_only_in_float_rounding(reflib):
     """The reference's AVX2 path is NOT bit-identical to its scalar path: the oracle restates both forms of
     the decimating FIR (orc_fir_ccf_dec / orc_fir_ccf_dec_avx2) and pins each to its reference kernel."""
