@@ -930,7 +930,8 @@ def main():
                                     "gathered_on_rank0": int(gathered.item())} if world > 1 else None),
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
                                                           "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists",
-                                                          "scan_chained", "scan_chain_undone")},
+                                                          "scan_chained", "scan_chain_undone",
+                                                          "band_steps")},      # (band_steps: update steps of the scans' last rounds, summed)
                        # the plan pass's own phase stamps, us per chunk (round 1: verdict loops, boundaries, bitmaps read,
                        # step count scan, step list, slot scan, end; last verdict: loops, boundaries)
                        # (--opt band_timeline=1) device timeline of the scan's passes, us per chunk: [time from the first

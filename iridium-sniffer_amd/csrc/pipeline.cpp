@@ -390,7 +390,7 @@ struct irdm_pipeline {
     std::vector<int> rot_slot_h;            // the host's view: rows handed out (their kernels may still be in flight)
     int rot_rows_used = 0, rot_rows_cap = 0;
     std::vector<float2 *> rot_retired;      // outgrown pools
-    uint64_t stat_rot_builds = 0, stat_rot_rows = 0;
+    uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_band_steps = 0;
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
     std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
     uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0;
@@ -1894,6 +1894,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             if (more_rounds() != 0) return -1;
         }
         p->stat_band_rounds += (uint64_t)ctl->rounds;
+        p->stat_band_steps += (uint64_t)(ctl->n_upd > 0 ? ctl->n_upd : 0);      // (update steps of the last round: what the sums pass walked)
         if (irdm::g_band_timeline && p->fl_band_ran) {
             // (diagnostic) the passes' device timeline of this scan: durations, and the idle time in front of each pass
             unsigned long long tl[2 * kBandTlSlots];
@@ -2953,6 +2954,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "rot_rows")) return (int64_t)p->rot_rows_used;
     if (!strcmp(key, "rot_rows_cap")) return (int64_t)p->rot_rows_cap;
     if (!strcmp(key, "rot_builds")) return (int64_t)p->stat_rot_builds;
+    if (!strcmp(key, "band_steps")) return (int64_t)p->stat_band_steps;
     if (!strcmp(key, "scratch_outputs")) return (int64_t)p->bc[0].dec_cap;
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
     if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;

@@ -698,45 +698,67 @@ __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWor
     const __amdgpu_buffer_rsrc_t r_snap = band_rsrc(snap, (size_t)W.snap_cap * row);
     const int boff = b * 4;
 
-    // Two batches of kSumDepth steps are in flight: the loads of batch i+1 are issued before batch i is consumed.  The
-    // step descriptors are wave-uniform and read a batch at a time (scalar loads of 16 bytes per step, unguarded: the
-    // plan pads the list).  A batch lies on one side of step kHistory (512 = 16 batches), where the replaced rows change
-    // from the carried history ring to the chunk's own magnitude rows.
+    // Two batches of kSumDepth steps are in flight: the loads of batch i+1 are issued before batch i is consumed.  A batch
+    // lies on one side of step kHistory (512 = 16 batches), where the replaced rows change from the carried history ring
+    // to the chunk's own magnitude rows.
+    // The step descriptors are wave-uniform.  Read with scalar loads (rounds 2-3: four groups of sixteen s_load per batch,
+    // each waited for before its rows could be asked for) they were a third of the pass: four scalar round trips per 32
+    // steps.  Now lane j of a register quadruple holds the descriptor of step k0 + j -- ONE vector load per 64 steps,
+    // issued 128 steps ahead (unguarded: the plan pads the list with 2 kSumDepth + 1 no-ops and the workspace has room
+    // behind it) -- and a step's offsets reach the loads' scalar-offset operand by v_readlane; the steps that store a
+    // snapshot are a ballot.  (2 bursts per Msample, 10 MHz: 429 -> 260 us for the first sums pass.  Measured without
+    // further gain: 16 / 32 bins per wavefront, sibling wavefronts reading the rows ahead, and a consumer wavefront of three
+    // issue slots per step fed through LDS by three loader wavefronts that also store the snapshots, -13 % --
+    // profiles/r4_sched_experiments.txt: with long lists the pass moves two rows in and a snapshot row out per step.)
     static_assert(kHistory % kSumDepth == 0, "a batch of steps must not straddle the history ring's length");
+    static_assert(kSumDepth == 32, "two batches per 64 descriptors");
+    static_assert(sizeof(SumStep) == 16, "a descriptor is one 16-byte load");
+    const int lane = (int)(threadIdx.x & 63);
+    const uint4 *steps4 = reinterpret_cast<const uint4 *>(steps);
     float nwA[kSumDepth], olA[kSumDepth], nwB[kSumDepth], olB[kSumDepth];
-    uint32_t slA[kSumDepth], slB[kSumDepth];
-#define IRDM_SUM_LOAD(NWv, OLv, SLv, k0)                                                                \
+#define IRDM_SUM_LOAD(NWv, OLv, D, half, k0)                                                            \
     {                                                                                                   \
         const __amdgpu_buffer_rsrc_t r_old = (k0) < kHistory ? r_hist : r_mag;                          \
         _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) {                                         \
-            const SumStep st = steps[(k0) + j];                                                         \
-            NWv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_mag, boff, (int)st.nw_off, 0)); \
-            OLv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_old, boff, (int)st.ol_off, 0)); \
-            SLv[j] = st.snap_off;                                                                       \
+            const int o_nw = __builtin_amdgcn_readlane((int)D.x, (half) * kSumDepth + j);               \
+            const int o_ol = __builtin_amdgcn_readlane((int)D.y, (half) * kSumDepth + j);               \
+            NWv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_mag, boff, o_nw, 0)); \
+            OLv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_old, boff, o_ol, 0)); \
         }                                                                                               \
     }
-#define IRDM_SUM_STEP(NWv, OLv, SLv)                                                                    \
+#define IRDM_SUM_STEP(NWv, OLv, D, half)                                                                \
     {                                                                                                   \
-        const float d = s - OLv[j]; /* simd_baseline_update: two separately rounded operations */       \
-        s = d + NWv[j];                                                                                 \
-        smin = s < smin ? s : smin;                                                                     \
-        if (SLv[j] != ~0u)                                                                              \
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s), r_snap, boff, (int)SLv[j], 0); \
+        const float dd = s - OLv[j]; /* simd_baseline_update: two separately rounded operations */      \
+        s = dd + NWv[j];                                                                                \
+        smin = __builtin_fminf(smin, s); /* (one v_min_f32; the sums are not NaNs) */                                                                     \
+        if ((snaps >> ((half) * kSumDepth + j)) & 1)                                                    \
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s), r_snap, boff,             \
+                                                  __builtin_amdgcn_readlane((int)D.z, (half) * kSumDepth + j), 0); \
     }
     // (a whole batch inside the list runs without the per-step test of the list's end)
-#define IRDM_SUM_CONSUME(NWv, OLv, SLv, k0)                                                             \
-    if ((k0) + kSumDepth <= n) {                                                                        \
-        _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) IRDM_SUM_STEP(NWv, OLv, SLv)              \
-    } else {                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < kSumDepth; j++)                                           \
-            if ((k0) + j < n) IRDM_SUM_STEP(NWv, OLv, SLv)                                              \
+#define IRDM_SUM_CONSUME(NWv, OLv, D, half, k0)                                                         \
+    {                                                                                                   \
+        const unsigned long long snaps = __builtin_amdgcn_ballot_w64(D.z != ~0u);                       \
+        if ((k0) + kSumDepth <= n) {                                                                    \
+            _Pragma("unroll") for (int j = 0; j < kSumDepth; j++) IRDM_SUM_STEP(NWv, OLv, D, half)      \
+        } else {                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < kSumDepth; j++)                                       \
+                if ((k0) + j < n) IRDM_SUM_STEP(NWv, OLv, D, half)                                      \
+        }                                                                                               \
     }
-    IRDM_SUM_LOAD(nwA, olA, slA, 0)
+    uint4 d = steps4[lane], dn = steps4[2 * kSumDepth + lane];
+    IRDM_SUM_LOAD(nwA, olA, d, 0, 0)
     for (int k0 = 0; k0 < n; k0 += 2 * kSumDepth) {
-        IRDM_SUM_LOAD(nwB, olB, slB, k0 + kSumDepth)
-        IRDM_SUM_CONSUME(nwA, olA, slA, k0)
-        if (k0 + 2 * kSumDepth < n) { IRDM_SUM_LOAD(nwA, olA, slA, k0 + 2 * kSumDepth) }
-        IRDM_SUM_CONSUME(nwB, olB, slB, k0 + kSumDepth)
+        const bool more = k0 + 2 * kSumDepth < n;
+        // (the descriptors of the 64 steps after the next 64, always: by the time they are needed they are older than
+        // every row in flight, so no wait is spent on them; past the list's padding this reads allocated words nobody uses)
+        const uint4 dnn = steps4[k0 + 4 * kSumDepth + lane];
+        IRDM_SUM_LOAD(nwB, olB, d, 1, k0 + kSumDepth)
+        IRDM_SUM_CONSUME(nwA, olA, d, 0, k0)
+        if (more) { IRDM_SUM_LOAD(nwA, olA, dn, 0, k0 + 2 * kSumDepth) }
+        IRDM_SUM_CONSUME(nwB, olB, d, 1, k0 + kSumDepth)
+        d = dn;
+        dn = dnn;
     }
 #undef IRDM_SUM_LOAD
 #undef IRDM_SUM_CONSUME
@@ -1347,7 +1369,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(F); add(F);                                  // uq, uf
     add(4 * (F + 2)); add(4 * (2 * F + 4));          // cnt_before, tmp
     add(4 * (2 * F + 4)); add(4 * (2 * F + 4)); add(4 * (2 * F + 4));   // upd_frame, old_row, snap_after
-    add(sizeof(SumStep) * (2 * F + 4 + 3 * kSumDepth));                // steps
+    add(sizeof(SumStep) * (2 * F + 4 + 3 * kSumDepth + 6 * kSumDepth));   // steps (+ the descriptor read-ahead of the sums pass)
     add(4 * (2 * F + 4)); add(4 * (2 * F + 4));      // need, snap_slot
     add(4 * F); add(4 * F);                          // slot_pre, slot_post
     add(F * (size_t)n / 8);                          // cross
@@ -1375,7 +1397,7 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->upd_frame = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->old_row = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->snap_after = static_cast<int32_t *>(take(4 * (2 * F + 4)));
-    W->steps = static_cast<SumStep *>(take(sizeof(SumStep) * (2 * F + 4 + 3 * kSumDepth)));
+    W->steps = static_cast<SumStep *>(take(sizeof(SumStep) * (2 * F + 4 + 3 * kSumDepth + 6 * kSumDepth)));
     W->need = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->snap_slot = static_cast<int32_t *>(take(4 * (2 * F + 4)));
     W->slot_pre = static_cast<int32_t *>(take(4 * F));

@@ -60,12 +60,13 @@ def test_whole_path_10mhz_register_resident_decimator(emul_lib):
     """10 MHz in four chunks at pipeline_depth 2, fed in place with look-ahead: 8192-point frames through K1's
     32-points-per-lane kernel (with the candidate lists once the detector is primed), decimation by 40 through fir_reg.hip
     -- columns of rotated samples in registers, accumulators travelling from lane to lane by DPP shifts: the fused
-    four-accumulator form of the reference's AVX2 kernel (default) and, in a second run, the scalar-order form
+    four-accumulator form of the reference's AVX2 kernel (default), and with the dispatched kernels in the reference's generic forms
     (IRDM_EMUL_FULL=1 adds the LDS decimator, another minute)"""
     res = run_case(emul_lib, "10mhz", timeout=1500)
     for name in res:
         assert res[name]["bursts"] >= 6 and res[name]["frames"] >= 4, res
     assert res["default"]["k1_lists"] >= 1, res          # a chunk whose candidate lists K1 wrote
+    assert {"default", "scalar_fir_order"} <= set(res)
 
 
 @pytest.mark.skipif(not os.environ.get("IRDM_EMUL_FULL"), reason="four minutes of emulation: set IRDM_EMUL_FULL=1")
