@@ -1309,7 +1309,17 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
     if (k < 0) return;
     const float4 *src = reinterpret_cast<const float4 *>(mag + (size_t)W.upd_frame[k] * P.n);
     float4 *dst = reinterpret_cast<float4 *>(hist + (size_t)((ctl->h0 + k) % kHistory) * P.n);
-    for (int i = threadIdx.x; i < P.n / 4; i += 256) dst[i] = src[i];
+    // (eight loads in flight per lane before the first store: a row at 8192 points in one round trip instead of eight
+    // dependent ones -- 48 us for 2 x 16 MB was 0.7 TB/s)
+    for (int i0 = threadIdx.x; i0 < P.n / 4; i0 += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 256 * u < P.n / 4) v[u] = src[i0 + 256 * u];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 256 * u < P.n / 4) dst[i0 + 256 * u] = v[u];
+    }
 }
 
 }  // namespace
