@@ -656,7 +656,14 @@ def main():
     traffic = None
     try:
         import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        import re
+        files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if re.search(r"r\d+_pmc\.json$", os.path.basename(f))]
+        files.sort(key=lambda f: int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1)))
+        if fs == 12_000_000 and args.density == 40:
+            files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_cfg5.json"))]
+            files.sort(key=lambda f: int(re.search(r"r(\d+)_pmc", os.path.basename(f)).group(1)))
+        elif not (fs == 10_000_000 and args.density == 10):
+            files = []
         if files:
             pmc = json.load(open(files[-1]))
             for kname, d in pmc.items():

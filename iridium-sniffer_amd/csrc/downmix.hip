@@ -85,19 +85,26 @@ int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ck
 }
 
 // The same rows ON DEMAND: the table is a pool of rows, a row is given to a centre bin when the first burst on that bin
-// reaches the decimator (pipeline.cpp, rot_rows_prepare).  news[i] = (bin, row); the lane that has written a row publishes
-// it in slot[bin] (read by the decimator's geometry pass and the LDS decimators of the SAME stream, launched behind this
-// kernel; later chains wait for the event recorded behind it).
+// reaches the decimator, and built as far as the bursts on the bin have needed so far (pipeline.cpp, rot_rows_prepare).
+// news[i] = (bin, row, from, to): checkpoints from .. to - 1 of the row, continued from checkpoint from - 1 (a row's earlier
+// checkpoints are final: chains in flight may be reading them).  The lane that has written a run publishes the row in
+// slot[bin] (read by the decimator's geometry pass and the LDS decimators of the SAME stream, launched behind this kernel;
+// later chains wait for the event recorded behind it).
 __global__ void rotator_rows_kernel(const float2 *__restrict__ incr, float2 *__restrict__ table, int n_ckpt,
-                                    const int2 *__restrict__ news, int n_new, int *__restrict__ slot)
+                                    const int4 *__restrict__ news, int n_new, int *__restrict__ slot)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_new) return;
-    const int bin = news[i].x, row_no = news[i].y;
+    const int bin = news[i].x, row_no = news[i].y, from = news[i].z, to = news[i].w;
     const float2 inc = incr[bin];
-    float2 ph = make_float2(1.0f, 0.0f);
     float2 *row = table + (size_t)row_no * n_ckpt;
-    for (int c = 0; c < n_ckpt; c++) {
+    float2 ph = make_float2(1.0f, 0.0f);
+    if (from > 0) {
+        ph = row[from - 1];
+#pragma unroll
+        for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
+    }
+    for (int c = from; c < to; c++) {
         row[c] = ph;
 #pragma unroll
         for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
@@ -105,7 +112,7 @@ __global__ void rotator_rows_kernel(const float2 *__restrict__ incr, float2 *__r
     slot[bin] = row_no;
 }
 
-int launch_rotator_rows(const float2 *incr, float2 *table, int n_ckpt, const int2 *news, int n_new, int *slot, hipStream_t stream)
+int launch_rotator_rows(const float2 *incr, float2 *table, int n_ckpt, const int4 *news, int n_new, int *slot, hipStream_t stream)
 {
     if (n_new <= 0) return 0;
     hipLaunchKernelGGL(rotator_rows_kernel, dim3((n_new + 63) / 64), dim3(64), 0, stream, incr, table, n_ckpt, news, n_new, slot);

@@ -199,7 +199,7 @@ struct BatchCtx {
     DemodOut *hp_demod;
     DemodPacked *d_packed, *hp_packed;      // packed_records: the demodulator's result without LLRs, bits 8 per byte
     uint32_t *hp_flag, *hp_flag_dev;    // [0] sequence number the helper publishes, [1] time-out flag of the waiting kernel
-    int2 *hp_rot_new, *hp_rot_new_dev, *d_rot_new;   // (bin, row) of the checkpoint rows this batch has to build: mapped pinned / device
+    int4 *hp_rot_new, *hp_rot_new_dev, *d_rot_new;   // (bin, row, from, to) of the checkpoint runs this batch has to build: mapped pinned / device
     uint32_t cfo_seq;
     bool packed;                 // this batch came back as DemodPacked records
     bool cfo_on_device;          // this batch's libm step ran on the device: h_cfreq is filled from the returned records
@@ -389,8 +389,9 @@ struct irdm_pipeline {
     int *d_rot_slot = nullptr;              // [n] centre bin -> row of d_rot_table, -1: none yet (written by the kernel that builds the row)
     std::vector<int> rot_slot_h;            // the host's view: rows handed out (their kernels may still be in flight)
     int rot_rows_used = 0, rot_rows_cap = 0;
+    std::vector<int> rot_len_h, rot_want, rot_bin_of_row, rot_touched;   // per row: checkpoints built (or being built) / wanted by the batch at hand / its bin
     std::vector<float2 *> rot_retired;      // outgrown pools
-    uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_band_steps = 0;
+    uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_band_steps = 0;
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
     std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
     uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0;
@@ -847,9 +848,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_flag), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_flag_dev), b.hp_flag, 0) == hipSuccess;
         if (ok) memset(b.hp_flag, 0, 64);
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_rot_new), sizeof(int2) * (size_t)p->burst_cap, hipHostMallocMapped) == hipSuccess &&
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_rot_new), sizeof(int4) * (size_t)p->burst_cap, hipHostMallocMapped) == hipSuccess &&
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_rot_new_dev), b.hp_rot_new, 0) == hipSuccess;
-        AL(b.d_rot_new, int2, (size_t)p->burst_cap);
+        AL(b.d_rot_new, int4, (size_t)p->burst_cap);
         ok = ok && hipEventCreateWithFlags(&b.ev_cfo, hipEventDisableTiming) == hipSuccess;
         for (auto &e : b.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         b.h_cfreq.assign((size_t)p->burst_cap, 0.0);
@@ -884,6 +885,9 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->rot_rows_cap = std::min(P.n, 1024);
     p->rot_rows_used = 0;
     p->rot_slot_h.assign((size_t)P.n, -1);
+    p->rot_len_h.assign((size_t)P.n, 0);
+    p->rot_want.assign((size_t)P.n, 0);
+    p->rot_bin_of_row.assign((size_t)P.n, -1);
     ok = ok && (p->d_rot_table = dev_alloc<float2>((size_t)p->rot_rows_cap * p->n_ckpt)) != nullptr;
     ok = ok && (p->d_rot_slot = dev_alloc<int>((size_t)P.n)) != nullptr;
     ok = ok && hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)P.n) == hipSuccess;
@@ -1192,40 +1196,62 @@ static void cfo_helper_main(irdm_pipeline *p)
 
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st)
 {
-    int n_new = 0;
+    // A row is built as far as the bursts on its bin have needed it so far (a window of n samples restores checkpoints
+    // 0 .. n / 16), in runs of 2048 checkpoints, and extended from its last checkpoint when a longer one comes: the
+    // recurrence is sequential, 9 ns a sample -- 12 ms for a whole row at 12 MHz, 1-2 ms for a typical burst's share.
+    const int kRun = 2048;
+    p->rot_touched.clear();
     for (int i = 0; i < nb; i++) {
         const BurstWork &w = b.hp_work[i];
         if (w.drop_reason) continue;
         const int bin = w.center_bin;
-        if (bin < 0 || bin >= p->P.n || p->rot_slot_h[(size_t)bin] >= 0) continue;
-        if (p->rot_rows_used == p->rot_rows_cap) {
-            // the pool is full: twice the rows (at most one per FFT bin), the rows built so far copied over on this
-            // chain's stream -- every build so far is complete there (ev_rot) -- and the old pool kept for the chains in
-            // flight that were launched with its address
-            const int cap2 = std::min(p->P.n, 2 * p->rot_rows_cap);
-            float2 *pool2 = nullptr;
-            if (cap2 <= p->rot_rows_cap || hipMalloc(reinterpret_cast<void **>(&pool2), sizeof(float2) * (size_t)cap2 * p->n_ckpt) != hipSuccess) {
-                fprintf(stderr, "irdm_hip: no memory for %d rotator checkpoint rows\n", cap2);
-                return -1;
+        if (bin < 0 || bin >= p->P.n) continue;
+        int row = p->rot_slot_h[(size_t)bin];
+        if (row < 0) {
+            if (p->rot_rows_used == p->rot_rows_cap) {
+                // the pool is full: twice the rows (at most one per FFT bin), the rows built so far copied over on this
+                // chain's stream -- every build so far is complete there (ev_rot) -- and the old pool kept for the chains in
+                // flight that were launched with its address
+                const int cap2 = std::min(p->P.n, 2 * p->rot_rows_cap);
+                float2 *pool2 = nullptr;
+                if (cap2 <= p->rot_rows_cap || hipMalloc(reinterpret_cast<void **>(&pool2), sizeof(float2) * (size_t)cap2 * p->n_ckpt) != hipSuccess) {
+                    fprintf(stderr, "irdm_hip: no memory for %d rotator checkpoint rows\n", cap2);
+                    return -1;
+                }
+                // (the runs of this batch's list so far are not built yet: they will be built in the new pool)
+                IRDM_HIP_CHECK(hipMemcpyAsync(pool2, p->d_rot_table, sizeof(float2) * (size_t)p->rot_rows_cap * p->n_ckpt,
+                                              hipMemcpyDeviceToDevice, st));
+                p->rot_retired.push_back(p->d_rot_table);
+                p->d_rot_table = pool2;
+                p->rot_rows_cap = cap2;
             }
-            // (the rows of this batch's list so far are not built yet: they will be built in the new pool)
-            IRDM_HIP_CHECK(hipMemcpyAsync(pool2, p->d_rot_table, sizeof(float2) * (size_t)p->rot_rows_cap * p->n_ckpt,
-                                          hipMemcpyDeviceToDevice, st));
-            p->rot_retired.push_back(p->d_rot_table);
-            p->d_rot_table = pool2;
-            p->rot_rows_cap = cap2;
+            row = p->rot_rows_used++;
+            p->rot_slot_h[(size_t)bin] = row;
+            p->rot_bin_of_row[(size_t)row] = bin;
+            p->rot_len_h[(size_t)row] = 0;
         }
-        const int row = p->rot_rows_used++;
-        p->rot_slot_h[(size_t)bin] = row;
-        b.hp_rot_new[n_new++] = int2{ bin, row };
+        int need = (w.n + kRotSeg - 1) / kRotSeg + 8;
+        need = (need + kRun - 1) / kRun * kRun;
+        if (need > p->n_ckpt) need = p->n_ckpt;
+        if (need > p->rot_len_h[(size_t)row] && need > p->rot_want[(size_t)row]) {
+            if (p->rot_want[(size_t)row] == 0) p->rot_touched.push_back(row);
+            p->rot_want[(size_t)row] = need;
+        }
+    }
+    int n_new = 0;
+    for (int row : p->rot_touched) {
+        b.hp_rot_new[n_new++] = int4{ p->rot_bin_of_row[(size_t)row], row, p->rot_len_h[(size_t)row], p->rot_want[(size_t)row] };
+        p->stat_rot_ckpts += (uint64_t)(p->rot_want[(size_t)row] - p->rot_len_h[(size_t)row]);
+        p->rot_len_h[(size_t)row] = p->rot_want[(size_t)row];
+        p->rot_want[(size_t)row] = 0;
     }
     if (!n_new) return 0;
     p->stat_rot_builds++;
     p->stat_rot_rows += (uint64_t)n_new;
     // (the list by copy kernel: a kernel's plain loads of mapped host memory may be served from stale L2 lines)
-    if (launch_copy_words(b.d_rot_new, b.hp_rot_new_dev, sizeof(int2) * (size_t)n_new, st) != 0) return -1;
+    if (launch_copy_words(b.d_rot_new, b.hp_rot_new_dev, sizeof(int4) * (size_t)n_new, st) != 0) return -1;
     if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_rot_new, n_new, p->d_rot_slot, st) != 0) return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev_rot, st));                  // later chains wait for these rows
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_rot, st));                  // later chains wait for these runs
     return 0;
 }
 
@@ -2954,6 +2980,8 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "rot_rows")) return (int64_t)p->rot_rows_used;
     if (!strcmp(key, "rot_rows_cap")) return (int64_t)p->rot_rows_cap;
     if (!strcmp(key, "rot_builds")) return (int64_t)p->stat_rot_builds;
+    if (!strcmp(key, "rot_runs")) return (int64_t)p->stat_rot_rows;
+    if (!strcmp(key, "rot_ckpts")) return (int64_t)p->stat_rot_ckpts;
     if (!strcmp(key, "band_steps")) return (int64_t)p->stat_band_steps;
     if (!strcmp(key, "scratch_outputs")) return (int64_t)p->bc[0].dec_cap;
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;

@@ -54,6 +54,15 @@ def main():
         ref8 = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
         res["ci8"] = parity.compare(parity.run_gpu(x, fs, fmt=irdm.FMT_CI8), ref8)
         res["sequential_scan"] = parity.compare(parity.run_gpu(iq, fs, scan_mode=1), ref)
+        # rotator checkpoint rows are built as far as needed and extended: a short burst, then a long one on the same carrier
+        import test_gpu_footprint as tf
+        fs2, iq2 = tf._short_then_long()
+        ref2 = orc.run_stream(iq2, fs2)
+        half = len(iq2) // 2 // 32768 * 32768
+        got = parity.run_gpu(iq2, fs2, chunks=[half, len(iq2) - half], depth=1)
+        res["rotator_row_extension"] = parity.compare(got, ref2)
+        assert res["rotator_row_extension"]["bursts"] == 4
+        assert got["stats"]["rot_runs"] > got["stats"]["rot_rows"] >= 2 and got["stats"]["rot_ckpts"] >= 3 * 2048, got["stats"]   # (a row was extended)
         # the decimated / low-passed rows of a batch lie end to end by actual length: a scratch of 64 outputs to begin
         # with grows by doubling, per context, while the other contexts' chains are in flight
         got = parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead", options={"scratch_outputs": 64})

@@ -58,6 +58,46 @@ def test_rotator_checkpoint_rows_on_demand_and_pool_growth():
     b.close()
 
 
+def _short_then_long(fs=2_000_000):
+    """a short burst and, later, a long one on the same carrier, and a long one on another carrier"""
+    rng = np.random.default_rng(3)
+    n = int(1.3 * fs) // 32768 * 32768
+    f0, f1 = siggen.channel_freq(2), siggen.channel_freq(-5)
+    bursts = [dict(start=520 * 2048 + 300, freq_hz=f0, payload=list(rng.integers(0, 4, 100))),
+              dict(start=int(0.62 * fs), freq_hz=f0, payload=list(rng.integers(0, 4, 1350))),
+              dict(start=int(0.80 * fs), freq_hz=f1, payload=list(rng.integers(0, 4, 1200))),
+              dict(start=int(0.98 * fs), freq_hz=f0, payload=list(rng.integers(0, 4, 300)))]
+    iq, _ = siggen.make_stream(fs, n, bursts, seed=8)
+    return fs, iq
+
+
+def test_rotator_rows_are_built_as_far_as_needed_and_extended():
+    """A row of rotator checkpoints is built only as far as the bursts on its bin have needed so far (runs of 2048
+    checkpoints) and continued from its last checkpoint when a longer burst arrives on the bin -- in the same chunk or a
+    later one; the records are the oracle's."""
+    fs, iq = _short_then_long()
+    ref = orc.run_stream(iq, fs)
+    assert len(ref.bursts) == 4 and 2 <= len({b.center_bin for b in ref.bursts}) <= 3
+    n = len(iq)
+    for chunks in (None, [n // 2 // 32768 * 32768, n - n // 2 // 32768 * 32768]):
+        p = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=64, pipeline_depth=1 if chunks else 0)
+        p.set_option("keep_frame_samples", 1)
+        off = 0
+        for c in (chunks or [n]):
+            p.feed_host(iq[off:off + c])
+            off += c
+        p.flush()
+        infos, samples = p.poll_frames()
+        got = dict(bursts=p.poll_bursts(), infos=infos, samples=samples, demods=p.poll_demods(), tagged=p.tagged)
+        st = {k: p.stat(k) for k in ("rot_rows", "rot_runs", "rot_ckpts", "rot_builds")}
+        p.close()
+        parity.compare(got, ref)
+        # a row per centre bin; the first carrier's row in two runs (2048-checkpoint runs: the short burst, then the long
+        # one's extension)
+        assert st["rot_runs"] > st["rot_rows"] >= 2, st
+        assert st["rot_ckpts"] % 2048 == 0 and st["rot_ckpts"] >= 3 * 2048, st
+
+
 def test_burst_scratch_rows_by_length_and_growth():
     """The per-burst scratch behind the decimator holds a batch's rows end to end (BurstWork::dec_off); one that starts
     with room for 64 outputs doubles, context by context, while other chains are in flight; records are the oracle's."""
