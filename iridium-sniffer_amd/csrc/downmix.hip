@@ -57,67 +57,69 @@ __device__ __forceinline__ void load_seg16(int fmt, const void *__restrict__ bas
 }
 
 // ---------------------------------------------------------------------------
-// Rotator checkpoint table: phase_k of the float recurrence phase *= incr
-// (rotator.h:38-39) for k = 0, 16, 32, ...; one lane per FFT bin.  The sequence
-// depends only on the burst's centre bin (rotator_init per burst,
-// burst_downmix.c:666-669), so it is computed once and kept in HBM.
+// Rotator checkpoints: phase_k of the float recurrence phase *= incr
+// (rotator.h:38-39) for k = 0, 16, 32, ...  The sequence depends only on the
+// burst's centre bin (rotator_init per burst, burst_downmix.c:666-669), so it
+// is computed once per bin -- as far as bursts have needed it -- and kept in HBM.
 // ---------------------------------------------------------------------------
-__global__ void rotator_table_kernel(const float2 *__restrict__ incr, float2 *__restrict__ table,
-                                     int n_bins, int n_ckpt)
-{
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= n_bins) return;
-    const float2 inc = incr[bin];
-    float2 ph = make_float2(1.0f, 0.0f);
-    float2 *row = table + (size_t)bin * n_ckpt;
-    for (int c = 0; c < n_ckpt; c++) {
-        row[c] = ph;
-#pragma unroll
-        for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
-    }
-}
-
-int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream)
-{
-    hipLaunchKernelGGL(rotator_table_kernel, dim3((n_bins + 63) / 64), dim3(64), 0, stream, incr,
-                       table, n_bins, n_ckpt);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-// The same rows ON DEMAND: the table is a pool of rows, a row is given to a centre bin when the first burst on that bin
-// reaches the decimator, and built as far as the bursts on the bin have needed so far (pipeline.cpp, rot_rows_prepare).
-// news[i] = (bin, row, from, to): checkpoints from .. to - 1 of the row, continued from checkpoint from - 1 (a row's earlier
-// checkpoints are final: chains in flight may be reading them).  The lane that has written a run publishes the row in
-// slot[bin] (read by the decimator's geometry pass and the LDS decimators of the SAME stream, launched behind this kernel;
-// later chains wait for the event recorded behind it).
-__global__ void rotator_rows_kernel(const float2 *__restrict__ incr, float2 *__restrict__ table, int n_ckpt,
-                                    const int4 *__restrict__ news, int n_new, int *__restrict__ slot)
+// The rows ON DEMAND, block by block.  The table is an ARENA of blocks of kRotRun checkpoints; a centre bin's row is the list
+// of its blocks, one per run of kRotRun checkpoints, runs[bin * n_runs + run] (-1: not built) -- a row exists as far as the
+// bursts on its bin have needed it so far (pipeline.cpp, rot_rows_prepare) and grows by blocks that need not be adjacent:
+// nothing ever moves, chains in flight keep reading the blocks they were launched for.  news[i] = (bin, from, to, block):
+// checkpoints from .. to - 1 (whole runs) into the blocks block, block + 1, ..; continued from checkpoint from - 1.  The lane
+// that has written a run publishes its block (read by the decimator's geometry pass and the one-tile-per-workgroup
+// decimators of the SAME stream, launched behind this kernel; later chains wait for the event recorded behind it).
+__global__ void rotator_rows_kernel(const float2 *__restrict__ incr, float2 *__restrict__ table, int n_runs,
+                                    const int4 *__restrict__ news, int n_new, int *__restrict__ runs_all)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_new) return;
-    const int bin = news[i].x, row_no = news[i].y, from = news[i].z, to = news[i].w;
+    const int bin = news[i].x, from = news[i].y, to = news[i].z, block0 = news[i].w;
     const float2 inc = incr[bin];
-    float2 *row = table + (size_t)row_no * n_ckpt;
+    int *runs = runs_all + (size_t)bin * n_runs;
     float2 ph = make_float2(1.0f, 0.0f);
     if (from > 0) {
-        ph = row[from - 1];
+        ph = table[(size_t)runs[(from - 1) / kRotRun] * kRotRun + (from - 1) % kRotRun];
 #pragma unroll
         for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
     }
-    for (int c = from; c < to; c++) {
-        row[c] = ph;
+    for (int c0 = from; c0 < to; c0 += kRotRun) {
+        const int block = block0 + (c0 - from) / kRotRun;
+        float2 *row = table + (size_t)block * kRotRun;
+        for (int c = 0; c < kRotRun; c++) {
+            row[c] = ph;
 #pragma unroll
-        for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
+            for (int u = 0; u < kRotSeg; u++) ph = cmul(ph, inc);
+        }
+        runs[c0 / kRotRun] = block;
     }
-    slot[bin] = row_no;
 }
 
-int launch_rotator_rows(const float2 *incr, float2 *table, int n_ckpt, const int4 *news, int n_new, int *slot, hipStream_t stream)
+int launch_rotator_rows(const float2 *incr, float2 *table, int n_runs, const int4 *news, int n_new, int *runs, hipStream_t stream)
 {
     if (n_new <= 0) return 0;
-    hipLaunchKernelGGL(rotator_rows_kernel, dim3((n_new + 63) / 64), dim3(64), 0, stream, incr, table, n_ckpt, news, n_new, slot);
+    hipLaunchKernelGGL(rotator_rows_kernel, dim3((n_new + 63) / 64), dim3(64), 0, stream, incr, table, n_runs, news, n_new, runs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// the checkpoints of a tile as the one-tile-per-workgroup kernels read them: `runs` = blocks of the bin's row
+// (rot_slot[bin * n_runs + run]), first checkpoint c0; a tile's checkpoints lie in one run or two
+struct RotCk {
+    const float2 *p0, *p1;
+    int wrap;
+    __device__ __forceinline__ RotCk(const float2 *table, const int *rot_slot, int n_runs, int bin, int c0)
+    {
+        const int r0 = c0 / kRotRun;
+        const int *runs = rot_slot + (size_t)bin * n_runs;
+        const int b0 = runs[r0];
+        int b1 = r0 + 1 < n_runs ? runs[r0 + 1] : b0;
+        if (b1 < 0) b1 = b0;
+        p0 = table + (size_t)b0 * kRotRun + c0 % kRotRun;
+        p1 = table + (size_t)b1 * kRotRun;
+        wrap = kRotRun - c0 % kRotRun;
+    }
+    __device__ __forceinline__ float2 at(int seg) const { return seg < wrap ? p0[seg] : p1[seg - wrap]; }
+};
 
 // ---------------------------------------------------------------------------
 // Rotate + decimate.  One workgroup = kFirTileOut outputs of one burst.
@@ -149,11 +151,11 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     const int span = (n_out - 1) * decim + kFirTaps;
     const int s0 = o0 * decim;                       // multiple of kRotSeg
     const float2 inc = rot_incr[w.center_bin];
-    const float2 *ck = rot_table + (size_t)rot_slot[w.center_bin] * n_ckpt + s0 / kRotSeg;
+    const RotCk ck(rot_table, rot_slot, n_ckpt, w.center_bin, s0 / kRotSeg);
     const int n_seg = (span + kRotSeg - 1) / kRotSeg;
 
     for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
-        float2 ph = ck[seg];
+        float2 ph = ck.at(seg);
         const int k0 = seg * kRotSeg;
         int p = k0 % decim, q = k0 / decim;
         const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
@@ -298,12 +300,12 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
     const int span = (n_out - 1) * M + kFirTaps;
     const int s0 = o0 * M;                           // multiple of kRotSeg
     const float2 inc = rot_incr[w.center_bin];
-    const float2 *ck = rot_table + (size_t)rot_slot[w.center_bin] * n_ckpt + s0 / kRotSeg;
+    const RotCk ck(rot_table, rot_slot, n_ckpt, w.center_bin, s0 / kRotSeg);
     const int n_seg = (span + kRotSeg - 1) / kRotSeg;
 
     for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
     for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
-        float2 ph = ck[seg];
+        float2 ph = ck.at(seg);
         const int k0 = seg * kRotSeg;
         int p = k0 % M, q = k0 / M;
         const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
@@ -409,12 +411,12 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
     const int span = (n_out - 1) * M + kFirTaps;
     const int s0 = o0 * M;                           // multiple of kRotSeg
     const float2 inc = rot_incr[w.center_bin];
-    const float2 *ck = rot_table + (size_t)rot_slot[w.center_bin] * n_ckpt + s0 / kRotSeg;
+    const RotCk ck(rot_table, rot_slot, n_ckpt, w.center_bin, s0 / kRotSeg);
     const int n_seg = (span + kRotSeg - 1) / kRotSeg;
 
     for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
     for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
-        float2 ph = ck[seg];
+        float2 ph = ck.at(seg);
         const int k0 = seg * kRotSeg;
         const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
         float2 x[kRotSeg];
@@ -561,10 +563,21 @@ __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts
     const float2 inc = rot_incr[cb];
     g.inc_re = inc.x;
     g.inc_im = inc.y;
-    g.ck_index = (uint64_t)rot_slot[cb] * (uint64_t)n_ckpt + (uint64_t)(g.s0 / kRotSeg);      // (the bin's row of the checkpoint pool)
+    {
+        // the bin's row of the checkpoint arena: a block per run of kRotRun checkpoints (rot_slot[cb * n_ckpt + run], n_ckpt =
+        // runs per bin here); a tile's checkpoints lie in one run or two
+        const int c0 = g.s0 / kRotSeg, r0 = c0 / kRotRun;
+        const int *runs = rot_slot + (size_t)cb * n_ckpt;
+        const int b0 = runs[r0];
+        int b1 = r0 + 1 < n_ckpt ? runs[r0 + 1] : b0;
+        if (b1 < 0) b1 = b0;                                  // (not built: not needed by this burst)
+        g.ck_index = (uint64_t)b0 * kRotRun + (uint64_t)(c0 % kRotRun);
+        g.ck_wrap = kRotRun - c0 % kRotRun;
+        g.ck_index2 = (uint64_t)b1 * kRotRun;
+    }
     g.out_base = (int64_t)w->dec_off + o0;
     g.stale_pos = (g.ring_pos + ring_len - ref_ring % ring_len) % ring_len;
-    for (int i = 0; i < 4; i++) g.pad[i] = 0;
+    g.pad = 0;
     geom[t] = g;
 }
 
@@ -609,7 +622,7 @@ __global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const void *base = in_chunk ? src.chunk : src.ring;
             const size_t idx = in_chunk ? (size_t)(a0 - src.chunk_start) : in_ring ? (size_t)rp : 0;
             load_seg16(FMT, base, idx, x[j]);
-            ph0[j] = rot_table[g.ck_index + (uint64_t)(seg < g.n_seg ? seg : 0)];
+            ph0[j] = rot_table[fir_ck(g, seg < g.n_seg ? seg : 0)];
         }
     };
     // rotate the samples of tile `g` (rotator.h:38-39) and store them in the tile

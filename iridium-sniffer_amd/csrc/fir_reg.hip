@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int j = 0; j < 2; j++) {
                 const int cr = 128 * d + 64 * j + lane;
                 const int k0 = cr < n_cols ? cr * M : 0;
-                const float2 c = rot_table[g.ck_index + (uint64_t)(k0 / kRotSeg)];
+                const float2 c = rot_table[fir_ck(g, k0 / kRotSeg)];
                 ph[j] = v2f{ c.x, c.y };
             }
             if (M % kRotSeg != 0) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int j = 0; j < 2; j++) {
                 const int cr = 2 * lane + j;
                 const int k0 = cr < n_cols ? cr * M : 0;
-                const float2 c = rot_table[g.ck_index + (uint64_t)(k0 / kRotSeg)];
+                const float2 c = rot_table[fir_ck(g, k0 / kRotSeg)];
                 ph[j] = v2f{ c.x, c.y };
             }
             if (M % kRotSeg != 0) {

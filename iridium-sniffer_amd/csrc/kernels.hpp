@@ -111,9 +111,8 @@ struct SampleSource {
 };
 
 // downmix.hip
-int launch_rotator_table(const float2 *incr, float2 *table, int n_bins, int n_ckpt, hipStream_t stream);
 // rows of the checkpoint pool for centre bins that have none yet: news[i] = (bin, row), slot[bin] = row when done
-int launch_rotator_rows(const float2 *incr, float2 *table, int n_ckpt, const int4 *news, int n_new, int *slot, hipStream_t stream);
+int launch_rotator_rows(const float2 *incr, float2 *table, int n_runs, const int4 *news, int n_new, int *runs, hipStream_t stream);
 int fir_tile_row(int decim);
 extern int g_fir_force_generic;   // 1: always the runtime-M decimator kernel
 extern int g_fir_layout;          // 2 (default): persistent column-major kernel, 1: column-major tile, 0: polyphase rows

@@ -386,12 +386,13 @@ struct irdm_pipeline {
     float last_ms[6];
     int keep_frame_samples;
     // rotator checkpoint rows on demand (rot_rows_prepare)
-    int *d_rot_slot = nullptr;              // [n] centre bin -> row of d_rot_table, -1: none yet (written by the kernel that builds the row)
-    std::vector<int> rot_slot_h;            // the host's view: rows handed out (their kernels may still be in flight)
-    int rot_rows_used = 0, rot_rows_cap = 0;
-    std::vector<int> rot_len_h, rot_want, rot_bin_of_row, rot_touched;   // per row: checkpoints built (or being built) / wanted by the batch at hand / its bin
+    int *d_rot_slot = nullptr;              // [n][rot_runs] centre bin, run -> block of d_rot_table, -1: none yet (written by the kernel that builds the run)
+    int rot_runs = 0;                       // runs of kRotRun checkpoints per bin
+    int rot_rows_used = 0;                  // bins that have a row
+    int rot_blocks_used = 0, rot_blocks_cap = 0;
+    std::vector<int> rot_len_h, rot_want, rot_touched;   // per bin: checkpoints built (or being built) / wanted by the batch at hand
     std::vector<float2 *> rot_retired;      // outgrown pools
-    uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_band_steps = 0;
+    uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_rot_grows = 0, stat_band_steps = 0;
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
     std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
     uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0;
@@ -882,15 +883,15 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     // 10 MHz) is not needed before the first burst reaches the decimator -- at the earliest 512 priming frames into
     // the stream -- so irdm_create does not wait for it: it runs on a per-burst stream, the chains wait for ev_rot.
     // rotator checkpoint rows: a pool, rows on first use of a centre bin (rot_rows_prepare); nothing is built here
-    p->rot_rows_cap = std::min(P.n, 1024);
+    p->rot_runs = (p->n_ckpt + kRotRun - 1) / kRotRun;
+    p->rot_blocks_cap = std::min(P.n, 1024) * p->rot_runs;        // (what 1024 whole rows would take: 0.57 GB at 10 MHz)
+    p->rot_blocks_used = 0;
     p->rot_rows_used = 0;
-    p->rot_slot_h.assign((size_t)P.n, -1);
     p->rot_len_h.assign((size_t)P.n, 0);
     p->rot_want.assign((size_t)P.n, 0);
-    p->rot_bin_of_row.assign((size_t)P.n, -1);
-    ok = ok && (p->d_rot_table = dev_alloc<float2>((size_t)p->rot_rows_cap * p->n_ckpt)) != nullptr;
-    ok = ok && (p->d_rot_slot = dev_alloc<int>((size_t)P.n)) != nullptr;
-    ok = ok && hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)P.n) == hipSuccess;
+    ok = ok && (p->d_rot_table = dev_alloc<float2>((size_t)p->rot_blocks_cap * kRotRun)) != nullptr;
+    ok = ok && (p->d_rot_slot = dev_alloc<int>((size_t)P.n * p->rot_runs)) != nullptr;
+    ok = ok && hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)P.n * p->rot_runs) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&p->ev_rot, hipEventDisableTiming) == hipSuccess &&
          hipEventRecord(p->ev_rot, p->bc[0].stream) == hipSuccess;
     mark("rotator row pool");
@@ -1197,60 +1198,63 @@ static void cfo_helper_main(irdm_pipeline *p)
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st)
 {
     // A row is built as far as the bursts on its bin have needed it so far (a window of n samples restores checkpoints
-    // 0 .. n / 16), in runs of 2048 checkpoints, and extended from its last checkpoint when a longer one comes: the
-    // recurrence is sequential, 9 ns a sample -- 12 ms for a whole row at 12 MHz, 1-2 ms for a typical burst's share.
-    const int kRun = 2048;
+    // 0 .. n / 16), in runs of kRotRun checkpoints -- a block of the arena each --, and continued from its last
+    // checkpoint when a longer burst comes: the recurrence is sequential, 9 ns a sample -- 12 ms for a whole row at
+    // 12 MHz, 1-2 ms for a typical burst's share.
     p->rot_touched.clear();
+    int blocks_wanted = 0;
     for (int i = 0; i < nb; i++) {
         const BurstWork &w = b.hp_work[i];
         if (w.drop_reason) continue;
         const int bin = w.center_bin;
         if (bin < 0 || bin >= p->P.n) continue;
-        int row = p->rot_slot_h[(size_t)bin];
-        if (row < 0) {
-            if (p->rot_rows_used == p->rot_rows_cap) {
-                // the pool is full: twice the rows (at most one per FFT bin), the rows built so far copied over on this
-                // chain's stream -- every build so far is complete there (ev_rot) -- and the old pool kept for the chains in
-                // flight that were launched with its address
-                const int cap2 = std::min(p->P.n, 2 * p->rot_rows_cap);
-                float2 *pool2 = nullptr;
-                if (cap2 <= p->rot_rows_cap || hipMalloc(reinterpret_cast<void **>(&pool2), sizeof(float2) * (size_t)cap2 * p->n_ckpt) != hipSuccess) {
-                    fprintf(stderr, "irdm_hip: no memory for %d rotator checkpoint rows\n", cap2);
-                    return -1;
-                }
-                // (the runs of this batch's list so far are not built yet: they will be built in the new pool)
-                IRDM_HIP_CHECK(hipMemcpyAsync(pool2, p->d_rot_table, sizeof(float2) * (size_t)p->rot_rows_cap * p->n_ckpt,
-                                              hipMemcpyDeviceToDevice, st));
-                p->rot_retired.push_back(p->d_rot_table);
-                p->d_rot_table = pool2;
-                p->rot_rows_cap = cap2;
-            }
-            row = p->rot_rows_used++;
-            p->rot_slot_h[(size_t)bin] = row;
-            p->rot_bin_of_row[(size_t)row] = bin;
-            p->rot_len_h[(size_t)row] = 0;
-        }
         int need = (w.n + kRotSeg - 1) / kRotSeg + 8;
-        need = (need + kRun - 1) / kRun * kRun;
-        if (need > p->n_ckpt) need = p->n_ckpt;
-        if (need > p->rot_len_h[(size_t)row] && need > p->rot_want[(size_t)row]) {
-            if (p->rot_want[(size_t)row] == 0) p->rot_touched.push_back(row);
-            p->rot_want[(size_t)row] = need;
+        need = (need + kRotRun - 1) / kRotRun * kRotRun;
+        if (need > p->rot_runs * kRotRun) need = p->rot_runs * kRotRun;
+        const int have = std::max(p->rot_len_h[(size_t)bin], p->rot_want[(size_t)bin]);
+        if (need > have) {
+            if (p->rot_want[(size_t)bin] == 0) p->rot_touched.push_back(bin);
+            p->rot_want[(size_t)bin] = need;
+            blocks_wanted += (need - have) / kRotRun;
         }
+    }
+    if (p->rot_touched.empty()) return 0;
+    if (p->rot_blocks_used + blocks_wanted > p->rot_blocks_cap) {
+        // the arena is full: twice the blocks (at most a whole row per FFT bin), the blocks built so far copied over on this
+        // chain's stream -- every build so far is complete there (ev_rot) -- and the old arena kept for the chains in
+        // flight that were launched with its address (block numbers stay what they are)
+        const long long max_blocks = (long long)p->P.n * p->rot_runs;
+        long long cap2 = p->rot_blocks_cap;
+        while (cap2 < (long long)p->rot_blocks_used + blocks_wanted && cap2 < max_blocks) cap2 = std::min(2 * cap2, max_blocks);
+        float2 *pool2 = nullptr;
+        if (cap2 < (long long)p->rot_blocks_used + blocks_wanted ||
+            hipMalloc(reinterpret_cast<void **>(&pool2), sizeof(float2) * (size_t)cap2 * kRotRun) != hipSuccess) {
+            for (int bin : p->rot_touched) p->rot_want[(size_t)bin] = 0;
+            fprintf(stderr, "irdm_hip: no memory for %lld blocks of rotator checkpoints\n", cap2);
+            return -1;
+        }
+        IRDM_HIP_CHECK(hipMemcpyAsync(pool2, p->d_rot_table, sizeof(float2) * (size_t)p->rot_blocks_used * kRotRun,
+                                      hipMemcpyDeviceToDevice, st));
+        p->rot_retired.push_back(p->d_rot_table);
+        p->d_rot_table = pool2;
+        p->rot_blocks_cap = (int)cap2;
+        p->stat_rot_grows++;
     }
     int n_new = 0;
-    for (int row : p->rot_touched) {
-        b.hp_rot_new[n_new++] = int4{ p->rot_bin_of_row[(size_t)row], row, p->rot_len_h[(size_t)row], p->rot_want[(size_t)row] };
-        p->stat_rot_ckpts += (uint64_t)(p->rot_want[(size_t)row] - p->rot_len_h[(size_t)row]);
-        p->rot_len_h[(size_t)row] = p->rot_want[(size_t)row];
-        p->rot_want[(size_t)row] = 0;
+    for (int bin : p->rot_touched) {
+        const int from = p->rot_len_h[(size_t)bin], to = p->rot_want[(size_t)bin];
+        if (from == 0) p->rot_rows_used++;
+        b.hp_rot_new[n_new++] = int4{ bin, from, to, p->rot_blocks_used };
+        p->rot_blocks_used += (to - from) / kRotRun;
+        p->stat_rot_ckpts += (uint64_t)(to - from);
+        p->rot_len_h[(size_t)bin] = to;
+        p->rot_want[(size_t)bin] = 0;
     }
-    if (!n_new) return 0;
     p->stat_rot_builds++;
     p->stat_rot_rows += (uint64_t)n_new;
     // (the list by copy kernel: a kernel's plain loads of mapped host memory may be served from stale L2 lines)
     if (launch_copy_words(b.d_rot_new, b.hp_rot_new_dev, sizeof(int4) * (size_t)n_new, st) != 0) return -1;
-    if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_rot_new, n_new, p->d_rot_slot, st) != 0) return -1;
+    if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->rot_runs, b.d_rot_new, n_new, p->d_rot_slot, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_rot, st));                  // later chains wait for these runs
     return 0;
 }
@@ -1365,7 +1369,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     if (tile_list && n_tiles && launch_copy_words(b.d_tiles, b.hp_tiles, sizeof(FirTile) * n_tiles, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
-                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->n_ckpt, b.d_dec, st,
+                            p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->rot_runs, b.d_dec, st,
                             p->kclk_rec((int)(&b - p->bc)), p->d_rot_slot) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
@@ -2908,11 +2912,11 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "rot_pool_rows")) {
         // (test hook) the rotator checkpoint pool with `value` rows to begin with; only before the first burst
         if (p->rot_rows_used != 0 || value < 1 || value > p->P.n) return -1;
-        float2 *pool = dev_alloc<float2>((size_t)value * p->n_ckpt);
+        float2 *pool = dev_alloc<float2>((size_t)value * p->rot_runs * kRotRun);
         if (!pool) return -1;
         (void)hipFree(p->d_rot_table);
         p->d_rot_table = pool;
-        p->rot_rows_cap = value;
+        p->rot_blocks_cap = value * p->rot_runs;
         return 0;
     }
     if (!strcmp(key, "scratch_outputs")) {
@@ -2978,7 +2982,10 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
         return i >= 0 && i < 16 ? (int64_t)p->stat_plan_tp[i] : -1;
     }
     if (!strcmp(key, "rot_rows")) return (int64_t)p->rot_rows_used;
-    if (!strcmp(key, "rot_rows_cap")) return (int64_t)p->rot_rows_cap;
+    if (!strcmp(key, "rot_rows_cap")) return (int64_t)(p->rot_blocks_cap / p->rot_runs);      // (in whole rows)
+    if (!strcmp(key, "rot_blocks")) return (int64_t)p->rot_blocks_used;
+    if (!strcmp(key, "rot_blocks_cap")) return (int64_t)p->rot_blocks_cap;
+    if (!strcmp(key, "rot_grows")) return (int64_t)p->stat_rot_grows;
     if (!strcmp(key, "rot_builds")) return (int64_t)p->stat_rot_builds;
     if (!strcmp(key, "rot_runs")) return (int64_t)p->stat_rot_rows;
     if (!strcmp(key, "rot_ckpts")) return (int64_t)p->stat_rot_ckpts;

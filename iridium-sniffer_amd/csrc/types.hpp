@@ -9,6 +9,8 @@ constexpr int kMaxActive = 1024;         // max_bursts (<= 240) + bursts one fra
 constexpr int kScanThreads = 1024;
 constexpr int kFirTaps = 801;            // lpf_taps(.., 1e7, 1e5, 5e4), burst_downmix.c:251-261
 constexpr int kRotSeg = 16;              // rotator checkpoint spacing (samples)
+constexpr int kRotRun = 2048;            // checkpoints per block of the checkpoint arena: a centre bin's row is a list of
+                                         // blocks, one per run of 2048 checkpoints (32768 samples) bursts on it have needed
 constexpr int kFirTileOut = 128;         // decimator outputs per workgroup
 constexpr int kMaxFrameSamples = 4440;   // IR_MAX_FRAME_LENGTH_SIMPLEX * 10
 constexpr int kMaxBits = 896;
@@ -102,14 +104,20 @@ struct FirGeom {
     uint64_t avail_end;
     uint64_t ring_pos;       // a_tile % ring_len
     uint64_t burst_start;
-    uint64_t ck_index;       // index of the rotator checkpoint of the tile's first segment
+    uint64_t ck_index;       // arena index of the rotator checkpoint of the tile's first segment
     float inc_re, inc_im;    // rotator increment of the burst's centre bin
     int32_t s0, span, n_seg, n_out;
     int64_t out_base;        // index of the tile's first output in dec[]
     uint64_t stale_pos;      // (a_tile - reference ring length) mod ring_len: where the tile's stale samples start
-    int32_t pad[4];
+    uint64_t ck_index2;      // arena index of the next run's first checkpoint (a tile crosses at most one run boundary)
+    int32_t ck_wrap;         // checkpoints of the tile in its first run: segment `seg` is ck_index + seg below it,
+    int32_t pad;             // ck_index2 + (seg - ck_wrap) from there on (fir_ck)
 };
 static_assert(sizeof(FirGeom) == 96, "FirGeom is read with scalar loads");
+__host__ __device__ inline uint64_t fir_ck(const FirGeom &g, int seg)
+{
+    return seg < g.ck_wrap ? g.ck_index + (uint64_t)seg : g.ck_index2 + (uint64_t)(seg - g.ck_wrap);
+}
 // device tile lists are allocated with room for the FirGeom records behind the FirTile array
 constexpr size_t kFirTileUnits = 1 + sizeof(FirGeom) / sizeof(FirTile);
 

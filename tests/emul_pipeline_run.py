@@ -63,6 +63,11 @@ def main():
         res["rotator_row_extension"] = parity.compare(got, ref2)
         assert res["rotator_row_extension"]["bursts"] == 4
         assert got["stats"]["rot_runs"] > got["stats"]["rot_rows"] >= 2 and got["stats"]["rot_ckpts"] >= 3 * 2048, got["stats"]   # (a row was extended)
+        # ... and the arena of checkpoint blocks grows when it is full (one whole row's worth of blocks to begin with), while
+        # chains launched with the old arena are in flight
+        got = parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead", options={"rot_pool_rows": 1})
+        res["rotator_arena_growth"] = parity.compare(got, ref)
+        assert got["stats"]["rot_grows"] >= 1 and got["stats"]["rot_blocks_cap"] >= got["stats"]["rot_blocks"], got["stats"]
         # the decimated / low-passed rows of a batch lie end to end by actual length: a scratch of 64 outputs to begin
         # with grows by doubling, per context, while the other contexts' chains are in flight
         got = parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead", options={"scratch_outputs": 64})

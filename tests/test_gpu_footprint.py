@@ -1,5 +1,6 @@
 """-m gpu: device memory of a context.  The rotator checkpoints (rotator.h:36-46 restated as checkpoints of the phase
-recurrence) are kept per centre bin that bursts have appeared on: a pool of rows handed out on first use.  The decimated
+recurrence) are kept per centre bin that bursts have appeared on, as far as those bursts have needed them: blocks of 2048
+checkpoints out of an arena.  The decimated
 and low-passed bursts of a batch lie end to end by their actual length in a scratch that grows on demand."""
 import numpy as np
 import pytest
@@ -20,9 +21,9 @@ def _used():
 
 
 def test_rotator_checkpoint_rows_on_demand_and_pool_growth():
-    """Rows of the rotator checkpoint pool are handed out when a burst first appears on a centre bin and built on the chain
-    that needs them; a pool that runs full doubles (here from two rows) while chains are in flight; the records are the
-    oracle's either way."""
+    """Blocks of the rotator checkpoint arena are handed out when a burst first appears on a centre bin (or needs more of
+    its row) and built on the chain that needs them; an arena that runs full doubles (here from one whole row's worth of
+    blocks) while chains are in flight; the records are the oracle's either way."""
     fs = 2_000_000
     n = int(0.9 * fs) // 32768 * 32768
     iq, _ = siggen.standard_scene(fs, n, 9, seed=5)
@@ -47,14 +48,19 @@ def test_rotator_checkpoint_rows_on_demand_and_pool_growth():
     a = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=256)
     assert a.stat("rot_rows") == 0 and a.stat("rot_rows_cap") == 1024
     parity.compare(run(a), ref)
-    assert a.stat("rot_rows") == len(bins) and a.stat("rot_builds") >= 1
+    assert a.stat("rot_rows") == len(bins) and a.stat("rot_builds") >= 1 and a.stat("rot_grows") == 0
+    blocks, cap0 = a.stat("rot_blocks"), a.stat("rot_blocks_cap")
+    assert len(bins) <= blocks < cap0 // 8           # (a few blocks per row, not whole rows)
     a.close()
-    # two rows to begin with, the stream in chunks at pipeline_depth 2: the pool doubles while earlier chains still run
+    # one whole row's worth of blocks to begin with, the stream in chunks at pipeline_depth 2: the arena doubles while
+    # earlier chains still run
     c = (n // 5) // 32768 * 32768
     b = irdm.Pipeline(fs, max_chunk_samples=n - 4 * c, max_bursts_per_chunk=256, pipeline_depth=2)
-    b.set_option("rot_pool_rows", 2)
+    b.set_option("rot_pool_rows", 1)
+    small = b.stat("rot_blocks_cap")
+    assert small < blocks
     parity.compare(run(b, chunks=[c, c, c, c, n - 4 * c]), ref)
-    assert b.stat("rot_rows") == len(bins) and b.stat("rot_rows_cap") >= len(bins)
+    assert b.stat("rot_rows") == len(bins) and b.stat("rot_grows") >= 1 and b.stat("rot_blocks_cap") >= b.stat("rot_blocks") == blocks
     b.close()
 
 
@@ -79,7 +85,7 @@ def test_rotator_rows_are_built_as_far_as_needed_and_extended():
     ref = orc.run_stream(iq, fs)
     assert len(ref.bursts) == 4 and 2 <= len({b.center_bin for b in ref.bursts}) <= 3
     n = len(iq)
-    for chunks in (None, [n // 2 // 32768 * 32768, n - n // 2 // 32768 * 32768]):
+    for chunks in ([n // 2 // 32768 * 32768, n - n // 2 // 32768 * 32768],):
         p = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=64, pipeline_depth=1 if chunks else 0)
         p.set_option("keep_frame_samples", 1)
         off = 0
@@ -92,8 +98,8 @@ def test_rotator_rows_are_built_as_far_as_needed_and_extended():
         st = {k: p.stat(k) for k in ("rot_rows", "rot_runs", "rot_ckpts", "rot_builds")}
         p.close()
         parity.compare(got, ref)
-        # a row per centre bin; the first carrier's row in two runs (2048-checkpoint runs: the short burst, then the long
-        # one's extension)
+        # a row per centre bin; the first carrier's row in two builds (runs of 2048 checkpoints: the short burst's in the
+        # first chunk, the long one's extension in the second)
         assert st["rot_runs"] > st["rot_rows"] >= 2, st
         assert st["rot_ckpts"] % 2048 == 0 and st["rot_ckpts"] >= 3 * 2048, st
 
