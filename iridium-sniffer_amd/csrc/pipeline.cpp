@@ -186,6 +186,7 @@ struct BatchCtx {
     hipStream_t stream;
     hipEvent_t ev[4];            // FIR begin / FIR end / post end / demod end
     hipEvent_t ev_cfo;           // work records are in the mapped buffer: the helper thread may do the host step
+    hipEvent_t ev_rot;           // behind this context's latest build of rotator checkpoints (rot_rows_prepare)
     BurstWork *d_work;
     FirTile *d_tiles;
     size_t tiles_cap;
@@ -335,7 +336,6 @@ struct irdm_pipeline {
     bool chain_pending;         // feed_end has enqueued this chunk's scan behind the previous one
     int chain_sel, chain_band_first;
     bool settle_clean;          // the scan settled last committed on its own (no continuation, retry or fallback)
-    hipEvent_t ev_rot;          // the rotator checkpoint table is complete
     hipEvent_t ev_ring;         // pipeline_depth >= 1: the history-ring copy of the last fed chunk
     uint64_t chunk_no;          // chunks fed so far
     // chunks between irdm_feed_begin and irdm_feed_end: at most one at pipeline_depth 0, two (one chunk of look-ahead:
@@ -391,6 +391,9 @@ struct irdm_pipeline {
     int rot_rows_used = 0;                  // bins that have a row
     int rot_blocks_used = 0, rot_blocks_cap = 0;
     std::vector<int> rot_len_h, rot_want, rot_touched;   // per bin: checkpoints built (or being built) / wanted by the batch at hand
+    std::vector<int> rot_build_ctx;         // per bin: the batch context whose chain built (or is building) its latest run, -1: none
+    std::vector<uint32_t> rot_build_gen;    // ... and which of that context's builds it was
+    uint32_t rot_gen[3] = { 0, 0, 0 }, rot_done_gen[3] = { 0, 0, 0 };   // per context: builds enqueued / known to be complete (its stream was waited for)
     std::vector<float2 *> rot_retired;      // outgrown pools
     uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_rot_grows = 0, stat_band_steps = 0;
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
@@ -452,6 +455,7 @@ static void pipeline_free(irdm_pipeline *p)
     for (int i = 0; i < 3; i++) {
         BatchCtx &b = p->bc[i];
         if (b.ev_cfo) (void)hipEventDestroy(b.ev_cfo);
+        if (b.ev_rot) (void)hipEventDestroy(b.ev_rot);
         for (auto &e : b.ev)
             if (e) (void)hipEventDestroy(e);
         if (b.hp_flag) (void)hipHostFree(b.hp_flag);
@@ -481,7 +485,6 @@ static void pipeline_free(irdm_pipeline *p)
     for (float2 *q : p->rot_retired) (void)hipFree(q);
     for (float2 *q : p->scratch_retired) (void)hipFree(q);
     if (p->d_rot_slot) (void)hipFree(p->d_rot_slot);
-    if (p->ev_rot) (void)hipEventDestroy(p->ev_rot);
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
     for (auto &set : p->ev_plan_set)
         for (auto &e : set)
@@ -704,7 +707,6 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_cand_b, PeakCand, (size_t)P.n);
     mark("detector buffers");
     p->d_rot_table = nullptr;
-    p->ev_rot = nullptr;
     AL(p->d_work, BurstWork, (size_t)p->burst_cap);
     p->tiles_cap = (size_t)p->burst_cap * 64;
     AL(p->d_tiles, FirTile, (p->tiles_cap + 1) * kFirTileUnits);
@@ -853,6 +855,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_rot_new_dev), b.hp_rot_new, 0) == hipSuccess;
         AL(b.d_rot_new, int4, (size_t)p->burst_cap);
         ok = ok && hipEventCreateWithFlags(&b.ev_cfo, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&b.ev_rot, hipEventDisableTiming) == hipSuccess;
         for (auto &e : b.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
         b.h_cfreq.assign((size_t)p->burst_cap, 0.0);
     }
@@ -879,10 +882,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
          hipMemset(p->d_ring, 0, p->ring_len * p->bps) == hipSuccess;
     ok = ok && hipDeviceSynchronize() == hipSuccess;
     mark("memsets, sync");
-    // The rotator checkpoint table (one sequential float recurrence per FFT bin, 12.5 ms of one-lane-per-bin work at
-    // 10 MHz) is not needed before the first burst reaches the decimator -- at the earliest 512 priming frames into
-    // the stream -- so irdm_create does not wait for it: it runs on a per-burst stream, the chains wait for ev_rot.
-    // rotator checkpoint rows: a pool, rows on first use of a centre bin (rot_rows_prepare); nothing is built here
+    // rotator checkpoints: an arena of blocks, handed out as bursts need their centre bin's row (rot_rows_prepare); nothing
+    // is built here
     p->rot_runs = (p->n_ckpt + kRotRun - 1) / kRotRun;
     p->rot_blocks_cap = std::min(P.n, 1024) * p->rot_runs;        // (what 1024 whole rows would take: 0.57 GB at 10 MHz)
     p->rot_blocks_used = 0;
@@ -892,8 +893,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     ok = ok && (p->d_rot_table = dev_alloc<float2>((size_t)p->rot_blocks_cap * kRotRun)) != nullptr;
     ok = ok && (p->d_rot_slot = dev_alloc<int>((size_t)P.n * p->rot_runs)) != nullptr;
     ok = ok && hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)P.n * p->rot_runs) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&p->ev_rot, hipEventDisableTiming) == hipSuccess &&
-         hipEventRecord(p->ev_rot, p->bc[0].stream) == hipSuccess;
+    p->rot_build_ctx.assign((size_t)P.n, -1);
+    p->rot_build_gen.assign((size_t)P.n, 0);
     mark("rotator row pool");
     if (!ok) {
         fprintf(stderr, "irdm_hip: device initialisation failed\n");
@@ -1201,13 +1202,22 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
     // 0 .. n / 16), in runs of kRotRun checkpoints -- a block of the arena each --, and continued from its last
     // checkpoint when a longer burst comes: the recurrence is sequential, 9 ns a sample -- 12 ms for a whole row at
     // 12 MHz, 1-2 ms for a typical burst's share.
+    // What this chain has to wait for: the builds, on other chains' streams, of the runs its bursts' bins already have
+    // (its decimator reads them, its own build continues them), unless the build is known to be complete (bursts_finish
+    // waited for that context's stream since).  A context's builds are ordered on its stream, so its latest event covers
+    // them all.  Chains whose bursts share no bin with a build in flight do not wait for it: the builds of consecutive
+    // chunks run side by side.
     p->rot_touched.clear();
+    const int me = (int)(&b - p->bc);
+    unsigned wait_mask = 0;
     int blocks_wanted = 0;
     for (int i = 0; i < nb; i++) {
         const BurstWork &w = b.hp_work[i];
         if (w.drop_reason) continue;
         const int bin = w.center_bin;
         if (bin < 0 || bin >= p->P.n) continue;
+        const int owner = p->rot_build_ctx[(size_t)bin];
+        if (owner >= 0 && owner != me && p->rot_build_gen[(size_t)bin] > p->rot_done_gen[owner]) wait_mask |= 1u << owner;
         int need = (w.n + kRotSeg - 1) / kRotSeg + 8;
         need = (need + kRotRun - 1) / kRotRun * kRotRun;
         if (need > p->rot_runs * kRotRun) need = p->rot_runs * kRotRun;
@@ -1218,11 +1228,17 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
             blocks_wanted += (need - have) / kRotRun;
         }
     }
+    const bool grow = !p->rot_touched.empty() && p->rot_blocks_used + blocks_wanted > p->rot_blocks_cap;
+    if (grow)                                    // (the copy below reads every block built so far)
+        for (int c = 0; c < p->n_bc; c++)
+            if (p->rot_gen[c] > p->rot_done_gen[c]) wait_mask |= 1u << c;
+    for (int c = 0; c < p->n_bc; c++)
+        if (c != me && ((wait_mask >> c) & 1)) IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->bc[c].ev_rot, 0));
     if (p->rot_touched.empty()) return 0;
-    if (p->rot_blocks_used + blocks_wanted > p->rot_blocks_cap) {
+    if (grow) {
         // the arena is full: twice the blocks (at most a whole row per FFT bin), the blocks built so far copied over on this
-        // chain's stream -- every build so far is complete there (ev_rot) -- and the old arena kept for the chains in
-        // flight that were launched with its address (block numbers stay what they are)
+        // chain's stream -- behind every build so far (the waits above) -- and the old arena kept for the chains in flight
+        // that were launched with its address (block numbers stay what they are)
         const long long max_blocks = (long long)p->P.n * p->rot_runs;
         long long cap2 = p->rot_blocks_cap;
         while (cap2 < (long long)p->rot_blocks_used + blocks_wanted && cap2 < max_blocks) cap2 = std::min(2 * cap2, max_blocks);
@@ -1249,13 +1265,16 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
         p->stat_rot_ckpts += (uint64_t)(to - from);
         p->rot_len_h[(size_t)bin] = to;
         p->rot_want[(size_t)bin] = 0;
+        p->rot_build_ctx[(size_t)bin] = me;
+        p->rot_build_gen[(size_t)bin] = p->rot_gen[me] + 1;
     }
+    p->rot_gen[me]++;
     p->stat_rot_builds++;
     p->stat_rot_rows += (uint64_t)n_new;
     // (the list by copy kernel: a kernel's plain loads of mapped host memory may be served from stale L2 lines)
     if (launch_copy_words(b.d_rot_new, b.hp_rot_new_dev, sizeof(int4) * (size_t)n_new, st) != 0) return -1;
     if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->rot_runs, b.d_rot_new, n_new, p->d_rot_slot, st) != 0) return -1;
-    IRDM_HIP_CHECK(hipEventRecord(p->ev_rot, st));                  // later chains wait for these runs
+    IRDM_HIP_CHECK(hipEventRecord(b.ev_rot, st));                   // chains with bursts on these bins wait for it
     return 0;
 }
 
@@ -1361,7 +1380,6 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         }
     }
     hipStream_t st = b.stream;
-    IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot, 0));           // rows an earlier chain is still building
     if (rot_rows_prepare(p, b, nb, st) != 0) return -1;
     // (copies by kernel, here and at the end of the chain: the runtime's copy path answers late next to the chains'
     // kernels, and an H2D from pinned memory may block the enqueueing thread)
@@ -1449,6 +1467,7 @@ static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
         return nb;
     }
     IRDM_HIP_CHECK(hipStreamSynchronize(b.stream));
+    p->rot_done_gen[(int)(&b - p->bc)] = p->rot_gen[(int)(&b - p->bc)];      // (its rotator checkpoint builds are complete)
     struct timespec ts_;
     clock_gettime(CLOCK_MONOTONIC, &ts_);
     const double t_rec0 = ts_.tv_sec * 1e6 + ts_.tv_nsec * 1e-3;

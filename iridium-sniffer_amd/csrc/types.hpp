@@ -114,7 +114,10 @@ struct FirGeom {
     int32_t pad;             // ck_index2 + (seg - ck_wrap) from there on (fir_ck)
 };
 static_assert(sizeof(FirGeom) == 96, "FirGeom is read with scalar loads");
-__host__ __device__ inline uint64_t fir_ck(const FirGeom &g, int seg)
+#if defined(__HIPCC__) || defined(__host__)
+__host__ __device__
+#endif
+inline uint64_t fir_ck(const FirGeom &g, int seg)
 {
     return seg < g.ck_wrap ? g.ck_index + (uint64_t)seg : g.ck_index2 + (uint64_t)(seg - g.ck_wrap);
 }
