@@ -1206,10 +1206,11 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
     // (its decimator reads them, its own build continues them), unless the build is known to be complete (bursts_finish
     // waited for that context's stream since).  A context's builds are ordered on its stream, so its latest event covers
     // them all.  Chains whose bursts share no bin with a build in flight do not wait for it: the builds of consecutive
-    // chunks run side by side.
+    // chunks run side by side.  And this chain's own build waits only for what it continues (a row whose last run is being
+    // built elsewhere) or copies (a growing arena); the builds its DECIMATOR needs are waited for behind its own build.
     p->rot_touched.clear();
     const int me = (int)(&b - p->bc);
-    unsigned wait_mask = 0;
+    unsigned wait_mask = 0, wait_first = 0;
     int blocks_wanted = 0;
     for (int i = 0; i < nb; i++) {
         const BurstWork &w = b.hp_work[i];
@@ -1223,6 +1224,7 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
         if (need > p->rot_runs * kRotRun) need = p->rot_runs * kRotRun;
         const int have = std::max(p->rot_len_h[(size_t)bin], p->rot_want[(size_t)bin]);
         if (need > have) {
+            if (have > 0 && owner >= 0 && owner != me && p->rot_build_gen[(size_t)bin] > p->rot_done_gen[owner]) wait_first |= 1u << owner;
             if (p->rot_want[(size_t)bin] == 0) p->rot_touched.push_back(bin);
             p->rot_want[(size_t)bin] = need;
             blocks_wanted += (need - have) / kRotRun;
@@ -1231,10 +1233,15 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
     const bool grow = !p->rot_touched.empty() && p->rot_blocks_used + blocks_wanted > p->rot_blocks_cap;
     if (grow)                                    // (the copy below reads every block built so far)
         for (int c = 0; c < p->n_bc; c++)
-            if (p->rot_gen[c] > p->rot_done_gen[c]) wait_mask |= 1u << c;
-    for (int c = 0; c < p->n_bc; c++)
-        if (c != me && ((wait_mask >> c) & 1)) IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->bc[c].ev_rot, 0));
-    if (p->rot_touched.empty()) return 0;
+            if (p->rot_gen[c] > p->rot_done_gen[c]) wait_first |= 1u << c;
+    // (the events as they are NOW: this chain's own build below does not touch them)
+    auto wait_for = [&](unsigned mask) -> int {
+        for (int c = 0; c < p->n_bc; c++)
+            if (c != me && ((mask >> c) & 1)) IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->bc[c].ev_rot, 0));
+        return 0;
+    };
+    if (p->rot_touched.empty()) return wait_for(wait_mask);
+    if (wait_for(wait_first) != 0) return -1;
     if (grow) {
         // the arena is full: twice the blocks (at most a whole row per FFT bin), the blocks built so far copied over on this
         // chain's stream -- behind every build so far (the waits above) -- and the old arena kept for the chains in flight
@@ -1275,7 +1282,7 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
     if (launch_copy_words(b.d_rot_new, b.hp_rot_new_dev, sizeof(int4) * (size_t)n_new, st) != 0) return -1;
     if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->rot_runs, b.d_rot_new, n_new, p->d_rot_slot, st) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev_rot, st));                   // chains with bursts on these bins wait for it
-    return 0;
+    return wait_for(wait_mask & ~wait_first);                        // what the decimator behind this build reads
 }
 
 static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src, const GoneBurst *gone_list, int nb)
