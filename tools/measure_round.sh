@@ -14,7 +14,9 @@ timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 2 2>/dev/null | ta
 timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 40 2>/dev/null | tail -1 > "$OUT/d40.json"
 timeout 120 python bench.py --steps 10 --warmup 3 $Q --alone-steps 3 $D12 2>/dev/null | tail -1 > "$OUT/cfg5_12mhz_d40.json"
 timeout 90 python bench.py --steps 20 --warmup 5 $Q --alone-steps 3 --opt fir_order=0 2>/dev/null | tail -1 > "$OUT/scalar_fir.json"
-timeout 120 python bench.py --shard time --steps 6 --warmup 2 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
+timeout 120 python bench.py --shard time --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
+# (the first eight chunks of that stream: every chunk brings centre bins never seen before -- rotator checkpoint builds)
+timeout 120 python bench.py --shard time --steps 6 --warmup 2 2>/dev/null | tail -1 > "$OUT/cfg4_n1_first8chunks.json"
 # the detector scan's own device timeline (option band_timeline: first workgroup's start / last one's end per pass), in
 # run and alone, both scenes
 timeout 90 python bench.py $Q --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/tl.json"
