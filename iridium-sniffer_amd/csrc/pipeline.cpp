@@ -413,13 +413,13 @@ struct irdm_pipeline {
     unsigned long long *kclk_rec(int i) const { return kernel_clock && d_kclk ? d_kclk + (size_t)i * kKClkWords : nullptr; }
 };
 
-// The rotator checkpoints (rotator.h:36-46 restated: the phase of the float recurrence every 16 samples, a row of
-// l_cap / 16 of them per centre bin -- 0.55 MB at 10 MHz) are kept for the centre bins bursts have actually appeared on: a
-// pool of rows handed out on first use, rows built by one lane each (the recurrence is sequential: 12 ms for any number of
-// new bins, on the chain that needs them; the bins of a band repeat, so this happens in a stream's first chunks).  The
-// whole table -- a row for every FFT bin, 4.5 GB at 10 MHz and 10.9 GB at 12 MHz, built at create in rounds 1-3 -- is the
-// pool's upper bound: it grows by doubling; a pool that has been outgrown stays allocated until the context is closed
-// (chains in flight still read it).
+// The rotator checkpoints (rotator.h:36-46 restated: the phase of the float recurrence every 16 samples -- a whole row for
+// a centre bin would be l_cap / 16 of them, 0.55 MB at 10 MHz) are kept for the centre bins bursts have actually appeared
+// on and as far as those bursts have needed them: an arena of blocks of kRotRun checkpoints, a bin's row = its list of
+// blocks (d_rot_slot[bin][run]), built by one lane per bin on the chain that needs them (the recurrence is sequential:
+// 9 ns a sample) and continued when a longer burst comes.  The whole table -- a row for every FFT bin, 4.5 GB at 10 MHz
+// and 10.9 GB at 12 MHz, built at create in rounds 1-3 -- is the arena's upper bound: it grows by doubling; an arena that
+// has been outgrown stays allocated until the context is closed (chains in flight still read it).
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st);
 
 static void pipeline_free(irdm_pipeline *p)

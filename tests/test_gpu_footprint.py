@@ -122,8 +122,8 @@ def test_burst_scratch_rows_by_length_and_growth():
 
 
 def test_context_footprint_10mhz():
-    """a 10 MHz context for 16 Mi-sample chunks: no table of a row per FFT bin (4.5 GB in rounds 1-3), a pool of 1024
-    rows (0.57 GB) instead; no decimated / low-passed scratch for 4096 bursts of the longest length per chain (3 x 1.8 GB
+    """a 10 MHz context for 16 Mi-sample chunks: no table of a row per FFT bin (4.5 GB in rounds 1-3), an arena of
+    checkpoint blocks (0.57 GB to begin with) instead; no decimated / low-passed scratch for 4096 bursts of the longest length per chain (3 x 1.8 GB
     up to round 4), 1/16 of that to begin with"""
     u0 = _used()
     p = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=2)
