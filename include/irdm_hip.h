@@ -383,7 +383,9 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof".
  * Stats (irdm_get_stat): "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks", "band_rounds",
  * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "host_us_0".."host_us_9", "rot_rows",
- * "rot_rows_cap", "rot_builds" (rotator checkpoint rows in use / allocated / build launches), "scratch_outputs",
+ * "rot_rows_cap", "rot_blocks", "rot_blocks_cap", "rot_builds", "rot_runs", "rot_ckpts", "rot_grows" (rotator checkpoints:
+ * centre bins with a row / the arena in whole rows / blocks of 2048 checkpoints in use / allocated / build launches / runs
+ * built / checkpoints built / times the arena doubled), "band_steps" (update steps the scans' last rounds walked), "scratch_outputs",
  * "scratch_grows", "scratch_peak" (decimated samples a batch context holds / times it doubled / most a batch needed). */
 int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);
 int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);
