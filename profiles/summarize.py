@@ -90,7 +90,7 @@ if sq:
     json.dump(sq, open(f"profiles/{tag}_fir_pmc.json", "w"), indent=1, sort_keys=True)
     print(json.dumps(sq, indent=1))
 
-for name in ("b", "b0", "d2", "d40", "cfg5_12mhz_d40", "lds_fir", "scalar_fir", "cfg4_n1"):
+for name in ("b", "b0", "d2", "d40", "cfg5_12mhz_d40", "lds_fir", "scalar_fir", "cfg4_n1", "cfg4_n1_first8chunks"):
     if os.path.exists(f"{src}/{name}.json") and os.path.getsize(f"{src}/{name}.json") > 10:
         shutil.copy(f"{src}/{name}.json", f"profiles/{tag}_bench_{name}.json")
 for name in ("k1_bench.txt", "hop_timing.txt"):
