@@ -7,6 +7,8 @@
 //      vector load), two batches of 32 steps in flight -- the product's loop without snapshots
 //   2  variant 1 + a snapshot store behind every step (offset by v_readlane, five wait states, store)
 //   3  variant 1 with rows 32 KB apart replaced by ONE row read again and again (L2 hits): memory latency taken out
+//   4  variant 2 with the store in two of the 64 lanes only (a snapshot for the bins a frame's list names)
+//   5  variant 2 with a store every eighth step
 // Prints ns per step and the implied cycles at the clock the device reports.
 // Build:  hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/ubench/sum_bench.hip -o tools/ubench/sum_bench
 // Usage:  sum_bench [steps=5000] [n_bins=8192] [reps=10]
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(64) void sum_kernel(const float *__restrict__ mag, 
         const float dd = s - OLv[j];                                                                                 \
         s = dd + NWv[j];                                                                                             \
         smin = __builtin_fminf(smin, s);                                                                             \
-        if (VARIANT == 2)                                                                                            \
+        if (VARIANT == 2 || (VARIANT == 5 && j % 8 == 0) || (VARIANT == 4 && ((lane + j) & 63) < 2))                 \
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, s), r_snap, boff,                          \
                                                   __builtin_amdgcn_readlane((int)D.z, (half) * kDepth + j), 0);      \
     }
@@ -119,7 +121,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     printf("# %d steps, %d bins (%d wavefronts), %d reps; device clock %.0f MHz\n", n, n_bins, n_bins / 64, reps, mhz);
-    for (int variant = 0; variant < 4; variant++) {
+    for (int variant = 0; variant < 6; variant++) {
         std::vector<Step> h(n + 512);
         for (int k = 0; k < n + 512; k++) {
             const bool one_row = variant == 3;
@@ -135,6 +137,8 @@ int main(int argc, char **argv)
             case 0: hipLaunchKernelGGL(sum_kernel<0>, grid, block, 0, st, mag, (size_t)rows * row, d_steps, n, snap, (size_t)n * row, out); break;
             case 1: hipLaunchKernelGGL(sum_kernel<1>, grid, block, 0, st, mag, (size_t)rows * row, d_steps, n, snap, (size_t)n * row, out); break;
             case 2: hipLaunchKernelGGL(sum_kernel<2>, grid, block, 0, st, mag, (size_t)rows * row, d_steps, n, snap, (size_t)n * row, out); break;
+            case 4: hipLaunchKernelGGL(sum_kernel<4>, grid, block, 0, st, mag, (size_t)rows * row, d_steps, n, snap, (size_t)n * row, out); break;
+            case 5: hipLaunchKernelGGL(sum_kernel<5>, grid, block, 0, st, mag, (size_t)rows * row, d_steps, n, snap, (size_t)n * row, out); break;
             default: hipLaunchKernelGGL(sum_kernel<1>, grid, block, 0, st, mag, (size_t)rows * row, d_steps, n, snap, (size_t)n * row, out); break;
             }
         };
@@ -152,7 +156,8 @@ int main(int argc, char **argv)
             total += ms;
         }
         static const char *names[] = { "chain alone (registers)", "rows from memory, readlane offsets", "... + a snapshot store per step",
-                                       "rows from one cached row (no HBM latency)" };
+                                       "rows from one cached row (no HBM latency)", "... + a store in 2 of 64 lanes per step",
+                                       "... + a snapshot store every 8th step" };
         const double ns = best * 1e6 / n;
         printf("variant %d  %-44s best %.1f us  mean %.1f us  %.1f ns/step = %.0f cycles\n", variant, names[variant], best * 1e3,
                total / reps * 1e3, ns, ns * mhz / 1e3);
