@@ -536,7 +536,7 @@ def main():
         tb = time.perf_counter()
         bursts = pipe.poll_bursts_raw()          # [n, 72] bytes
         pipe.drop_frames()
-        demods = poll_demods()          # [n, 4544] bytes: everything frame_output_print needs
+        demods = poll_demods()          # [n, 176] bytes (packed records; 4544 with the full ones): everything frame_output_print needs
         tc = time.perf_counter()
         if first_chunk["bursts"] is None and len(bursts):
             first_chunk["bursts"], first_chunk["demods"] = bursts.copy(), demods.copy()
@@ -845,8 +845,10 @@ def main():
         cdt = time.perf_counter() - t1
         cpu1 = {"value": round(max(args.cpu_passes, 1) * m / cdt / 1e6, 3), "unit": "Msamples/s", "cores": 1,
                 "kind": "port",
-                "sample": "%d passes over the first %d samples of the rank-0 stream (%.1f s of CPU), scalar C oracle "
-                          "(reference --no-simd --no-gpu algorithm, pinned FFT), %d bursts -> %d RAW frames per pass"
+                "sample": "%d passes over the first %d samples of the rank-0 stream (%.1f s of CPU), the C oracle in one thread "
+                          "(reference --no-gpu algorithm, pinned FFT; the dispatched kernels in simd_avx2.c's operation ORDER but "
+                          "written as scalar fmaf loops, not intrinsics -- a port's artefact: slower than the oracle's "
+                          "--no-simd forms, 16 vs 23 Msamples/s), %d bursts -> %d RAW frames per pass"
                           % (max(args.cpu_passes, 1), m, cdt, ref.n_tagged, len(ref.demods))}
         # (b) the reference's thread layout: 1 detector thread -> 4 downmix workers -> 1 demod / output thread
         #     (main.c:175, :667-694); the oracle's stage functions release the GIL while they run

@@ -527,7 +527,7 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
     kclk_leave(kclk);
 }
 
-int g_fir_order = 1;          // the form of the reference's dispatched kernels the product follows: 1 simd_avx2.c, 0 simd_generic.c (downmix.hip)
+thread_local int g_fir_order = 1;          // the form of the reference's dispatched kernels the product follows: 1 simd_avx2.c, 0 simd_generic.c (downmix.hip)
 int g_fft_kernel = 1;         // 1 (default): the 32-points-per-lane streaming kernel where it applies (N = 8192, 16384); 0: radix-16 kernel
 int g_fft_force_radix2 = 0;   // test hook: 1 = always use the radix-2 LDS kernel
 

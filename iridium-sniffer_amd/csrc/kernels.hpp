@@ -123,7 +123,7 @@ extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the ot
 extern int g_fir_strip;           // double blocks of 128 columns per strip
 extern int g_fir_grid;            // workgroups of the register-resident decimator (0: one per strip)
 extern int g_fir_slice;           // strips per launch of the register-resident decimator (0: all in one launch)
-extern int g_fir_order;           // 1 (default): the decimating FIR in the order of the reference's AVX2 kernel (simd_avx2.c:62-108),
+extern thread_local int g_fir_order;           // 1 (default): the decimating FIR in the order of the reference's AVX2 kernel (simd_avx2.c:62-108),
                                   // 0: of its scalar kernel (simd_generic.c:86-96, --no-simd)
 int fir_fma_tile_out(int decim);
 int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,

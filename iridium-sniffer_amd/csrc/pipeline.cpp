@@ -241,6 +241,7 @@ struct irdm_pipeline {
     hipEvent_t ev_plan_set[2][kBandRounds + 2] = {};
     unsigned walk_launched = 0;             // BandWork::walk_host
     int scan_events = 1;     // 0: no timing events around the band scan (stage time of the scan reads -1)
+    int fir_order = 1;       // option fir_order / simd_order: 1 simd_avx2.c's operation order, 0 simd_generic.c's (--no-simd); per pipeline
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
     hipEvent_t ev[10];   // 0 start,1 fft,2 scan,3 pre-fir,4 fir,5 post,6 demod,7 end,8 caller sync
 
@@ -398,7 +399,8 @@ struct irdm_pipeline {
     uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_rot_grows = 0, stat_band_steps = 0;
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
     std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
-    uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0;
+    std::vector<void *> tiles_retired, tiles_host_retired;   // outgrown strip lists (device / pinned host): likewise
+    uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0, stat_tiles_grows = 0;
     // time-chunk sharding: the previous chunk's 512-frame history may arrive AFTER this chunk's scan has been enqueued
     // (irdm_expect_history / irdm_import_state_history_device): [0] sequence number the import publishes, [1] time-out
     // flag of the waiting kernel, in mapped pinned memory; the import's copies run on gstream
@@ -421,6 +423,17 @@ struct irdm_pipeline {
 // and 10.9 GB at 12 MHz, built at create in rounds 1-3 -- is the arena's upper bound: it grows by doubling; an arena that
 // has been outgrown stays allocated until the context is closed (chains in flight still read it).
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st);
+
+// Every C-ABI entry that enqueues work for a pipeline: the calling thread is put on the pipeline's device and the
+// arithmetic-order switch the launch helpers read (irdm::g_fir_order, thread-local) is set to THIS pipeline's -- two
+// contexts of one process may follow different orders (option fir_order; --no-simd of the host binary).
+static inline void pipeline_enter(const irdm_pipeline *p);
+
+static inline void pipeline_enter(const irdm_pipeline *p)
+{
+    (void)hipSetDevice(p->cfg.device);
+    irdm::g_fir_order = p->fir_order;
+}
 
 static void pipeline_free(irdm_pipeline *p)
 {
@@ -484,6 +497,8 @@ static void pipeline_free(irdm_pipeline *p)
     if (p->d_rot_table) (void)hipFree(p->d_rot_table);
     for (float2 *q : p->rot_retired) (void)hipFree(q);
     for (float2 *q : p->scratch_retired) (void)hipFree(q);
+    for (void *q : p->tiles_retired) (void)hipFree(q);
+    for (void *q : p->tiles_host_retired) (void)hipHostFree(q);
     if (p->d_rot_slot) (void)hipFree(p->d_rot_slot);
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
     for (auto &set : p->ev_plan_set)
@@ -1180,7 +1195,7 @@ static void fine_cfo_host(BatchCtx &b)
 
 static void cfo_helper_main(irdm_pipeline *p)
 {
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     for (;;) {
         BatchCtx *b;
         {
@@ -1262,6 +1277,16 @@ static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t s
         p->d_rot_table = pool2;
         p->rot_blocks_cap = (int)cap2;
         p->stat_rot_grows++;
+        // The copy is ordered on THIS chain's stream only, but the host switches to pool2 at once: a chain enqueued on
+        // another context a moment later (0.3 ms at bench rates: inside the copy's window) whose bins all have a finished
+        // owner would read -- or continue a row from -- blocks of pool2 the copy has not written yet.  So this build
+        // becomes the owner of every row built so far: whoever touches one of them waits for ev_rot below (recorded behind
+        // the copy) until bursts_finish has synchronised this context.
+        for (int bin = 0; bin < p->P.n; bin++)
+            if (p->rot_len_h[(size_t)bin] > 0) {
+                p->rot_build_ctx[(size_t)bin] = me;
+                p->rot_build_gen[(size_t)bin] = p->rot_gen[me] + 1;
+            }
     }
     int n_new = 0;
     for (int bin : p->rot_touched) {
@@ -1368,8 +1393,12 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     }
     const bool tile_list = fir_needs_tile_list(p->decim, fir_aligned) != 0;
     if (n_tiles > b.tiles_cap) {
-        (void)hipFree(b.d_tiles);
-        if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
+        // (like the scratch above: no hipFree / hipHostFree here -- either waits for the whole device, and in the time-shard
+        // flow a gated scan spins on the device until THIS thread has returned from irdm_feed_end and published the history:
+        // the free would sit out the gate's two-second time limit and the scan would fail.  The outgrown lists stay until
+        // the context is closed.)
+        if (b.d_tiles) p->tiles_retired.push_back(b.d_tiles);
+        if (b.hp_tiles) p->tiles_host_retired.push_back(b.hp_tiles);
         b.hp_tiles = nullptr;
         b.tiles_cap = n_tiles * 2;
         b.d_tiles = dev_alloc<FirTile>((b.tiles_cap + 1) * kFirTileUnits);
@@ -1377,6 +1406,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         if (!b.d_tiles ||
             hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) != hipSuccess)
             return -1;
+        p->stat_tiles_grows++;
     }
     if (tile_list) {
         n_tiles = 0;
@@ -2079,7 +2109,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
 static int settle(irdm_pipeline *p)
 {
     if (!p->fl_active) return 0;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     const uint64_t c1 = p->fl_c1;
     int n_gone = 0;
     if (scan_finish(p, &n_gone) != 0) return -1;
@@ -2094,7 +2124,7 @@ static int settle(irdm_pipeline *p)
 // idle -- the pipeline's streams are non-blocking, a null-stream copy orders against none of them
 static int quiesce(irdm_pipeline *p)
 {
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (settle(p) != 0) return -1;
     IRDM_HIP_CHECK(hipDeviceSynchronize());
     return 0;
@@ -2141,7 +2171,7 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
     if (!p) return -1;
     if (!p->depth) return 0;
     if (p->begin_no != p->end_no) return -1;        // a chunk handed over with irdm_feed_begin is still pending
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (settle(p) != 0) return -1;
     int emitted = 0;
     // records leave in chunk order: the batches in flight, oldest first, then the pending bursts of the last scan
@@ -2181,7 +2211,7 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
         return -1;
     }
     if (n_samples % p->feed_block != 0) p->stream_closed = true;     // last, ragged chunk of the stream
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     // order after the caller's stream (the producer of d_iq)
     hipStream_t caller = static_cast<hipStream_t>(stream_v);
     // stream == NULL: the chunk is already complete in memory, nothing to order against.  (Not the legacy null stream,
@@ -2244,7 +2274,7 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
 extern "C" int irdm_feed_end(irdm_pipeline_t *p)
 {
     if (!p || p->begin_no == p->end_no) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     irdm_pipeline::FeedSlot &f = p->fs[p->end_no % 3];
     const void *d_iq = f.iq;
     const uint64_t c0 = f.c0, c1 = f.c1;
@@ -2402,7 +2432,7 @@ extern "C" int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_sam
 {
     if (!p || (!h_iq && n_samples)) return -1;
     if (n_samples > p->max_chunk) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     // throughput mode: the H2D copy lands in the chunk's slot of the history ring and the chunk is fed in place (no staging
     // buffer, no device-to-device copy behind K1)
     if (void *slot = irdm_ingest_ptr(p, n_samples)) {
@@ -2547,7 +2577,7 @@ extern "C" size_t irdm_state_bytes(const irdm_pipeline_t *p)
 extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap)
 {
     if (!p || !buf || cap < irdm_state_bytes(p) || quiesce(p) != 0) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     char *o = static_cast<char *>(buf);
     StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
                       p->start_time_ns, p->host_primed, p->host_hist_idx };
@@ -2564,7 +2594,7 @@ extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap
 extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
 {
     if (!p || !buf || n < irdm_state_bytes(p) || quiesce(p) != 0) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     const char *i = static_cast<const char *>(buf);
     StateHeader h;
     memcpy(&h, i, sizeof(h));
@@ -2589,7 +2619,7 @@ extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
 extern "C" long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, size_t cap)
 {
     if (!p || !d_buf || cap < irdm_state_bytes(p)) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (settle(p) != 0) return -1;
     char *o = static_cast<char *>(d_buf);
     const StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
@@ -2608,7 +2638,7 @@ extern "C" long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, s
 extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, size_t n)
 {
     if (!p || !d_buf || n < irdm_state_bytes(p)) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (settle(p) != 0) return -1;
     const char *i = static_cast<const char *>(d_buf);
     StateHeader h;
@@ -2643,7 +2673,7 @@ extern "C" size_t irdm_state_head_bytes(const irdm_pipeline_t *p)
 extern "C" int irdm_import_state_head_device(irdm_pipeline_t *p, const void *d_buf, size_t n)
 {
     if (!p || !d_buf || n < irdm_state_head_bytes(p)) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (settle(p) != 0) return -1;
     const char *i = static_cast<const char *>(d_buf);
     StateHeader h;
@@ -2673,6 +2703,9 @@ extern "C" int irdm_expect_history(irdm_pipeline_t *p, const void *d_hist_buf)
 {
     if (!p || !d_hist_buf || !p->hp_gate_dev || !p->depth || !p->host_primed || scan_pick(p) != 2 || p->begin_no == p->end_no)
         return 0;
+    // (test hook band_first 1: the launch ends with round 0's verdict, before the pass the gate sits in front of -- the
+    // continuation would run on a history that was never copied in)
+    if (p->band_first == 1) return 0;
     p->gate_seq++;
     p->gate_src = d_hist_buf;
     p->gate_armed = true;
@@ -2685,7 +2718,7 @@ extern "C" int irdm_import_state_history_device(irdm_pipeline_t *p, const void *
 {
     const size_t bytes = p ? sizeof(float) * (size_t)kHistory * p->P.n : 0;
     if (!p || !d_hist_buf || n < bytes) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (p->gate_open_pending) {
         // a scan is waiting for it: the word it polls is written by the HOST (no GPU work of ours that could queue up
         // behind the waiting kernel); the scan's stream copies the history in and goes on
@@ -2704,7 +2737,7 @@ extern "C" int irdm_import_state_history_device(irdm_pipeline_t *p, const void *
 extern "C" int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, uint64_t abs_start)
 {
     if (!p || (!d_iq && n_samples) || n_samples > abs_start || p->begin_no != p->end_no) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (n_samples > p->ring_len) {
         d_iq = static_cast<const char *>(d_iq) + (n_samples - p->ring_len) * p->bps;
         n_samples = p->ring_len;
@@ -2792,7 +2825,7 @@ extern "C" int irdm_qpsk_demod_batch(irdm_pipeline_t *p, const float *samples, c
                                      const int *direction, int n, irdm_demod_t *out)
 {
     if (!p || !samples || !num_samples || !direction || !out || n < 0) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     for (int base = 0; base < n; base += p->burst_cap) {
         const int nb = std::min(p->burst_cap, n - base);
         p->h_work.assign(nb, BurstWork());
@@ -2840,7 +2873,7 @@ extern "C" int irdm_poll_decoded(irdm_pipeline_t *p, irdm_decoded_t *out, int ma
 extern "C" int irdm_frame_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_decoded_t *out)
 {
     if (!p || !in || !out || n < 0) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     std::vector<int> nbits;
     for (int base = 0; base < n; base += p->burst_cap) {
         const int nb = std::min(p->burst_cap, n - base);
@@ -2880,7 +2913,7 @@ extern "C" int irdm_poll_ida(irdm_pipeline_t *p, irdm_ida_t *out, int max)
 extern "C" int irdm_ida_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in, int n, int use_llr, irdm_ida_t *out)
 {
     if (!p || !in || !out || n < 0) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     std::vector<int> nbits, dirs;
     for (int base = 0; base < n; base += p->burst_cap) {
         const int nb = std::min(p->burst_cap, n - base);
@@ -2934,7 +2967,12 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
-    if (!strcmp(key, "fir_order") || !strcmp(key, "simd_order")) { irdm::g_fir_order = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "fir_order") || !strcmp(key, "simd_order")) {
+        // (per pipeline; the calling thread's switch follows at once for the stage-level calls that take no pipeline)
+        p->fir_order = value ? 1 : 0;
+        irdm::g_fir_order = p->fir_order;
+        return 0;
+    }
     if (!strcmp(key, "rot_pool_rows")) {
         // (test hook) the rotator checkpoint pool with `value` rows to begin with; only before the first burst
         if (p->rot_rows_used != 0 || value < 1 || value > p->P.n) return -1;
@@ -3018,6 +3056,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "band_steps")) return (int64_t)p->stat_band_steps;
     if (!strcmp(key, "scratch_outputs")) return (int64_t)p->bc[0].dec_cap;
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
+    if (!strcmp(key, "tiles_grows")) return (int64_t)p->stat_tiles_grows;
     if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;
@@ -3029,7 +3068,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
 extern "C" int irdm_kernel_clock(irdm_pipeline_t *p, int which, double *sum_ms, uint64_t *launches, double *last_ms, int reset)
 {
     if (!p || !p->d_kclk || which < 0 || which > 1) return -1;
-    (void)hipSetDevice(p->cfg.device);
+    pipeline_enter(p);
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     std::vector<unsigned long long> h((size_t)6 * kKClkWords);
     if (hipMemcpy(h.data(), p->d_kclk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;

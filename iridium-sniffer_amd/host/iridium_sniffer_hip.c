@@ -3,7 +3,7 @@
  *
  * Mirrors the reference's file-mode surface (options.c:186-551, main.c:223-284, frame_output.c:160-199):
  *     iridium-sniffer-hip -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB]
- *                         [--file-info STR] [--no-gardner] [--chunk SAMPLES] [-v]
+ *                         [--file-info STR] [--no-gardner] [--no-simd] [--chunk SAMPLES] [-v]
  * IQ file in, iridium-toolkit "RAW:" lines on stdout, "burst_detect: tagged N bursts total" on stderr
  * (burst_detect.c:350-351, the line test-configurations.sh:140 greps).  Everything between the file
  * read and the line printer runs on the GPU through the C-ABI in include/irdm_hip.h; there is no CPU
@@ -82,13 +82,16 @@ static size_t read_slices(reader_t *r, void *dst)
     if (r->pos >= r->size) return 0;
     if ((off_t)want > r->size - r->pos) want = (size_t)(r->size - r->pos);
     const int T = r->n_slices;
-    size_t per = (want / (size_t)T + 4095) & ~(size_t)4095;
+    /* ceil(want / T) rounded up to a page: T slices of `per` bytes always cover `want` (floor here handed out a
+     * T + 1-th slice that has no thread when want / T was a multiple of 4096 and want % T != 0); the last slice used
+     * takes what is left */
+    const size_t per = ((want + (size_t)T - 1) / (size_t)T + 4095) & ~(size_t)4095;
     int used = 0;
-    for (size_t o = 0; o < want; o += per, used++) {
+    for (size_t o = 0; o < want && used < T; o += per, used++) {
         slice_t *s = &r->sl[used];
         s->dst = (char *)dst + o;
         s->off = r->pos + (off_t)o;
-        s->len = want - o < per ? want - o : per;
+        s->len = (want - o < per || used == T - 1) ? want - o : per;
         sem_post(&s->go);
     }
     size_t got = 0;
@@ -165,7 +168,7 @@ int main(int argc, char **argv)
     unsigned long long fed = 0;
     const char *file = NULL, *file_info = NULL, *format = NULL;
     double rate = 0, freq = 1622000000.0, db = 0;
-    int gardner = 1, verbose = 0;
+    int gardner = 1, verbose = 0, no_simd = 0;
     size_t chunk = (size_t)16 << 20;
     int depth = 1;
     int read_threads = 6;       /* pread() helpers per chunk of a regular file (0: one fread thread) */
@@ -186,7 +189,8 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "--depth")) depth = atoi(NEXT());       /* 0: per-chunk latency, 1: throughput (default) */
         else if (!strcmp(a, "-v") || !strcmp(a, "--verbose")) verbose = 1;
         else if (!strcmp(a, "--timing")) timing = 1;                /* start-up and streaming time on stderr */
-        else if (!strcmp(a, "--no-simd") || !strcmp(a, "--no-gpu")) {
+        else if (!strcmp(a, "--no-simd")) no_simd = 1;              /* options.c:240, :351; main.c:567 simd_init(no_simd) */
+        else if (!strcmp(a, "--no-gpu")) {
             fprintf(stderr, "%s: this binary is the GPU path; use the reference binary for the CPU path\n", a);
             return 2;
         } else {
@@ -195,7 +199,7 @@ int main(int argc, char **argv)
         }
     }
     if (!file || rate <= 0) {
-        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR] [--save-bursts DIR]\n", argv[0]);
+        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR] [--no-simd] [--save-bursts DIR]\n", argv[0]);
         return 2;
     }
     if (!format) format = ext_of(file);              /* autodetect by extension, options.c:533-544 */
@@ -219,6 +223,12 @@ int main(int argc, char **argv)
     irdm_pipeline_t *p = irdm_create(&c);
     if (!p) {
         fprintf(stderr, "irdm_create failed (no MI355X / bad parameters)\n");
+        return 1;
+    }
+    /* --no-simd: the reference points its eleven dispatched kernels at simd_generic.c instead of simd_avx2.c
+     * (simd_generic.c:33-57); here the same switch selects the kernels that follow the generic file's operation order */
+    if (no_simd && irdm_set_option(p, "fir_order", 0) != 0) {
+        fprintf(stderr, "--no-simd: the library refused fir_order 0\n");
         return 1;
     }
     if (save_dir) irdm_set_option(p, "keep_frame_samples", 1);

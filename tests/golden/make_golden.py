@@ -133,8 +133,11 @@ def build_scene(name):
     return fs, iq, 2
 
 
-def e2e():
+def e2e(order=0):
+    """order 0: the dispatched kernels in simd_generic.c's operation order (e2e_scenes.json, recorded before the oracle
+    knew the other one and kept byte for byte); order 1: in simd_avx2.c's, the product's default (e2e_scenes_avx2.json)."""
     out = {}
+    orc.set_fir_order(order)
     for name in SCENES:
         fs, iq, fmt = build_scene(name)
         res = orc.run_stream(iq, fs, fmt=fmt)
@@ -150,7 +153,8 @@ def e2e():
             raw=res.raw_lines("golden"))
         out[name] = rec
         print(name, "bursts", len(rec["bursts"]), "raw lines", len(rec["raw"]))
-    json.dump(out, open(os.path.join(HERE, "e2e_scenes.json"), "w"), indent=1)
+    orc.set_fir_order(1)
+    json.dump(out, open(os.path.join(HERE, "e2e_scenes_avx2.json" if order else "e2e_scenes.json"), "w"), indent=1)
 
 
 def ref_bitlayer(R):
@@ -186,7 +190,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bitlayer":      # only the newer fixture; the others stay byte-identical
         ref_bitlayer(R)
         raise SystemExit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "e2e_avx2":      # likewise: the end-to-end scenes in the AVX2 kernels' order
+        e2e(1)
+        raise SystemExit(0)
     ref_stage_c(R)
     ref_designs(R)
-    e2e()
+    e2e(0)
+    e2e(1)
     ref_bitlayer(R)

@@ -458,6 +458,75 @@ def test_cli_binary_raw_lines(tmp_path):
             assert abs(fa[2] - fb[2]) <= 1 and abs(fa[6] - fb[6]) <= 1e-4
 
 
+def _cli_lines_equal(lines, want):
+    assert len(lines) == len(want)
+    for a, b in zip(lines, want):
+        fa, fb = parity.raw_fields(a), parity.raw_fields(b)
+        assert fa[0] == fb[0] and fa[3:6] == fb[3:6] and fa[7:] == fb[7:]
+        assert abs(fa[2] - fb[2]) <= 1 and abs(fa[6] - fb[6]) <= 1e-4
+
+
+def test_cli_no_simd_selects_the_generic_order(tmp_path):
+    """--no-simd (options.c:240, :351; main.c:567 simd_init(no_simd)): the binary follows simd_generic.c's operation order
+    (option fir_order 0) and prints what the oracle prints in that order; without the flag, simd_avx2.c's.  At 10 MHz, where
+    the two decimators are different kernels (fir_decimate_kernel_r / _f)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(irdm.LIB_PATH), "iridium-sniffer-hip")
+    if not os.path.exists(exe):
+        irdm.build(force=True)
+    fs = 10_000_000
+    iq = siggen.standard_scene(fs, int(0.62 * fs) // 32768 * 32768, 5, seed=77)[0]
+    path = tmp_path / "scene.cf32"
+    np.ascontiguousarray(iq).tofile(path)
+    refs = {}
+    try:
+        for order in (0, 1):
+            orc.set_fir_order(order)
+            refs[order] = orc.run_stream(iq, fs)
+    finally:
+        orc.set_fir_order(1)
+    outs = {}
+    for order, flag in ((1, []), (0, ["--no-simd"])):
+        out = subprocess.run([exe, "-f", str(path), "-r", str(fs), "--file-info", "golden", "--chunk", str(32768 * 64)] + flag,
+                             capture_output=True, text=True, timeout=180)
+        assert out.returncode == 0, out.stderr
+        ref = refs[order]
+        assert "tagged %d bursts total" % ref.n_tagged in out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("RAW:")]
+        assert len(lines) >= 3
+        _cli_lines_equal(lines, [l.strip() for l in ref.raw_lines("golden")])
+        outs[order] = lines
+    # (--no-gpu stays refused: this binary has no CPU path)
+    out = subprocess.run([exe, "-f", str(path), "-r", str(fs), "--no-gpu"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2
+
+
+def test_cli_file_tail_that_does_not_divide_into_the_read_slices(tmp_path):
+    """A regular file is read by --read-threads pread() slices per chunk.  A tail of T * 4096 * k + r bytes (r < T) used to
+    be cut into T + 1 slices -- one more than there are threads: the reader waited for it forever."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(irdm.LIB_PATH), "iridium-sniffer-hip")
+    if not os.path.exists(exe):
+        irdm.build(force=True)
+    fs = 2_000_000
+    chunk = 32768 * 16
+    iq = siggen.standard_scene(fs, int(0.81 * fs), 3, seed=5)[0]
+    data = siggen.to_ci16(iq)
+    n = 3 * chunk + (6 * 4096 * 3 + 4) // 4                 # ci16: 4 bytes a sample; the tail is 6 * 4096 * 3 + 4 bytes
+    data = np.ascontiguousarray(data.reshape(-1)[:2 * n])
+    path = tmp_path / "tail.ci16"
+    data.tofile(path)
+    assert os.path.getsize(path) == 4 * n
+    ref = orc.run_stream(data, fs, fmt=1)
+    for threads in (6, 5, 3):
+        out = subprocess.run([exe, "-f", str(path), "-r", str(fs), "--file-info", "golden", "--chunk", str(chunk),
+                              "--read-threads", str(threads)], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert "tagged %d bursts total" % ref.n_tagged in out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("RAW:")]
+        _cli_lines_equal(lines, [l.strip() for l in ref.raw_lines("golden")])
+
+
 def test_cli_save_bursts_dumps_every_downmixed_frame(tmp_path):
     """--save-bursts (qpsk_demod.c:339-389): one .cf32/.meta pair per frame handed to the demodulator, named with the
     direction the demodulator settled on (UN when the unique word was rejected); payload == the frame samples."""
