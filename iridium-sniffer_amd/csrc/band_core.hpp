@@ -73,6 +73,9 @@ struct BandParams {
                                  // BandWork::tl (diagnostic, option band_timeline)
     int32_t chained = 0;         // 1: enqueued behind a band scan whose verdict the host had not seen: valid only if that
                                  // scan committed (BandWork::bar[4]), else every pass of this launch returns untouched
+    int32_t tail = 0;            // 1: the launch-saving form (scan_band.hip, g_band_tail): pair list, plan pass in the walk pass's
+                                 // last workgroup, history on a side stream
+    uint32_t seq = 0;            // tail: number of the SCAN this launch belongs to (HistJob::seq)
 };
 
 struct BandRec {

@@ -1,6 +1,7 @@
 // kernels.hpp -- host-callable launchers of the gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "types.hpp"
 
 namespace irdm {
@@ -48,6 +49,15 @@ struct SumStep {                         // one update step of the sums pass, as
     uint32_t snap_off;                   // offset into BandWork::snap of the snapshot after the step, ~0u: none
     uint32_t pad;
 };
+// What the history pass needs of an accepted scan, written by its commit (band_tail, below): the pass runs on a side
+// stream beside the NEXT chunk's round 0, whose first pass resets the control block and whose plan passes reuse the
+// update-step arrays -- so the last <= 512 update frames are listed here.
+struct HistJob {
+    uint32_t seq;                        // BandParams::seq of the scan that wrote it (a history launch of another scan does nothing)
+    int32_t n;                           // rows to copy: min(n_upd, kHistory)
+    int32_t h0, n_upd;                   // ring position before the chunk, update steps of the chunk
+    int32_t frame[kHistory];             // frame[i]: the magnitude row of update step n_upd - 1 - i
+};
 struct BandWork {                        // device workspace, carved out of one allocation (band_work_carve)
     BandCtl *ctl;
     uint8_t *uq, *uf;                    // speculated per-frame updates: frame ends quiet / forces an update
@@ -68,8 +78,18 @@ struct BandWork {                        // device workspace, carved out of one 
     unsigned long long *tl;              // [2 halves][2][32] pass timeline (BandParams::tl_sel): per slot earliest start | latest end, 10 ns ticks
     unsigned *walk_host;                 // HOST counter: walk workgroups launched with BandParams::ahead so far (what bar[8] will reach)
     unsigned *bar;                       // [8] walk workgroups done (never reset; BandParams::ahead); [0..2] grid barrier of the cooperative kernel: arrive count, generation, abort (zero
-                                         // when idle); [4] the last scan committed; [5] serial number of a void launch
+                                         // when idle); [4] the last scan committed; [5] serial number of a void launch;
+                                         // band_tail: [9] / [10] workgroups of the crossing / walk pass that have left (back to zero by
+                                         // the last one), [11] next entry of the pair list to hand out, [12] entries, [13] of them heavy
+    uint32_t *pairs;                     // band_tail: the (band, 64-frame block) pairs with a segment start, listed by the crossing
+                                         // pass's last workgroup: heavy ones from the front, the others from the back
+    HistJob *hist_job;                   // band_tail: see HistJob
 };
+extern int g_band_tail;                  // 1 (default): fewer launches per scan -- the walk pass's last workgroup runs the next plan
+                                         // pass (verdict, commit, export), the walk hands out its pairs from a list the crossing
+                                         // pass's last workgroup made, the history copy runs on a side stream
+extern std::atomic<unsigned long long> g_band_tail_launches;
+extern int g_band_tail_threads;          // threads per workgroup of the walk pass with the tail (256 / 512 / 1024)
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
 extern int g_band_plan_ahead;            // 1: plan passes launched ahead on the side stream (-1 until band_resolve_env(): IRDM_PLAN_AHEAD or the default)
 constexpr int kBandPlanAheadDefault = 0;
@@ -93,7 +113,13 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                      uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream,
                      hipStream_t side = nullptr, hipEvent_t *plan_ev = nullptr, const uint32_t *gate_flag = nullptr,
                      uint32_t gate_seq = 0, uint32_t *gate_err = nullptr, const void *gate_src = nullptr,
-                     size_t gate_bytes = 0);                                  // gate: see irdm_expect_history
+                     size_t gate_bytes = 0,                                   // gate: see irdm_expect_history
+                     uint32_t scan_seq = 0, hipEvent_t hist_wait = nullptr, hipEvent_t hist_done = nullptr,
+                     hipEvent_t hist_hop = nullptr);
+// band_tail (scan_seq != 0, side, hist_done and hist_hop given): scan_seq numbers the SCAN (the same for its first launch,
+// a continuation and a retry); hist_wait: the previous scan's history copy (on `side`) -- waited for before the first pass
+// that may read or overwrite what that copy uses; hist_done: recorded on `side` behind this scan's history copy;
+// hist_hop: scratch event that carries the order from `stream` to `side`.
 constexpr int kBandTlSlots = 32;         // plan / sums / cross / walk of round r: 4 r + 0..3; commit 24; history 25
 // smin != nullptr: keep `pre` where it is lower and cap it by 0.45 * thr * smin (retry after a stale list)
 int launch_prefilter_lists(const float *sum, float thr, float *pre, const float *smin, const float *mag, int n,

@@ -240,6 +240,13 @@ struct irdm_pipeline {
     hipStream_t stream_side = nullptr;      // plan passes launched ahead (option band_plan_ahead)
     hipEvent_t ev_plan_set[2][kBandRounds + 2] = {};
     unsigned walk_launched = 0;             // BandWork::walk_host
+    // band_tail (scan_band.hip): the history copy of scan k runs on stream_side beside scan k + 1's round 0
+    hipEvent_t ev_hist_set[3] = {};         // recorded behind the history copy of the scan of chunk k: [k % 3] (the magnitude buffer it reads)
+    hipEvent_t ev_hist_hop = nullptr;       // scan stream -> side stream
+    hipEvent_t ev_hist_last = nullptr;      // the latest history copy enqueued (nullptr: none): whatever touches the ring next waits for it
+    uint32_t seq_counter = 0;               // scans numbered so far (HistJob::seq; never 0)
+    uint32_t fl_seq = 0;                    // number of the scan in flight
+    uint32_t chain_seq = 0;                 // ... of the chained launch (scan_chain_try), taken over by scan_launch
     int scan_events = 1;     // 0: no timing events around the band scan (stage time of the scan reads -1)
     int fir_order = 1;       // option fir_order / simd_order: 1 simd_avx2.c's operation order, 0 simd_generic.c's (--no-simd); per pipeline
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
@@ -504,6 +511,9 @@ static void pipeline_free(irdm_pipeline *p)
     for (auto &set : p->ev_plan_set)
         for (auto &e : set)
             if (e) (void)hipEventDestroy(e);
+    for (auto &e : p->ev_hist_set)
+        if (e) (void)hipEventDestroy(e);
+    if (p->ev_hist_hop) (void)hipEventDestroy(p->ev_hist_hop);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
@@ -821,6 +831,8 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             ok = hipStreamCreateWithPriority(&p->stream_side, hipStreamNonBlocking, prio_hi) == hipSuccess;
             for (auto &set : p->ev_plan_set)
                 for (auto &e : set) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            for (auto &e : p->ev_hist_set) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&p->ev_hist_hop, hipEventDisableTiming) == hipSuccess;
         }
         if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // the cooperative kernel's grid barrier starts idle
     }
@@ -1671,6 +1683,20 @@ static int process_bursts(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
 // finished bursts into h_gone.  pipeline_depth 0 calls them back to back; pipeline_depth 1 calls scan_finish at the
 // start of the NEXT feed, so the detector of chunk k runs while the host returns, the caller produces chunk k+1 and
 // the FFT of chunk k+1 executes.
+// Whatever reads or writes the noise-floor history ring on the detector's stream outside a band scan (the sequential
+// scans, snapshots, state export / import) goes behind the history copy a band scan may have left on the side stream.
+static int hist_fence(irdm_pipeline *p)
+{
+    if (p->ev_hist_last) IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_hist_last, 0));
+    return 0;
+}
+
+static uint32_t next_scan_seq(irdm_pipeline *p)
+{
+    if (++p->seq_counter == 0) ++p->seq_counter;
+    return p->seq_counter;
+}
+
 static int scan_hop_in(irdm_pipeline *p)
 {
     if (p->sstream == p->stream) return 0;
@@ -1689,7 +1715,7 @@ static int scan_hop_out(irdm_pipeline *p)
 
 static int scan_dense(irdm_pipeline *p, const float *mag, int n_frames, bool timed)
 {
-    if (scan_hop_in(p) != 0) return -1;
+    if (hist_fence(p) != 0 || scan_hop_in(p) != 0) return -1;
     if (timed) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk[0], p->sstream));
     if (launch_detect_scan(p->P, p->d_state, p->d_sum, p->d_hist, mag, n_frames, p->d_gone, p->gone_cap,
                            p->d_cand_a, p->d_cand_b, p->sstream) != 0)
@@ -1714,6 +1740,7 @@ static int scan_snapshot(irdm_pipeline *p)
     const DetParams &P = p->P;
     // snapshot of the carried state (a few tens of MB, D2D): restored if the sparse scan aborts or the burst-record
     // buffer turns out too small (scan_finish then redoes the chunk)
+    if (hist_fence(p) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum_bak, p->d_sum, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist_bak, p->d_hist, sizeof(float) * (size_t)kHistory * P.n,
                                   hipMemcpyDeviceToDevice, p->stream));
@@ -1724,6 +1751,7 @@ static int scan_snapshot(irdm_pipeline *p)
 static int scan_restore(irdm_pipeline *p)
 {
     const DetParams &P = p->P;
+    if (hist_fence(p) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_sum, p->d_sum_bak, sizeof(float) * P.n, hipMemcpyDeviceToDevice, p->stream));
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, p->d_hist_bak, sizeof(float) * (size_t)kHistory * P.n,
                                   hipMemcpyDeviceToDevice, p->stream));
@@ -1734,8 +1762,16 @@ static int scan_restore(irdm_pipeline *p)
 // the band scan proper over the primed frames [done, n_frames) of the chunk; retry = 1: the lists went stale, rebuild
 // them against the lowered reference first
 static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds,
-                                uint64_t c0, const irdm_pipeline::FeedSlot *feed, int sel, int first, int chained)
+                                uint64_t c0, const irdm_pipeline::FeedSlot *feed, int sel, int first, int chained,
+                                uint32_t seq, uint64_t chunk_no)
 {
+    // (band_tail: this scan's history copy is recorded in the event of the magnitude buffer it reads; it waits for the latest
+    // one enqueued before -- the previous scan's, or this scan's own from an earlier launch)
+    hipEvent_t hist_done = p->ev_hist_set[chunk_no % 3], hist_wait = p->ev_hist_last;
+    struct HistNote {
+        irdm_pipeline *p; hipEvent_t e;
+        ~HistNote() { if (irdm::g_band_tail) p->ev_hist_last = e; }
+    } hist_note{ p, hist_done };
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
     const uint64_t idx0 = c0 + (uint64_t)done * (uint64_t)P.n;           // chunks start on frame boundaries
@@ -1753,7 +1789,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
         return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
                                 p->d_smin, p->d_gone, p->gone_cap, first, kBandRounds, hpg,
                                 reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, sel, p->stream, p->stream_side,
-                                p->ev_plan_set[sel]);
+                                p->ev_plan_set[sel], nullptr, 0, nullptr, nullptr, 0, seq, hist_wait, hist_done, p->ev_hist_hop);
     }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
@@ -1772,7 +1808,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
                          entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, first, hpg,
                          reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream, p->stream_side,
                          p->ev_plan_set[sel], gate ? p->hp_gate_dev : nullptr, p->gate_seq, gate ? p->hp_gate_dev + 1 : nullptr,
-                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n) != 0)
+                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n, seq, hist_wait, hist_done, p->ev_hist_hop) != 0)
         return -1;
     if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
@@ -1783,13 +1819,15 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
 static int scan_band_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds = false)
 {
     if (!more_rounds && !retry) p->fl_band_first = p->band_first ? p->band_first : p->band_auto;
-    return scan_band_enqueue_at(p, mag, n_frames, done, retry, more_rounds, p->fl_c0, p->fl_feed, p->out_sel, p->fl_band_first, 0);
+    return scan_band_enqueue_at(p, mag, n_frames, done, retry, more_rounds, p->fl_c0, p->fl_feed, p->out_sel, p->fl_band_first, 0,
+                                p->fl_seq, p->fl_no);
 }
 
 // the sequential forms: the sparse leader scan with the dense kernel as its exact fallback, or the dense kernel alone
 static int scan_legacy_enqueue(irdm_pipeline *p, const float *mag, int n_frames, int done, bool sparse)
 {
     const DetParams &P = p->P;
+    if (hist_fence(p) != 0) return -1;
     if (sparse) {
         IRDM_HIP_CHECK(hipMemsetAsync(p->d_status, 0, sizeof(int) * 64, p->stream));
         if (done < n_frames) {
@@ -1863,7 +1901,8 @@ static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f)
     IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, f.ev_k1, 0));
     memset(p->h_pin_set[sel] + 96, 0, sizeof(BandCtl));
     p->chain_band_first = p->band_first ? p->band_first : p->band_auto;
-    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1) != 0) return -1;
+    p->chain_seq = next_scan_seq(p);
+    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1, p->chain_seq, p->chunk_no) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_end_set[sel], p->stream));
     p->chain_pending = true;
     p->chain_sel = sel;
@@ -1886,6 +1925,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
         p->fl_done = 0;
         p->fl_band_ran = true;
         p->fl_band_first = p->chain_band_first;
+        p->fl_seq = p->chain_seq;
         scan_select_outputs(p, p->chain_sel);
         p->fl_active = true;
         return 0;
@@ -1900,6 +1940,7 @@ static int scan_launch(irdm_pipeline *p, const float *mag, int n_frames, uint64_
     p->fl_c1 = c1;
     p->fl_c0 = p->total_samples;
     p->fl_no = p->chunk_no;
+    p->fl_seq = next_scan_seq(p);
     // stream start: the first 512 frames only prime the baseline (burst_detect.c:427-428) -- dense kernel, no bursts
     int done = 0;
     if (!p->host_primed && p->fl_mode != 0) {
@@ -2232,6 +2273,12 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
     irdm_pipeline::FeedSlot &f = p->fs[p->begin_no % 3];
     float *const mags[3] = { p->d_mag, p->d_mag2, p->d_mag3 };
     float *mag = p->depth ? mags[p->begin_no % 3] : p->d_mag;
+    // (band_tail: the history copy of the scan that last read this magnitude buffer -- three chunks ago, one with
+    // pipeline_depth 0 -- ran on the side stream: long over, but nothing else orders K1 behind it)
+    if (p->band_ok) {
+        if (p->depth) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_set[p->begin_no % 3]));
+        else if (p->ev_hist_last) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_last));
+    }
     // written in place (irdm_ingest_ptr)?  Then the ring already holds the chunk.
     const uint64_t pos = c0 % p->ring_len;
     const bool in_ring = p->depth && n_samples > 0 && pos + n_samples <= p->ring_len &&
@@ -2620,7 +2667,7 @@ extern "C" long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, s
 {
     if (!p || !d_buf || cap < irdm_state_bytes(p)) return -1;
     pipeline_enter(p);
-    if (settle(p) != 0) return -1;
+    if (settle(p) != 0 || hist_fence(p) != 0) return -1;
     char *o = static_cast<char *>(d_buf);
     const StateHeader h = { 0x4952444d53544154ull, (uint64_t)p->P.n, (uint64_t)kHistory, p->total_samples, p->tagged,
                             p->start_time_ns, p->host_primed, p->host_hist_idx };
@@ -2639,7 +2686,7 @@ extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, s
 {
     if (!p || !d_buf || n < irdm_state_bytes(p)) return -1;
     pipeline_enter(p);
-    if (settle(p) != 0) return -1;
+    if (settle(p) != 0 || hist_fence(p) != 0) return -1;
     const char *i = static_cast<const char *>(d_buf);
     StateHeader h;
     IRDM_HIP_CHECK(hipMemcpyAsync(&h, i, sizeof(h), hipMemcpyDeviceToHost, p->stream));
@@ -2727,7 +2774,7 @@ extern "C" int irdm_import_state_history_device(irdm_pipeline_t *p, const void *
         return 0;
     }
     p->gate_armed = false;               // (announced, but the scan was never enqueued: the ordinary import)
-    if (settle(p) != 0) return -1;
+    if (settle(p) != 0 || hist_fence(p) != 0) return -1;
     IRDM_HIP_CHECK(hipMemcpyAsync(p->d_hist, d_hist_buf, bytes, hipMemcpyDeviceToDevice, p->stream));
     IRDM_HIP_CHECK(hipStreamSynchronize(p->stream));
     return 0;
@@ -3005,6 +3052,12 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     }
     if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
+    if (!strcmp(key, "band_tail")) { irdm::g_band_tail = value != 0; return 0; }
+    if (!strcmp(key, "band_tail_threads")) {
+        if (value != 256 && value != 512 && value != 1024) return -1;
+        irdm::g_band_tail_threads = value;
+        return 0;
+    }
     if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
     if (!strcmp(key, "band_sum_bins")) { irdm::g_band_sum_bins = value; return 0; }
     if (!strcmp(key, "band_selfcheck")) { irdm::g_band_selfcheck = value; return 0; }
@@ -3057,6 +3110,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "scratch_outputs")) return (int64_t)p->bc[0].dec_cap;
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
     if (!strcmp(key, "tiles_grows")) return (int64_t)p->stat_tiles_grows;
+    if (!strcmp(key, "band_tail_launches")) return (int64_t)irdm::g_band_tail_launches.load();      // (process-wide)
     if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;

@@ -79,12 +79,38 @@ struct TlScope {
             atomicMin(lo, (unsigned long long)wall_clock64());
         }
     }
-    __device__ __forceinline__ ~TlScope()
+    // (the pass proper is over: what the workgroup does from here on is stamped by another scope)
+    __device__ __forceinline__ void leave()
     {
         if (hi) atomicMax(hi, (unsigned long long)wall_clock64());
+        hi = nullptr;
     }
+    __device__ __forceinline__ ~TlScope() { leave(); }
 };
 
+// band_tail: "the workgroup that leaves a pass last does what depends on the whole pass".  Every workgroup of the pass calls
+// this once, when its own work is done; exactly one call -- the one that brings the counter to the grid's size -- returns
+// true, with everything the other workgroups wrote before their call visible to the whole workgroup, and the counter back at
+// zero for the next pass.  No workgroup waits for another: unlike a grid barrier this needs no residency, and the emulation
+// (workgroups one after the other, in any order) runs it as it is.
+__device__ __forceinline__ bool last_arriver(unsigned *ctr)
+{
+    __shared__ int s_last_arriver;
+    // (every wavefront's own stores have reached the L2 before the workgroup counts as arrived)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)gridDim.x - 1u;
+        if (last) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        s_last_arriver = last;
+    }
+    __syncthreads();
+    return s_last_arriver != 0;
+}
 
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
 constexpr int kSumDepth = 32;             // update steps per batch of the sums pass (two batches of loads in flight)
@@ -953,6 +979,118 @@ __global__ __launch_bounds__(256) void band_walk_wave_kernel(BandParams P, BandW
     }
 }
 
+// ---- band_tail: the walk whose last workgroup judges the round ----
+// The same walk (a wavefront per band and segment), its pairs taken one at a time from the list the crossing pass's last
+// workgroup made; the workgroup that leaves last then runs what used to be the next launch -- the plan pass of round
+// `round` + 1: the verdict on this round, the commit if it is accepted (always fused here), else the next round's plan --
+// and, in the last round the host enqueued (`final`), the export of the control block and the finished bursts' records to
+// pinned host memory (band_history_kernel's first workgroups before).  Per two-round scan: plan0 . cross0 . walk0 . sums1 .
+// cross1 . walk1 and the history copy beside the next chunk, six dependent launches where there were nine -- three times
+// the idle time in front of a single-workgroup launch (26-70 us each at 10 MHz in run, up to 340 us at 12 MHz dense,
+// profiles/r4_scan_timeline.json) and the history pass's 56 us off every chunk's scan.
+// NT threads per workgroup: the plan's own width (its LDS form holds 8192 / NT frames per thread).
+__device__ void band_tail_export(const DetState *__restrict__ st, const uint32_t *__restrict__ gone, int cap,
+                                 uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr, const uint32_t *__restrict__ ctl,
+                                 uint32_t *__restrict__ hp_ctl, int ctl_words, bool voided)
+{
+    // (one workgroup's form of gone_export_body, types.hpp)
+    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+    if (voided) {
+        // (the host drains and ignores a void launch; its export slot says so for whoever looks)
+        if (tid == 0) {
+            __hip_atomic_store(hp_ctl + 2, (uint32_t)BAND_F_CHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // flags
+            __hip_atomic_store(hp_ctl + 0, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                      // status
+        }
+        __threadfence_system();
+        return;
+    }
+    for (int i = tid; i < ctl_words; i += nt) __hip_atomic_store(hp_ctl + i, ctl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint32_t n = st->n_gone;
+    const size_t words = (size_t)(n < (uint32_t)cap ? n : (uint32_t)cap) * (sizeof(GoneBurst) / 4);
+    for (size_t i = (size_t)tid; i < words; i += (size_t)nt)
+        __hip_atomic_store(hp_gone + i, gone[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {
+        __hip_atomic_store(hp_hdr + 0, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hp_hdr + 1, st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hp_hdr + 2, (uint32_t)st->hist_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(hp_hdr + 3, (uint32_t)st->primed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+}
+
+template <int NW, int NT>
+__global__ __launch_bounds__(NT) void band_walk_tail_kernel(BandParams P, BandWork W, BandIO io, DetState *st,
+                                                            const unsigned *__restrict__ counts, int round, int final,
+                                                            float *sum, GoneBurst *gone, int gone_cap, int hp_cap,
+                                                            uint32_t *hp_gone, uint32_t *hp_hdr, uint32_t *hp_ctl)
+{
+    IRDM_DETECTOR_PRIO();
+    extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
+    __shared__ PlanShared sh;
+    const bool live = !(band_void(P, W) || W.ctl->status != 0);
+    if (live) {
+        TlScope tl(P, W, 4 * round + 3);
+        io.act_in = st->act;
+        io.n_act_in = (int32_t)wv_first((uint32_t)st->n_act);
+        const int lane = threadIdx.x & 63;
+        const int n_pairs = P.n_bands * P.occ_words;
+        const unsigned total = wv_first(W.bar[12]), n_heavy = wv_first(W.bar[13]);
+        unsigned long long *tl_stat = nullptr;
+        if (P.tl_sel >= 0) tl_stat = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + (round == 0 ? 26 : 28);
+        int wave_events = 0;
+        const unsigned long long t_wave = tl_stat ? wall_clock64() : 0;
+        for (;;) {
+            unsigned idx = 0;
+            if (lane == 0) idx = __hip_atomic_fetch_add(W.bar + 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            idx = wv_first(idx);
+            if (idx >= total) break;
+            const int p = (int)wv_first(idx < n_heavy ? W.pairs[idx] : W.pairs[n_pairs - 1 - (int)(idx - n_heavy)]);
+            const int band = p / P.occ_words, blk = p % P.occ_words;
+            bool carried = false;
+            int events = 0;
+            if (blk == 0) {
+                WaveWalker<NW> w(P, io, band, lane);
+                if (w.load_carried() > 0) {
+                    carried = true;
+                    w.run(0, true);
+                    events += w.n_events;
+                }
+            }
+            uint64_t starts = wv_first64(band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, carried));
+            while (starts) {
+                const int q = __builtin_ctzll(starts);
+                starts &= starts - 1;
+                WaveWalker<NW> w(P, io, band, lane);
+                w.run(64 * blk + q, false);
+                events += w.n_events;
+            }
+            wave_events += events;
+            if (tl_stat && lane == 0) {
+                atomicMax(tl_stat, (unsigned long long)events);
+                atomicAdd(tl_stat + 1, (unsigned long long)events);
+            }
+        }
+        if (tl_stat && lane == 0 && round != 0) {
+            unsigned long long *x = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + 30;
+            atomicMax(x, (unsigned long long)wave_events);
+            atomicMax(x + 1, wall_clock64() - t_wave);
+        }
+    }
+    if (!last_arriver(W.bar + 10)) return;
+    const bool voided = band_void(P, W);
+    if (!voided && W.ctl->status == 0) {
+        TlScope tl(P, W, 4 * (round + 1));
+        band_plan_body<NT>(P, W, counts, st, round + 1, sh, tail_lds);
+        __syncthreads();
+        if (!band_void(P, W) && W.ctl->status == 1) band_commit_body(P, W, st, sum, gone, gone_cap, tail_lds);
+    }
+    if (final && hp_hdr) {
+        __syncthreads();
+        band_tail_export(st, reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap, hp_gone, hp_hdr,
+                         reinterpret_cast<const uint32_t *>(W.ctl), hp_ctl, (int)(sizeof(BandCtl) / 4), voided);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // The rounds as ONE launch (option band_coop): kCoopGroups workgroups stay resident through plan -> sums -> cross ->
 // walk -> plan ... until a round is accepted or the scan declines, with a grid-wide barrier between the passes.  What
@@ -1056,10 +1194,12 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 2);
     __shared__ uint32_t s_bits_all[4][16384 / 32];
-    if (band_void(P, W) || W.ctl->status != 0) return;
+    const bool live = !(band_void(P, W) || W.ctl->status != 0);
+    if (!live && !P.tail) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
     uint32_t *s_bits = s_bits_all[wave];
+    if (live)
     for (int f0 = gw; f0 < P.n_frames; f0 += 64 * n_waves) {
         const int fl = f0 + lane * n_waves;
         const unsigned cl = fl < P.n_frames ? counts[fl] : 0u;
@@ -1070,6 +1210,38 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
             const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cl, j);
             band_cross_wave(P, W, c, entries, f0 + j * n_waves, s_bits, lane);
         }
+    }
+    if (!P.tail) return;
+    // band_tail: the workgroup that leaves last lists the (band, 64-frame block) pairs in which a segment starts -- what every
+    // wavefront of the walk pass used to find out for its own share of the pairs, a fixed share: the walk then lasted as long
+    // as its unluckiest wavefront (72 events where the mean was 15: 80 us of a pass whose longest single pair is 31 events).
+    // The walk's wavefronts take the pairs from this list one at a time, the heavy ones (many occupied frames in the block,
+    // block 0 with its carried bursts) first.
+    tl.leave();
+    if (!last_arriver(W.bar + 9)) return;
+    __shared__ unsigned s_nh, s_nl;
+    const int tid = (int)threadIdx.x;
+    if (tid == 0) {
+        s_nh = 0;
+        s_nl = 0;
+    }
+    __syncthreads();
+    const int n_pairs = P.n_bands * P.occ_words;
+    if (live)
+        for (int p = tid; p < n_pairs; p += 256) {
+            const int band = p / P.occ_words, blk = p % P.occ_words;
+            const uint64_t *occ = W.occ + (size_t)band * P.occ_words;
+            if (blk == 0 || band_segment_starts(occ, blk, P.gap, false) != 0) {
+                const bool heavy = blk == 0 || __builtin_popcountll(occ[blk]) >= 12;
+                if (heavy) W.pairs[atomicAdd(&s_nh, 1u)] = (uint32_t)p;
+                else W.pairs[n_pairs - 1 - (int)atomicAdd(&s_nl, 1u)] = (uint32_t)p;
+            }
+        }
+    __syncthreads();
+    if (tid == 0) {
+        W.bar[11] = 0;
+        W.bar[12] = s_nh + s_nl;
+        W.bar[13] = s_nh;
     }
 }
 
@@ -1254,6 +1426,17 @@ __device__ void band_commit_body(const BandParams &P, const BandWork &W, DetStat
         }
     }
     for (int b = tid; b < P.n; b += kPlanThreads) sum[b] = W.sum_new[b];
+    if (P.tail && W.hist_job) {
+        // what the history pass needs of this chunk, where the next chunk's scan does not touch it (HistJob)
+        const int nu = ctl->n_upd, cnt = nu < kHistory ? nu : kHistory;
+        for (int i = tid; i < cnt; i += kPlanThreads) W.hist_job->frame[i] = W.upd_frame[nu - 1 - i];
+        if (tid == 0) {
+            W.hist_job->n = cnt;
+            W.hist_job->h0 = ctl->h0;
+            W.hist_job->n_upd = nu;
+            W.hist_job->seq = P.seq;
+        }
+    }
     if (tid == 0) {
         const int F = P.n_frames;
         st->index += (uint64_t)F * (uint64_t)P.n;
@@ -1285,11 +1468,31 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
                                                            float *__restrict__ hist, const DetState *__restrict__ st,
                                                            const uint32_t *__restrict__ gone, int gone_cap,
                                                            uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr,
-                                                           uint32_t *__restrict__ hp_ctl)
+                                                           uint32_t *__restrict__ hp_ctl, const HistJob *__restrict__ job,
+                                                           uint32_t seq)
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 25);
     const BandCtl *ctl = W.ctl;
+    if (job != nullptr) {
+        // band_tail: on a side stream, beside the next chunk's round 0 (which has reset the control block by now): the rows
+        // are the ones the commit listed.  A launch behind a scan that did not commit (verdict open, declined, void) finds
+        // another scan's number and does nothing.
+        if (job->seq != seq || (int)blockIdx.x >= job->n) return;
+        const int k = job->n_upd - 1 - (int)blockIdx.x;
+        const float4 *src = reinterpret_cast<const float4 *>(mag + (size_t)job->frame[blockIdx.x] * P.n);
+        float4 *dst = reinterpret_cast<float4 *>(hist + (size_t)((job->h0 + k) % kHistory) * P.n);
+        for (int i0 = threadIdx.x; i0 < P.n / 4; i0 += 8 * 256) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + 256 * u < P.n / 4) v[u] = src[i0 + 256 * u];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (i0 + 256 * u < P.n / 4) dst[i0 + 256 * u] = v[u];
+        }
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x < 3) W.bar[threadIdx.x] = 0;      // (the cooperative kernel's barrier: idle here)
     if (band_void(P, W)) {
         // (the host drains and ignores a void launch; its export slot says so for whoever looks)
@@ -1338,6 +1541,10 @@ int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment
 int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
 int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
 int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
+int g_band_tail = 1;        // 1: six dependent launches per two-round scan instead of nine (band_walk_tail_kernel); needs the wavefront
+                            // walk, the wavefront crossing pass and the LDS plan; 0: a launch per pass
+std::atomic<unsigned long long> g_band_tail_launches{ 0 };     // launches that took the tail form (stat band_tail_launches)
+int g_band_tail_threads = 1024;   // workgroup size of the walk pass that carries the tail (the plan's width): 256 / 512 / 1024
 
 int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
 
@@ -1391,6 +1598,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(4 * (size_t)n); add(4 * kBandMaxTotal); add(8 * kBandMaxTotal); add(256);    // sum_new, tot, ids, flags
     add(256); add(4 * kBandMaxTotal);                                                // bar, rank
     add(8 * 4 * kBandTlSlots);                                                       // tl
+    add(4 * 64 * ((F + 63) / 64)); add(sizeof(HistJob));                             // pairs, hist_job
     return b;
 }
 
@@ -1430,6 +1638,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->rank = static_cast<uint32_t *>(take(4 * kBandMaxTotal));
     W->walk_host = nullptr;
     W->tl = static_cast<unsigned long long *>(take(8 * 4 * kBandTlSlots));
+    W->pairs = static_cast<uint32_t *>(take(4 * 64 * ((F + 63) / 64)));
+    W->hist_job = static_cast<HistJob *>(take(sizeof(HistJob)));
     return 0;
 }
 
@@ -1450,7 +1660,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
                      uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream, hipStream_t side,
                      hipEvent_t *plan_ev, const uint32_t *gate_flag, uint32_t gate_seq, uint32_t *gate_err, const void *gate_src,
-                     size_t gate_bytes)
+                     size_t gate_bytes, uint32_t scan_seq, hipEvent_t hist_wait, hipEvent_t hist_done, hipEvent_t hist_hop)
 {
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
@@ -1497,6 +1707,76 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     (void)hipFuncSetAttribute((const void *)band_plan_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
     (void)hipFuncSetAttribute((const void *)band_plan_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
     (void)hipFuncSetAttribute((const void *)band_plan_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
+    const bool tail = g_band_tail && !g_band_coop && !P.ahead && g_band_walk_wave && g_band_cross_wave && !(P.selfcheck & 16) &&
+                      scan_seq != 0 && side && hist_done && hist_hop && round_end > round_begin;
+    if (tail) {
+        // ---- band_tail: plan0 . [sums . cross . walk + the next plan] per round; the history copy on the side stream ----
+        P.tail = 1;
+        P.seq = scan_seq;
+        g_band_tail_launches++;
+        const int nt = g_band_tail_threads == 256 ? 256 : g_band_tail_threads == 512 ? 512 : 1024;
+        const int walk_groups = kWalkWaveGroups * 256 / nt;
+        bool waited = hist_wait == nullptr;
+        // the previous scan's history copy (side stream) must be over before this launch reads or rewrites the ring, or
+        // commits (the commit rewrites the one HistJob); round 0's plan, crossing pass and -- the wait sits in front of it --
+        // walk run beside it
+        auto wait_hist = [&]() -> int {
+            if (!waited && hipStreamWaitEvent(stream, hist_wait, 0) != hipSuccess) return -1;
+            waited = true;
+            return 0;
+        };
+        for (int round = round_begin; round < round_end; round++) {
+            if (round == 0) {
+                const float *pre0 = g_band_fold_sums0 ? pre : nullptr;
+                if (g_band_plan_threads == 256)
+                    hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), kPlanLdsBytes, stream, P, W, counts, st, 0, sum, gone, gone_cap, 0, 0u, pre0, smin);
+                else if (g_band_plan_threads == 512)
+                    hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), kPlanLdsBytes, stream, P, W, counts, st, 0, sum, gone, gone_cap, 0, 0u, pre0, smin);
+                else
+                    hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), kPlanLdsBytes, stream, P, W, counts, st, 0, sum, gone, gone_cap, 0, 0u, pre0, smin);
+            }
+            if (gate_flag && round == (round_begin > 1 ? round_begin : 1)) {
+                if (wait_hist() != 0) return -1;
+                if (launch_wait_host_flag(gate_flag, gate_seq, gate_err, stream) != 0) return -1;
+                if (hipMemcpyAsync(hist, gate_src, gate_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
+            }
+            if (!(round == 0 && g_band_fold_sums0)) {
+                if (round >= 1 && wait_hist() != 0) return -1;
+                if (g_band_sum_bins == 32)
+                    hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+                else if (g_band_sum_bins == 16)
+                    hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+                else
+                    hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+            }
+            hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
+            if (wait_hist() != 0) return -1;
+            const int final = round + 1 == round_end ? 1 : 0;
+            uint32_t *hpg = reinterpret_cast<uint32_t *>(hp_gone), *hpc = static_cast<uint32_t *>(hp_ctl);
+#define IRDM_WALK_TAIL(NWv, NTv)                                                                                              \
+            {                                                                                                                 \
+                (void)hipFuncSetAttribute((const void *)band_walk_tail_kernel<NWv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes); \
+                hipLaunchKernelGGL((band_walk_tail_kernel<NWv, NTv>), dim3(walk_groups), dim3(NTv), kPlanLdsBytes, stream, P, W, io, st, counts, round, \
+                                   final, sum, gone, gone_cap, hp_cap, hpg, hp_hdr, hpc);                                      \
+            }
+            if (P.band_w == 128) {
+                if (nt == 256) IRDM_WALK_TAIL(4, 256) else if (nt == 512) IRDM_WALK_TAIL(4, 512) else IRDM_WALK_TAIL(4, 1024)
+            } else {
+                if (nt == 256) IRDM_WALK_TAIL(8, 256) else if (nt == 512) IRDM_WALK_TAIL(8, 512) else IRDM_WALK_TAIL(8, 1024)
+            }
+#undef IRDM_WALK_TAIL
+        }
+        // the history copy: behind this launch's last pass, on the side stream -- the next scan's round 0 runs beside it
+        if (hipEventRecord(hist_hop, stream) != hipSuccess || hipStreamWaitEvent(side, hist_hop, 0) != hipSuccess) return -1;
+        hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, side, P, W, mag, hist, st,
+                           reinterpret_cast<const uint32_t *>(gone), 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                           W.hist_job, scan_seq);
+        if (hipEventRecord(hist_done, side) != hipSuccess) return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    // (a launch per pass, or the cooperative kernel: everything on `stream`, behind a history copy a tail-form scan may have
+    // left on the side stream)
+    if (hist_wait && hipStreamWaitEvent(stream, hist_wait, 0) != hipSuccess) return -1;
     if (g_band_coop) {
         // every round up to the verdict in one launch (the kernel leaves as soon as a round is accepted or declined)
         (void)round_end;
@@ -1573,7 +1853,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     static_assert(kHistory >= kExportBlocks, "the export rides on the history pass's first workgroups");
     hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist, st,
                        reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap,
-                       reinterpret_cast<uint32_t *>(hp_gone), hp_hdr, static_cast<uint32_t *>(hp_ctl));
+                       reinterpret_cast<uint32_t *>(hp_gone), hp_hdr, static_cast<uint32_t *>(hp_ctl), (const HistJob *)nullptr, 0u);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

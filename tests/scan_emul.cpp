@@ -35,12 +35,14 @@ void scan_emul_option(const char *key, int value)
     else if (!strcmp(key, "band_cross_wave")) g_band_cross_wave = value;
     else if (!strcmp(key, "band_timeline")) g_band_timeline = value;
     else if (!strcmp(key, "band_fold_sums0")) g_band_fold_sums0 = value;
+    else if (!strcmp(key, "band_tail")) g_band_tail = value;
+    else if (!strcmp(key, "band_tail_threads")) g_band_tail_threads = value;
 }
 
 // mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
 // (burst_detect.c:427-428, :448-452); the rest is scanned in chunks of chunk_frames.  Returns the number of finished
 // bursts written to out (emission order), or -(flags) - 1000 if a chunk was declined.  stats: [0] rounds, [1] chunks,
-// [2] bursts still active, [3] stale-list retries, [4] continuation launches.
+// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] launches in the tail form so far.
 int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_len, int width, int max_bursts, int max_len,
                   float threshold, int chunk_frames, int first_rounds, GoneBurst *out, int out_cap, float *sum_out, int *stats)
 {
@@ -82,9 +84,14 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     std::vector<ListEntry> entries((size_t)F_cap * cap);
     const int gone_cap = 8192;
     std::vector<GoneBurst> gone(gone_cap), all;
-    memset(stats, 0, sizeof(int) * 5);
+    memset(stats, 0, sizeof(int) * 6);
     hipEvent_t plan_ev[kBandRounds + 2] = {};
+    // (band_tail, the default form: a side "stream" for the history copy, the scans numbered, the events the emulation's)
+    hipStream_t side = reinterpret_cast<hipStream_t>(2);
+    hipEvent_t ev_hist = reinterpret_cast<hipEvent_t>(3), ev_hop = reinterpret_cast<hipEvent_t>(4);
+    uint32_t scan_seq = 0;
     for (int f0 = kHistory; f0 < n_frames; f0 += chunk_frames) {
+        scan_seq++;
         const int F = std::min(chunk_frames, n_frames - f0);
         const float *m0 = mag + (size_t)f0 * n;
         for (int b = 0; b < n; b++) pre[b] = 0.5f * threshold * sum[b];
@@ -105,14 +112,15 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
             const int first = first_rounds > 0 ? first_rounds : kBandFirst;
             if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(), pre.data(),
                                  smin.data(), gone.data(), gone_cap, 0, first, nullptr, nullptr, nullptr, gone_cap, 0, 0,
-                                 nullptr, reinterpret_cast<hipStream_t>(1), plan_ev) != 0)
+                                 nullptr, side, plan_ev, nullptr, 0, nullptr, nullptr, 0, scan_seq, ev_hist, ev_hist, ev_hop) != 0)
                 return -3;
             if (W.ctl->status == 0 && W.ctl->flags == 0) {
                 // verdict still open after the rounds enqueued up front: the rest (csrc/pipeline.cpp: more_rounds)
                 stats[4]++;
                 if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(),
                                      pre.data(), smin.data(), gone.data(), gone_cap, first, kBandRounds, nullptr, nullptr,
-                                     nullptr, gone_cap, 0, 0, nullptr, reinterpret_cast<hipStream_t>(1), plan_ev) != 0)
+                                     nullptr, gone_cap, 0, 0, nullptr, side, plan_ev, nullptr, 0, nullptr, nullptr, 0, scan_seq,
+                                     ev_hist, ev_hist, ev_hop) != 0)
                     return -3;
             }
             if (W.ctl->status == 1 || W.ctl->flags != BAND_F_STALE || tries >= 2) break;
@@ -130,6 +138,7 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     for (size_t i = 0; i < all.size(); i++) out[i] = all[i];
     memcpy(sum_out, sum.data(), sizeof(float) * n);
     stats[2] = st->n_act;
+    stats[5] = (int)g_band_tail_launches.load();      // (since the library was loaded)
     return (int)all.size();
 }
 

@@ -60,6 +60,17 @@ def run(L, mag, fs, chunk_frames, first_rounds=0):
     return rc, recs, sums, list(stats)
 
 
+_TINY = []
+
+
+def _tiny_scene():
+    """(mag, fs, chunk_frames) of a short scene: a run of it reads the emulation's counters"""
+    if not _TINY:
+        fs, iq = scenes.ALL["junk"]()
+        _TINY.append((oracle_detect(iq, fs)[0], fs, 1 << 20))
+    return _TINY[0]
+
+
 def check(L, iq, fs, chunks, **kw):
     mag, ref, ref_sums = oracle_detect(iq, fs)
     assert len(ref) > 0
@@ -76,8 +87,10 @@ def check(L, iq, fs, chunks, **kw):
 def test_scan_kernels_scene_zoo(emul, name):
     """whole stream in one chunk and cut into chunks that split bursts (carried bursts, history ring across chunks)"""
     fs, iq = scenes.ALL[name]()
+    before = run(emul, *_tiny_scene())[3][5]
     stats = check(emul, iq, fs, chunks=(1 << 20, 97))
     assert stats[1] >= 1
+    assert stats[5] - before >= stats[1], "the default form of the scan (band_tail) did not run: %r" % stats
 
 
 def test_scan_kernels_continuation_and_options(emul):
@@ -86,18 +99,34 @@ def test_scan_kernels_continuation_and_options(emul):
     fs, iq = scenes.ALL["too_long"]()
     stats = check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
     assert stats[4] >= 1, "no continuation launch was needed: %r" % stats
+    defaults = {b"band_walk_wave": 1, b"band_fuse_commit": 1, b"band_selfcheck": 0, b"band_plan_threads": 1024,
+                b"band_plan_ahead": 0, b"band_fold_sums0": 1, b"band_tail": 1, b"band_tail_threads": 1024}
     try:
-        # (band_fold_sums0 0: round 0's sums pass as a launch of its own instead of inside its plan pass)
+        # the default form (band_tail: pair list, the plan pass in the walk pass's last workgroup, the history copy apart)
+        # with narrower workgroups, with round 0's sums pass as a launch of its own, with the walk's look-ahead off and the
+        # boundary test's two forms compared
+        for key, value in ((b"band_tail_threads", 256), (b"band_tail_threads", 512), (b"band_fold_sums0", 0),
+                           (b"band_selfcheck", 8), (b"band_selfcheck", 1), (b"band_plan_threads", 256)):
+            emul.scan_emul_option(key, value)
+            check(emul, iq, fs, chunks=(131,))
+            check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
+            emul.scan_emul_option(key, defaults[key])
+        # a launch per pass (band_tail 0), and every option of that form (the lane-per-band walk, the commit as a launch of
+        # its own, plan passes "launched ahead" ... switch the tail form off by themselves)
+        emul.scan_emul_option(b"band_tail", 0)
+        check(emul, iq, fs, chunks=(131, 1 << 20))
         for key, value in ((b"band_walk_wave", 0), (b"band_fuse_commit", 0), (b"band_selfcheck", 8), (b"band_selfcheck", 1),
                            (b"band_plan_threads", 256), (b"band_plan_ahead", 1), (b"band_fold_sums0", 0)):
             emul.scan_emul_option(key, value)
             check(emul, iq, fs, chunks=(131,))
-            emul.scan_emul_option(key, {b"band_walk_wave": 1, b"band_fuse_commit": 1, b"band_selfcheck": 0,
-                                        b"band_plan_threads": 1024, b"band_plan_ahead": 0,
-                                        b"band_fold_sums0": 1}[key])
+            emul.scan_emul_option(key, defaults[key])
+        emul.scan_emul_option(b"band_tail", 1)
+        for key, value in ((b"band_walk_wave", 0), (b"band_plan_ahead", 1), (b"band_selfcheck", 16)):
+            emul.scan_emul_option(key, value)
+            check(emul, iq, fs, chunks=(131,))
+            emul.scan_emul_option(key, defaults[key])
     finally:
-        for key, value in ((b"band_walk_wave", 1), (b"band_fuse_commit", 1), (b"band_selfcheck", 0),
-                           (b"band_plan_threads", 1024), (b"band_plan_ahead", 0), (b"band_fold_sums0", 1)):
+        for key, value in defaults.items():
             emul.scan_emul_option(key, value)
 
 
