@@ -221,8 +221,11 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
             piece = torch.cat([flat[lo:], flat[:hi]]) if lo < 0 else flat[lo:hi].clone()
             parts.append(piece if nccl else piece.cpu())
         del x, flat
-    buf = torch.empty((ov + chunk) * bps, dtype=torch.uint8, device=device)
-    stage = None if nccl else torch.empty((ov + chunk) * bps, dtype=torch.uint8)
+    # two slices' worth of landing buffers: the slice of super-step s + 1 travels while super-step s computes (a slice is
+    # (overlap + chunk) * 8 bytes = 739 MB at 12 MHz: 10-12 ms on one xGMI link, more than the N scans of a super-step)
+    n_buf = 2 if world > 1 else 1
+    bufs = [torch.empty((ov + chunk) * bps, dtype=torch.uint8, device=device) for _ in range(n_buf)]
+    stages = None if nccl else [torch.empty((ov + chunk) * bps, dtype=torch.uint8) for _ in range(n_buf)]
     # (several ranks: a rank works on one chunk per super-step, its per-burst chain overlaps the other ranks' scans --
     # pipeline_depth 1; one rank: the ordinary chained feed, chunk k + 1 begun before chunk k ends)
     pipe = irdm.Pipeline(fs, fmt=irdm.FMT_CF32, max_chunk_samples=chunk, max_bursts_per_chunk=8192, device=local,
@@ -245,19 +248,60 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
             ingest = False
     cap = 8192                           # = max_bursts_per_chunk above: more frames in one chunk are an error, not truncated
     msg = record_msg_bytes(irdm, cap)
-    ghost = torch.zeros((msg,), dtype=torch.uint8).pin_memory() if world > 1 else None
-    gbuf = torch.zeros((msg,), dtype=torch.uint8, device=cdev) if world > 1 else None
-    glist = [torch.zeros((msg,), dtype=torch.uint8, device=cdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # (the record gather is double-buffered and asynchronous like the stream mode's: a step's message travels while the next
+    # step computes)
+    ghost = [torch.zeros((msg,), dtype=torch.uint8).pin_memory() for _ in range(2)] if world > 1 else None
+    gbuf = [torch.zeros((msg,), dtype=torch.uint8, device=cdev) for _ in range(2)] if world > 1 else None
+    glist = [[torch.zeros((msg,), dtype=torch.uint8, device=cdev) for _ in range(world)] for _ in range(2)] if (world > 1 and rank == 0) else [None, None]
     counts = torch.zeros((4,), dtype=torch.int64, device=cdev)       # bursts, frames produced, frames sent, frames gathered
     step_no = [0]
+    scatter = {"work": None}
+    gather = {"work": None, "slot": 0, "record": False}
+    parts_t = {"scatter_wait": 0.0, "collect": 0.0}      # host seconds per part of a super-step beside TimeShard.t (rank 0's are printed)
+
+    def issue_scatter(i):
+        return dist.scatter(bufs[i] if nccl else stages[i], parts if rank == 0 else None, src=0, async_op=True)
+
+    def finish_gather():
+        if gather["work"] is not None:
+            gather["work"].wait()
+            if gather["record"] and rank == 0:
+                counts[3] += torch.stack([l[:8] for l in glist[gather["slot"]]]).view(torch.int64).sum()
+            gather["work"] = None
+
+    def collect(record):
+        """the records that have come out of the pipeline so far: counted, packed, sent towards rank 0"""
+        nbst = len(pipe.poll_bursts_raw())
+        pipe.drop_frames()
+        demods = pipe.poll_demods_raw()
+        k = 0
+        if world > 1:
+            finish_gather()                          # (the message before the last one: its buffers are free again)
+            slot = gather["slot"] ^ 1
+            k = pack_records(irdm, demods, ghost[slot].numpy(), cap)
+            gbuf[slot].copy_(ghost[slot])
+            if cdev.type == "cuda":
+                torch.cuda.current_stream().synchronize()
+            gather.update(work=dist.gather(gbuf[slot], glist[slot], dst=0, async_op=True), slot=slot, record=record)
+        if record:
+            counts[0] += nbst
+            counts[1] += len(demods)
+            counts[2] += k
 
     def super_step(record):
         if world > 1:
-            dist.scatter(buf if nccl else stage, parts if rank == 0 else None, src=0)
+            i = step_no[0] % 2
+            tq = time.perf_counter()
+            if scatter["work"] is None:
+                scatter["work"] = issue_scatter(i)              # (the very first slice: nothing to hide it behind)
+            scatter["work"].wait()
             if not nccl:
-                buf.copy_(stage)
-            torch.cuda.synchronize()
-            ts.step(buf, first_of_stream=True)
+                bufs[i].copy_(stages[i])
+            # the stream the slice arrived on, not the device: the previous super-step's per-burst chain is still running
+            torch.cuda.current_stream().synchronize()
+            scatter["work"] = issue_scatter(1 - i)              # the next super-step's slices, under this one's compute
+            parts_t["scatter_wait"] += time.perf_counter() - tq
+            ts.step(bufs[i], first_of_stream=True)
         elif not args.depth:
             pipe.feed_device(parts[0].data_ptr() + ov * bps, chunk, None)
         else:
@@ -265,26 +309,19 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
             if step_no[0] > 0:
                 pipe.feed_end()
         step_no[0] += 1
-        nbst = len(pipe.poll_bursts_raw())
-        pipe.drop_frames()
-        demods = pipe.poll_demods_raw()
-        k = 0
-        if world > 1:
-            k = pack_records(irdm, demods, ghost.numpy(), cap)
-            gbuf.copy_(ghost)
-            dist.gather(gbuf, glist, dst=0)
-        if record:
-            counts[0] += nbst
-            counts[1] += len(demods)
-            counts[2] += k
-            if world > 1 and rank == 0:
-                counts[3] += torch.stack([l[:8] for l in glist]).view(torch.int64).sum()
+        tq = time.perf_counter()
+        collect(record)
+        parts_t["collect"] += time.perf_counter() - tq
 
     for _ in range(args.warmup):
         super_step(False)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if ts is not None:
+        ts.t = dict.fromkeys(ts.t, 0.0)
+        ts.steps_timed = 0
+    parts_t = dict.fromkeys(parts_t, 0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         super_step(True)
@@ -296,12 +333,18 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
         counts[0] += len(pipe.poll_bursts_raw())
         pipe.drop_frames()
         counts[1] += len(pipe.poll_demods_raw())
+    if world > 1:
+        # drain: the last super-step's chains, their records, the gathers in flight and the slice that was sent ahead for a
+        # super-step that does not come all belong to the timed work
+        ts.drain()
+        collect(True)
+        finish_gather()
+        scatter["work"].wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        ts.drain()
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -324,6 +367,13 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                        "records": ({"produced": int(counts[1].item()), "sent": int(counts[2].item()),
                                     "gathered_on_rank0": int(counts[3].item())} if world > 1 else None),
                        "pipeline_depth": args.depth, "backend": backend,
+                       # host milliseconds per super-step on rank 0, part by part: waiting for this step's slice (sent under the
+                       # previous step), overlap + K1 enqueue, the previous rank's head, scan enqueue, the history, the scan
+                       # itself, the sends, enqueueing the chain (irdm_advance), collecting / gathering records
+                       "parts_ms_rank0": ({**{k: round(v / K * 1e3, 3) for k, v in parts_t.items()},
+                                           **{k: round(v / max(ts.steps_timed, 1) * 1e3, 3) for k, v in ts.t.items()}}
+                                          if ts is not None else None),
+                       "ring_waits": pipe.stat("ring_waits"),
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
             "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_f", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
@@ -940,7 +990,9 @@ def main():
                        "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
                                                           "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists",
                                                           "scan_chained", "scan_chain_undone",
-                                                          "band_steps")},      # (band_steps: update steps of the scans' last rounds, summed)
+                                                          "band_steps",      # (band_steps: update steps of the scans' last rounds, summed)
+                                                          # scans that opened with round 1 behind a speculation pass (band_spec) / passes
+                                                          "spec_scans", "spec_passes")},
                        # the plan pass's own phase stamps, us per chunk (round 1: verdict loops, boundaries, bitmaps read,
                        # step count scan, step list, slot scan, end; last verdict: loops, boundaries)
                        # (--opt band_timeline=1) device timeline of the scan's passes, us per chunk: [time from the first

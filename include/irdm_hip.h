@@ -249,6 +249,12 @@ int irdm_feed_host(irdm_pipeline_t *p, const void *h_iq, size_t n_samples);
  * chunks fed so far are pollable afterwards.  Returns bursts processed or -1 (also when a chunk handed over with
  * irdm_feed_begin still waits for its irdm_feed_end). */
 int irdm_flush(irdm_pipeline_t *p);
+/* irdm_flush without the waiting (pipeline_depth >= 1): settles the detector scan in flight, enqueues the per-burst work of
+ * its bursts and returns; records of batches that have already finished become pollable.  For callers that interleave
+ * other work -- a time-sharded rank's next super-step -- with the chain.  Returns the number of bursts whose records were
+ * emitted, -1 on error.  (No reference counterpart: burst_downmix / qpsk_demod run on their own threads there,
+ * main.c:667-694.) */
+int irdm_advance(irdm_pipeline_t *p);
 /* Pinned (page-locked) host memory for feed buffers, for hosts without HIP headers.  NULL on failure. */
 void *irdm_host_alloc(size_t bytes);
 void irdm_host_free(void *ptr);

@@ -76,6 +76,8 @@ struct BandParams {
     int32_t tail = 0;            // 1: the launch-saving form (scan_band.hip, g_band_tail): pair list, plan pass in the walk pass's
                                  // last workgroup, history on a side stream
     uint32_t seq = 0;            // tail: number of the SCAN this launch belongs to (HistJob::seq)
+    int32_t spec_in = 0;         // 1: this scan has no round 0 of its own -- a speculation pass on a second workspace, run beside
+                                 // the previous chunk's scan, produced the update vector round 1 starts from (scan_band.hip, band_spec)
 };
 
 struct BandRec {

@@ -85,10 +85,11 @@ struct BandWork {                        // device workspace, carved out of one 
                                          // pass's last workgroup: heavy ones from the front, the others from the back
     HistJob *hist_job;                   // band_tail: see HistJob
 };
-extern int g_band_tail;                  // 1 (default): fewer launches per scan -- the walk pass's last workgroup runs the next plan
+extern int g_band_tail;                  // 1: fewer launches per scan (default 0: measured slower) -- the walk pass's last workgroup runs the next plan
                                          // pass (verdict, commit, export), the walk hands out its pairs from a list the crossing
                                          // pass's last workgroup made, the history copy runs on a side stream
 extern std::atomic<unsigned long long> g_band_tail_launches;
+extern int g_band_hist_side;             // 1: a launch per pass, but the history copy on the side stream (HistJob) and the export in the last plan pass
 extern int g_band_tail_threads;          // threads per workgroup of the walk pass with the tail (256 / 512 / 1024)
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16
 extern int g_band_plan_ahead;            // 1: plan passes launched ahead on the side stream (-1 until band_resolve_env(): IRDM_PLAN_AHEAD or the default)
@@ -105,8 +106,10 @@ extern int g_band_cross_wave;            // 1 (default): crossing pass = fixed g
 extern int g_band_coop;                  // 1: the rounds of a band scan as one cooperative launch; 0 (default): a launch per pass
 int band_list_cap(int n);                // entries per frame the band scan's lists hold
 int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint64_t idx0);
-size_t band_work_bytes(int n, size_t max_chunk);
-int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk);
+size_t band_work_bytes(int n, size_t max_chunk, bool spec = false);
+int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk, bool spec = false);
+int launch_band_spec(const DetParams &D, BandWork S, DetState *st_spec, const float *sum_src, int n_frames, uint64_t idx0,
+                     const unsigned *counts, const ListEntry *entries, int have_prev, hipStream_t stream);
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
@@ -115,7 +118,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                      uint32_t gate_seq = 0, uint32_t *gate_err = nullptr, const void *gate_src = nullptr,
                      size_t gate_bytes = 0,                                   // gate: see irdm_expect_history
                      uint32_t scan_seq = 0, hipEvent_t hist_wait = nullptr, hipEvent_t hist_done = nullptr,
-                     hipEvent_t hist_hop = nullptr);
+                     hipEvent_t hist_hop = nullptr, const BandWork *spec = nullptr, hipEvent_t sums_done = nullptr);
 // band_tail (scan_seq != 0, side, hist_done and hist_hop given): scan_seq numbers the SCAN (the same for its first launch,
 // a continuation and a retry); hist_wait: the previous scan's history copy (on `side`) -- waited for before the first pass
 // that may read or overwrite what that copy uses; hist_done: recorded on `side` behind this scan's history copy;

@@ -208,6 +208,8 @@ struct BatchCtx {
     std::vector<irdm_burst_t> recs;
     int n;                       // bursts in flight (0: idle)
     uint64_t chunk_no;           // the chunk they come from
+    uint64_t ring_lo = 0, ring_hi = 0;   // absolute sample range this batch's decimator may read from the history ring (incl. the
+                                 // stale slots one reference ring length back); it reads nothing behind ev[1]
     bool owns_buffers;           // context 1 allocates its own device scratch; context 0 aliases the pipeline's
     float ms[3];                 // fir, post, demod of the last finished batch
 };
@@ -244,6 +246,18 @@ struct irdm_pipeline {
     hipEvent_t ev_hist_set[3] = {};         // recorded behind the history copy of the scan of chunk k: [k % 3] (the magnitude buffer it reads)
     hipEvent_t ev_hist_hop = nullptr;       // scan stream -> side stream
     hipEvent_t ev_hist_last = nullptr;      // the latest history copy enqueued (nullptr: none): whatever touches the ring next waits for it
+    // band_spec (scan_band.hip): round 0 of chunk k + 1 as a speculation pass on a second workspace and stream, beside chunk
+    // k's scan; the scan of chunk k + 1 then opens with round 1
+    int band_spec_opt = 1;                  // option band_spec
+    void *d_band_spec = nullptr;
+    BandWork band_spec = {};
+    DetState *d_state_spec = nullptr;       // the carried bursts a speculation pass starts from (the previous pass's survivors)
+    hipStream_t stream_spec = nullptr;
+    hipEvent_t ev_sums1 = nullptr;          // behind the first sums pass of the latest band-scan launch (its sum_new: the pass's sums)
+    hipEvent_t ev_spec_done = nullptr;      // behind the latest speculation pass
+    uint64_t spec_for_no = ~0ull;           // the chunk the speculation workspace holds a pass for (~0: none)
+    int spec_frames = 0;                    // ... and its frames
+    uint64_t stat_spec_passes = 0, stat_spec_scans = 0;
     uint32_t seq_counter = 0;               // scans numbered so far (HistJob::seq; never 0)
     uint32_t fl_seq = 0;                    // number of the scan in flight
     uint32_t chain_seq = 0;                 // ... of the chained launch (scan_chain_try), taken over by scan_launch
@@ -407,7 +421,7 @@ struct irdm_pipeline {
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
     std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
     std::vector<void *> tiles_retired, tiles_host_retired;   // outgrown strip lists (device / pinned host): likewise
-    uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0, stat_tiles_grows = 0;
+    uint64_t stat_scratch_grows = 0, stat_scratch_peak = 0, stat_tiles_grows = 0, stat_ring_waits = 0;
     // time-chunk sharding: the previous chunk's 512-frame history may arrive AFTER this chunk's scan has been enqueued
     // (irdm_expect_history / irdm_import_state_history_device): [0] sequence number the import publishes, [1] time-out
     // flag of the waiting kernel, in mapped pinned memory; the import's copies run on gstream
@@ -454,7 +468,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_fir_off, p->d_mag2, p->d_mag3, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
                      p->k1_pre[0] != p->d_pre ? p->k1_pre[0] : nullptr, p->k1_counts[0] != p->d_counts ? p->k1_counts[0] : nullptr,
                      p->k1_entries[0] != p->d_entries ? p->k1_entries[0] : nullptr, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
-                     p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin, p->d_kclk };
+                     p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin, p->d_kclk, p->d_state_spec };
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     for (int s = 0; s < 2; s++) {
@@ -508,6 +522,10 @@ static void pipeline_free(irdm_pipeline *p)
     for (void *q : p->tiles_host_retired) (void)hipHostFree(q);
     if (p->d_rot_slot) (void)hipFree(p->d_rot_slot);
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
+    if (p->stream_spec) (void)hipStreamDestroy(p->stream_spec);
+    if (p->ev_sums1) (void)hipEventDestroy(p->ev_sums1);
+    if (p->ev_spec_done) (void)hipEventDestroy(p->ev_spec_done);
+    if (p->d_band_spec) (void)hipFree(p->d_band_spec);
     for (auto &set : p->ev_plan_set)
         for (auto &e : set)
             if (e) (void)hipEventDestroy(e);
@@ -835,6 +853,21 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             ok = ok && hipEventCreateWithFlags(&p->ev_hist_hop, hipEventDisableTiming) == hipSuccess;
         }
         if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // the cooperative kernel's grid barrier starts idle
+        if (ok && p->depth) {
+            // the speculation passes' workspace (one snapshot row; 0.27 GB at 64 Mi-sample chunks, most of it the sparse
+            // relative-magnitude plane), carried-burst list, stream and events
+            const size_t sb = band_work_bytes(P.n, p->max_chunk, true);
+            ok = hipMalloc(&p->d_band_spec, sb) == hipSuccess;
+            if (ok) band_work_carve(&p->band_spec, p->d_band_spec, P.n, p->max_chunk, true);
+            // (control words, record counts, the void marker: zero; the planes are written before they are read)
+            if (ok) ok = hipMemset(p->band_spec.ctl, 0, sizeof(BandCtl)) == hipSuccess && hipMemset(p->band_spec.bar, 0, 256) == hipSuccess &&
+                         hipMemset(p->band_spec.rec_count, 0, 4 * 64) == hipSuccess && hipMemset(p->band_spec.flags, 0, 256) == hipSuccess;
+            AL(p->d_state_spec, DetState, 1);
+            if (ok) ok = hipMemset(p->d_state_spec, 0, sizeof(DetState)) == hipSuccess;
+            ok = ok && hipStreamCreateWithPriority(&p->stream_spec, hipStreamNonBlocking, prio_hi) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->ev_sums1, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&p->ev_spec_done, hipEventDisableTiming) == hipSuccess;
+        }
     }
     mark("band scan workspace");
     if (ok) ok = hipMalloc(&p->d_ring, p->ring_len * p->bps) == hipSuccess;
@@ -1026,6 +1059,29 @@ static SampleSource make_source(const irdm_pipeline *p, const void *chunk, uint6
 }
 
 // copy the chunk's tail into the history ring (absolute index % ring_len)
+// Samples [a0, a1) are about to be written into the history ring on stream `st`: behind the decimator of every batch in
+// flight that may still read the slots they land in.  Consecutive chunks of a stream never meet a batch in flight (the
+// ring is sized for that); a rank of a time-sharded stream jumps `world` chunks ahead per super-step and may (section 6).
+static int ring_guard(irdm_pipeline *p, uint64_t a0, uint64_t a1, hipStream_t st)
+{
+    const uint64_t L = p->ring_len;
+    if (a1 <= a0 || L == 0) return 0;
+    for (int i = 0; i < p->n_bc; i++) {
+        const BatchCtx &b = p->bc[i];
+        if (b.n <= 0 || b.ring_hi <= b.ring_lo) continue;
+        bool hit = a1 - a0 >= L || b.ring_hi - b.ring_lo >= L;
+        if (!hit) {
+            const uint64_t x0 = a0 % L, y0 = b.ring_lo % L;
+            hit = (y0 + L - x0) % L < a1 - a0 || (x0 + L - y0) % L < b.ring_hi - b.ring_lo;
+        }
+        if (hit) {
+            IRDM_HIP_CHECK(hipStreamWaitEvent(st, b.ev[1], 0));
+            p->stat_ring_waits++;
+        }
+    }
+    return 0;
+}
+
 static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t c1, hipStream_t st)
 {
     uint64_t a0 = c1 > p->ring_len ? std::max(c0, c1 - p->ring_len) : c0;
@@ -1377,7 +1433,20 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             dec_need += ((size_t)w.dec_len + 15) & ~(size_t)15;           // rows start on 128-byte lines
         }
     }
+    b.ring_lo = b.ring_hi = 0;
     if (p->detect_only || nb == 0) return 0;      // stage A alone: burst records, no downmix / demod
+    {
+        uint64_t lo = ~0ull, hi = 0;
+        for (int i = 0; i < nb; i++) {
+            const BurstWork &w = b.hp_work[i];
+            if (w.drop_reason) continue;
+            // (a window that ends behind what its feed block had delivered reads the slots one reference ring length back)
+            const uint64_t back = w.start + (uint64_t)w.n > w.avail_end ? p->ref_ring : 0;
+            lo = std::min(lo, w.start > back ? w.start - back : 0);
+            hi = std::max(hi, w.start + (uint64_t)w.n);
+        }
+        if (lo < hi) { b.ring_lo = lo; b.ring_hi = hi; }
+    }
     if (dec_need > p->stat_scratch_peak) p->stat_scratch_peak = dec_need;
     if (dec_need > b.dec_cap) {
         // more outputs than this context's scratch holds: twice as much (the context is idle -- its last batch has been
@@ -1763,14 +1832,14 @@ static int scan_restore(irdm_pipeline *p)
 // them against the lowered reference first
 static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames, int done, int retry, bool more_rounds,
                                 uint64_t c0, const irdm_pipeline::FeedSlot *feed, int sel, int first, int chained,
-                                uint32_t seq, uint64_t chunk_no)
+                                uint32_t seq, uint64_t chunk_no, bool use_spec = false)
 {
     // (band_tail: this scan's history copy is recorded in the event of the magnitude buffer it reads; it waits for the latest
     // one enqueued before -- the previous scan's, or this scan's own from an earlier launch)
     hipEvent_t hist_done = p->ev_hist_set[chunk_no % 3], hist_wait = p->ev_hist_last;
     struct HistNote {
         irdm_pipeline *p; hipEvent_t e;
-        ~HistNote() { if (irdm::g_band_tail) p->ev_hist_last = e; }
+        ~HistNote() { if (irdm::g_band_tail || irdm::g_band_hist_side) p->ev_hist_last = e; }
     } hist_note{ p, hist_done };
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
@@ -1804,12 +1873,15 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
         p->gate_armed = false;
         p->gate_open_pending = true;
     }
+    // (use_spec: this chunk's round 0 was made by a speculation pass, spec_enqueue: the scan opens with round 1)
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
-                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, 0, first, hpg,
+                         entries, pre, p->d_smin, p->d_gone, p->gone_cap, use_spec ? 1 : 0, first, hpg,
                          reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream, p->stream_side,
                          p->ev_plan_set[sel], gate ? p->hp_gate_dev : nullptr, p->gate_seq, gate ? p->hp_gate_dev + 1 : nullptr,
-                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n, seq, hist_wait, hist_done, p->ev_hist_hop) != 0)
+                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n, seq, hist_wait, hist_done, p->ev_hist_hop,
+                         use_spec ? &p->band_spec : nullptr, p->ev_sums1) != 0)
         return -1;
+    if (use_spec) p->stat_spec_scans++;
     if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
     return 0;
@@ -1902,11 +1974,39 @@ static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f)
     memset(p->h_pin_set[sel] + 96, 0, sizeof(BandCtl));
     p->chain_band_first = p->band_first ? p->band_first : p->band_auto;
     p->chain_seq = next_scan_seq(p);
-    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1, p->chain_seq, p->chunk_no) != 0) return -1;
+    // a speculation pass for exactly this chunk (spec_enqueue, at the end of the previous feed)?  Then round 0 is done: the
+    // scan waits for that pass and opens with round 1.  (Only here, in the chained launch: a scan that is launched again
+    // after its predecessor's trouble, a retry or a continuation finds the speculation workspace taken by the next pass.)
+    const bool use_spec = p->band_spec_opt && p->d_band_spec && p->spec_for_no == p->chunk_no && p->chain_band_first >= 2 &&
+                          f.frames == p->spec_frames && !p->gate_armed;
+    if (use_spec) IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_spec_done, 0));
+    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1, p->chain_seq, p->chunk_no, use_spec) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_end_set[sel], p->stream));
     p->chain_pending = true;
     p->chain_sel = sel;
     p->stat_chained++;
+    return 0;
+}
+
+// The speculation pass of the NEXT chunk (feed slot `nx`, chunk number `no`; K1 and its candidate lists are enqueued or
+// done), on its own stream: behind K1 of that chunk and behind the first sums pass of the scan just enqueued -- the sums it
+// tests against -- which is also behind that scan's plan pass, the one reader of the workspace this pass overwrites.
+static int spec_enqueue(irdm_pipeline *p, irdm_pipeline::FeedSlot &nx, uint64_t no)
+{
+    if (!p->band_spec_opt || !p->d_band_spec || !p->scan_chain || !p->host_primed || scan_pick(p) != 2 || nx.frames < 1 || !nx.lists ||
+        irdm::g_band_coop)
+        return 0;
+    const int ls = (int)(&nx - p->fs);
+    IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream_spec, nx.ev_k1, 0));
+    IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream_spec, p->ev_sums1, 0));
+    const int have_prev = p->spec_for_no != ~0ull && p->spec_for_no + 1 == no;
+    if (launch_band_spec(p->P, p->band_spec, p->d_state_spec, p->band.sum_new, nx.frames, nx.c0, p->k1_counts[ls], p->k1_entries[ls],
+                         have_prev, p->stream_spec) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_spec_done, p->stream_spec));
+    p->spec_for_no = no;
+    p->spec_frames = nx.frames;
+    p->stat_spec_passes++;
     return 0;
 }
 
@@ -2235,6 +2335,42 @@ extern "C" int irdm_flush(irdm_pipeline_t *p)
     return emitted;
 }
 
+// irdm_flush without the waiting: the detector scan in flight is settled and its bursts' per-burst chain ENQUEUED; records
+// of batches that have finished come out, nothing else is waited for (a context that is still busy with an older batch is
+// waited for only if the new chain needs that very context).  What a rank of a time-sharded stream calls at the end of a
+// super-step: its chain then runs beside the next super-step's scatter, K1 and scan (sharding.TimeShard).  Returns the
+// number of bursts whose records were emitted, -1 on error.
+extern "C" int irdm_advance(irdm_pipeline_t *p)
+{
+    if (!p) return -1;
+    if (!p->depth) return 0;
+    if (p->begin_no != p->end_no) return -1;
+    pipeline_enter(p);
+    if (settle(p) != 0) return -1;
+    int emitted = 0;
+    auto oldest_of = [&]() -> BatchCtx * {
+        BatchCtx *o = nullptr;
+        for (int i = 0; i < p->n_bc; i++)
+            if (p->bc[i].n > 0 && (!o || p->bc[i].chunk_no < o->chunk_no)) o = &p->bc[i];
+        return o;
+    };
+    for (BatchCtx *o; (o = oldest_of()) != nullptr && (p->detect_only || hipStreamQuery(o->stream) == hipSuccess);) {
+        const int e = deferred_finish(p, *o);
+        if (e < 0) return -1;
+        emitted += e;
+    }
+    if (p->has_pending) {
+        BatchCtx &b = p->bc[p->pend_no % p->n_bc];
+        while (b.n > 0) {            // (records leave in chunk order: everything older than the batch in the way goes first)
+            const int e = deferred_finish(p, *oldest_of());
+            if (e < 0) return -1;
+            emitted += e;
+        }
+        if (deferred_enqueue(p) != 0) return -1;
+    }
+    return emitted;
+}
+
 // A feed in two halves.  irdm_feed_begin: everything that does not depend on the detector state -- K1 of the chunk and
 // (pipeline_depth >= 1) its copy into the history ring.  irdm_feed_end: the detector scan and the per-burst work.  A
 // time-sharded rank calls them around the arrival of the previous rank's state (sharding.py); irdm_feed_device is the
@@ -2305,7 +2441,7 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
     if (n_frames > 0 && launch_kclk_fold(p->kclk_rec(3 + ls), p->fstream) != 0) return -1;   // (behind the event the scan waits for)
     // this chunk into the history ring, behind K1 on its stream (the ring keeps the chunks the per-burst chains in
     // flight still read: the copy never overwrites them)
-    if (p->depth && !in_ring && ring_update(p, d_iq, c0, c1, p->fstream) != 0) return -1;
+    if (p->depth && !in_ring && (ring_guard(p, c0, c1, p->fstream) != 0 || ring_update(p, d_iq, c0, c1, p->fstream) != 0)) return -1;
     IRDM_HIP_CHECK(hipEventRecord(f.ev_copy, p->fstream));
     f.iq = d_iq;
     f.c0 = c0;
@@ -2387,6 +2523,10 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         //    context of the chunk before that is still at work: its tail overlaps this one's FIR.)
         if (deferred_enqueue(p) != 0) return -1;
         IRDM_HOST_PHASE(2);
+        // 3b. the next chunk, if its feed has begun (look-ahead): its round 0 as a speculation pass beside this chunk's scan
+        if (p->begin_no > p->end_no + 1 && p->fl_mode == 2 && p->fl_band_ran &&
+            spec_enqueue(p, p->fs[(p->end_no + 1) % 3], p->chunk_no + 1) != 0)
+            return -1;
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
         if (!finished_early) {
             emitted = deferred_finish(p, oldest);
@@ -2789,7 +2929,9 @@ extern "C" int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, si
         d_iq = static_cast<const char *>(d_iq) + (n_samples - p->ring_len) * p->bps;
         n_samples = p->ring_len;
     }
-    // behind whatever the ring stream still has to do; the per-burst chains wait for ev_ring before they read the ring
+    // behind whatever the ring stream still has to do -- and behind the decimators in flight that still read the slots
+    // (irdm_advance leaves the previous chunk's chain running); the per-burst chains wait for ev_ring before they read the ring
+    if (ring_guard(p, abs_start - n_samples, abs_start, p->fstream) != 0) return -1;
     if (ring_update(p, d_iq, abs_start - n_samples, abs_start, p->fstream) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_ring, p->fstream));
     IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
@@ -3053,6 +3195,8 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
     if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
     if (!strcmp(key, "band_tail")) { irdm::g_band_tail = value != 0; return 0; }
+    if (!strcmp(key, "band_spec")) { p->band_spec_opt = value != 0; return 0; }
+    if (!strcmp(key, "band_hist_side")) { irdm::g_band_hist_side = value != 0; return 0; }
     if (!strcmp(key, "band_tail_threads")) {
         if (value != 256 && value != 512 && value != 1024) return -1;
         irdm::g_band_tail_threads = value;
@@ -3110,6 +3254,9 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "scratch_outputs")) return (int64_t)p->bc[0].dec_cap;
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
     if (!strcmp(key, "tiles_grows")) return (int64_t)p->stat_tiles_grows;
+    if (!strcmp(key, "ring_waits")) return (int64_t)p->stat_ring_waits;
+    if (!strcmp(key, "spec_passes")) return (int64_t)p->stat_spec_passes;
+    if (!strcmp(key, "spec_scans")) return (int64_t)p->stat_spec_scans;
     if (!strcmp(key, "band_tail_launches")) return (int64_t)irdm::g_band_tail_launches.load();      // (process-wide)
     if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;

@@ -280,17 +280,26 @@ constexpr size_t kPlanLdsBytes = ((2 * kPlanLdsFrames + 2 + 15) & ~15) + sizeof(
 static_assert(kZoneLdsBytes <= kPlanLdsBytes, "the boundary test's lists live in the plan's LDS before the plan needs it");
 
 // lds: kPlanLdsBytes of dynamic LDS, or nullptr (the general path through the workspace arrays)
+// u_busy / u_forced: the busy / forced bitmaps the round's update vector is taken from -- W's own (what the previous
+// round's walk produced), or, for the first round of a scan fed by a speculation pass (P.spec_in, round 1), that pass's
 template <int NT>
 __device__ void band_plan_body(const BandParams &P, const BandWork &W, const unsigned *__restrict__ counts,
-                               DetState *__restrict__ st, int round, PlanShared &sh, uint8_t *lds)
+                               DetState *__restrict__ st, int round, PlanShared &sh, uint8_t *lds,
+                               const uint64_t *u_busy = nullptr, const uint64_t *u_forced = nullptr)
 {
+    // first: this pass opens the scan (round 0, or round 1 of a scan whose round 0 was a speculation pass elsewhere)
+    const bool first = round == 0 || (P.spec_in && round == 1);
+    if (!(P.spec_in && round == 1) || u_busy == nullptr) {
+        u_busy = W.busy;
+        u_forced = W.forced;
+    }
     constexpr int kPlanThreads = NT;      // (shadows the launch constant: every stride below is the workgroup's size)
     int32_t *s_part = sh.part;
     int &s_mismatch = sh.mismatch, &s_first = sh.first, &s_status = sh.status, &s_agree_fail = sh.agree_fail;
     unsigned &s_flags = sh.flags;
     const int tid = threadIdx.x;
     BandCtl *ctl = W.ctl;
-    if (round == 0) {
+    if (first) {
         // the scan in front committed (bar[4], set by its commit pass)?  A chained launch that finds it did not leaves
         // everything -- workspace, control block, carried state -- as it is: the host continues or redoes that scan
         if (tid == 0) {
@@ -305,7 +314,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
     } else if (band_void(P, W)) {
         return;
     }
-    if (round == 0) {
+    if (first) {
         // a new scan: control block, abort flags and the chunk's finished-burst count start from zero (what three
         // memset launches did before)
         if (tid < (int)(sizeof(BandCtl) / 4)) reinterpret_cast<uint32_t *>(ctl)[tid] = 0;
@@ -314,6 +323,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             st->n_gone = 0;
         }
         __syncthreads();
+        if (round != 0 && tid == 0) ctl->h0 = st->hist_idx;       // (round 0 notes it with its plan below)
     }
     if (ctl->status != 0) return;
     const int F = P.n_frames;
@@ -372,6 +382,25 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             }
         }
         return;
+    } else if (first) {
+        // no previous round of this scan to judge: the update vector comes from the speculation pass.  What round 0's plan
+        // checks of the lists is checked here.
+        for (int f = tid; f < F; f += kPlanThreads)
+            if (counts[f] > (unsigned)P.list_cap) atomicOr(&s_flags, BAND_F_LIST);
+        __syncthreads();
+        if (s_flags) {
+            if (tid == 0) {
+                ctl->flags = s_flags;
+                ctl->rounds = 1;
+                ctl->status = 2;
+            }
+            return;
+        }
+        // (the planned vector, as the next round's verdict compares it with what this round produces)
+        for (int f = tid; f < F; f += kPlanThreads) {
+            W.uq[f] = ((u_busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
+            W.uf[f] = (uint8_t)((u_forced[f >> 6] >> (f & 63)) & 1);
+        }
     } else {
         // verdict on the previous round
         for (int f = tid; f < F; f += kPlanThreads) {
@@ -467,8 +496,8 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         for (int j = 0; j < FPT; j++) {
             const int f = f0 + j;
             if (f < F) {
-                const int q = ((W.busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
-                const int fc = (int)((W.forced[f >> 6] >> (f & 63)) & 1);
+                const int q = ((u_busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
+                const int fc = (int)((u_forced[f >> 6] >> (f & 63)) & 1);
                 uqb |= q << j;
                 ufb |= fc << j;
                 cnz |= (counts[f] > 0 ? 1 : 0) << j;
@@ -635,6 +664,9 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
 __device__ void band_commit_body(const BandParams &P, const BandWork &W, DetState *__restrict__ st,
                                  float *__restrict__ sum, GoneBurst *__restrict__ gone, int gone_cap,
                                  unsigned char *smem_raw);
+__device__ void band_tail_export(const DetState *__restrict__ st, const uint32_t *__restrict__ gone, int cap,
+                                 uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr, const uint32_t *__restrict__ ctl,
+                                 uint32_t *__restrict__ hp_ctl, int ctl_words, bool voided);
 
 // fuse != 0: a verdict "accepted" is followed by the commit in the same workgroup (the commit pass enqueued behind the
 // rounds then finds its work done) -- one launch and its wait less on the scan's critical path
@@ -643,8 +675,13 @@ __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W,
                                                        DetState *__restrict__ st, int round, float *__restrict__ sum,
                                                        GoneBurst *__restrict__ gone, int gone_cap, int fuse,
                                                        unsigned wait_target, const float *__restrict__ pre,
-                                                       float *__restrict__ smin_out)
+                                                       float *__restrict__ smin_out, const uint64_t *u_busy,
+                                                       const uint64_t *u_forced, int hp_cap, uint32_t *hp_gone,
+                                                       uint32_t *hp_hdr, uint32_t *hp_ctl)
 {
+    // hp_hdr != nullptr (band_hist_side: the launch's last plan pass): this workgroup also exports the control block and the
+    // finished bursts' records to pinned host memory -- what band_history_kernel's first workgroups do otherwise; the
+    // history copy then runs on a side stream, off the chain of scans
     IRDM_DETECTOR_PRIO();
     if (P.ahead && round >= 1) {
         // launched ahead of the walk pass whose results it judges (on a second stream): resident, waiting for that pass's
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W,
     __shared__ PlanShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
     static_assert(kPlanLdsBytes >= (size_t)kBandMaxTotal * 10, "the fused commit sorts in the plan pass's LDS");
-    band_plan_body<NT>(P, W, counts, st, round, sh, (P.selfcheck & 16) ? nullptr : plan_lds);
+    band_plan_body<NT>(P, W, counts, st, round, sh, (P.selfcheck & 16) ? nullptr : plan_lds, u_busy, u_forced);
     if (round == 0 && pre != nullptr) {
         // Round 0 has no update steps: its sums pass would copy the carried sums into snapshot 0 and check the lists'
         // levels against them (band_sum_body with n_upd = 0) -- N loads and stores, done here by the workgroup that is
@@ -690,6 +727,11 @@ __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W,
     if (fuse && round >= 1 && !(P.selfcheck & 16)) {
         __syncthreads();
         if (!band_void(P, W) && W.ctl->status == 1) band_commit_body(P, W, st, sum, gone, gone_cap, plan_lds);
+    }
+    if (hp_hdr != nullptr) {
+        __syncthreads();
+        band_tail_export(st, reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap, hp_gone, hp_hdr,
+                         reinterpret_cast<const uint32_t *>(W.ctl), hp_ctl, (int)(sizeof(BandCtl) / 4), band_void(P, W));
     }
 }
 
@@ -1195,7 +1237,7 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 2);
     __shared__ uint32_t s_bits_all[4][16384 / 32];
     const bool live = !(band_void(P, W) || W.ctl->status != 0);
-    if (!live && !P.tail) return;
+    if (!live && !(P.tail & 1)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
     uint32_t *s_bits = s_bits_all[wave];
@@ -1211,7 +1253,7 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
             band_cross_wave(P, W, c, entries, f0 + j * n_waves, s_bits, lane);
         }
     }
-    if (!P.tail) return;
+    if (!(P.tail & 1)) return;
     // band_tail: the workgroup that leaves last lists the (band, 64-frame block) pairs in which a segment starts -- what every
     // wavefront of the walk pass used to find out for its own share of the pairs, a fixed share: the walk then lasted as long
     // as its unluckiest wavefront (72 events where the mean was 15: 80 us of a pass whose longest single pair is 31 events).
@@ -1296,6 +1338,71 @@ __global__ __launch_bounds__(kCoopThreads) void band_coop_kernel(BandParams P, B
     if (!ok && blockIdx.x == 0 && tid == 0) {
         ctl->flags |= BAND_F_COOP;
         ctl->status = 2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// band_spec: round 0 as a SPECULATION PASS beside the previous chunk's scan.
+//
+// Round 0 of a scan exists to guess the update vector u (which frames end quiet, which force an update): it speculates
+// "no update", lets the bands walk the chunk on the frozen sums and hands what they produce to round 1, whose verdict --
+// produced u == planned u, neighbouring bands agree, no squelch -- is what makes a result exact.  Nothing of round 0 is
+// kept but that guess.  And a guess needs no exact inputs: run on the sums as chunk k's round 1 leaves them (available
+// after its sums pass) and on the bursts the PREVIOUS speculation pass left active at its chunk's end, the guess for chunk
+// k + 1 can be made on a second workspace while chunk k's round 1 is still crossing, walking and committing.  The scan of
+// chunk k + 1 then opens with round 1 (BandParams::spec_in): plan . sums . cross . walk . verdict + commit -- half the
+// dependent launches per chunk on the stream whose back-to-back scans are the pipeline's period.  A wrong guess (a carried
+// burst the speculation did not know) costs a further round like any other mismatch; the verdict never looks at where a
+// plan came from.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void band_spec_prep_kernel(BandParams P, BandWork S, const unsigned *__restrict__ counts,
+                                                              const float *__restrict__ sum_src, DetState *__restrict__ st_spec,
+                                                              int have_prev)
+{
+    IRDM_DETECTOR_PRIO();
+    const int tid = threadIdx.x, F = P.n_frames;
+    __shared__ unsigned s_n;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // what the previous speculation pass left active at the end of ITS chunk is what this one takes over at the start of
+    // its own (records still hold that pass's walk; ids do not matter to a guess)
+    if (have_prev)
+        for (int band = tid >> 4; band < P.n_bands; band += 1024 / 16) {
+            const int cnt = min((int)S.rec_count[band], kBandRecCap);
+            for (int j = tid & 15; j < cnt; j += 16) {
+                const BandRec &r = S.recs[(size_t)band * kBandRecCap + j];
+                if (!(r.flags & 1) || r.stop >= 0) continue;
+                const unsigned at = atomicAdd(&s_n, 1u);
+                if (at < (unsigned)kMaxActive) {
+                    ActiveBurst a;
+                    a.id = 0; a.start = (uint64_t)r.start; a.last_active = (uint64_t)r.last_active;
+                    a.center_bin = r.cb; a.peak_rel = r.rel; a.base_sum = r.base; a.pad = 0;
+                    st_spec->act[at] = a;
+                }
+            }
+        }
+    __syncthreads();
+    if (tid == 0) st_spec->n_act = (uint32_t)min(s_n, (unsigned)kMaxActive);
+    // round 0's plan on the speculation workspace: no update steps, one snapshot -- the sums handed in
+    if (tid < (int)(sizeof(BandCtl) / 4)) reinterpret_cast<uint32_t *>(S.ctl)[tid] = 0;
+    for (int f = tid; f < F; f += 1024) {
+        const int slot = counts[f] > 0 ? 0 : -1;
+        S.slot_pre[f] = slot;
+        S.slot_post[f] = slot;
+    }
+    for (int i = tid; i < P.n_bands * P.occ_words; i += 1024) S.occ[i] = 0;
+    for (int i = tid; i < P.occ_words; i += 1024) {
+        S.busy[i] = 0;
+        S.forced[i] = 0;
+        S.conc[i] = 0;
+    }
+    for (int i = tid; i < P.n_bands; i += 1024) S.rec_count[i] = 0;
+    for (int b = tid; b < P.n; b += 1024) S.snap[b] = sum_src[b];
+    __syncthreads();
+    if (tid == 0) {
+        *S.flags = 0;
+        S.ctl->rounds = 1;
+        S.snap_slot[0] = 0;
     }
 }
 
@@ -1426,7 +1533,7 @@ __device__ void band_commit_body(const BandParams &P, const BandWork &W, DetStat
         }
     }
     for (int b = tid; b < P.n; b += kPlanThreads) sum[b] = W.sum_new[b];
-    if (P.tail && W.hist_job) {
+    if ((P.tail & 2) && W.hist_job) {
         // what the history pass needs of this chunk, where the next chunk's scan does not touch it (HistJob)
         const int nu = ctl->n_upd, cnt = nu < kHistory ? nu : kHistory;
         for (int i = tid; i < cnt; i += kPlanThreads) W.hist_job->frame[i] = W.upd_frame[nu - 1 - i];
@@ -1541,7 +1648,8 @@ int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment
 int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
 int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
 int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
-int g_band_tail = 1;        // 1: six dependent launches per two-round scan instead of nine (band_walk_tail_kernel); needs the wavefront
+int g_band_hist_side = 0;   // 1: a launch per pass with the history copy on the side stream and the export in the last plan pass
+int g_band_tail = 0;        // 1: six dependent launches per two-round scan instead of nine (band_walk_tail_kernel); needs the wavefront
                             // walk, the wavefront crossing pass and the LDS plan; 0: a launch per pass
 std::atomic<unsigned long long> g_band_tail_launches{ 0 };     // launches that took the tail form (stat band_tail_launches)
 int g_band_tail_threads = 1024;   // workgroup size of the walk pass that carries the tail (the plan's width): 256 / 512 / 1024
@@ -1577,7 +1685,8 @@ int band_scan_supported(const DetParams &D, BandParams *out, int n_frames, uint6
     return 1;
 }
 
-size_t band_work_bytes(int n, size_t max_chunk)
+// spec: the workspace of the speculation passes (band_spec): one snapshot row instead of F + 2
+size_t band_work_bytes(int n, size_t max_chunk, bool spec)
 {
     const size_t F = max_chunk / (size_t)n + 2;
     size_t b = 0;
@@ -1591,7 +1700,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     add(4 * F); add(4 * F);                          // slot_pre, slot_post
     add(F * (size_t)n / 8);                          // cross
     add(F * (size_t)n * 4);                          // relq
-    add((F + 2) * (size_t)n * 4);                    // snap
+    add((spec ? 2 : F + 2) * (size_t)n * 4);         // snap
     add(64 * ((F + 63) / 64) * 8);                   // occ
     add(((F + 63) / 64) * 8); add(((F + 63) / 64) * 8); add(((F + 63) / 64) * 4);   // busy, forced, conc
     add(sizeof(BandRec) * 64 * kBandRecCap); add(4 * 64);                            // recs, rec_count
@@ -1602,7 +1711,7 @@ size_t band_work_bytes(int n, size_t max_chunk)
     return b;
 }
 
-int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
+int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk, bool spec)
 {
     const size_t F = max_chunk / (size_t)n + 2;
     unsigned char *p = static_cast<unsigned char *>(base);
@@ -1622,8 +1731,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk)
     W->slot_post = static_cast<int32_t *>(take(4 * F));
     W->cross = static_cast<uint64_t *>(take(F * (size_t)n / 8));
     W->relq = static_cast<float *>(take(F * (size_t)n * 4));
-    W->snap = static_cast<float *>(take((F + 2) * (size_t)n * 4));
-    W->snap_cap = (int)(F + 2);
+    W->snap = static_cast<float *>(take((spec ? 2 : F + 2) * (size_t)n * 4));
+    W->snap_cap = (int)(spec ? 2 : F + 2);
     W->occ = static_cast<uint64_t *>(take(64 * ((F + 63) / 64) * 8));
     W->busy = static_cast<uint64_t *>(take(((F + 63) / 64) * 8));
     W->forced = static_cast<uint64_t *>(take(((F + 63) / 64) * 8));
@@ -1655,13 +1764,62 @@ void band_resolve_env()
     });
 }
 
+// (one counter for all contexts of the process, fed from any thread: two launches never share a serial number)
+static unsigned next_launch_serial()
+{
+    static std::atomic<unsigned> launch_serial{ 0 };
+    unsigned serial = launch_serial.fetch_add(1) + 1;
+    if (serial == 0) serial = launch_serial.fetch_add(1) + 1;       // (never 0: the idle value of bar[5])
+    return serial;
+}
+
+// The speculation pass of a chunk (band_spec, above) on `stream`: prep . cross . walk on the workspace S.  sum_src: the sums
+// the crossings are tested against (the scan workspace's sum_new: what the previous chunk's round 1 computed); have_prev: S
+// still holds the previous speculation pass's records (its bursts active at the end become this pass's carried bursts).
+int launch_band_spec(const DetParams &D, BandWork S, DetState *st_spec, const float *sum_src, int n_frames, uint64_t idx0,
+                     const unsigned *counts, const ListEntry *entries, int have_prev, hipStream_t stream)
+{
+    BandParams P;
+    if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
+    P.serial = (int32_t)next_launch_serial();
+    P.selfcheck = g_band_selfcheck & 8;
+    BandIO io;
+    io.cross = S.cross;
+    io.occ = S.occ;
+    io.relq = S.relq;
+    io.snap = S.snap;
+    io.slot_post = S.slot_post;
+    io.act_in = nullptr;
+    io.n_act_in = 0;
+    io.recs = S.recs;
+    io.rec_count = S.rec_count;
+    io.busy = S.busy;
+    io.forced = S.forced;
+    io.conc = S.conc;
+    io.flags = S.flags;
+    hipLaunchKernelGGL(band_spec_prep_kernel, dim3(1), dim3(1024), 0, stream, P, S, counts, sum_src, st_spec, have_prev);
+    hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, S, counts, entries);
+    if (P.band_w == 128)
+        hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, S, io, st_spec);
+    else
+        hipLaunchKernelGGL((band_walk_wave_kernel<8>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, S, io, st_spec);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
                      uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream, hipStream_t side,
                      hipEvent_t *plan_ev, const uint32_t *gate_flag, uint32_t gate_seq, uint32_t *gate_err, const void *gate_src,
-                     size_t gate_bytes, uint32_t scan_seq, hipEvent_t hist_wait, hipEvent_t hist_done, hipEvent_t hist_hop)
+                     size_t gate_bytes, uint32_t scan_seq, hipEvent_t hist_wait, hipEvent_t hist_done, hipEvent_t hist_hop,
+                     const BandWork *spec, hipEvent_t sums_done)
 {
+    // spec: a speculation pass made this chunk's round 0 on that workspace (launch_band_spec): the scan opens with round 1,
+    // whose plan takes the update vector from spec's bitmaps (round_begin must be 1).  sums_done: recorded behind the first
+    // sums pass of this launch (its sum_new is what the NEXT chunk's speculation pass tests against).
+    if (spec && round_begin != 1) return -1;
+    const uint64_t *ub = spec ? spec->busy : nullptr, *uf = spec ? spec->forced : nullptr;
+    bool sums_noted = sums_done == nullptr;
     // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
     // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
     // verdict is still open (status 0, no flags), the rest up to kBandRounds with round_begin = kBandFirst: everything a
@@ -1669,12 +1827,9 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     if (g_band_plan_ahead < 0) band_resolve_env();
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
-    // (one counter for all contexts of the process, fed from any thread: two launches never share a serial number)
-    static std::atomic<unsigned> launch_serial{ 0 };
-    unsigned serial = launch_serial.fetch_add(1) + 1;
-    if (serial == 0) serial = launch_serial.fetch_add(1) + 1;       // (never 0: the idle value of bar[5])
-    P.serial = (int32_t)serial;
+    P.serial = (int32_t)next_launch_serial();
     P.chained = chained;
+    P.spec_in = spec ? 1 : 0;
     P.selfcheck = g_band_selfcheck;
     P.ahead = (g_band_plan_ahead && !g_band_coop && side && plan_ev && W.walk_host) ? 1 : 0;
     P.tl_sel = g_band_timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;
@@ -1711,7 +1866,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                       scan_seq != 0 && side && hist_done && hist_hop && round_end > round_begin;
     if (tail) {
         // ---- band_tail: plan0 . [sums . cross . walk + the next plan] per round; the history copy on the side stream ----
-        P.tail = 1;
+        P.tail = 3;
         P.seq = scan_seq;
         g_band_tail_launches++;
         const int nt = g_band_tail_threads == 256 ? 256 : g_band_tail_threads == 512 ? 512 : 1024;
@@ -1726,14 +1881,14 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             return 0;
         };
         for (int round = round_begin; round < round_end; round++) {
-            if (round == 0) {
-                const float *pre0 = g_band_fold_sums0 ? pre : nullptr;
+            if (round == 0 || (spec && round == 1)) {
+                const float *pre0 = (round == 0 && g_band_fold_sums0) ? pre : nullptr;
                 if (g_band_plan_threads == 256)
-                    hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), kPlanLdsBytes, stream, P, W, counts, st, 0, sum, gone, gone_cap, 0, 0u, pre0, smin);
+                    hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), kPlanLdsBytes, stream, P, W, counts, st, round, sum, gone, gone_cap, 0, 0u, pre0, smin, ub, uf, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
                 else if (g_band_plan_threads == 512)
-                    hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), kPlanLdsBytes, stream, P, W, counts, st, 0, sum, gone, gone_cap, 0, 0u, pre0, smin);
+                    hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), kPlanLdsBytes, stream, P, W, counts, st, round, sum, gone, gone_cap, 0, 0u, pre0, smin, ub, uf, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
                 else
-                    hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), kPlanLdsBytes, stream, P, W, counts, st, 0, sum, gone, gone_cap, 0, 0u, pre0, smin);
+                    hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), kPlanLdsBytes, stream, P, W, counts, st, round, sum, gone, gone_cap, 0, 0u, pre0, smin, ub, uf, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
             }
             if (gate_flag && round == (round_begin > 1 ? round_begin : 1)) {
                 if (wait_hist() != 0) return -1;
@@ -1748,6 +1903,11 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
                     hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
                 else
                     hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+            if (!sums_noted && round >= 1) {
+                // (the first real sums pass of the scan: its sum_new is what the next chunk's speculation pass tests against)
+                if (hipEventRecord(sums_done, stream) != hipSuccess) return -1;
+                sums_noted = true;
+            }
             }
             hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
             if (wait_hist() != 0) return -1;
@@ -1774,9 +1934,26 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         if (hipEventRecord(hist_done, side) != hipSuccess) return -1;
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
-    // (a launch per pass, or the cooperative kernel: everything on `stream`, behind a history copy a tail-form scan may have
-    // left on the side stream)
-    if (hist_wait && hipStreamWaitEvent(stream, hist_wait, 0) != hipSuccess) return -1;
+    // band_hist_side: a launch per pass, but the history copy on the side stream (from the HistJob the commit writes) and the
+    // export in the launch's last plan pass -- the copy of 2 x 16-32 MB (56-63 us in run, plus the launch) leaves the chain
+    // of scans.  The previous scan's copy must be over before a pass of this one reads the ring (a sums pass of round >= 1)
+    // or may commit (a plan pass of round >= 1 rewrites the one HistJob).
+    const bool hside = g_band_hist_side && !g_band_coop && !P.ahead && g_band_fuse_commit && !(P.selfcheck & 16) && scan_seq != 0 &&
+                       side && hist_done && hist_hop;
+    bool waited_legacy = hist_wait == nullptr;
+    auto wait_hist_legacy = [&]() -> int {
+        if (!waited_legacy && hipStreamWaitEvent(stream, hist_wait, 0) != hipSuccess) return -1;
+        waited_legacy = true;
+        return 0;
+    };
+    if (hside) {
+        P.tail = 2;
+        P.seq = scan_seq;
+    } else if (wait_hist_legacy() != 0) {
+        // (a launch per pass, or the cooperative kernel: everything on `stream`, behind a history copy an earlier scan may
+        // have left on the side stream)
+        return -1;
+    }
     if (g_band_coop) {
         // every round up to the verdict in one launch (the kernel leaves as soon as a round is accepted or declined)
         (void)round_end;
@@ -1792,7 +1969,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     } else
     for (int round = round_begin; round <= round_end; round++) {
         // (a continuation starts behind the plan its predecessor's verdict pass already made)
-        if (round > round_begin || round_begin == 0)
+        if (round > round_begin || round_begin == 0 || spec)
         {
             const size_t plan_lds = (P.selfcheck & 16) ? 0 : kPlanLdsBytes;
             // (ahead: the walk pass this plan judges was enqueued just above; its workgroups bring bar[8] to *walk_host)
@@ -1802,12 +1979,17 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             Pp.ahead = ahead ? 1 : 0;
             const unsigned target = ahead ? *W.walk_host : 0u;
             const float *pre0 = (round == 0 && g_band_fold_sums0) ? pre : nullptr;      // round 0's sums pass inside its plan pass
+            // (band_hist_side: the launch's last plan pass exports; one that may commit goes behind the previous history copy)
+            const bool exp = hside && round == round_end;
+            uint32_t *xg = exp ? reinterpret_cast<uint32_t *>(hp_gone) : nullptr, *xh = exp ? hp_hdr : nullptr,
+                     *xc = exp ? static_cast<uint32_t *>(hp_ctl) : nullptr;
+            if (hside && round >= 1 && !(spec && round == 1) && wait_hist_legacy() != 0) return -1;
             if (g_band_plan_threads == 256)
-                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin);
+                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin, ub, uf, hp_cap, xg, xh, xc);
             else if (g_band_plan_threads == 512)
-                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin);
+                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin, ub, uf, hp_cap, xg, xh, xc);
             else
-                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin);
+                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin, ub, uf, hp_cap, xg, xh, xc);
             if (ahead) {
                 // what follows on the scan's own stream waits for this plan
                 (void)hipEventRecord(plan_ev[round], side);
@@ -1821,9 +2003,11 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
         // arrived in the caller's receive buffer) and the copy of it into the ring, both on this stream: nothing the
         // waiting kernel depends on needs another queue of the GPU.
         if (gate_flag && round == (round_begin > 1 ? round_begin : 1)) {
+            if (wait_hist_legacy() != 0) return -1;
             if (launch_wait_host_flag(gate_flag, gate_seq, gate_err, stream) != 0) return -1;
             if (hipMemcpyAsync(hist, gate_src, gate_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
         }
+        if (hside && round >= 1 && wait_hist_legacy() != 0) return -1;
         if (round == 0 && g_band_fold_sums0) {
             // (done by the plan pass above)
         } else if (g_band_sum_bins == 32)
@@ -1832,6 +2016,11 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
             hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         else
             hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+        if (!sums_noted && round >= 1) {
+            // (the first real sums pass of the scan: its sum_new is what the next chunk's speculation pass tests against)
+            if (hipEventRecord(sums_done, stream) != hipSuccess) return -1;
+            sums_noted = true;
+        }
         if (g_band_cross_wave)
             hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
         else
@@ -1851,6 +2040,15 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     if (g_band_coop || !g_band_fuse_commit || (P.selfcheck & 16))
         hipLaunchKernelGGL(band_commit_kernel, dim3(1), dim3(kPlanThreads), commit_lds, stream, P, W, st, sum, gone, gone_cap);
     static_assert(kHistory >= kExportBlocks, "the export rides on the history pass's first workgroups");
+    if (hside) {
+        // (the export went with the last plan pass; the copy: behind this launch's last pass, on the side stream)
+        if (hipEventRecord(hist_hop, stream) != hipSuccess || hipStreamWaitEvent(side, hist_hop, 0) != hipSuccess) return -1;
+        hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, side, P, W, mag, hist, st,
+                           reinterpret_cast<const uint32_t *>(gone), 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                           W.hist_job, scan_seq);
+        if (hipEventRecord(hist_done, side) != hipSuccess) return -1;
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist, st,
                        reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap,
                        reinterpret_cast<uint32_t *>(hp_gone), hp_hdr, static_cast<uint32_t *>(hp_ctl), (const HistJob *)nullptr, 0u);

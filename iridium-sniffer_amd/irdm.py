@@ -114,6 +114,8 @@ def lib():
         L.irdm_feed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.irdm_feed_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.irdm_flush.argtypes = [C.c_void_p]
+        if hasattr(L, "irdm_advance"):
+            L.irdm_advance.argtypes = [C.c_void_p]
         L.irdm_host_alloc.argtypes = [C.c_size_t]
         L.irdm_host_alloc.restype = C.c_void_p
         L.irdm_host_free.argtypes = [C.c_void_p]
@@ -373,6 +375,13 @@ class Pipeline:
         rc = self.L.irdm_flush(self.h)
         if rc < 0:
             raise RuntimeError("irdm_flush failed")
+        return rc
+
+    def advance(self):
+        """irdm_flush without the waiting: the scan in flight settled, its bursts' chain enqueued, finished records out"""
+        rc = self.L.irdm_advance(self.h)
+        if rc < 0:
+            raise RuntimeError("irdm_advance failed")
         return rc
 
     def _poll(self, fn, typ, chunk=256):

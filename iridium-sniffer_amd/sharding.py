@@ -134,14 +134,15 @@ class TimeShard:
                               waits for it on the device (irdm_expect_history)
         export + send         head, then history, as soon as the scan has settled; only recv head -> scan -> send head
                               is sequential across the ranks (burst_detect.c:438-454, :594-631)
-        flush                 the chunk's per-burst stages, overlapping the next ranks' scans
+        advance               the chunk's per-burst stages ENQUEUED (irdm_advance): they overlap the next ranks' scans and
+                              this rank's next super-step (scatter, K1); records one step late, drain() at the end
 
     With "nccl" the blob is a device tensor (RCCL send/recv over xGMI); with "gloo" (CPU tests, or several ranks
     sharing one GPU) it bounces through a host tensor.  Expected throughput: world * chunk / max(world * t_hop,
     t_rank), t_hop = recv + import + scan + export + send, t_rank = t_hop + K1 + per-burst chain -- the state chain
     caps the speed-up at t_rank / t_hop however many GPUs there are."""
 
-    def __init__(self, dist, pipe, torch, device, chunk_samples, bps, overlap):
+    def __init__(self, dist, pipe, torch, device, chunk_samples, bps, overlap, overlap_chain=True):
         self.dist, self.pipe, self.torch, self.device = dist, pipe, torch, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.chunk, self.bps, self.overlap = chunk_samples, bps, overlap
@@ -153,18 +154,31 @@ class TimeShard:
         self.state = torch.empty(self.nbytes, dtype=torch.uint8, device=device)
         self.host_state = None if self.nccl else torch.empty(self.nbytes, dtype=torch.uint8)
         self.step_no = 0
-        self.have_head = self.have_hist = False       # rank 0: parts of the last rank's state already received
+        # overlap_chain: a step ends with irdm_advance (the chunk's per-burst chain enqueued, not waited for): the chain runs
+        # beside the next super-step's scatter, K1 and scan, and its records come out one step later (drain() brings the
+        # last ones).  False: irdm_flush at the end of every step (records of a chunk with its own step).
+        self.overlap_chain = overlap_chain and hasattr(pipe.L, "irdm_advance")
+        self.pending = None               # rank 0: (work_head, work_history) of the last rank's state, receives posted ahead
+        # host time per part of a step, seconds, summed (bench.py reports them per super-step: what a rank waits for where)
+        self.t = {k: 0.0 for k in ("seed_k1", "recv_head", "scan_enqueue", "recv_history", "scan_settle", "send", "chain")}
+        self.steps_timed = 0
 
-    def _recv_part(self, src, lo, hi):
-        if self.nccl:
-            self.dist.recv(self.state[lo:hi], src=src)
-        else:
-            self.dist.recv(self.host_state[lo:hi], src=src)
+    # ---- the two parts of the state blob: receives may be posted ahead (rank 0), sends block ----
+    def _post_recv(self, src, lo, hi):
+        t = self.state if self.nccl else self.host_state
+        return self.dist.irecv(t[lo:hi], src=src)
+
+    def _finish_recv(self, work, lo, hi):
+        work.wait()
+        if not self.nccl:
             self.state[lo:hi].copy_(self.host_state[lo:hi])
         if self.device.type == "cuda":          # (a CPU device only in the emulated tests: nothing is in flight there)
             # the stream the part arrived on, NOT the device: this rank's scan may be on the GPU waiting for exactly this
             # part (irdm_expect_history), and a device-wide wait would wait for the scan
             self.torch.cuda.current_stream(self.device).synchronize()
+
+    def _recv_part(self, src, lo, hi):
+        self._finish_recv(self._post_recv(src, lo, hi), lo, hi)
 
     def _send_part(self, dst, lo, hi):
         if self.nccl:
@@ -175,10 +189,11 @@ class TimeShard:
 
     def step(self, buf, first_of_stream):
         """buf: device uint8 tensor holding [overlap samples | chunk samples] for this rank's chunk of the current
-        super-step (the overlap part is ignored for the very first chunk of the stream).  Returns after the chunk's
-        records are in the pipeline's queues.  Every rank's point-to-point traffic of a super-step is complete when
-        step() returns on all ranks (rank 0 takes the last rank's state at the END of its step and keeps it for the
-        next one), so collectives may follow."""
+        super-step (the overlap part is ignored for the very first chunk of the stream).  Returns when this rank's scan has
+        settled and its state is on its way; with overlap_chain the chunk's per-burst chain is still running (its records
+        reach the pipeline's queues during the next step, the last ones at drain()).  Rank 0 has POSTED the receives of the
+        last rank's state and completes them at the start of its next step: the only point-to-point traffic that crosses a
+        step boundary, matched by the last rank's sends of this step."""
         pipe, rank, world = self.pipe, self.rank, self.world
         abs_start = (self.step_no * world + rank) * self.chunk
         base = buf.data_ptr()
@@ -188,42 +203,73 @@ class TimeShard:
             pipe.flush()
             self.step_no += 1
             return
+        import time
+        t = self.t
+        tp = [time.perf_counter()]
+
+        def lap(key):
+            now = time.perf_counter()
+            t[key] += now - tp[0]
+            tp[0] = now
         first = first_of_stream and self.step_no == 0 and rank == 0
         head, nbytes, sp = self.head, self.nbytes, self.state.data_ptr()
         if not first:
             pipe.seed_history_device(base, self.overlap, abs_start)
         pipe.feed_begin(base + self.overlap * self.bps, self.chunk, None)
+        lap("seed_k1")
         late_history = False
+        w_hist = None
         if not first:
             prev = (rank - 1) % world
-            if not self.have_head:
-                self._recv_part(prev, 0, head)
-            # (rank 0 received what had arrived of the last rank's state at the end of its previous step)
+            if self.pending is not None:
+                w_head, w_hist = self.pending            # (rank 0: posted at the end of the previous step)
+                self.pending = None
+            else:
+                w_head = self._post_recv(prev, 0, head)
+            self._finish_recv(w_head, 0, head)
             pipe.import_state_head_device(sp, head)
             # the history follows while K1 and round 0 of the scan run -- if this scan can wait for it on the device
             # (a primed detector, the band scan, pipeline_depth >= 1, a real GPU: the emulated device runs a launch to
             # its end when it is enqueued)
-            late_history = (not self.have_hist) and self.device.type == "cuda" and pipe.expect_history(sp + head)
+            late_history = self.device.type == "cuda" and pipe.expect_history(sp + head)
+            if w_hist is None:
+                w_hist = self._post_recv(prev, head, nbytes)
+            lap("recv_head")
             if not late_history:
-                if not self.have_hist:
-                    self._recv_part(prev, head, nbytes)
+                self._finish_recv(w_hist, head, nbytes)
                 pipe.import_state_history_device(sp + head, nbytes - head)
+                lap("recv_history")
         pipe.feed_end()
+        lap("scan_enqueue")
         if late_history:
-            self._recv_part((rank - 1) % world, head, nbytes)
+            self._finish_recv(w_hist, head, nbytes)
             pipe.import_state_history_device(sp + head, nbytes - head)
-        self.have_head = self.have_hist = False
+            lap("recv_history")
         pipe.export_state_device(sp, nbytes)             # (waits for this chunk's scan)
+        lap("scan_settle")
         nxt = (rank + 1) % world
         self._send_part(nxt, 0, head)                    # the next rank's scan can start: head first ...
         self._send_part(nxt, head, nbytes)               # ... the history behind it
-        pipe.flush()
+        lap("send")
+        if self.overlap_chain:
+            pipe.advance()                               # this chunk's per-burst chain: enqueued, not waited for
+        else:
+            pipe.flush()
+        lap("chain")
+        self.steps_timed += 1
         if rank == 0:
-            self._recv_part(world - 1, 0, head)
-            self._recv_part(world - 1, head, nbytes)
-            self.have_head = self.have_hist = True
+            # the last rank's state of this super-step is what rank 0's next chunk starts from: the receives are posted
+            # now and completed when the next step needs them -- rank 0 does not idle until the last rank's scan settles
+            self.pending = (self._post_recv(world - 1, 0, head), self._post_recv(world - 1, head, nbytes))
         self.step_no += 1
 
     def drain(self):
-        """Nothing left in flight (kept for callers of the earlier protocol)."""
+        """End of the stream: the chains still in flight finish (their records become pollable) and rank 0 takes delivery of
+        the last rank's final state, so that no point-to-point message is left unmatched."""
+        if self.world > 1:
+            self.pipe.flush()
+            if self.pending is not None:
+                self._finish_recv(self.pending[0], 0, self.head)
+                self._finish_recv(self.pending[1], self.head, self.nbytes)
+                self.pending = None
         return

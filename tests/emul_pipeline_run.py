@@ -87,10 +87,27 @@ def main():
         iq = scene(fs, 0.95, 8, 77)
         ref = orc.run_stream(iq, fs)
         first = 512 * 8192
-        c = ((len(iq) - first) // 3) // 32768 * 32768
-        got = parity.run_gpu(iq, fs, chunks=[first, c, c, len(iq) - first - 2 * c], depth=2, feed="ingest_lookahead")
+        c = ((len(iq) - first) // 5) // 32768 * 32768
+        sizes = [first, c, c, c, c, len(iq) - first - 4 * c]
+        got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead")
         res["default"] = parity.compare(got, ref)
         res["default"]["k1_lists"] = got["stats"]["k1_lists"]
+        # fed with look-ahead, the chained scans open with round 1: their round 0 was a speculation pass on the second
+        # workspace, enqueued with the previous chunk (band_spec)
+        assert got["stats"]["spec_scans"] >= 2 and got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
+        res["default"]["spec_scans"] = got["stats"]["spec_scans"]
+        got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"band_spec": 0})
+        res["without_speculation_pass"] = parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] == 0 and got["stats"]["scan_chained"] >= 2, got["stats"]
+        got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"band_tail": 1})
+        res["tail_form"] = parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] >= 2, got["stats"]
+        got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"band_tail": 0, "band_hist_side": 1})
+        res["history_copy_on_the_side_stream"] = parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] >= 2, got["stats"]
+        irdm_p = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        irdm_p.set_option("band_hist_side", 0)
+        irdm_p.close()
         # the same stream with the decimating FIR in the reference's scalar order (--no-simd: fir_decimate_kernel_r, one
         # accumulator per output travelling from lane to lane) against the oracle in that order
         orc.set_fir_order(0)

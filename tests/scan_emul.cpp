@@ -21,6 +21,11 @@ namespace irdm {
 int launch_wait_host_flag(const uint32_t *, uint32_t, uint32_t *, hipStream_t) { return -1; }
 }
 
+// 1: every chunk but the first gets its round 0 from a speculation pass on a second workspace (launch_band_spec), run
+// before the scan as csrc/pipeline.cpp's spec_enqueue does -- on the sums the previous scan computed and the bursts the
+// previous pass left active; 2: the same with the carried bursts withheld (a wrong guess must cost a round, not a result)
+static int g_emul_spec = 0;
+
 extern "C" {
 
 // test hooks of the scan (csrc/kernels.hpp: g_band_*)
@@ -35,6 +40,8 @@ void scan_emul_option(const char *key, int value)
     else if (!strcmp(key, "band_cross_wave")) g_band_cross_wave = value;
     else if (!strcmp(key, "band_timeline")) g_band_timeline = value;
     else if (!strcmp(key, "band_fold_sums0")) g_band_fold_sums0 = value;
+    else if (!strcmp(key, "band_spec")) g_emul_spec = value;
+    else if (!strcmp(key, "band_hist_side")) g_band_hist_side = value;
     else if (!strcmp(key, "band_tail")) g_band_tail = value;
     else if (!strcmp(key, "band_tail_threads")) g_band_tail_threads = value;
 }
@@ -42,7 +49,7 @@ void scan_emul_option(const char *key, int value)
 // mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
 // (burst_detect.c:427-428, :448-452); the rest is scanned in chunks of chunk_frames.  Returns the number of finished
 // bursts written to out (emission order), or -(flags) - 1000 if a chunk was declined.  stats: [0] rounds, [1] chunks,
-// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] launches in the tail form so far.
+// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] launches in the tail form so far, [6] speculation passes.
 int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_len, int width, int max_bursts, int max_len,
                   float threshold, int chunk_frames, int first_rounds, GoneBurst *out, int out_cap, float *sum_out, int *stats)
 {
@@ -84,12 +91,21 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     std::vector<ListEntry> entries((size_t)F_cap * cap);
     const int gone_cap = 8192;
     std::vector<GoneBurst> gone(gone_cap), all;
-    memset(stats, 0, sizeof(int) * 6);
+    memset(stats, 0, sizeof(int) * 7);
     hipEvent_t plan_ev[kBandRounds + 2] = {};
     // (band_tail, the default form: a side "stream" for the history copy, the scans numbered, the events the emulation's)
     hipStream_t side = reinterpret_cast<hipStream_t>(2);
     hipEvent_t ev_hist = reinterpret_cast<hipEvent_t>(3), ev_hop = reinterpret_cast<hipEvent_t>(4);
     uint32_t scan_seq = 0;
+    std::vector<unsigned char> ws2(band_work_bytes(n, max_chunk, true) + 256);
+    BandWork S;
+    band_work_carve(&S, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(ws2.data()) + 255) & ~(uintptr_t)255), n, max_chunk, true);
+    memset(S.bar, 0, 256);
+    memset(S.ctl, 0, sizeof(BandCtl));
+    memset(S.rec_count, 0, 4 * 64);
+    std::vector<DetState> st_spec_store(1);
+    memset(st_spec_store.data(), 0, sizeof(DetState));
+    bool have_prev_spec = false;
     for (int f0 = kHistory; f0 < n_frames; f0 += chunk_frames) {
         scan_seq++;
         const int F = std::min(chunk_frames, n_frames - f0);
@@ -110,9 +126,20 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
                 counts[f] = c;
             }
             const int first = first_rounds > 0 ? first_rounds : kBandFirst;
+            // (the speculation pass of this chunk: only for the first attempt -- a retry is launched the classical way, as
+            // the pipeline does -- and not for the stream's first chunk, whose predecessor left no sums in the workspace)
+            const bool use_spec = g_emul_spec && tries == 0 && f0 > kHistory && first >= 2;
+            if (use_spec) {
+                if (launch_band_spec(D, S, st_spec_store.data(), W.sum_new, F, st->index, counts.data(), entries.data(),
+                                     (have_prev_spec && g_emul_spec == 1) ? 1 : 0, reinterpret_cast<hipStream_t>(5)) != 0)
+                    return -3;
+                have_prev_spec = true;
+                stats[6]++;
+            }
             if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(), pre.data(),
-                                 smin.data(), gone.data(), gone_cap, 0, first, nullptr, nullptr, nullptr, gone_cap, 0, 0,
-                                 nullptr, side, plan_ev, nullptr, 0, nullptr, nullptr, 0, scan_seq, ev_hist, ev_hist, ev_hop) != 0)
+                                 smin.data(), gone.data(), gone_cap, use_spec ? 1 : 0, first, nullptr, nullptr, nullptr, gone_cap, 0, 0,
+                                 nullptr, side, plan_ev, nullptr, 0, nullptr, nullptr, 0, scan_seq, ev_hist, ev_hist, ev_hop,
+                                 use_spec ? &S : nullptr, nullptr) != 0)
                 return -3;
             if (W.ctl->status == 0 && W.ctl->flags == 0) {
                 // verdict still open after the rounds enqueued up front: the rest (csrc/pipeline.cpp: more_rounds)
@@ -128,6 +155,20 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
             tries++;
             stats[3]++;
             for (int b = 0; b < n; b++) pre[b] = std::min(pre[b], 0.45f * threshold * smin[b]);
+        }
+        if (getenv("IRDM_EMUL_DEBUG") && g_emul_spec && f0 > kHistory) {
+            // how good was the speculation pass's guess?  its update vector against the accepted round's
+            int diff = 0, first_diff = -1, quiet = 0;
+            for (int f = 0; f < F; f++) {
+                const int qs = ((S.busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1, fs_ = (int)((S.forced[f >> 6] >> (f & 63)) & 1);
+                quiet += W.uq[f];
+                if (qs != W.uq[f] || fs_ != W.uf[f]) {
+                    if (first_diff < 0) first_diff = f;
+                    diff++;
+                }
+            }
+            fprintf(stderr, "chunk at frame %d (%d frames): rounds %d, accepted u has %d quiet frames; the guess differs in %d frames (first %d); carried guessed %u, real %u\n",
+                    f0, F, W.ctl->rounds, quiet, diff, first_diff, st_spec_store[0].n_act, (unsigned)0);
         }
         stats[0] += W.ctl->rounds;
         stats[1]++;

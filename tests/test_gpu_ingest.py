@@ -127,3 +127,32 @@ def test_band_scan_continues_its_rounds(name):
         p.close()
     parity.compare(got, ref)
     assert got["stats"]["band_extra"] == 0 and got["stats"]["scan_fallbacks"] == 0 and got["stats"]["band_chunks"] >= 1, got["stats"]
+
+
+def test_scan_opens_with_round_1_behind_a_speculation_pass():
+    """band_spec (default): fed with look-ahead, the chained scans have no round 0 of their own -- a speculation pass on a
+    second workspace and stream, enqueued with the previous chunk, made the guess of the update vector -- and open with
+    round 1; same records as without (band_spec 0), as with the launch-saving form of the passes (band_tail 1), and when
+    the guess is spoilt chunk after chunk by a different chunking (bursts carried across every boundary)."""
+    fs, iq = scenes.ALL["many_active_10m"]()
+    ref = orc.run_stream(iq, fs)
+    for parts in (12, 7):
+        blocks = max(1, (len(iq) // 32768) // parts)
+        chunks = _equal_chunks(len(iq), blocks)
+        got = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead")
+        parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] >= 2 and got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
+        assert got["stats"]["scan_fallbacks"] == 0 and got["stats"]["band_aborts"] == 0, got["stats"]
+        # (rounds per chunk stay what they were: a good guess is accepted by the first verdict)
+        assert got["stats"]["band_rounds"] <= 3 * got["stats"]["band_chunks"], got["stats"]
+    off = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead", options={"band_spec": 0})
+    parity.compare(off, ref)
+    assert off["stats"]["spec_scans"] == 0 and off["stats"]["scan_chained"] >= 2, off["stats"]
+    try:
+        tail = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead", options={"band_tail": 1})
+    finally:
+        p = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        p.set_option("band_tail", 0)
+        p.close()
+    parity.compare(tail, ref)
+    assert tail["stats"]["spec_scans"] >= 2, tail["stats"]

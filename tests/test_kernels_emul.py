@@ -87,10 +87,35 @@ def check(L, iq, fs, chunks, **kw):
 def test_scan_kernels_scene_zoo(emul, name):
     """whole stream in one chunk and cut into chunks that split bursts (carried bursts, history ring across chunks)"""
     fs, iq = scenes.ALL[name]()
-    before = run(emul, *_tiny_scene())[3][5]
     stats = check(emul, iq, fs, chunks=(1 << 20, 97))
     assert stats[1] >= 1
-    assert stats[5] - before >= stats[1], "the default form of the scan (band_tail) did not run: %r" % stats
+    try:
+        # the launch-saving form (band_tail: pair list, the plan pass in the walk pass's last workgroup, the history copy apart)
+        emul.scan_emul_option(b"band_tail", 1)
+        before = run(emul, *_tiny_scene())[3][5]
+        stats = check(emul, iq, fs, chunks=(1 << 20, 97))
+        assert stats[5] - before >= stats[1], "the tail form of the scan did not run: %r" % stats
+        emul.scan_emul_option(b"band_tail", 0)
+        # round 0 as a speculation pass on a second workspace (band_spec): with the carried bursts the previous pass left,
+        # and with that guess withheld (2) -- a wrong guess costs a round, never a result
+        for mode in (1, 2):
+            emul.scan_emul_option(b"band_spec", mode)
+            stats = check(emul, iq, fs, chunks=(97, 33))
+            assert stats[6] >= stats[1] - 1 >= 2, "no speculation passes: %r" % stats
+        emul.scan_emul_option(b"band_tail", 1)
+        check(emul, iq, fs, chunks=(97,))
+        emul.scan_emul_option(b"band_tail", 0)
+        # a launch per pass with the history copy on the side stream and the export in the last plan pass (band_hist_side),
+        # with and without the speculation pass
+        emul.scan_emul_option(b"band_hist_side", 1)
+        check(emul, iq, fs, chunks=(97, 33))
+        emul.scan_emul_option(b"band_spec", 0)
+        check(emul, iq, fs, chunks=(1 << 20, 97))
+        check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
+    finally:
+        emul.scan_emul_option(b"band_tail", 0)
+        emul.scan_emul_option(b"band_spec", 0)
+        emul.scan_emul_option(b"band_hist_side", 0)
 
 
 def test_scan_kernels_continuation_and_options(emul):
@@ -100,11 +125,12 @@ def test_scan_kernels_continuation_and_options(emul):
     stats = check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
     assert stats[4] >= 1, "no continuation launch was needed: %r" % stats
     defaults = {b"band_walk_wave": 1, b"band_fuse_commit": 1, b"band_selfcheck": 0, b"band_plan_threads": 1024,
-                b"band_plan_ahead": 0, b"band_fold_sums0": 1, b"band_tail": 1, b"band_tail_threads": 1024}
+                b"band_plan_ahead": 0, b"band_fold_sums0": 1, b"band_tail": 0, b"band_tail_threads": 1024}
     try:
-        # the default form (band_tail: pair list, the plan pass in the walk pass's last workgroup, the history copy apart)
+        # the tail form (band_tail: pair list, the plan pass in the walk pass's last workgroup, the history copy apart)
         # with narrower workgroups, with round 0's sums pass as a launch of its own, with the walk's look-ahead off and the
         # boundary test's two forms compared
+        emul.scan_emul_option(b"band_tail", 1)
         for key, value in ((b"band_tail_threads", 256), (b"band_tail_threads", 512), (b"band_fold_sums0", 0),
                            (b"band_selfcheck", 8), (b"band_selfcheck", 1), (b"band_plan_threads", 256)):
             emul.scan_emul_option(key, value)
