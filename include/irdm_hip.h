@@ -77,14 +77,16 @@ typedef struct {
     int max_bursts_per_chunk;  /* sizing hint for the burst-record buffers, 0 -> 4096; a chunk with more finished bursts
                                   is redone with larger buffers (costs one dense scan), never dropped */
     int pipeline_depth;        /* 0: irdm_feed_* returns with the chunk's results pollable.
-                                  1, 2: throughput mode.  irdm_feed_*(k) returns once chunk k is ingested (FFT done,
+                                  1 .. 5: throughput mode.  irdm_feed_*(k) returns once chunk k is ingested (FFT done,
                                      samples in the history ring) and its detector scan is launched; the scan stays in
                                      flight while the caller produces chunk k+1.  The bursts of chunk k enter their
                                      per-burst chain (decimator .. demodulator, on a stream of its own) during
                                      irdm_feed_*(k+1); pipeline_depth + 1 chains are in flight and their records
                                      become pollable when their context is needed again, i.e. during
                                      irdm_feed_*(k+1+pipeline_depth), or at irdm_flush -- identical records, same order.
-                                     Values above 2 are treated as 2. */
+                                     A chain is 2.5-3 ms of dependent launches: the pipeline's period is at least that
+                                     latency / (pipeline_depth + 1).  Every context holds ~0.5 GB of per-burst scratch and
+                                     the history ring one more chunk.  Values above 5 are treated as 5. */
 } irdm_config_t;
 
 /* burst_info_t (burst_detect.h:29-37) + what emit_gone_bursts adds (burst_detect.c:703-742) */

@@ -178,6 +178,13 @@ extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, flo
 // ===========================================================================
 struct irdm_pipeline;
 
+// Batch contexts a pipeline may hold (pipeline_depth + 1 of them are used).  A chunk's per-burst chain is a string of
+// dependent launches, several of them a handful of wavefronts long (the phase recurrence, the Gardner / PLL loop): 2.5-3 ms
+// from first to last in run, whatever the chip could do beside it.  With three contexts the pipeline's period was that
+// latency divided by three -- the feeding thread spent 0.6 ms of every 1.05 ms step waiting for the oldest chain
+// (profiles/r5_spec_ab.json, host_us "wait_older_chain") -- and nothing done to the scan or the decimator moved it.
+constexpr int kMaxBc = 6;
+
 // One batch of finished bursts on its way through the per-burst stages K4..K7.  pipeline_depth 0 uses one context on the
 // detector's stream; pipeline_depth >= 1 alternates between two, each on a stream of its own, so that the FIR of one
 // chunk's bursts overlaps the latency-bound tail (sync correlation, demodulator, result copies) of the previous one's.
@@ -338,7 +345,7 @@ struct irdm_pipeline {
     float *d_mag2;           // pipeline_depth 1: second magnitude buffer
     std::vector<BurstWork> h_work;
     // the per-burst chains (bursts_enqueue / bursts_finish) and the helper thread that does their host step
-    BatchCtx bc[3];
+    BatchCtx bc[kMaxBc];
     int n_bc;
     std::thread cfo_thread;
     std::mutex cfo_mu;
@@ -415,7 +422,7 @@ struct irdm_pipeline {
     std::vector<int> rot_len_h, rot_want, rot_touched;   // per bin: checkpoints built (or being built) / wanted by the batch at hand
     std::vector<int> rot_build_ctx;         // per bin: the batch context whose chain built (or is building) its latest run, -1: none
     std::vector<uint32_t> rot_build_gen;    // ... and which of that context's builds it was
-    uint32_t rot_gen[3] = { 0, 0, 0 }, rot_done_gen[3] = { 0, 0, 0 };   // per context: builds enqueued / known to be complete (its stream was waited for)
+    uint32_t rot_gen[kMaxBc] = {}, rot_done_gen[kMaxBc] = {};   // per context: builds enqueued / known to be complete (its stream was waited for)
     std::vector<float2 *> rot_retired;      // outgrown pools
     uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_rot_grows = 0, stat_band_steps = 0;
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
@@ -434,6 +441,8 @@ struct irdm_pipeline {
     unsigned long long *d_kclk = nullptr;
     int kernel_clock = 0;
     unsigned long long *kclk_rec(int i) const { return kernel_clock && d_kclk ? d_kclk + (size_t)i * kKClkWords : nullptr; }
+    // (the decimator of batch context c: records 0..2, and 6.. for the contexts beyond the third)
+    unsigned long long *kclk_fir(int c) const { return kclk_rec(c < 3 ? c : 3 + c); }
 };
 
 // The rotator checkpoints (rotator.h:36-46 restated: the phase of the float recurrence every 16 samples -- a whole row for
@@ -621,7 +630,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     if (p->ref_ring < (uint64_t)2 * fs) p->ref_ring = (uint64_t)2 * fs;
     // longest possible burst window: stop - start < max_len + post_len + N, plus pre_len
     p->l_cap = (size_t)P.max_len + P.post_len + P.pre_len + 2 * (size_t)P.n;
-    p->depth = cfg->pipeline_depth > 0 ? std::min(cfg->pipeline_depth, 2) : 0;
+    p->depth = cfg->pipeline_depth > 0 ? std::min(cfg->pipeline_depth, kMaxBc - 1) : 0;
     p->k1_first = 1;
     p->k1_lists = 1;
     p->band_first = 0;
@@ -832,10 +841,10 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&p->hp_gate), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
          hipHostGetDevicePointer(reinterpret_cast<void **>(&p->hp_gate_dev), p->hp_gate, 0) == hipSuccess;
     if (ok) memset(p->hp_gate, 0, 64);
-    AL(p->d_kclk, unsigned long long, (size_t)6 * kKClkWords);
+    AL(p->d_kclk, unsigned long long, (size_t)(6 + kMaxBc - 3) * kKClkWords);
     if (ok) {
-        std::vector<unsigned long long> init((size_t)6 * kKClkWords, 0ull);
-        for (int r = 0; r < 6; r++)
+        std::vector<unsigned long long> init((size_t)(6 + kMaxBc - 3) * kKClkWords, 0ull);
+        for (int r = 0; r < 6 + kMaxBc - 3; r++)
             for (int i = 0; i < 64; i++) init[(size_t)r * kKClkWords + i] = ~0ull;
         ok = hipMemcpy(p->d_kclk, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice) == hipSuccess;
     }
@@ -874,7 +883,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     mark("history ring");
     // batch contexts: [0] aliases the pipeline's per-burst scratch and runs on bstream; [1] (pipeline_depth >= 1) has
     // scratch and a stream of its own
-    p->n_bc = p->depth ? std::min(p->depth + 1, 3) : 1;
+    p->n_bc = p->depth ? std::min(p->depth + 1, kMaxBc) : 1;
     for (int i = 0; i < p->n_bc && ok; i++) {
         BatchCtx &b = p->bc[i];
         b.owner = p;
@@ -1506,7 +1515,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
                             p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->rot_runs, b.d_dec, st,
-                            p->kclk_rec((int)(&b - p->bc)), p->d_rot_slot) != 0)
+                            p->kclk_fir((int)(&b - p->bc)), p->d_rot_slot) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
     if (launch_downmix_post1(b.d_work, nb, b.d_dec, b.d_lpf, p->d_noise_taps,
@@ -1562,12 +1571,12 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_packed, b.d_packed,
                                  sizeof(DemodPacked) * nb, st) != 0)
             return -1;
-        return launch_kclk_fold(p->kclk_rec((int)(&b - p->bc)), st);
+        return launch_kclk_fold(p->kclk_fir((int)(&b - p->bc)), st);
     }
     if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_demod, b.d_demod, sizeof(DemodOut) * nb,
                              st) != 0)
         return -1;
-    return launch_kclk_fold(p->kclk_rec((int)(&b - p->bc)), st);
+    return launch_kclk_fold(p->kclk_fir((int)(&b - p->bc)), st);
 }
 
 // returns the number of bursts whose records were emitted, -1 on error
@@ -3271,10 +3280,15 @@ extern "C" int irdm_kernel_clock(irdm_pipeline_t *p, int which, double *sum_ms, 
     if (!p || !p->d_kclk || which < 0 || which > 1) return -1;
     pipeline_enter(p);
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    std::vector<unsigned long long> h((size_t)6 * kKClkWords);
+    std::vector<unsigned long long> h((size_t)(6 + kMaxBc - 3) * kKClkWords);
     if (hipMemcpy(h.data(), p->d_kclk, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     unsigned long long ticks = 0, n = 0, last = 0;
-    for (int r = 3 * which; r < 3 * which + 3; r++) {
+    // (records 0..2 and 6..: the decimator per batch context; 3..5: K1 per feed slot)
+    std::vector<int> recs;
+    if (which == 1) recs = { 3, 4, 5 };
+    else
+        for (int c = 0; c < kMaxBc; c++) recs.push_back(c < 3 ? c : 3 + c);
+    for (int r : recs) {
         ticks += h[(size_t)r * kKClkWords + 128];
         n += h[(size_t)r * kKClkWords + 129];
         if (h[(size_t)r * kKClkWords + 130] > last) last = h[(size_t)r * kKClkWords + 130];
@@ -3283,7 +3297,7 @@ extern "C" int irdm_kernel_clock(irdm_pipeline_t *p, int which, double *sum_ms, 
     if (launches) *launches = n;
     if (last_ms) *last_ms = (double)last * 1e-5;
     if (reset) {
-        for (int r = 3 * which; r < 3 * which + 3; r++) {
+        for (int r : recs) {
             unsigned long long z[3] = { 0, 0, 0 };
             if (hipMemcpy(p->d_kclk + (size_t)r * kKClkWords + 128, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) return -1;
         }

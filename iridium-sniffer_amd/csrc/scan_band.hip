@@ -1833,7 +1833,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     P.selfcheck = g_band_selfcheck;
     P.ahead = (g_band_plan_ahead && !g_band_coop && side && plan_ev && W.walk_host) ? 1 : 0;
     P.tl_sel = g_band_timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;
-    if (P.tl_sel >= 0 && round_begin == 0) {
+    if (P.tl_sel >= 0 && (round_begin == 0 || spec)) {
         unsigned long long *half = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots;
         (void)hipMemsetAsync(half, 0xff, 8 * kBandTlSlots, stream);
         (void)hipMemsetAsync(half + kBandTlSlots, 0, 8 * kBandTlSlots, stream);

@@ -50,6 +50,9 @@ def main():
         res["chunked_depth1"] = parity.compare(parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 4), depth=1), ref)
         res["chunked_depth2_in_place_lookahead"] = parity.compare(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead"), ref)
+        # five batch contexts (pipeline_depth 4): records five chunks late, same records, same order
+        res["chunked_depth4_in_place_lookahead"] = parity.compare(
+            parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=4, feed="ingest_lookahead"), ref)
         x = siggen.to_ci8(iq)
         ref8 = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
         res["ci8"] = parity.compare(parity.run_gpu(x, fs, fmt=irdm.FMT_CI8), ref8)
@@ -96,6 +99,9 @@ def main():
         # workspace, enqueued with the previous chunk (band_spec)
         assert got["stats"]["spec_scans"] >= 2 and got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
         res["default"]["spec_scans"] = got["stats"]["spec_scans"]
+        got = parity.run_gpu(iq, fs, chunks=sizes, depth=5, feed="ingest_lookahead")
+        res["depth5"] = parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] >= 2, got["stats"]
         got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"band_spec": 0})
         res["without_speculation_pass"] = parity.compare(got, ref)
         assert got["stats"]["spec_scans"] == 0 and got["stats"]["scan_chained"] >= 2, got["stats"]
