@@ -680,6 +680,8 @@ def main():
     fir_name = "fir_decimate_kernel_w"
     if decim in (40, 48):
         fir_name = "fir_decimate_kernel_f" if opts.get("fir_order", 1) else "fir_decimate_kernel_r"
+        if opts.get("fir_layout", 3) == 4 and opts.get("fir_order", 1):
+            fir_name = "fir_decimate_kernel_x"           # (the same arithmetic on the matrix cores: v_mfma_f32_16x16x4_f32)
     k1_name = "fft_mag_p32_kernel" if opts.get("k1_kernel", 1) and pipe.fft_size >= 8192 else "fft_mag_r16_kernel"
     kernels = {"fft_mag": k1_name, "scan": "band_* (scan_band.hip passes)", "fir": fir_name}
     # the dominant KERNEL: the scan is a chain of ~25 short launches of six kernels (its stage time is their sum plus

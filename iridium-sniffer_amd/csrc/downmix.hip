@@ -782,6 +782,12 @@ int g_fir_budget = 4;          // persistent kernel: tiles per workgroup before 
 // (the other dispatched kernels are the same operations in both forms: tests/test_oracle_vs_ref.py)
 
 // `aligned`: the pipeline's ring lengths are multiples of 8 samples (fir_reg.hip fetches columns in pieces of 8)
+// fir_layout 4 (fir_order 1 only): the AVX2 order on the matrix cores
+static bool fir_mfma_ok(int decim, int aligned)
+{
+    return !g_fir_force_generic && g_fir_order == 1 && g_fir_layout == 4 && aligned && fir_reg_supported(decim);
+}
+
 static bool fir_fma_ok(int decim, int aligned)
 {
     return !g_fir_force_generic && g_fir_order == 1 && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
@@ -806,11 +812,15 @@ static int fir_wide_tile(int)
 }
 
 // 1: launch_fir_decimate() reads the FirTile list (the one-tile-per-workgroup kernels); 0: only BurstWork::tile_base
-int fir_needs_tile_list(int decim, int aligned) { return fir_wide_ok(decim, aligned) || fir_reg_ok(decim, aligned) || fir_fma_ok(decim, aligned) ? 0 : 1; }
+int fir_needs_tile_list(int decim, int aligned)
+{
+    return fir_wide_ok(decim, aligned) || fir_reg_ok(decim, aligned) || fir_fma_ok(decim, aligned) || fir_mfma_ok(decim, aligned) ? 0 : 1;
+}
 
 // outputs per FirTile for the kernel launch_fir_decimate() will pick
 int fir_tile_out(int decim, int aligned)
 {
+    if (fir_mfma_ok(decim, aligned)) return fir_mfma_tile_out(decim);
     if (fir_fma_ok(decim, aligned)) return fir_fma_tile_out(decim);
     if (fir_reg_ok(decim, aligned)) return fir_reg_tile_out(decim);
     return fir_wide_ok(decim, aligned) ? fir_wide_tile(decim) : kFirTileOut;
@@ -888,6 +898,13 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
     } while (0)
     const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
+    if (fir_mfma_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
+        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
+        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
+        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
+                           fir_mfma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
+        return launch_fir_mfma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
+    }
     if (fir_fma_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);

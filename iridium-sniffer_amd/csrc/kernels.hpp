@@ -155,6 +155,9 @@ extern int g_fir_slice;           // strips per launch of the register-resident 
 extern thread_local int g_fir_order;           // 1 (default): the decimating FIR in the order of the reference's AVX2 kernel (simd_avx2.c:62-108),
                                   // 0: of its scalar kernel (simd_generic.c:86-96, --no-simd)
 int fir_fma_tile_out(int decim);
+int fir_mfma_tile_out(int decim);          // fir_layout 4: the decimator on the matrix cores (fir_reg.hip, fir_decimate_kernel_x)
+int launch_fir_mfma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
+                    const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk = nullptr);
 int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
                    const float2 *rot_table, float2 *dec, hipStream_t stream,
                    unsigned long long *kclk = nullptr);   // fir_decimate_kernel_f; 0 ok, -1 error, 1 not applicable

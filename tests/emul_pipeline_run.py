@@ -114,6 +114,17 @@ def main():
         irdm_p = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
         irdm_p.set_option("band_hist_side", 0)
         irdm_p.close()
+        # the decimator on the matrix cores (fir_layout 4, fir_decimate_kernel_x: the AVX2 order as a Toeplitz x samples product on
+        # v_mfma_f32_16x16x4_f32, emulated as the fmaf chain the instruction is): whole stream at once and in chunks
+        try:
+            got = parity.run_gpu(iq, fs, options={"fir_layout": 4})
+            res["mfma_decimator"] = parity.compare(got, ref)
+            got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"fir_layout": 4})
+            res["mfma_decimator_chunked"] = parity.compare(got, ref)
+        finally:
+            pz = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+            pz.set_option("fir_layout", 3)
+            pz.close()
         # the same stream with the decimating FIR in the reference's scalar order (--no-simd: fir_decimate_kernel_r, one
         # accumulator per output travelling from lane to lane) against the oracle in that order
         orc.set_fir_order(0)

@@ -130,3 +130,49 @@ def test_ring_wrap_chunks_and_ragged_end_10mhz_ci8():
     assert s["demods"] >= 12, s
     stale = [b for b in ref.bursts if b.avail_end < b.start + b.num_samples]
     assert stale, "no burst of the scene had a stale tail"
+
+
+def test_matrix_core_decimator_10mhz(scene10):
+    """fir_layout 4 (fir_decimate_kernel_x): the AVX2 order -- four fused accumulators per output -- as a Toeplitz-taps x
+    samples product on v_mfma_f32_16x16x4_f32; downmixed samples bit for bit the oracle's: whole, in chunks (strips in the
+    chunk, in the ring, across the boundary), with a capped grid (a few workgroups walking all octets of strips)"""
+    iq, ref, _ = scene10
+    try:
+        s = parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_layout": 4}), ref)
+        assert s["demods"] >= 4, s
+        n = len(iq)
+        c = (n // 3) // 32768 * 32768
+        parity.compare(parity.run_gpu(iq, 10_000_000, chunks=[c, c, n - 2 * c], depth=1, options={"fir_layout": 4}), ref)
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_layout": 4, "fir_grid": 3}), ref)
+    finally:
+        _restore()
+
+
+@pytest.mark.parametrize("fs,fmt", [(10_000_000, irdm.FMT_CI16), (12_000_000, irdm.FMT_CI8), (12_000_000, irdm.FMT_CF32)])
+def test_matrix_core_decimator_formats(fs, fmt):
+    iq = _scene(fs, 1.0, 6, seed=fs // 1_000_000 + fmt)
+    x = siggen.to_ci16(iq) if fmt == irdm.FMT_CI16 else siggen.to_ci8(iq) if fmt == irdm.FMT_CI8 else iq
+    ref = orc.run_stream(x, fs, fmt=fmt)
+    try:
+        got = parity.run_gpu(x, fs, fmt=fmt, options={"fir_layout": 4})
+    finally:
+        _restore()
+    s = parity.compare(got, ref)
+    assert s["demods"] >= 3, s
+
+
+def test_matrix_core_decimator_ring_wrap_and_stale_tails_10mhz_ci8():
+    """the ring wraps, windows straddle chunk boundaries, stale tails, a ragged end (the scene of the test above)"""
+    fs = 10_000_000
+    n = int(3.1 * fs) // 32768 * 32768 + 1234
+    iq, _ = siggen.standard_scene(fs, n, 24, seed=77)
+    x = siggen.to_ci8(iq)
+    ref = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
+    chunk = 4 * 1024 * 1024
+    sizes = [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
+    try:
+        got = parity.run_gpu(x, fs, fmt=irdm.FMT_CI8, chunks=sizes, options={"fir_layout": 4})
+    finally:
+        _restore()
+    s = parity.compare(got, ref)
+    assert s["demods"] >= 12, s

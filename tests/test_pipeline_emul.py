@@ -68,7 +68,7 @@ def test_whole_path_10mhz_register_resident_decimator(emul_lib):
         assert res[name]["bursts"] >= 6 and res[name]["frames"] >= 4, res
     assert res["default"]["k1_lists"] >= 1, res          # a chunk whose candidate lists K1 wrote
     assert res["default"]["spec_scans"] >= 2, res        # scans that opened with round 1 behind a speculation pass
-    assert {"default", "scalar_fir_order", "without_speculation_pass", "tail_form"} <= set(res)
+    assert {"default", "scalar_fir_order", "without_speculation_pass", "tail_form", "mfma_decimator", "mfma_decimator_chunked"} <= set(res)
 
 
 @pytest.mark.skipif(not os.environ.get("IRDM_EMUL_FULL"), reason="four minutes of emulation: set IRDM_EMUL_FULL=1")
