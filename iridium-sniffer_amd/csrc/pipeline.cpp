@@ -268,6 +268,8 @@ struct irdm_pipeline {
     uint32_t seq_counter = 0;               // scans numbered so far (HistJob::seq; never 0)
     uint32_t fl_seq = 0;                    // number of the scan in flight
     uint32_t chain_seq = 0;                 // ... of the chained launch (scan_chain_try), taken over by scan_launch
+    uint64_t chain_no = 0;                  // the chunk the chained launch in flight (chain_pending) scans
+    int chain_early = 1;                    // option scan_chain_early: chain the NEXT chunk's scan before waiting for the oldest chain
     int scan_events = 1;     // 0: no timing events around the band scan (stage time of the scan reads -1)
     int fir_order = 1;       // option fir_order / simd_order: 1 simd_avx2.c's operation order, 0 simd_generic.c's (--no-simd); per pipeline
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
@@ -1970,7 +1972,8 @@ static void scan_select_outputs(irdm_pipeline *p, int sel)
 // (BandWork::bar[4]) and declines itself otherwise (BAND_F_CHAIN), the host sees the predecessor's trouble when it
 // settles it, drains the declined launch and launches again the ordinary way.  Exports go to the other set of pinned
 // targets.
-static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f)
+// (no: the chunk's number -- this feed's, or, from the end of the previous feed, the next one's)
+static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f, uint64_t no)
 {
     p->chain_pending = false;
     // (only with K1's own candidate lists: the prefilter pass that builds them otherwise writes the one set of buffers
@@ -1986,12 +1989,13 @@ static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f)
     // a speculation pass for exactly this chunk (spec_enqueue, at the end of the previous feed)?  Then round 0 is done: the
     // scan waits for that pass and opens with round 1.  (Only here, in the chained launch: a scan that is launched again
     // after its predecessor's trouble, a retry or a continuation finds the speculation workspace taken by the next pass.)
-    const bool use_spec = p->band_spec_opt && p->d_band_spec && p->spec_for_no == p->chunk_no && p->chain_band_first >= 2 &&
+    const bool use_spec = p->band_spec_opt && p->d_band_spec && p->spec_for_no == no && p->chain_band_first >= 2 &&
                           f.frames == p->spec_frames && !p->gate_armed;
     if (use_spec) IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_spec_done, 0));
-    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1, p->chain_seq, p->chunk_no, use_spec) != 0) return -1;
+    if (scan_band_enqueue_at(p, f.mag, f.frames, 0, 0, false, f.c0, &f, sel, p->chain_band_first, 1, p->chain_seq, no, use_spec) != 0) return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_end_set[sel], p->stream));
     p->chain_pending = true;
+    p->chain_no = no;
     p->chain_sel = sel;
     p->stat_chained++;
     return 0;
@@ -2513,7 +2517,8 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         IRDM_HOST_PHASE(4);
         // 1. this chunk's band scan goes behind the previous chunk's (scan_chain_try), then the previous chunk's is
         //    settled and its bursts collected
-        if (scan_chain_try(p, f) != 0) return -1;
+        // (already chained at the end of the previous feed -- scan_chain_early, below -- unless that could not be done)
+        if (!(p->chain_pending && p->chain_no == p->chunk_no) && scan_chain_try(p, f, p->chunk_no) != 0) return -1;
         if (settle(p) != 0) return -1;
         if (p->chain_pending && !p->settle_clean) {
             // the scan in front did not commit on its own: the chained launch has declined itself (nothing written)
@@ -2535,6 +2540,13 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         // 3b. the next chunk, if its feed has begun (look-ahead): its round 0 as a speculation pass beside this chunk's scan
         if (p->begin_no > p->end_no + 1 && p->fl_mode == 2 && p->fl_band_ran &&
             spec_enqueue(p, p->fs[(p->end_no + 1) % 3], p->chunk_no + 1) != 0)
+            return -1;
+        // 3c. ... and its scan, chained behind this chunk's, NOW: what follows -- the wait for the oldest chain, the records,
+        //     the caller's polls and its next irdm_feed_begin -- took 0.4-0.8 ms, during which the scan's stream ran dry
+        //     after every scan: the period was (that host time + a scan) / 2, not a scan.
+        //     The same launch the next irdm_feed_end would make first thing -- it finds it done.
+        if (p->chain_early && p->begin_no > p->end_no + 1 && !p->chain_pending &&
+            scan_chain_try(p, p->fs[(p->end_no + 1) % 3], p->chunk_no + 1) != 0)
             return -1;
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
         if (!finished_early) {
@@ -3224,6 +3236,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
     if (!strcmp(key, "kernel_clock")) { p->kernel_clock = value != 0; return 0; }
     if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
+    if (!strcmp(key, "scan_chain_early")) { p->chain_early = value != 0; return 0; }
     if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
     if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
     if (!strcmp(key, "k1_kernel")) { irdm::g_fft_kernel = value; return 0; }
