@@ -7,7 +7,7 @@ One "step" = one pass of the whole hot path (K1..K7) over one chu
 synthetic 10 MHz cf32 IQ that is already resident in HBM (complex
 AWGN + 10 DQPSK bursts per Msample) -- by default in the chunk's slot of the context's
 history ring (irdm_ingest_ptr: where a producer that feeds in place writes it; every slot
-is filled before the timed region), fed with one chunk of look-ahead at pipeline_depth 2;
+is filled before the timed region), fed with one chunk of look-ahead at pipeline_depth 3 (four batch contexts);
 the drain of the last chunks' per-burst chains is inside the timed region.  Every rank
 processes its own stream (the path
 partitions by stream / time-chunk, no data-path collective); per step the demodulated
@@ -425,10 +425,11 @@ def main():
     ap.add_argument("--format", choices=("cf32", "ci16", "ci8"), default="cf32",
                     help="device sample format of the chunk (the headline metric is cf32; ci16 / ci8 = the reference's "
                          "integer file formats, quantised from the same scene)")
-    ap.add_argument("--depth", type=int, default=2,
-                    help="pipeline_depth: 1, 2 (default) = the detector scan of chunk k stays in flight while the per-burst "
-                         "chains of the previous 2 / 3 chunks and chunk k+1's FFT run (results later, identical); 0 = "
-                         "every feed returns its own chunk's results")
+    ap.add_argument("--depth", type=int, default=3,
+                    help="pipeline_depth: 1 .. 5 (default 3: four batch contexts) = the detector scan of chunk k stays in flight "
+                         "while the per-burst chains of the previous depth + 1 chunks and chunk k+1's FFT run (results later, "
+                         "identical); 0 = every feed returns its own chunk's results.  (A chain is ~3 ms of dependent launches "
+                         "in run: with three contexts the period was that latency / 3, profiles/r5_depth_sweep.json)")
     ap.add_argument("--cpu-samples", type=int, default=64 * 1024 * 1024,
                     help="prefix of the stream the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--cpu-passes", type=int, default=3, help="one-core oracle passes over that prefix (~3 s each)")
@@ -576,7 +577,7 @@ def main():
             nb += pipe.feed_end()
         return nb
 
-    # the records of the stream's FIRST chunk as the timed context produces them (pipeline_depth 2, fed in place with
+    # the records of the stream's FIRST chunk as the timed context produces them (pipeline_depth 3, fed in place with
     # look-ahead, the other chunks' stages running beside it): what parity_checked compares with the oracle
     first_chunk = {"bursts": None, "demods": None}
 
