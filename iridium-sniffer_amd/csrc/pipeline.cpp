@@ -255,6 +255,7 @@ struct irdm_pipeline {
     hipEvent_t ev_hist_last = nullptr;      // the latest history copy enqueued (nullptr: none): whatever touches the ring next waits for it
     // band_spec (scan_band.hip): round 0 of chunk k + 1 as a speculation pass on a second workspace and stream, beside chunk
     // k's scan; the scan of chunk k + 1 then opens with round 1
+    int chain_cu_reserved = 0;              // CUs the per-burst chains' streams are masked off (IRDM_CHAIN_CU_RESERVE)
     int band_spec_opt = 1;                  // option band_spec
     void *d_band_spec = nullptr;
     BandWork band_spec = {};
@@ -558,6 +559,38 @@ extern "C" void irdm_destroy(irdm_pipeline_t *p) { pipeline_free(p); }
 
 static void cfo_helper_main(irdm_pipeline *p);
 
+// A stream for a per-burst chain.  IRDM_CHAIN_CU_RESERVE=R in the environment (0 = off, the default): a CU mask that keeps
+// the chains off R CUs of the device (the last CU of each 32-CU mask word in turn), so that the decimator's resident grid --
+// seven 256-register wavefronts per CU for 0.35-0.45 ms per chunk, on every CU it may use -- cannot hold ALL of them: a
+// 1024-thread workgroup (the scan's plan passes) needs a CU to itself and otherwise waits until the decimator's launch has
+// drained (kernel trace).  A masked stream has the default priority, not the chains' low one.
+static bool chain_stream_create(irdm_pipeline *p, hipStream_t *out, int prio)
+{
+    static const int reserve = [] {
+        const char *e = getenv("IRDM_CHAIN_CU_RESERVE");
+        const int r = e ? atoi(e) : 0;
+        return r < 0 ? 0 : r > 64 ? 64 : r;
+    }();
+    if (reserve > 0) {
+        hipDeviceProp_t prop;
+        int n_cu = hipGetDeviceProperties(&prop, p->cfg.device) == hipSuccess ? prop.multiProcessorCount : 0;
+        if (n_cu >= 64) {
+            const int words = (n_cu + 31) / 32;
+            std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+            if (n_cu % 32) mask[(size_t)words - 1] = (1u << (n_cu % 32)) - 1u;
+            for (int r = 0; r < reserve; r++) {
+                const int w = r % words, bit = 31 - r / words;          // (one CU per mask word before a second one anywhere)
+                mask[(size_t)w] &= ~(1u << bit);
+            }
+            if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) {
+                p->chain_cu_reserved = reserve;
+                return true;
+            }
+        }
+    }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio) == hipSuccess;
+}
+
 extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
 {
     if (!cfg || cfg->sample_rate <= 0) return nullptr;
@@ -697,7 +730,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         if (const char *e = getenv("IRDM_K1_PRIO")) prio_k1 = atoi(e);
         ok = hipStreamCreateWithPriority(&p->stream, hipStreamNonBlocking, prio_hi) == hipSuccess &&
              hipStreamCreateWithPriority(&p->fstream, hipStreamNonBlocking, prio_k1) == hipSuccess &&
-             hipStreamCreateWithPriority(&p->stream2, hipStreamNonBlocking, prio_lo) == hipSuccess;
+             chain_stream_create(p, &p->stream2, prio_lo);
         p->bstream = p->stream2;
     } else {
         ok = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) == hipSuccess;
@@ -900,7 +933,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             b.d_rrc_ws = p->d_rrc_ws; b.d_frames = p->d_frames; b.d_demod_ws = p->d_demod_ws; b.d_demod = p->d_demod;
             b.d_decoded = p->d_decoded; b.d_ida = p->d_ida;
         } else {
-            ok = ok && hipStreamCreateWithPriority(&b.stream, hipStreamNonBlocking, p->bstream_prio) == hipSuccess;
+            ok = ok && chain_stream_create(p, &b.stream, p->bstream_prio);
             AL(b.d_work, BurstWork, (size_t)p->burst_cap);
             AL(b.d_tiles, FirTile, (b.tiles_cap + 1) * kFirTileUnits);
             AL(b.d_dec, float2, p->scratch_init);
@@ -3277,6 +3310,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
     if (!strcmp(key, "tiles_grows")) return (int64_t)p->stat_tiles_grows;
     if (!strcmp(key, "ring_waits")) return (int64_t)p->stat_ring_waits;
+    if (!strcmp(key, "chain_cu_reserved")) return (int64_t)p->chain_cu_reserved;
     if (!strcmp(key, "spec_passes")) return (int64_t)p->stat_spec_passes;
     if (!strcmp(key, "spec_scans")) return (int64_t)p->stat_spec_scans;
     if (!strcmp(key, "band_tail_launches")) return (int64_t)irdm::g_band_tail_launches.load();      // (process-wide)

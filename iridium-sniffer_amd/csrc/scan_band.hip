@@ -1355,7 +1355,9 @@ __global__ __launch_bounds__(kCoopThreads) void band_coop_kernel(BandParams P, B
 // burst the speculation did not know) costs a further round like any other mismatch; the verdict never looks at where a
 // plan came from.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void band_spec_prep_kernel(BandParams P, BandWork S, const unsigned *__restrict__ counts,
+// (256 threads and no LDS to speak of: four wavefronts find room beside the decimator's resident grid, where a
+// 1024-thread workgroup waited for that launch to drain -- 210-220 us "long" in the kernel trace, ending with the decimator)
+__global__ __launch_bounds__(256) void band_spec_prep_kernel(BandParams P, BandWork S, const unsigned *__restrict__ counts,
                                                               const float *__restrict__ sum_src, DetState *__restrict__ st_spec,
                                                               int have_prev)
 {
@@ -1367,7 +1369,7 @@ __global__ __launch_bounds__(1024) void band_spec_prep_kernel(BandParams P, Band
     // what the previous speculation pass left active at the end of ITS chunk is what this one takes over at the start of
     // its own (records still hold that pass's walk; ids do not matter to a guess)
     if (have_prev)
-        for (int band = tid >> 4; band < P.n_bands; band += 1024 / 16) {
+        for (int band = tid >> 4; band < P.n_bands; band += 256 / 16) {
             const int cnt = min((int)S.rec_count[band], kBandRecCap);
             for (int j = tid & 15; j < cnt; j += 16) {
                 const BandRec &r = S.recs[(size_t)band * kBandRecCap + j];
@@ -1385,19 +1387,19 @@ __global__ __launch_bounds__(1024) void band_spec_prep_kernel(BandParams P, Band
     if (tid == 0) st_spec->n_act = (uint32_t)min(s_n, (unsigned)kMaxActive);
     // round 0's plan on the speculation workspace: no update steps, one snapshot -- the sums handed in
     if (tid < (int)(sizeof(BandCtl) / 4)) reinterpret_cast<uint32_t *>(S.ctl)[tid] = 0;
-    for (int f = tid; f < F; f += 1024) {
+    for (int f = tid; f < F; f += 256) {
         const int slot = counts[f] > 0 ? 0 : -1;
         S.slot_pre[f] = slot;
         S.slot_post[f] = slot;
     }
-    for (int i = tid; i < P.n_bands * P.occ_words; i += 1024) S.occ[i] = 0;
-    for (int i = tid; i < P.occ_words; i += 1024) {
+    for (int i = tid; i < P.n_bands * P.occ_words; i += 256) S.occ[i] = 0;
+    for (int i = tid; i < P.occ_words; i += 256) {
         S.busy[i] = 0;
         S.forced[i] = 0;
         S.conc[i] = 0;
     }
-    for (int i = tid; i < P.n_bands; i += 1024) S.rec_count[i] = 0;
-    for (int b = tid; b < P.n; b += 1024) S.snap[b] = sum_src[b];
+    for (int i = tid; i < P.n_bands; i += 256) S.rec_count[i] = 0;
+    for (int b = tid; b < P.n; b += 256) S.snap[b] = sum_src[b];
     __syncthreads();
     if (tid == 0) {
         *S.flags = 0;
@@ -1797,7 +1799,7 @@ int launch_band_spec(const DetParams &D, BandWork S, DetState *st_spec, const fl
     io.forced = S.forced;
     io.conc = S.conc;
     io.flags = S.flags;
-    hipLaunchKernelGGL(band_spec_prep_kernel, dim3(1), dim3(1024), 0, stream, P, S, counts, sum_src, st_spec, have_prev);
+    hipLaunchKernelGGL(band_spec_prep_kernel, dim3(1), dim3(256), 0, stream, P, S, counts, sum_src, st_spec, have_prev);
     hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, S, counts, entries);
     if (P.band_w == 128)
         hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, S, io, st_spec);

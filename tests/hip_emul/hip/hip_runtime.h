@@ -511,6 +511,7 @@ inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return 
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = reinterpret_cast<hipStream_t>(0x10); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { return hipStreamCreate(s); }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = reinterpret_cast<hipEvent_t>(0x20); return hipSuccess; }
