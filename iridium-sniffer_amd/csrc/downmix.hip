@@ -910,7 +910,7 @@ int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bu
         unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
                            fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
-        return launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
+        return launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk, next_tile) == 0 ? 0 : -1;
     }
     if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);

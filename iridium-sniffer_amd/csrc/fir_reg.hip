@@ -380,7 +380,8 @@ __device__ __forceinline__ void fir_fetch_column(const SampleSource &src, const 
 template <int M, int FMT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_f(
     SampleSource src, const FirGeom *__restrict__ geom, const float *__restrict__ taps,
-    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk)
+    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk,
+    unsigned *__restrict__ next_tile)
 {
     using R = FirR<M>;
     constexpr int NR = R::NR, REM = R::REM;
@@ -389,9 +390,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     static_assert(M % 4 == 0 && VT % 8 == 0 && (kFirTaps - 1) % 4 == 0, "tap k -> accumulator k % 4 = (k % M) % 4; one tap left over");
     const int lane = threadIdx.x;
     kclk_enter(kclk);
+    // Strips: the workgroup's first one is its index; every further one is CLAIMED from a counter (next_tile, zeroed by
+    // fir_geom_kernel) when the grid is smaller than the strips -- a resident grid with fixed shares (tile += gridDim.x) ends
+    // when its slowest wavefront does, and in run the wavefronts do not run at one speed: the ones that share a SIMD with the
+    // lane-per-burst kernels of the other chains (priority 3, 0.2-0.8 ms long) fall behind (decimator in run 0.46 ms against
+    // 0.33 alone at four contexts).  The claim for the strip after this one is made before this one's work: its latency is
+    // the strip's.
+    const bool claim = next_tile != nullptr && (int)gridDim.x < n_tiles;
 #pragma unroll 1
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles;) {
+        int tile_next = tile + (int)gridDim.x;
+        if (claim) {
+            unsigned c = 0;
+            if (lane == 0) c = atomicAdd(next_tile, 1u);
+            tile_next = (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane((int)c);
+        }
         const FirGeom g = geom[tile];
+        tile = tile_next;
         const int n_cols = g.n_out + NR;                     // columns that feed a stored output (<= 128)
         const v2f inc = { g.inc_re, g.inc_im };
         const uint64_t *taps64 = reinterpret_cast<const uint64_t *>(taps);
@@ -501,10 +516,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     kclk_leave(kclk);
 }
 
+int g_fir_claim = 1;           // 1 (default): the resident grid of fir_decimate_kernel_f claims its strips from a counter; 0: fixed shares
+
 template <int M>
 static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
-                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
+                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk, unsigned *next_tile)
 {
+    if (!g_fir_claim) next_tile = nullptr;
     // Workgroups: by default a resident grid of seven single-wavefront workgroups per CU that walk the strips, i.e. seven
     // of a CU's eight 256-register slots (two per SIMD) -- the eighth is where the waves of K1, the scan's passes and
     // the per-burst filters of the other streams live while this kernel runs.  Measured (10 MHz, in run, six / seven per
@@ -523,19 +541,19 @@ static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_
         }
         if (7 * n_cu < n_tiles) grid = 7 * n_cu;
     }
-    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
-    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
-    else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
+    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
+    else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
-                   const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
+                   const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk, unsigned *next_tile)
 {
     if (src.ring_len % 8 != 0 || src.ref_ring % 8 != 0 || (src.chunk_start != ~0ull && src.chunk_start % 8 != 0)) return 1;
     switch (decim) {
-    case 40: return launch_fir_f_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
-    case 48: return launch_fir_f_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
+    case 40: return launch_fir_f_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk, next_tile);
+    case 48: return launch_fir_f_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk, next_tile);
     default: return 1;
     }
 }

@@ -3210,6 +3210,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
+    if (!strcmp(key, "fir_claim")) { irdm::g_fir_claim = value != 0; return 0; }
     if (!strcmp(key, "fir_order") || !strcmp(key, "simd_order")) {
         // (per pipeline; the calling thread's switch follows at once for the stage-level calls that take no pipeline)
         p->fir_order = value ? 1 : 0;
