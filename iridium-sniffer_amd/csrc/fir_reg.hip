@@ -390,12 +390,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     static_assert(M % 4 == 0 && VT % 8 == 0 && (kFirTaps - 1) % 4 == 0, "tap k -> accumulator k % 4 = (k % M) % 4; one tap left over");
     const int lane = threadIdx.x;
     kclk_enter(kclk);
-    // Strips: the workgroup's first one is its index; every further one is CLAIMED from a counter (next_tile, zeroed by
-    // fir_geom_kernel) when the grid is smaller than the strips -- a resident grid with fixed shares (tile += gridDim.x) ends
-    // when its slowest wavefront does, and in run the wavefronts do not run at one speed: the ones that share a SIMD with the
-    // lane-per-burst kernels of the other chains (priority 3, 0.2-0.8 ms long) fall behind (decimator in run 0.46 ms against
-    // 0.33 alone at four contexts).  The claim for the strip after this one is made before this one's work: its latency is
-    // the strip's.
+    // Strips: fixed shares (tile += gridDim.x), or -- option fir_claim, off: measured slower -- the workgroup's first strip
+    // its index and every further one CLAIMED from a counter (next_tile, zeroed by fir_geom_kernel): a resident grid with
+    // fixed shares ends when its slowest wavefront does, and in run the wavefronts that share a SIMD with the lane-per-burst
+    // kernels of the other chains fall behind (0.46 ms in run against 0.33 alone at four contexts); the claim for the strip
+    // after this one is made before this one's work.
     const bool claim = next_tile != nullptr && (int)gridDim.x < n_tiles;
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < n_tiles;) {
@@ -516,7 +515,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     kclk_leave(kclk);
 }
 
-int g_fir_claim = 1;           // 1 (default): the resident grid of fir_decimate_kernel_f claims its strips from a counter; 0: fixed shares
+int g_fir_claim = 0;           // 1: the resident grid of fir_decimate_kernel_f claims its strips from a counter; 0 (default): fixed shares.
+                               // Measured (profiles/r5_fir_claim.json): with the claim the kernel takes 0.54 ms ALONE against 0.33 -- the strip
+                               // index reaches the geometry record's scalar loads through an atomic and a v_readfirstlane at every strip --
+                               // and 58-59 Gsamples/s against 68.5-70.2 in run: fixed shares stay.
 
 template <int M>
 static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,

@@ -161,7 +161,7 @@ int launch_fir_mfma(const SampleSource &src, const FirGeom *geom, int n_tiles, i
 int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
                    const float2 *rot_table, float2 *dec, hipStream_t stream,
                    unsigned long long *kclk = nullptr, unsigned *next_tile = nullptr);
-extern int g_fir_claim;           // 1 (default): the resident decimator grid claims its strips from a counter   // fir_decimate_kernel_f; 0 ok, -1 error, 1 not applicable
+extern int g_fir_claim;           // 1: the resident decimator grid claims its strips from a counter (default 0: measured slower)   // fir_decimate_kernel_f; 0 ok, -1 error, 1 not applicable
 int fir_reg_supported(int decim);
 int fir_reg_tile_out(int decim);
 int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,

@@ -51,8 +51,8 @@ def test_fused_four_accumulator_kernel_10mhz(scene10):
     c = (n // 3) // 32768 * 32768
     parity.compare(parity.run_gpu(iq, 10_000_000, chunks=[c, c, n - 2 * c], depth=1), ref)
     try:
-        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 300}), ref)      # (strips claimed from the counter)
-        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 300, "fir_claim": 0}), ref)   # fixed shares
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 300}), ref)      # fixed shares
+        parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 300, "fir_claim": 1}), ref)   # strips claimed from a counter
         parity.compare(parity.run_gpu(iq, 10_000_000, options={"fir_grid": 0}), ref)      # one workgroup per strip
     finally:
         _restore()
@@ -74,7 +74,7 @@ def _restore():
     p.set_option("fir_layout", 3)
     p.set_option("fir_strip", 3)
     p.set_option("fir_grid", -1)
-    p.set_option("fir_claim", 1)
+    p.set_option("fir_claim", 0)
     p.set_option("fir_order", 1)
     p.close()
 
