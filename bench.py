@@ -451,7 +451,8 @@ def main():
                     help="pipeline_depth >= 1: 1 = the chunk lives in its slot of the history ring (irdm_ingest_ptr; the ring is "
                          "filled with the synthetic chunk before the timed region), 0 = fed from a separate buffer and copied")
     ap.add_argument("--lookahead", type=int, default=1,
-                    help="pipeline_depth >= 1: 1 = irdm_feed_begin(k+1) before irdm_feed_end(k)")
+                    help="pipeline_depth >= 1: 1 = irdm_feed_begin(k+1) before irdm_feed_end(k); 2 = two chunks begun ahead "
+                         "(K1 of chunk k+2 on the GPU a period early); 0 = irdm_feed_device")
     ap.add_argument("--host-steps", type=int, default=6,
                     help="extra, separately timed steps fed from pinned HOST memory (PCIe-inclusive rate; 0 = skip)")
     args = ap.parse_args()
@@ -565,7 +566,7 @@ def main():
             return pipe.feed_device(ptr, n, stream)
         pipe.feed_begin(ptr, n, stream)
         pending[0] += 1
-        if pending[0] > 1:
+        if pending[0] > min(max(args.lookahead, 1), 2):          # (chunks begun ahead of the one that is ended: 1 or 2)
             pending[0] -= 1
             return pipe.feed_end()
         return 0
@@ -986,7 +987,7 @@ def main():
                        "samples_per_step_per_gpu": n, "bursts_per_step": totals["bursts"] / K,
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
-                       "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": look,
+                       "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": (min(max(args.lookahead, 1), 2) if look else 0),
                        "packed_records": packed,      # the timed context returns 176-byte frame records (what frame_output_print reads: no LLRs)
                        "records": ({"produced": int(counts[1].item()), "sent": int(counts[2].item()),
                                     "gathered_on_rank0": int(gathered.item())} if world > 1 else None),

@@ -377,7 +377,7 @@ __device__ __forceinline__ void fir_fetch_column(const SampleSource &src, const 
     }
 }
 
-template <int M, int FMT>
+template <int M, int FMT, bool CLAIM = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_f(
     SampleSource src, const FirGeom *__restrict__ geom, const float *__restrict__ taps,
     const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk,
@@ -395,11 +395,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // fixed shares ends when its slowest wavefront does, and in run the wavefronts that share a SIMD with the lane-per-burst
     // kernels of the other chains fall behind (0.46 ms in run against 0.33 alone at four contexts); the claim for the strip
     // after this one is made before this one's work.
-    const bool claim = next_tile != nullptr && (int)gridDim.x < n_tiles;
+    // (a template parameter: the claim's few registers cost the fixed-share kernel a 20-byte spill when both lived in one body)
+    const bool claim = CLAIM && next_tile != nullptr && (int)gridDim.x < n_tiles;
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < n_tiles;) {
         int tile_next = tile + (int)gridDim.x;
-        if (claim) {
+        if (CLAIM && claim) {
             unsigned c = 0;
             if (lane == 0) c = atomicAdd(next_tile, 1u);
             tile_next = (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane((int)c);
@@ -542,6 +543,12 @@ static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_
             if (n_cu <= 0) n_cu = 256;
         }
         if (7 * n_cu < n_tiles) grid = 7 * n_cu;
+    }
+    if (next_tile != nullptr) {
+        if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
+        else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
+        else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
     else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);

@@ -184,6 +184,13 @@ struct irdm_pipeline;
 // latency divided by three -- the feeding thread spent 0.6 ms of every 1.05 ms step waiting for the oldest chain
 // (profiles/r5_spec_ab.json, host_us "wait_older_chain") -- and nothing done to the scan or the decimator moved it.
 constexpr int kMaxBc = 6;
+// Feed slots: chunks that may be between irdm_feed_begin and the settling of their scan -- the one being scanned, the one
+// whose scan is chained behind it, and TWO begun ahead (round 5: one more than before, so that K1 of chunk k + 2 is on the GPU
+// a period early and runs in the stretches where the chains in flight are in their lane-per-burst kernels instead of in
+// front of the decimator of every period, kernel trace in profiles/r5_kernel_trace_gantt.txt).  A slot owns a magnitude
+// buffer, K1's candidate lists with the levels they were built against, and the events of its K1 and ring copy.
+constexpr int kFeedSlots = 4;
+constexpr unsigned kLookAhead = 2;
 
 // One batch of finished bursts on its way through the per-burst stages K4..K7.  pipeline_depth 0 uses one context on the
 // detector's stream; pipeline_depth >= 1 alternates between two, each on a stream of its own, so that the FIR of one
@@ -250,7 +257,7 @@ struct irdm_pipeline {
     hipEvent_t ev_plan_set[2][kBandRounds + 2] = {};
     unsigned walk_launched = 0;             // BandWork::walk_host
     // band_tail (scan_band.hip): the history copy of scan k runs on stream_side beside scan k + 1's round 0
-    hipEvent_t ev_hist_set[3] = {};         // recorded behind the history copy of the scan of chunk k: [k % 3] (the magnitude buffer it reads)
+    hipEvent_t ev_hist_set[kFeedSlots] = {};   // recorded behind the history copy of the scan of chunk k: [k % kFeedSlots] (the magnitude buffer it reads)
     hipEvent_t ev_hist_hop = nullptr;       // scan stream -> side stream
     hipEvent_t ev_hist_last = nullptr;      // the latest history copy enqueued (nullptr: none): whatever touches the ring next waits for it
     // band_spec (scan_band.hip): round 0 of chunk k + 1 as a speculation pass on a second workspace and stream, beside chunk
@@ -380,21 +387,22 @@ struct irdm_pipeline {
         bool in_ring;           // the caller wrote the chunk where irdm_ingest_ptr() said: no copy into the ring
         bool lists;             // K1 wrote the band scan's candidate lists of the chunk (k1_pre / k1_counts / k1_entries)
         hipEvent_t ev_start, ev_k1, ev_copy;
-    } fs[3];
+    } fs[kFeedSlots];
     // candidate lists written by K1 (fft_mag_r16_kernel<.., LISTS>), one set per feed slot: the reference levels the
     // lists were built against, the per-frame counts and entries
-    float *k1_pre[3];
-    unsigned *k1_counts[3];
-    ListEntry *k1_entries[3];
+    float *k1_pre[kFeedSlots];
+    unsigned *k1_counts[kFeedSlots];
+    ListEntry *k1_entries[kFeedSlots];
     int k1_lists;               // option: 1 = let K1 build the lists where it can
     int band_first;             // band-scan rounds enqueued up front: 0 = as many as the previous chunk needed (at least
                                 // 2, kBandFirst to begin with), n = always n (test hook)
     int band_auto, fl_band_first;
     const FeedSlot *fl_feed;    // feed slot of the scan in flight
     uint64_t stat_k1_lists;
-    uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % 3
+    uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % kFeedSlots
     uint64_t begun_samples;     // absolute index the next irdm_feed_begin starts at
     float *d_mag3;
+    float *d_mag4 = nullptr;
     double host_us[10];         // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
@@ -477,7 +485,8 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
                      p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
-                     p->d_fir_off, p->d_mag2, p->d_mag3, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
+                     p->d_fir_off, p->d_mag2, p->d_mag3, p->d_mag4, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
+                     p->k1_pre[3], p->k1_counts[3], p->k1_entries[3],
                      p->k1_pre[0] != p->d_pre ? p->k1_pre[0] : nullptr, p->k1_counts[0] != p->d_counts ? p->k1_counts[0] : nullptr,
                      p->k1_entries[0] != p->d_entries ? p->k1_entries[0] : nullptr, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin, p->d_kclk, p->d_state_spec };
@@ -498,7 +507,7 @@ static void pipeline_free(irdm_pipeline *p)
         p->cfo_cv.notify_one();
         p->cfo_thread.join();
     }
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < kMaxBc; i++) {
         BatchCtx &b = p->bc[i];
         if (b.ev_cfo) (void)hipEventDestroy(b.ev_cfo);
         if (b.ev_rot) (void)hipEventDestroy(b.ev_rot);
@@ -672,7 +681,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->band_auto = kBandFirst;
     p->ring_len = p->ref_ring + p->l_cap + p->feed_block;
     // the per-burst chains in flight read the previous depth+1 chunks while this one and the next (look-ahead) arrive
-    if (p->depth) p->ring_len += (size_t)(p->depth + 3) * p->max_chunk;
+    if (p->depth) p->ring_len += (size_t)(p->depth + 2 + kLookAhead) * p->max_chunk;
     p->ring_len = (p->ring_len + 15) / 16 * 16;     // 16-sample segments never straddle the wrap
     // whole chunks: a chunk written in place (irdm_ingest_ptr) is contiguous (max_chunk is a multiple of feed_block)
     if (p->depth) p->ring_len = (p->ring_len + p->max_chunk - 1) / p->max_chunk * p->max_chunk;
@@ -788,6 +797,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_mag, float, p->max_chunk);
     if (p->depth) AL(p->d_mag2, float, p->max_chunk);
     if (p->depth) AL(p->d_mag3, float, p->max_chunk);
+    if (p->depth) AL(p->d_mag4, float, p->max_chunk);
     AL(p->d_state, DetState, 1);
     AL(p->d_gone, GoneBurst, (size_t)p->gone_cap);
     AL(p->d_cand_a, PeakCand, (size_t)P.n);
@@ -859,7 +869,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         p->k1_pre[0] = p->d_pre;
         p->k1_counts[0] = p->d_counts;
         p->k1_entries[0] = p->d_entries;
-        for (int i = 0; i < 3 && p->depth; i++) {
+        for (int i = 0; i < kFeedSlots && p->depth; i++) {
             AL(p->k1_pre[i], float, (size_t)P.n);
             AL(p->k1_counts[i], unsigned, max_frames);
             AL(p->k1_entries[i], ListEntry, max_frames * (size_t)std::max(kListCap, band_list_cap(P.n)));
@@ -1880,7 +1890,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
 {
     // (band_tail: this scan's history copy is recorded in the event of the magnitude buffer it reads; it waits for the latest
     // one enqueued before -- the previous scan's, or this scan's own from an earlier launch)
-    hipEvent_t hist_done = p->ev_hist_set[chunk_no % 3], hist_wait = p->ev_hist_last;
+    hipEvent_t hist_done = p->ev_hist_set[chunk_no % kFeedSlots], hist_wait = p->ev_hist_last;
     struct HistNote {
         irdm_pipeline *p; hipEvent_t e;
         ~HistNote() { if (irdm::g_band_tail || irdm::g_band_hist_side) p->ev_hist_last = e; }
@@ -2330,11 +2340,11 @@ static int deferred_enqueue(irdm_pipeline *p)
     int base = 0;
     // the chain reads the ring: it must hold the chunk these bursts come from (ev_ring: a seeded history)
     IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, p->ev_ring, 0));
-    IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, p->fs[p->pend_no % 3].ev_copy, 0));
+    IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, p->fs[p->pend_no % kFeedSlots].ev_copy, 0));
     // ... and K1 of the newest chunk goes first (k1_first 1), or K1 and its ring copy (2): a detector scan waits for
     // it, and K1 next to the decimator took 1.0-1.6 ms instead of 0.24 ms
     if (p->begin_no > 0) {
-        const irdm_pipeline::FeedSlot &newest = p->fs[(p->begin_no - 1) % 3];
+        const irdm_pipeline::FeedSlot &newest = p->fs[(p->begin_no - 1) % kFeedSlots];
         if (p->k1_first >= 2) IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, newest.ev_copy, 0));
         else if (p->k1_first == 1) IRDM_HIP_CHECK(hipStreamWaitEvent(b.stream, newest.ev_k1, 0));
     }
@@ -2424,7 +2434,7 @@ extern "C" int irdm_advance(irdm_pipeline_t *p)
 extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream_v)
 {
     if (!p || (!d_iq && n_samples)) return -1;
-    if (p->begin_no - p->end_no > (p->depth ? 1u : 0u)) return -1;      // one chunk of look-ahead, pipeline_depth >= 1 only
+    if (p->begin_no - p->end_no > (p->depth ? kLookAhead : 0u)) return -1;      // two chunks of look-ahead, pipeline_depth >= 1 only
     if (p->stream_closed) {
         fprintf(stderr, "irdm_hip: stream already ended by a chunk that was not a multiple of feed_block\n");
         return -1;
@@ -2452,13 +2462,13 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
 
     // K1 of this chunk.  pipeline_depth 1: on its own stream and into the other magnitude buffer, while the detector
     // scan of the previous chunk may still be running
-    irdm_pipeline::FeedSlot &f = p->fs[p->begin_no % 3];
-    float *const mags[3] = { p->d_mag, p->d_mag2, p->d_mag3 };
-    float *mag = p->depth ? mags[p->begin_no % 3] : p->d_mag;
+    irdm_pipeline::FeedSlot &f = p->fs[p->begin_no % kFeedSlots];
+    float *const mags[kFeedSlots] = { p->d_mag, p->d_mag2, p->d_mag3, p->d_mag4 };
+    float *mag = p->depth ? mags[p->begin_no % kFeedSlots] : p->d_mag;
     // (band_tail: the history copy of the scan that last read this magnitude buffer -- three chunks ago, one with
     // pipeline_depth 0 -- ran on the side stream: long over, but nothing else orders K1 behind it)
     if (p->band_ok) {
-        if (p->depth) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_set[p->begin_no % 3]));
+        if (p->depth) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_set[p->begin_no % kFeedSlots]));
         else if (p->ev_hist_last) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_last));
     }
     // written in place (irdm_ingest_ptr)?  Then the ring already holds the chunk.
@@ -2470,21 +2480,21 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
     // sums as they are NOW (the previous chunk's scan may still be at work on them -- any levels do, the scan checks the
     // lists against the ones they were built with, scan_band.hip band_sum_kernel); not before the detector is primed
     // (no sums yet: every bin would be listed)
-    const int ls = p->depth ? (int)(p->begin_no % 3) : 0;       // (pipeline_depth 0: one chunk at a time, one set)
+    const int ls = p->depth ? (int)(p->begin_no % kFeedSlots) : 0;       // (pipeline_depth 0: one chunk at a time, one set)
     f.lists = false;
     if (p->k1_lists && p->host_primed && scan_pick(p) == 2 && p->k1_pre[ls] && n_frames > 0) {
         if (launch_prefilter_threshold(p->d_sum, P.threshold, p->k1_pre[ls], P.n, p->fstream) != 0) return -1;
         const int rc = launch_fft_mag_lists(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->k1_pre[ls],
                                             p->k1_counts[ls], p->k1_entries[ls], band_list_cap(P.n), p->fstream,
-                                            p->kclk_rec(3 + ls));
+                                            p->kclk_rec(3 + ls % 3));
         if (rc < 0) return -1;
         f.lists = rc == 0;
     }
     if (!f.lists && launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream,
-                                   p->kclk_rec(3 + ls)) != 0)
+                                   p->kclk_rec(3 + ls % 3)) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(f.ev_k1, p->fstream));
-    if (n_frames > 0 && launch_kclk_fold(p->kclk_rec(3 + ls), p->fstream) != 0) return -1;   // (behind the event the scan waits for)
+    if (n_frames > 0 && launch_kclk_fold(p->kclk_rec(3 + ls % 3), p->fstream) != 0) return -1;   // (behind the event the scan waits for)
     // this chunk into the history ring, behind K1 on its stream (the ring keeps the chunks the per-burst chains in
     // flight still read: the copy never overwrites them)
     if (p->depth && !in_ring && (ring_guard(p, c0, c1, p->fstream) != 0 || ring_update(p, d_iq, c0, c1, p->fstream) != 0)) return -1;
@@ -2504,7 +2514,7 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
 {
     if (!p || p->begin_no == p->end_no) return -1;
     pipeline_enter(p);
-    irdm_pipeline::FeedSlot &f = p->fs[p->end_no % 3];
+    irdm_pipeline::FeedSlot &f = p->fs[p->end_no % kFeedSlots];
     const void *d_iq = f.iq;
     const uint64_t c0 = f.c0, c1 = f.c1;
     float *mag = f.mag;
@@ -2572,14 +2582,14 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         IRDM_HOST_PHASE(2);
         // 3b. the next chunk, if its feed has begun (look-ahead): its round 0 as a speculation pass beside this chunk's scan
         if (p->begin_no > p->end_no + 1 && p->fl_mode == 2 && p->fl_band_ran &&
-            spec_enqueue(p, p->fs[(p->end_no + 1) % 3], p->chunk_no + 1) != 0)
+            spec_enqueue(p, p->fs[(p->end_no + 1) % kFeedSlots], p->chunk_no + 1) != 0)
             return -1;
         // 3c. ... and its scan, chained behind this chunk's, NOW: what follows -- the wait for the oldest chain, the records,
         //     the caller's polls and its next irdm_feed_begin -- took 0.4-0.8 ms, during which the scan's stream ran dry
         //     after every scan: the period was (that host time + a scan) / 2, not a scan.
         //     The same launch the next irdm_feed_end would make first thing -- it finds it done.
         if (p->chain_early && p->begin_no > p->end_no + 1 && !p->chain_pending &&
-            scan_chain_try(p, p->fs[(p->end_no + 1) % 3], p->chunk_no + 1) != 0)
+            scan_chain_try(p, p->fs[(p->end_no + 1) % kFeedSlots], p->chunk_no + 1) != 0)
             return -1;
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
         if (!finished_early) {

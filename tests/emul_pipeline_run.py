@@ -53,6 +53,8 @@ def main():
         # five batch contexts (pipeline_depth 4): records five chunks late, same records, same order
         res["chunked_depth4_in_place_lookahead"] = parity.compare(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=4, feed="ingest_lookahead"), ref)
+        res["chunked_depth3_two_ahead"] = parity.compare(
+            parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=3, feed="lookahead2"), ref)
         x = siggen.to_ci8(iq)
         ref8 = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
         res["ci8"] = parity.compare(parity.run_gpu(x, fs, fmt=irdm.FMT_CI8), ref8)
@@ -102,6 +104,9 @@ def main():
         got = parity.run_gpu(iq, fs, chunks=sizes, depth=5, feed="ingest_lookahead")
         res["depth5"] = parity.compare(got, ref)
         assert got["stats"]["spec_scans"] >= 2, got["stats"]
+        got = parity.run_gpu(iq, fs, chunks=sizes, depth=3, feed="ingest_lookahead2")
+        res["two_chunks_begun_ahead"] = parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] >= 1, got["stats"]
         got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"band_spec": 0})
         res["without_speculation_pass"] = parity.compare(got, ref)
         assert got["stats"]["spec_scans"] == 0 and got["stats"]["scan_chained"] >= 2, got["stats"]

@@ -36,7 +36,7 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
         import ctypes as C
         assert depth >= 1
         ingest = feed.startswith("ingest")
-        look = feed.endswith("lookahead")
+        look = feed.endswith("lookahead") or feed.endswith("lookahead2")
         held = []                # device buffers of chunks begun (not "ingest"): released after their feed_end
 
         def begin(c, off):
@@ -58,11 +58,12 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
                 irdm.device_free(ptr)
 
         pending = 0
+        ahead = 2 if feed.endswith("lookahead2") else 1 if look else 0      # chunks begun ahead of the one that is ended
         for c in sizes:
             begin(c, off)
             off += c
             pending += 1
-            if pending > (1 if look else 0):
+            if pending > ahead:
                 end()
                 pending -= 1
         while pending:

@@ -33,7 +33,7 @@ def long_scene():
 
 
 @pytest.mark.parametrize("depth", [1, 2])
-@pytest.mark.parametrize("feed", ["ingest", "lookahead", "ingest_lookahead"])
+@pytest.mark.parametrize("feed", ["ingest", "lookahead", "ingest_lookahead", "ingest_lookahead2"])
 def test_feed_variants_long_stream(long_scene, feed, depth):
     fs, iq, ref = long_scene
     got = parity.run_gpu(iq, fs, chunks=_equal_chunks(len(iq), 8), depth=depth, feed=feed)
@@ -67,15 +67,18 @@ def test_ingest_ptr_contract():
         z = np.zeros(chunk, np.complex64)
         p.feed_host(z)                                  # an ordinary feed moves the position as well
         assert p.ingest_ptr(chunk) == base + chunk * 8
-        # two begins may be pending, not three; flush refuses while one is
-        a, b = irdm.device_buffer(z), irdm.device_buffer(z)
+        # three begins may be pending (two chunks of look-ahead), not four; flush refuses while one is
+        a, b, c = irdm.device_buffer(z), irdm.device_buffer(z), irdm.device_buffer(z)
         p.feed_begin(a, chunk)
         p.feed_begin(b, chunk)
+        p.feed_begin(c, chunk)
         with pytest.raises(RuntimeError):
             p.feed_begin(a, chunk)
         assert p.L.irdm_flush(p.h) == -1
         p.feed_end()
         p.feed_end()
+        p.feed_end()
+        irdm.device_free(c)
         with pytest.raises(RuntimeError):
             p.feed_end()
         p.flush()
@@ -136,10 +139,10 @@ def test_scan_opens_with_round_1_behind_a_speculation_pass():
     the guess is spoilt chunk after chunk by a different chunking (bursts carried across every boundary)."""
     fs, iq = scenes.ALL["many_active_10m"]()
     ref = orc.run_stream(iq, fs)
-    for parts in (12, 7):
+    for parts, feed in ((12, "ingest_lookahead"), (7, "ingest_lookahead"), (12, "ingest_lookahead2"), (9, "lookahead2")):
         blocks = max(1, (len(iq) // 32768) // parts)
         chunks = _equal_chunks(len(iq), blocks)
-        got = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead")
+        got = parity.run_gpu(iq, fs, chunks=chunks, depth=3 if feed.endswith("2") else 2, feed=feed)
         parity.compare(got, ref)
         assert got["stats"]["spec_scans"] >= 2 and got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
         assert got["stats"]["scan_fallbacks"] == 0 and got["stats"]["band_aborts"] == 0, got["stats"]

@@ -1,0 +1,256 @@
+#!/bin/bash
+# Round 5's experiment runs on the GPU box, one function per gpurun call (tools/r5_experiments.sh <a..h> [out-dir]); the
+# condensed results are the profiles/r5_*.json files named in DESIGN.md.  (tools/measure_round.sh is the round-end measurement.)
+set -u
+EXP=${1:?which experiment: a .. h}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${2:-r5_$EXP}
+mkdir -p "$OUT"
+cd "$GRAFT_REPO_ROOT"
+
+# round 5, first GPU call: the whole -m gpu suite with the tail form of the scan (default), the MFMA decimator ubench, and
+# A/B bench lines of the scan's forms (band_tail 0 / 1, workgroup width of the walk that carries the tail), with timelines
+exp_a() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 900 python -m pytest tests -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 5 "$OUT/tests.log"
+  timeout 300 tools/ubench/mfma_fir 40 2048 512 5 > "$OUT/mfma_fir.txt" 2>&1
+  timeout 200 tools/ubench/mfma_fir 48 2048 512 5 >> "$OUT/mfma_fir.txt" 2>&1
+  cat "$OUT/mfma_fir.txt"
+  run() { # name, args...
+    local name=$1; shift
+    timeout 120 python bench.py --steps 20 --warmup 5 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run t1_1024 --opt band_tail=1
+  run t0 --opt band_tail=0
+  run t1_512 --opt band_tail=1 --opt band_tail_threads=512
+  run t1_256 --opt band_tail=1 --opt band_tail_threads=256
+  run t1_1024b --opt band_tail=1
+  run t0b --opt band_tail=0
+  run tl_t1 --opt band_tail=1 --opt band_timeline=1
+  run tl_t0 --opt band_tail=0 --opt band_timeline=1
+  run tl_t1_d0 --depth 0 --opt band_tail=1 --opt band_timeline=1
+  run tl_t1_256 --opt band_tail=1 --opt band_tail_threads=256 --opt band_timeline=1
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_tail=1 2>/dev/null | tail -1 > "$OUT/c5_t1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_tail=0 2>/dev/null | tail -1 > "$OUT/c5_t0.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_tail=1 --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/c5_tl_t1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q --density 2 --opt band_tail=1 2>/dev/null | tail -1 > "$OUT/d2_t1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q --density 2 --opt band_tail=0 2>/dev/null | tail -1 > "$OUT/d2_t0.json"
+}
+
+# round 5, second GPU call: round 0 as a speculation pass beside the previous chunk's scan (band_spec, default on) against
+# the classical scan; the whole -m gpu suite first
+exp_b() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 900 python -m pytest tests -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 5 "$OUT/tests.log"
+  run() { # name, args...
+    local name=$1; shift
+    timeout 120 python bench.py --steps 20 --warmup 5 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run s1 --opt band_spec=1
+  run s0 --opt band_spec=0
+  run s1b --opt band_spec=1
+  run s0b --opt band_spec=0
+  run s1_h1 --opt band_spec=1 --opt band_hist_side=1
+  run s0_h1 --opt band_spec=0 --opt band_hist_side=1
+  run s1_h1b --opt band_spec=1 --opt band_hist_side=1
+  run tl_s1_h1 --opt band_spec=1 --opt band_hist_side=1 --opt band_timeline=1
+  run tl_s1 --opt band_spec=1 --opt band_timeline=1
+  run s1_fir0 --opt band_spec=1 --opt fir_order=0
+  run s1_d3 --opt band_spec=1 --depth 3
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_spec=1 2>/dev/null | tail -1 > "$OUT/c5_s1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_spec=0 2>/dev/null | tail -1 > "$OUT/c5_s0.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_spec=1 --opt band_hist_side=1 2>/dev/null | tail -1 > "$OUT/c5_s1_h1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_spec=1 --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/c5_tl_s1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_spec=1 --opt fir_grid=1536 2>/dev/null | tail -1 > "$OUT/c5_s1_grid1536.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q $D12 --opt band_spec=1 --opt fir_grid=1280 2>/dev/null | tail -1 > "$OUT/c5_s1_grid1280.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q --density 2 --opt band_spec=1 2>/dev/null | tail -1 > "$OUT/d2_s1.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q --density 2 --opt band_spec=0 2>/dev/null | tail -1 > "$OUT/d2_s0.json"
+  timeout 120 python bench.py --steps 10 --warmup 3 $Q --density 40 --opt band_spec=1 2>/dev/null | tail -1 > "$OUT/d40_s1.json"
+  timeout 200 python bench.py --shard time --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
+}
+
+# round 5, third GPU call: more batch contexts (pipeline_depth 2..5) x the scan's forms.  The feeding thread waited 0.6 ms of
+# every 1.05 ms step for the oldest per-burst chain (profiles/r5_spec_ab.json): the period was chain latency / 3 contexts.
+exp_c() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  run() { # name, args...
+    local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run d2_s1 --depth 2
+  run d3_s1 --depth 3
+  run d4_s1 --depth 4
+  run d5_s1 --depth 5
+  run d3_s0 --depth 3 --opt band_spec=0
+  run d4_s0 --depth 4 --opt band_spec=0
+  run d5_s0 --depth 5 --opt band_spec=0
+  run d4_s1_h1 --depth 4 --opt band_hist_side=1
+  run d5_s1_h1 --depth 5 --opt band_hist_side=1
+  run d4_s1_fir0 --depth 4 --opt fir_order=0
+  run tl_d4_s1 --depth 4 --opt band_timeline=1
+  run tl_d4_s0 --depth 4 --opt band_spec=0 --opt band_timeline=1
+  run d4_s1_b --depth 4
+  for d in 2 4 5; do
+    timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --depth $d 2>/dev/null | tail -1 > "$OUT/c5_d$d.json"
+    timeout 150 python bench.py --steps 10 --warmup 6 $Q --density 2 --depth $d 2>/dev/null | tail -1 > "$OUT/dens2_d$d.json"
+  done
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q --density 40 --depth 4 2>/dev/null | tail -1 > "$OUT/dens40_d4.json"
+}
+
+# round 5, fourth GPU call: the decimator on the matrix cores (fir_layout 4) -- its tests, then bench lines against the
+# VALU kernel at pipeline_depth 2 / 3, alone (depth 0) and in the dense 12 MHz scene
+exp_d() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 900 python -m pytest tests/test_gpu_fir_reg.py -x -q -m gpu -k "matrix_core" > "$OUT/tests.log" 2>&1
+  tail -n 15 "$OUT/tests.log"
+  run() { # name, args...
+    local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run d0_l4 --depth 0 --opt fir_layout=4
+  run d0_l3 --depth 0
+  run d3_l4 --depth 3 --opt fir_layout=4
+  run d3_l3 --depth 3
+  run d2_l4 --depth 2 --opt fir_layout=4
+  run d3_l4_b --depth 3 --opt fir_layout=4
+  run d3_l3_b --depth 3
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --depth 3 --opt fir_layout=4 2>/dev/null | tail -1 > "$OUT/c5_d3_l4.json"
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --depth 3 2>/dev/null | tail -1 > "$OUT/c5_d3_l3.json"
+  timeout 150 python bench.py --steps 6 --warmup 3 $Q $D12 --depth 0 --opt fir_layout=4 2>/dev/null | tail -1 > "$OUT/c5_d0_l4.json"
+}
+
+# round 5, fifth GPU call: the next chunk's scan chained BEFORE the feeding thread waits for the oldest chain
+# (scan_chain_early) x pipeline_depth x speculation pass x history copy on the side stream; a kernel trace of the best
+exp_e() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  run() { # name, args...
+    local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run d3_e1_s1 --depth 3
+  run d3_e0_s1 --depth 3 --opt scan_chain_early=0
+  run d3_e1_s0 --depth 3 --opt band_spec=0
+  run d2_e1_s1 --depth 2
+  run d4_e1_s1 --depth 4
+  run d5_e1_s1 --depth 5
+  run d3_e1_s1_h1 --depth 3 --opt band_hist_side=1
+  run d4_e1_s1_h1 --depth 4 --opt band_hist_side=1
+  run d4_e1_s0 --depth 4 --opt band_spec=0
+  run d3_e1_s1_b --depth 3
+  run tl_d3_e1_s1 --depth 3 --opt band_timeline=1
+  for d in 3 4; do
+    timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --depth $d 2>/dev/null | tail -1 > "$OUT/c5_d$d.json"
+    timeout 150 python bench.py --steps 10 --warmup 6 $Q --density 2 --depth $d 2>/dev/null | tail -1 > "$OUT/dens2_d$d.json"
+  done
+  cd /tmp && export TMPDIR=/tmp
+  timeout 200 rocprofv3 --kernel-trace --stats -d "$OUT" -o kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 6 --depth 3 $Q > "$OUT/kt.log" 2>&1
+  cd "$GRAFT_REPO_ROOT"
+  ls "$OUT" | head -50
+}
+
+# round 5, sixth GPU call: the whole -m gpu suite at the round's defaults (speculation pass, early chaining; bench at
+# pipeline_depth 3), decimator grid sizes at depth 3, and the full default bench line
+exp_f() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  timeout 900 python -m pytest tests -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 5 "$OUT/tests.log"
+  run() { # name, args...
+    local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run g_default
+  run g_1536 --opt fir_grid=1536
+  run g_1280 --opt fir_grid=1280
+  run g_2048 --opt fir_grid=2048
+  run g_0 --opt fir_grid=0
+  run k1first2 --opt k1_first=2
+  run k1first0 --opt k1_first=0
+  run g_default_b
+  timeout 600 python bench.py 2>"$OUT/full.err" | tail -1 > "$OUT/full.json"
+}
+
+# round 5, seventh GPU call: CUs kept free of the per-burst chains' streams (IRDM_CHAIN_CU_RESERVE) so that the scan's
+# 1024-thread plan passes never wait for the decimator's resident grid to drain; the speculation pass's prep as 256 threads
+exp_g() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  run() { # name, env, args...
+    local name=$1; shift
+    local r=$1; shift
+    IRDM_CHAIN_CU_RESERVE=$r timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"
+  }
+  run r0_d3 0 --depth 3
+  run r8_d3 8 --depth 3
+  run r16_d3 16 --depth 3
+  run r4_d3 4 --depth 3
+  run r8_d4 8 --depth 4
+  run r8_d5 8 --depth 5
+  run r16_d5 16 --depth 5
+  run r8_d3_s0 8 --depth 3 --opt band_spec=0
+  run r8_d3_b 8 --depth 3
+  run r0_d3_b 0 --depth 3
+  run r32_d4 32 --depth 4
+  run tl_r8_d3 8 --depth 3 --opt band_timeline=1
+  IRDM_CHAIN_CU_RESERVE=8 timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --depth 3 2>/dev/null | tail -1 > "$OUT/c5_r8_d3.json"
+  IRDM_CHAIN_CU_RESERVE=8 timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --depth 5 2>/dev/null | tail -1 > "$OUT/c5_r8_d5.json"
+  IRDM_CHAIN_CU_RESERVE=8 timeout 150 python bench.py --steps 10 --warmup 6 $Q --density 2 --depth 3 2>/dev/null | tail -1 > "$OUT/dens2_r8_d3.json"
+}
+
+# round 5, eighth GPU call: the resident decimator grid claiming its strips from a counter (fir_claim 1 / 0), k1_first variants
+exp_h() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 600 python -m pytest tests/test_gpu_fir_reg.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run c1 
+  run c0 --opt fir_claim=0
+  run c1_b
+  run c0_b --opt fir_claim=0
+  run c1_k0 --opt k1_first=0
+  run c1_k0_b --opt k1_first=0
+  run c1_d4 --depth 4
+  run c1_d5 --depth 5
+  run c1_d0 --depth 0
+  run c1_g2048 --opt fir_grid=2048
+  run c1_d4_k0 --depth 4 --opt k1_first=0
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 2>/dev/null | tail -1 > "$OUT/c5_c1.json"
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --opt fir_claim=0 2>/dev/null | tail -1 > "$OUT/c5_c0.json"
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --opt k1_first=0 2>/dev/null | tail -1 > "$OUT/c5_c1_k0.json"
+}
+
+exp_$EXP
+
+# one line per bench result of the call
+python - "$OUT" <<'P'
+import json, sys, glob, os
+def find(d, key):
+    if isinstance(d, dict):
+        if key in d: return d[key]
+        for v in d.values():
+            r = find(v, key)
+            if r is not None: return r
+    return None
+for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
+    try:
+        d = json.load(open(f))
+        st = find(d, "stage_ms") or {}
+        sc = find(d, "scan") or {}
+        h = find(d, "host_us_total") or {}
+        n = d["steps"] + d["warmup"]
+        print(os.path.basename(f), d["value"], d["ms_per_step"], "scan_ms", st.get("scan"), "k1", st.get("fft_mag"), "fir", st.get("fir"), "post", st.get("post"),
+              "rounds/chunks", sc.get("band_rounds"), sc.get("band_chunks"), "undone", sc.get("scan_chain_undone"), "spec", sc.get("spec_scans"),
+              "host/step: settle", round(h.get("settle", 0) / n), "older_chain", round(h.get("wait_older_chain", 0) / n), "parity", (find(d, "parity_checked") or {}).get("ok"),
+              "kclk", find(d, "kernel_clock_ms"), "frac", find(d, "frac"))
+        tl = find(d, "scan_timeline_us")
+        if tl: print("   ", {k: v[:2] for k, v in tl.items()})
+    except Exception as e:
+        print(os.path.basename(f), "ERR", e)
+P
