@@ -2,7 +2,7 @@
 # Round 5's experiment runs on the GPU box, one function per gpurun call (tools/r5_experiments.sh <a..h> [out-dir]); the
 # condensed results are the profiles/r5_*.json files named in DESIGN.md.  (tools/measure_round.sh is the round-end measurement.)
 set -u
-EXP=${1:?which experiment: a .. h}
+EXP=${1:?which experiment: a .. i}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${2:-r5_$EXP}
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
@@ -224,6 +224,29 @@ exp_h() {
   timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 2>/dev/null | tail -1 > "$OUT/c5_c1.json"
   timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --opt fir_claim=0 2>/dev/null | tail -1 > "$OUT/c5_c0.json"
   timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --opt k1_first=0 2>/dev/null | tail -1 > "$OUT/c5_c1_k0.json"
+}
+
+# round 5, ninth GPU call: two chunks begun ahead (K1 of chunk k + 2 on the GPU a period early) against one
+exp_i() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 900 python -m pytest tests/test_gpu_ingest.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run l1
+  run l2 --lookahead 2
+  run l1_b
+  run l2_b --lookahead 2
+  run l2_d4 --lookahead 2 --depth 4
+  run l2_d5 --lookahead 2 --depth 5
+  run l2_k0 --lookahead 2 --opt k1_first=0
+  run l2_d4_k0 --lookahead 2 --depth 4 --opt k1_first=0
+  run l2_s0 --lookahead 2 --opt band_spec=0
+  run l2_d2 --lookahead 2 --depth 2
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --lookahead 2 2>/dev/null | tail -1 > "$OUT/c5_l2.json"
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q $D12 --lookahead 2 --opt k1_first=0 2>/dev/null | tail -1 > "$OUT/c5_l2_k0.json"
+  timeout 150 python bench.py --steps 10 --warmup 6 $Q --density 2 --lookahead 2 2>/dev/null | tail -1 > "$OUT/dens2_l2.json"
 }
 
 exp_$EXP
