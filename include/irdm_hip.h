@@ -231,9 +231,11 @@ int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, voi
 /* irdm_feed_device in two halves: _begin = what does not depend on the detector state (K1 of the chunk, its copy into
  * the history ring), _end = detector scan + per-burst work.  A time-sharded rank calls _begin, receives the previous
  * rank's state (irdm_import_state_device), then calls _end.
- * pipeline_depth >= 1: one chunk of look-ahead -- irdm_feed_begin(k+1) may be called before irdm_feed_end(k) (the
- * calls still alternate after that), which puts K1 of chunk k+1 on the GPU before the host waits for the detector
- * scan of chunk k-1.  The buffer handed to _begin may be reused when the matching _end has returned. */
+ * pipeline_depth >= 1: up to two chunks of look-ahead -- irdm_feed_begin(k+1), and irdm_feed_begin(k+2), may be called
+ * before irdm_feed_end(k) (the calls alternate after that; a fourth pending begin returns -1), which puts K1 of the
+ * chunks ahead on the GPU before the host waits for the detector scan of chunk k-1, and lets the library enqueue the
+ * speculation pass and the scan of chunk k+1 with chunk k's.  The buffer handed to _begin may be reused when the matching
+ * _end has returned. */
 int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
 int irdm_feed_end(irdm_pipeline_t *p);
 /* pipeline_depth >= 1: where the producer of the next chunk (an H2D copy, a conversion kernel) may write it so that the

@@ -144,7 +144,10 @@ def test_scan_opens_with_round_1_behind_a_speculation_pass():
         chunks = _equal_chunks(len(iq), blocks)
         got = parity.run_gpu(iq, fs, chunks=chunks, depth=3 if feed.endswith("2") else 2, feed=feed)
         parity.compare(got, ref)
-        assert got["stats"]["spec_scans"] >= 2 and got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
+        # (begun two chunks ahead, a chunk more is fed before the host learns that the detector is primed: fewer scans are
+        # chained at all on this short stream)
+        assert got["stats"]["spec_scans"] >= (1 if feed.endswith("2") else 2), got["stats"]
+        assert got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
         assert got["stats"]["scan_fallbacks"] == 0 and got["stats"]["band_aborts"] == 0, got["stats"]
         # (rounds per chunk stay what they were: a good guess is accepted by the first verdict)
         assert got["stats"]["band_rounds"] <= 3 * got["stats"]["band_chunks"], got["stats"]
