@@ -66,7 +66,8 @@ struct BandParams {
     int32_t selfcheck = 0;       // test hook (option band_selfcheck): bit 0 run both forms of the boundary test and compare,
                                  // bit 1 spoil band i+1's copy of every record in a boundary zone first (both must object),
                                  // bit 3 the wavefront walk without its 64-frame look-ahead (band_wave.hpp: skim),
-                                 // bit 4 the plan pass without its LDS (through the workspace arrays, wavefront boundary test)
+                                 // bit 4 the plan pass without its LDS (through the workspace arrays, wavefront boundary test),
+                                 // bit 5 the speculation pass's guess spoilt in one late frame (a round more, its sums pass restarted)
     int32_t ahead = 0;           // 1: the plan passes of this launch are launched ahead on a second stream and wait for
                                  // the walk pass's workgroups to count themselves done (BandWork::bar[8])
     int32_t tl_sel = -1;         // >= 0: the passes stamp their first workgroup's start and last one's end into half tl_sel of
@@ -76,6 +77,8 @@ struct BandParams {
     int32_t tail = 0;            // 1: the launch-saving form (scan_band.hip, g_band_tail): pair list, plan pass in the walk pass's
                                  // last workgroup, history on a side stream
     uint32_t seq = 0;            // tail: number of the SCAN this launch belongs to (HistJob::seq)
+    int32_t sum_restart = 1;     // 1: a later round's sums pass restarts at the last stored state in front of the first frame whose u
+                                 // changed (a snapshot every 64 update steps); 0: every sums pass walks all steps (option band_sum_restart)
     int32_t spec_in = 0;         // 1: this scan has no round 0 of its own -- a speculation pass on a second workspace, run beside
                                  // the previous chunk's scan, produced the update vector round 1 starts from (scan_band.hip, band_spec)
 };

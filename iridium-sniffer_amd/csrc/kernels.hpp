@@ -39,7 +39,9 @@ struct BandCtl {                         // control block on the device, copied 
     uint32_t flags;                      // BAND_F_* abort reasons
     int32_t n_upd, n_snap, agree_fail, mismatch, first_mismatch;
     int32_t n_gone, n_total, committed, h0;
-    int32_t pad[4];
+    int32_t k_restart, restart_slot;     // the sums pass of this round starts at update step k_restart (a multiple of 64) from the
+                                         // snapshot restart_slot the previous round stored: every step before is unchanged (0: from the start)
+    int32_t n_restarts, pad1;            // (statistics: rounds of this scan whose sums pass was restarted)
     uint32_t tp[16];                     // plan pass phase stamps (10 ns ticks since the pass began): [0..7] round 1, [8..15] the last verdict
 };
 struct SumStep {                         // one update step of the sums pass, as the byte offsets its buffer accesses take
@@ -89,6 +91,7 @@ extern int g_band_tail;                  // 1: fewer launches per scan (default 
                                          // pass (verdict, commit, export), the walk hands out its pairs from a list the crossing
                                          // pass's last workgroup made, the history copy runs on a side stream
 extern std::atomic<unsigned long long> g_band_tail_launches;
+extern int g_band_sum_restart;           // 1 (default): later rounds' sums passes restart at the last stored state in front of the first changed frame
 extern int g_band_hist_side;             // 1: a launch per pass, but the history copy on the side stream (HistJob) and the export in the last plan pass
 extern int g_band_tail_threads;          // threads per workgroup of the walk pass with the tail (256 / 512 / 1024)
 extern int g_band_sum_bins;              // bins per wavefront of the sums pass: 64 (default), 32 or 16

@@ -272,7 +272,7 @@ struct irdm_pipeline {
     hipEvent_t ev_spec_done = nullptr;      // behind the latest speculation pass
     uint64_t spec_for_no = ~0ull;           // the chunk the speculation workspace holds a pass for (~0: none)
     int spec_frames = 0;                    // ... and its frames
-    uint64_t stat_spec_passes = 0, stat_spec_scans = 0;
+    uint64_t stat_spec_passes = 0, stat_spec_scans = 0, stat_sum_restarts = 0;
     uint32_t seq_counter = 0;               // scans numbered so far (HistJob::seq; never 0)
     uint32_t fl_seq = 0;                    // number of the scan in flight
     uint32_t chain_seq = 0;                 // ... of the chained launch (scan_chain_try), taken over by scan_launch
@@ -2194,6 +2194,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
             }
         }
         for (int i = 0; i < 16; i++) p->stat_plan_tp[i] += ctl->tp[i];
+        p->stat_sum_restarts += (uint64_t)(ctl->n_restarts > 0 ? ctl->n_restarts : 0);
         if (ctl->status == 1) {
             p->band_auto = std::min(std::max(ctl->rounds, 2), kBandRounds);
             p->stat_band_chunks++;
@@ -3262,6 +3263,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_tail")) { irdm::g_band_tail = value != 0; return 0; }
     if (!strcmp(key, "band_spec")) { p->band_spec_opt = value != 0; return 0; }
     if (!strcmp(key, "band_hist_side")) { irdm::g_band_hist_side = value != 0; return 0; }
+    if (!strcmp(key, "band_sum_restart")) { irdm::g_band_sum_restart = value != 0; return 0; }
     if (!strcmp(key, "band_tail_threads")) {
         if (value != 256 && value != 512 && value != 1024) return -1;
         irdm::g_band_tail_threads = value;
@@ -3324,6 +3326,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "chain_cu_reserved")) return (int64_t)p->chain_cu_reserved;
     if (!strcmp(key, "spec_passes")) return (int64_t)p->stat_spec_passes;
     if (!strcmp(key, "spec_scans")) return (int64_t)p->stat_spec_scans;
+    if (!strcmp(key, "sum_restarts")) return (int64_t)p->stat_sum_restarts;
     if (!strcmp(key, "band_tail_launches")) return (int64_t)irdm::g_band_tail_launches.load();      // (process-wide)
     if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;

@@ -273,6 +273,7 @@ struct PlanShared {
     int32_t part[kPlanThreads / 64 + 1];
     int mismatch, first, status, agree_fail;
     unsigned flags;
+    int kstar;
 };
 
 constexpr int kPlanLdsFrames = 8192;     // frames the LDS form of the plan holds (need flags + snapshot slots: 80 KB)
@@ -401,6 +402,13 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             W.uq[f] = ((u_busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
             W.uf[f] = (uint8_t)((u_forced[f >> 6] >> (f & 63)) & 1);
         }
+        if (P.selfcheck & 32) {
+            // (test hook) the guess spoilt in ONE late frame: this round's verdict finds it, the next round's sums pass has a
+            // long unchanged prefix to restart behind
+            __syncthreads();
+            if (tid == 0 && F >= 8) W.uq[(3 * F) / 4] ^= 1;
+            __syncthreads();
+        }
     } else {
         // verdict on the previous round
         for (int f = tid; f < F; f += kPlanThreads) {
@@ -496,8 +504,9 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         for (int j = 0; j < FPT; j++) {
             const int f = f0 + j;
             if (f < F) {
-                const int q = ((u_busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
+                int q = ((u_busy[f >> 6] >> (f & 63)) & 1) ? 0 : 1;
                 const int fc = (int)((u_forced[f >> 6] >> (f & 63)) & 1);
+                if ((P.selfcheck & 32) && first && round == 1 && F >= 8 && f == (3 * F) / 4) q ^= 1;       // (test hook, as above)
                 uqb |= q << j;
                 ufb |= fc << j;
                 cnz |= (counts[f] > 0 ? 1 : 0) << j;
@@ -536,7 +545,9 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
         int n_upd = 0;
         const int base = scan1(c_t, n_upd);
         stamp(3);
-        for (int k = tid; k <= n_upd + 1; k += kPlanThreads) s_need[k] = 0;
+        // (a snapshot of every 64th state whether a frame needs it or not: where a later round's sums pass may restart --
+        // the same states in every round, so the slots of an unchanged prefix keep their numbers)
+        for (int k = tid; k <= n_upd + 1; k += kPlanThreads) s_need[k] = (P.sum_restart && k > 0 && (k & 63) == 0) ? 1 : 0;
         __syncthreads();
         {
             int k = base;
@@ -545,6 +556,7 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
                 const int f = f0 + j;
                 if (f < F) {
                     const int q = (uqb >> j) & 1, fc = (ufb >> j) & 1;
+                    if (f == s_first) sh.kstar = k;    // (the update steps in front of the first frame whose u changed)
                     if ((cnz >> j) & 1) {
                         s_need[k] = 1;
                         if (fc) s_need[k + 1] = 1;
@@ -601,6 +613,22 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
             if (n_snap > W.snap_cap) {
                 ctl->flags = BAND_F_SNAP;
                 ctl->status = 2;
+            }
+            // Restart (rounds >= 2 of a scan, i.e. a previous sums pass ran on a plan that agrees with this one up to the first
+            // frame whose u changed): that frame has k* update steps in front of it; the steps below k* replace the same rows
+            // with the same rows, and the previous pass stored the state after step 64 m - 1 as a snapshot for every m.  The
+            // sums pass starts at the last such state at or below k*.  (simd_baseline_update's order per bin is untouched:
+            // the prefix IS the previous round's, bit for bit.)
+            int kr = 0;
+            if (P.sum_restart && !first && round >= 2 && s_first != 0x7fffffff && s_first < F) kr = (sh.kstar / 64) * 64;
+            if (kr > n_upd) kr = (n_upd / 64) * 64;
+            if (kr >= 64 && s_slot[kr] >= 0) {
+                ctl->k_restart = kr;
+                ctl->restart_slot = s_slot[kr];
+                ctl->n_restarts++;
+            } else {
+                ctl->k_restart = 0;
+                ctl->restart_slot = -1;
             }
         }
         return;
@@ -752,9 +780,17 @@ __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWor
     const BandCtl *ctl = W.ctl;
     const int N = P.n;
     const int n = ctl->n_upd;
+    // (k_begin > 0: the steps below it are the previous round's, whose pass stored the state in front of step k_begin; the
+    // smallest sum so far is then the previous pass's -- over all of ITS steps, a lower bound: the list check stays safe)
+    const int k_begin = ctl->k_restart;
     float s = sum[b], smin = s;
     const int slot0 = W.snap_slot[0];
-    if (slot0 >= 0) snap[(size_t)slot0 * N + b] = s;
+    if (k_begin > 0) {
+        s = snap[(size_t)ctl->restart_slot * N + b];
+        smin = __builtin_fminf(smin_out[b], s);
+    } else if (slot0 >= 0) {
+        snap[(size_t)slot0 * N + b] = s;
+    }
     // This pass is one wavefront per 64 bins with nothing to hide behind, so what a step costs is its instruction count:
     // with row numbers in the descriptors the 64-bit address arithmetic (13 scalar and one vector instruction per load)
     // was most of the 140 ns a step took.  The rows are read as buffer loads instead -- resource = the whole array, the
@@ -814,9 +850,9 @@ __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWor
                 if ((k0) + j < n) IRDM_SUM_STEP(NWv, OLv, D, half)                                      \
         }                                                                                               \
     }
-    uint4 d = steps4[lane], dn = steps4[2 * kSumDepth + lane];
-    IRDM_SUM_LOAD(nwA, olA, d, 0, 0)
-    for (int k0 = 0; k0 < n; k0 += 2 * kSumDepth) {
+    uint4 d = steps4[k_begin + lane], dn = steps4[k_begin + 2 * kSumDepth + lane];
+    IRDM_SUM_LOAD(nwA, olA, d, 0, k_begin)
+    for (int k0 = k_begin; k0 < n; k0 += 2 * kSumDepth) {
         const bool more = k0 + 2 * kSumDepth < n;
         // (the descriptors of the 64 steps after the next 64, always: by the time they are needed they are older than
         // every row in flight, so no wait is spent on them; past the list's padding this reads allocated words nobody uses)
@@ -1650,6 +1686,7 @@ int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment
 int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
 int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
 int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
+int g_band_sum_restart = 1;   // BandParams::sum_restart of the launches that follow
 int g_band_hist_side = 0;   // 1: a launch per pass with the history copy on the side stream and the export in the last plan pass
 int g_band_tail = 0;        // 1: six dependent launches per two-round scan instead of nine (band_walk_tail_kernel); needs the wavefront
                             // walk, the wavefront crossing pass and the LDS plan; 0: a launch per pass
@@ -1702,7 +1739,7 @@ size_t band_work_bytes(int n, size_t max_chunk, bool spec)
     add(4 * F); add(4 * F);                          // slot_pre, slot_post
     add(F * (size_t)n / 8);                          // cross
     add(F * (size_t)n * 4);                          // relq
-    add((spec ? 2 : F + 2) * (size_t)n * 4);         // snap
+    add((spec ? 2 : F + 2 + F / 32 + 4) * (size_t)n * 4);         // snap (+ the restart points: a state in 64)
     add(64 * ((F + 63) / 64) * 8);                   // occ
     add(((F + 63) / 64) * 8); add(((F + 63) / 64) * 8); add(((F + 63) / 64) * 4);   // busy, forced, conc
     add(sizeof(BandRec) * 64 * kBandRecCap); add(4 * 64);                            // recs, rec_count
@@ -1733,8 +1770,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk, bool spec)
     W->slot_post = static_cast<int32_t *>(take(4 * F));
     W->cross = static_cast<uint64_t *>(take(F * (size_t)n / 8));
     W->relq = static_cast<float *>(take(F * (size_t)n * 4));
-    W->snap = static_cast<float *>(take((spec ? 2 : F + 2) * (size_t)n * 4));
-    W->snap_cap = (int)(spec ? 2 : F + 2);
+    W->snap = static_cast<float *>(take((spec ? 2 : F + 2 + F / 32 + 4) * (size_t)n * 4));
+    W->snap_cap = (int)(spec ? 2 : F + 2 + F / 32 + 4);
     W->occ = static_cast<uint64_t *>(take(64 * ((F + 63) / 64) * 8));
     W->busy = static_cast<uint64_t *>(take(((F + 63) / 64) * 8));
     W->forced = static_cast<uint64_t *>(take(((F + 63) / 64) * 8));
@@ -1832,6 +1869,7 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     P.serial = (int32_t)next_launch_serial();
     P.chained = chained;
     P.spec_in = spec ? 1 : 0;
+    P.sum_restart = g_band_sum_restart;
     P.selfcheck = g_band_selfcheck;
     P.ahead = (g_band_plan_ahead && !g_band_coop && side && plan_ev && W.walk_host) ? 1 : 0;
     P.tl_sel = g_band_timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;

@@ -80,7 +80,7 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
                stats={k: p.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
                                              "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists", "band_extra",
                                              "scratch_outputs", "scratch_grows", "scratch_peak", "rot_rows", "rot_runs", "rot_ckpts", "rot_blocks", "rot_blocks_cap", "rot_grows",
-                                             "spec_passes", "spec_scans", "scan_chained", "scan_chain_undone")})
+                                             "spec_passes", "spec_scans", "scan_chained", "scan_chain_undone", "sum_restarts")})
     p.close()
     return res
 

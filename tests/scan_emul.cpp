@@ -41,6 +41,7 @@ void scan_emul_option(const char *key, int value)
     else if (!strcmp(key, "band_timeline")) g_band_timeline = value;
     else if (!strcmp(key, "band_fold_sums0")) g_band_fold_sums0 = value;
     else if (!strcmp(key, "band_spec")) g_emul_spec = value;
+    else if (!strcmp(key, "band_sum_restart")) g_band_sum_restart = value;
     else if (!strcmp(key, "band_hist_side")) g_band_hist_side = value;
     else if (!strcmp(key, "band_tail")) g_band_tail = value;
     else if (!strcmp(key, "band_tail_threads")) g_band_tail_threads = value;
@@ -49,7 +50,7 @@ void scan_emul_option(const char *key, int value)
 // mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
 // (burst_detect.c:427-428, :448-452); the rest is scanned in chunks of chunk_frames.  Returns the number of finished
 // bursts written to out (emission order), or -(flags) - 1000 if a chunk was declined.  stats: [0] rounds, [1] chunks,
-// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] launches in the tail form so far, [6] speculation passes.
+// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] launches in the tail form so far, [6] speculation passes, [7] sums passes restarted.
 int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_len, int width, int max_bursts, int max_len,
                   float threshold, int chunk_frames, int first_rounds, GoneBurst *out, int out_cap, float *sum_out, int *stats)
 {
@@ -91,7 +92,7 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     std::vector<ListEntry> entries((size_t)F_cap * cap);
     const int gone_cap = 8192;
     std::vector<GoneBurst> gone(gone_cap), all;
-    memset(stats, 0, sizeof(int) * 7);
+    memset(stats, 0, sizeof(int) * 8);
     hipEvent_t plan_ev[kBandRounds + 2] = {};
     // (band_tail, the default form: a side "stream" for the history copy, the scans numbered, the events the emulation's)
     hipStream_t side = reinterpret_cast<hipStream_t>(2);
@@ -172,6 +173,7 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
         }
         stats[0] += W.ctl->rounds;
         stats[1]++;
+        stats[7] += W.ctl->n_restarts;
         if (W.ctl->status != 1 || !W.ctl->committed) return -(int)W.ctl->flags - 1000;
         for (uint32_t i = 0; i < st->n_gone; i++) all.push_back(gone[i]);
     }

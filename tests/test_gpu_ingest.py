@@ -162,3 +162,26 @@ def test_scan_opens_with_round_1_behind_a_speculation_pass():
         p.close()
     parity.compare(tail, ref)
     assert tail["stats"]["spec_scans"] >= 2, tail["stats"]
+
+
+def test_sums_pass_restart_behind_an_unchanged_prefix():
+    """band_sum_restart (default): with the speculation pass's guess spoilt in one late frame (band_selfcheck 32) the scans
+    need a third round whose update steps agree with the second's up to that frame -- its sums pass starts from the state
+    the second stored there (one in 64); same records as the oracle, and as with the restart off."""
+    fs, iq = scenes.ALL["many_active_10m"]()
+    ref = orc.run_stream(iq, fs)
+    blocks = max(1, (len(iq) // 32768) // 6)
+    chunks = _equal_chunks(len(iq), blocks)
+    try:
+        got = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead", options={"band_selfcheck": 32})
+        parity.compare(got, ref)
+        assert got["stats"]["spec_scans"] >= 1 and got["stats"]["band_rounds"] >= 2 * got["stats"]["band_chunks"], got["stats"]
+        assert got["stats"]["scan_fallbacks"] == 0, got["stats"]
+        off = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead", options={"band_selfcheck": 32, "band_sum_restart": 0})
+        parity.compare(off, ref)
+        assert off["stats"]["sum_restarts"] == 0, off["stats"]
+    finally:
+        p = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+        p.set_option("band_selfcheck", 0)
+        p.set_option("band_sum_restart", 1)
+        p.close()

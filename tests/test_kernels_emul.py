@@ -156,6 +156,31 @@ def test_scan_kernels_continuation_and_options(emul):
             emul.scan_emul_option(key, value)
 
 
+def test_scan_kernels_sums_pass_restart(emul):
+    """A later round's sums pass restarts at the last stored state (one in 64 update steps) in front of the first frame
+    whose update flag changed: a long quiet stream, the speculation pass's guess spoilt in ONE late frame (band_selfcheck
+    32) so that a third round is needed whose prefix is unchanged -- same records, and the final sums bit for bit (the
+    restarted recurrence IS the sequential one, simd_generic.c:129-135); with the restart off, the same."""
+    fs = 2_000_000
+    n = int(3.0 * fs) // 32768 * 32768
+    iq = siggen.standard_scene(fs, n, 9, seed=101, first_start=int(0.7 * fs))[0]
+    mag, ref, ref_sums = oracle_detect(iq, fs)
+    try:
+        emul.scan_emul_option(b"band_spec", 1)
+        emul.scan_emul_option(b"band_selfcheck", 32)
+        for restart, chunk in ((1, 800), (1, 500), (0, 800)):
+            emul.scan_emul_option(b"band_sum_restart", restart)
+            rc, got, sums, stats = run(emul, mag, fs, chunk)
+            assert rc >= 0 and got == ref
+            assert np.array_equal(sums.view(np.uint32), ref_sums.view(np.uint32))
+            assert stats[0] > 2 * stats[1], stats                      # (the spoilt guess cost rounds)
+            assert (stats[7] >= 2) if restart else (stats[7] == 0), stats
+    finally:
+        emul.scan_emul_option(b"band_spec", 0)
+        emul.scan_emul_option(b"band_selfcheck", 0)
+        emul.scan_emul_option(b"band_sum_restart", 1)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_scan_kernels_random_scenes(emul, seed):
     fs, iq = scenes.random_scene(seed)
