@@ -996,7 +996,9 @@ def main():
                                                           "scan_chained", "scan_chain_undone",
                                                           "band_steps",      # (band_steps: update steps of the scans' last rounds, summed)
                                                           # scans that opened with round 1 behind a speculation pass (band_spec) / passes
-                                                          "spec_scans", "spec_passes")},
+                                                          "spec_scans", "spec_passes",
+                                                          # later rounds' sums passes that began behind an unchanged prefix
+                                                          "sum_restarts")},
                        # the plan pass's own phase stamps, us per chunk (round 1: verdict loops, boundaries, bitmaps read,
                        # step count scan, step list, slot scan, end; last verdict: loops, boundaries)
                        # (--opt band_timeline=1) device timeline of the scan's passes, us per chunk: [time from the first

@@ -249,6 +249,26 @@ exp_i() {
   timeout 150 python bench.py --steps 10 --warmup 6 $Q --density 2 --lookahead 2 2>/dev/null | tail -1 > "$OUT/dens2_l2.json"
 }
 
+# j: the final commit: whole suite, smoke, the default line (round_end quick), then the sums-pass restart on and off on the
+# sparse scene, the default scene and the 12 MHz dense one
+exp_j() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  bash tools/round_end.sh "$(basename "$OUT")" quick
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run d2_r1 --density 2
+  run d2_r0 --density 2 --opt band_sum_restart=0
+  run c3_r1
+  run c3_r0 --opt band_sum_restart=0
+  run d2_r1_b --density 2
+  run d2_r0_b --density 2 --opt band_sum_restart=0
+  run d2_r1_tl --density 2 --opt band_timeline=1
+  run d2_r0_tl --density 2 --opt band_sum_restart=0 --opt band_timeline=1
+  run c5_r1 $D12
+  run c5_r0 $D12 --opt band_sum_restart=0
+}
+
 exp_$EXP
 
 # one line per bench result of the call
@@ -269,7 +289,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*.json")):
         h = find(d, "host_us_total") or {}
         n = d["steps"] + d["warmup"]
         print(os.path.basename(f), d["value"], d["ms_per_step"], "scan_ms", st.get("scan"), "k1", st.get("fft_mag"), "fir", st.get("fir"), "post", st.get("post"),
-              "rounds/chunks", sc.get("band_rounds"), sc.get("band_chunks"), "undone", sc.get("scan_chain_undone"), "spec", sc.get("spec_scans"),
+              "rounds/chunks", sc.get("band_rounds"), sc.get("band_chunks"), "undone", sc.get("scan_chain_undone"), "spec", sc.get("spec_scans"), "restarts", sc.get("sum_restarts"),
               "host/step: settle", round(h.get("settle", 0) / n), "older_chain", round(h.get("wait_older_chain", 0) / n), "parity", (find(d, "parity_checked") or {}).get("ok"),
               "kclk", find(d, "kernel_clock_ms"), "frac", find(d, "frac"))
         tl = find(d, "scan_timeline_us")
