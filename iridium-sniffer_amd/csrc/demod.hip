@@ -68,13 +68,16 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
     float2 *dec = ws + (size_t)b * 2 * kMaxSymbols;
     float2 *po = dec + kMaxSymbols;
 
-    // Steps 1 and 2 in ONE loop: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141) produces symbol n,
-    // qpsk_pll (:145-195, alpha = 0.2) consumes it in the same iteration.  The two recurrences -- the timing loop's
-    // position and the PLL's phase -- do not feed each other (the reference runs them one after the other over the
-    // whole frame), so in one instruction stream the scheduler interleaves symbol n's PLL chain (cabsf, atan2f,
-    // sincosf, cabsf: ~100 dependent instructions) with symbol n + 1's interpolation: the kernel is pure dependent-chain
-    // latency (a dependent instruction issues ~20 cycles after its producer at this occupancy), and two independent
-    // chains cost little more than the longer one.  Same operations on the same operands in the same order per chain.
+    // Steps 1 and 2 in ONE loop: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141) produces the
+    // symbols, qpsk_pll (:145-195, alpha = 0.2) consumes them.  The two recurrences -- the timing loop's position and the
+    // PLL's phase -- do not feed each other (the reference runs them one after the other over the whole frame), and a
+    // wavefront issues in order: what the instruction stream holds between a load and its first use is all that hides
+    // the load.  So the loop is skewed by one symbol: an iteration produces symbol i + 1 (four-sample loads at pos and
+    // pos - sps/2 out of L2, the two interpolations, the timing error: ~0.6 k cycles of which the loads are most) and
+    // runs the PLL on symbol i (cabsf, two divisions, atan2f, sincosf, cabsf, two divisions: ~130 dependent
+    // instructions, ~2.2 k cycles), and both are written without branches (the reference's `if`s as selects of values
+    // computed either way) so that the two chains sit in ONE basic block and the scheduler interleaves them: an
+    // iteration costs the PLL chain, not the sum.  Same operations on the same operands in the same order per chain.
     int n = 0;
     float2 phi = make_float2(1.0f, 0.0f);
     float total_phase = 0.0f;
@@ -82,59 +85,79 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
         const float2 v = cmul(sym, phi);
         po[i] = v;
         float2 xh;
-        if (v.x >= 0 && v.y >= 0)      xh = make_float2(kSqrt1_2, kSqrt1_2);
-        else if (v.x >= 0)             xh = make_float2(kSqrt1_2, -kSqrt1_2);
-        else if (v.y < 0)              xh = make_float2(-kSqrt1_2, -kSqrt1_2);
-        else                           xh = make_float2(-kSqrt1_2, kSqrt1_2);
+        xh.x = v.x >= 0 ? kSqrt1_2 : -kSqrt1_2;
+        // (:160-167: ++, +-, -- else -+: the imaginary sign follows v.y >= 0 in the right half plane, !(v.y < 0) in the left)
+        xh.y = v.x >= 0 ? (v.y >= 0 ? kSqrt1_2 : -kSqrt1_2) : (v.y < 0 ? -kSqrt1_2 : kSqrt1_2);
         const float2 er = cmul(make_float2(xh.x, -xh.y), v);
         const float em = cabs_f(er);
-        if (em < 1e-10f) return;
+        const bool go = !(em < 1e-10f);               // (:174: `continue` below that)
         const float2 unit = make_float2(er.x / em, er.y / em);
         const float ang = atan2f(unit.y, unit.x);
         const float sa = 0.2f * ang;
         float sn, cs;
         sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
         const float2 corr = make_float2(cs, sn);
-        total_phase += sa;
-        phi = cmul(make_float2(corr.x, -corr.y), phi);
-        const float pm = cabs_f(phi);
-        if (pm > 0) phi = make_float2(phi.x / pm, phi.y / pm);
+        const float tp = total_phase + sa;
+        const float2 p1 = cmul(make_float2(corr.x, -corr.y), phi);
+        const float pm = cabs_f(p1);
+        const float2 p2 = make_float2(p1.x / pm, p1.y / pm);
+        const float2 p3 = pm > 0 ? p2 : p1;
+        total_phase = go ? tp : total_phase;
+        phi = go ? p3 : phi;
     };
     if (use_gardner) {
         float pos = 0.0f, toff = 0.0f;
         float2 prev = make_float2(0.0f, 0.0f);
-        while (pos < (float)(n_samples - 3) && n < kMaxSymbols) {
+        int made = 0;
+        // symbol `made` at the loop's position, then the timing update (the position of the next one).  `live` false (the
+        // frame has ended: its last iteration only runs the PLL): the same instructions on clamped positions, nothing
+        // kept -- the store rewrites the last symbol with itself -- so that the loop body stays one basic block.
+        auto produce = [&](bool live, float2 last) -> float2 {
             const float mid_pos = pos - sps * 0.5f;
             // the on-time sample and the mid-point sample (used only where the reference computes it) are independent
             const float2 on = cubic_interp(fr, n_samples, pos);
             const float2 mid = cubic_interp(fr, n_samples, mid_pos >= 1.0f ? mid_pos : 1.0f);
-            dec[n] = on;
-            if (n > 0 && mid_pos >= 1.0f) {
-                const float2 diff = csub(prev, on);
-                // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
-                const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
-                float err = p0 - p1;
-                if (err > 1.0f) err = 1.0f;
-                if (err < -1.0f) err = -1.0f;
-                toff += 0.0002f * err;
-                float adj = 0.02f * err + toff;
-                if (adj > 0.5f) adj = 0.5f;
-                if (adj < -0.5f) adj = -0.5f;
-                pos += adj;
-            }
+            dec[live ? made : made - 1] = live ? on : last;
+            const bool upd = made > 0 && mid_pos >= 1.0f;
+            const float2 diff = csub(prev, on);
+            // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
+            const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
+            float err = p0 - p1;
+            err = err > 1.0f ? 1.0f : err;
+            err = err < -1.0f ? -1.0f : err;
+            const float t1 = toff + 0.0002f * err;
+            float adj = 0.02f * err + t1;
+            adj = adj > 0.5f ? 0.5f : adj;
+            adj = adj < -0.5f ? -0.5f : adj;
+            toff = upd ? t1 : toff;
+            pos = upd ? pos + adj : pos;
             prev = on;
             pos += sps;
-            pll(n, on);
+            made++;
+            return on;
+        };
+        const float lim = (float)(n_samples - 3);
+        bool have = pos < lim && made < kMaxSymbols;
+        float2 cur = make_float2(0.0f, 0.0f);
+        if (have) cur = produce(true, cur);
+        while (have) {
+            const bool more = pos < lim && made < kMaxSymbols;
+            const float2 nxt = produce(more, cur);
+            pll(n, cur);
             n++;
+            cur = nxt;
+            have = more;
         }
     } else {
         const int step = (int)sps;
         n = (n_samples + step - 1) / step;
         if (n > kMaxSymbols) n = kMaxSymbols;
+        float2 sym = n > 0 ? fr[0] : make_float2(0.0f, 0.0f);
         for (int i = 0; i < n; i++) {
-            const float2 sym = fr[i * step];
+            const float2 nxt = i + 1 < n ? fr[(size_t)(i + 1) * step] : sym;
             dec[i] = sym;
             pll(i, sym);
+            sym = nxt;
         }
     }
     out[b].n_symbols = n;               // (demod_par_kernel replaces it by the frame's symbol count)

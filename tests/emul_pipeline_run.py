@@ -101,6 +101,17 @@ def main():
         # workspace, enqueued with the previous chunk (band_spec)
         assert got["stats"]["spec_scans"] >= 2 and got["stats"]["spec_passes"] >= got["stats"]["spec_scans"], got["stats"]
         res["default"]["spec_scans"] = got["stats"]["spec_scans"]
+        # the guess spoilt in one late frame (band_selfcheck 32): the next round's sums pass restarts behind the prefix of
+        # update steps both rounds share (band_sum_restart), from the state the earlier round stored there
+        try:
+            got = parity.run_gpu(iq, fs, chunks=sizes, depth=2, feed="ingest_lookahead", options={"band_selfcheck": 32})
+            res["sums_pass_restart"] = parity.compare(got, ref)
+            assert got["stats"]["sum_restarts"] >= 1, got["stats"]
+            res["sums_pass_restart"]["restarts"] = got["stats"]["sum_restarts"]
+        finally:
+            pz = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+            pz.set_option("band_selfcheck", 0)
+            pz.close()
         got = parity.run_gpu(iq, fs, chunks=sizes, depth=5, feed="ingest_lookahead")
         res["depth5"] = parity.compare(got, ref)
         assert got["stats"]["spec_scans"] >= 2, got["stats"]
