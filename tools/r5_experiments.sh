@@ -269,6 +269,39 @@ exp_j() {
   run c5_r0 $D12 --opt band_sum_restart=0
 }
 
+# k: demod_seq with the loop skewed by one symbol: the stage-C / libm / ingest tests, then the default line twice, every
+# stage serial (pipeline_depth 0: the kernel alone), the sparse and the dense scene and one stream in time-chunks
+exp_k() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ingest.py tests/test_gpu_scenes.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run c3
+  run c3_b
+  run c3_d0 --depth 0
+  run c3_d2 --depth 2
+  run d2 --density 2
+  run c5 $D12
+  timeout 200 python bench.py --shard time --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
+  timeout 120 python bench.py --shard time --steps 6 --warmup 2 2>/dev/null | tail -1 > "$OUT/cfg4_n1_first8chunks.json"
+  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-samples 0 --file-run 0 2>/dev/null | tail -1 > "$OUT/b_alone.json"
+  python - "$OUT" <<'P'
+import json, sys
+d = json.load(open(sys.argv[1] + "/b_alone.json"))
+def find(o, k):
+    if isinstance(o, dict):
+        if k in o: return o[k]
+        for v in o.values():
+            r = find(v, k)
+            if r is not None: return r
+    return None
+print("alone", find(d, "stage_ms_alone"), "kernel_ms_alone", find(d, "kernel_ms_alone"))
+print("cfg4_n1", json.load(open(sys.argv[1] + "/cfg4_n1.json"))["value"], "first eight chunks", json.load(open(sys.argv[1] + "/cfg4_n1_first8chunks.json"))["value"])
+P
+}
+
 exp_$EXP
 
 # one line per bench result of the call
