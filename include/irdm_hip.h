@@ -210,6 +210,14 @@ typedef struct {
     int32_t pad;
 } irdm_ida_t;
 
+/* option "chunk_marks" 1: one mark per batch of records a context pushes to its queues -- the chunk they belong to (chunks
+ * counted from 0 in the order fed) and how many records each queue received, in queue order.  A chunk without bursts
+ * leaves no mark; a chunk with more bursts than a batch holds leaves several, one after the other. */
+typedef struct {
+    uint64_t chunk;
+    uint32_t n_bursts, n_frames, n_demods, n_packed, n_decoded, n_ida;
+} irdm_chunk_mark_t;
+
 typedef struct irdm_pipeline irdm_pipeline_t;
 
 /* burst_detector_create + burst_downmix_create (burst_detect.c:174, burst_downmix.c:223):
@@ -285,6 +293,13 @@ int irdm_poll_demods_packed(irdm_pipeline_t *p, irdm_demod_packed_t *out, int ma
 /* "tagged N bursts total" (burst_detect.c:350-351) and stat_sample_count (main.c:199) */
 uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p);
 uint64_t irdm_sample_count(const irdm_pipeline_t *p);
+size_t irdm_max_chunk_samples(const irdm_pipeline_t *p);      /* the configured value with its default resolved */
+size_t irdm_bytes_per_sample(const irdm_pipeline_t *p);       /* of the configured input format */
+/* samples in front of a stream position that a context taking over there must be given (irdm_seed_history*): the
+ * reference's ring (stale-slot reads reach one ring length back, burst_detect.c:292-296, :401-422) + the longest burst window */
+size_t irdm_required_overlap(const irdm_pipeline_t *p);
+/* host wait until K1 and the history-ring copy of every chunk handed over so far have read their input buffers */
+int irdm_wait_ingest(irdm_pipeline_t *p);
 int irdm_fft_size(const irdm_pipeline_t *p);
 int irdm_set_stream_origin(irdm_pipeline_t *p, double center_frequency, uint64_t start_time_ns);  /* for the stage-level calls */
 uint64_t irdm_start_time_ns(const irdm_pipeline_t *p);   /* burst_data_t.start_time_ns (burst_detect.c:849-853) */
@@ -369,6 +384,57 @@ int irdm_import_state_head_device(irdm_pipeline_t *p, const void *d_buf, size_t 
 int irdm_expect_history(irdm_pipeline_t *p, const void *d_hist_buf);   /* d_hist_buf: where the history will arrive (device memory) */
 int irdm_import_state_history_device(irdm_pipeline_t *p, const void *d_hist_buf, size_t n);
 int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, uint64_t abs_start);
+
+/* ---- a group: ONE stream across several GPUs of ONE process (replaces main.c:667-694's thread layout
+ * for N > 1) ----
+ * irdm_group_create builds one context per device (cfg->device is ignored; devices == NULL: 0 .. n_gpus-1; pipeline_depth
+ * at least 1), two RCCL communicator sets over them (ncclCommInitAll: one for IQ samples, one for the detector state, so
+ * that a 16-32 MiB state hop never queues behind a 0.5 GB slice) and per member two landing buffers of
+ * [overlap | cfg->max_chunk_samples] samples.  The stream is cut into chunks of max_chunk_samples; chunk k goes to member
+ * k mod N.  librccl is loaded when the first group is created (dlopen: a process that never makes a group never loads it;
+ * IRDM_RCCL_LIB names another file); a group of one member needs no RCCL at all unless "group_loopback" is set.
+ *
+ * irdm_group_stage_host / _device: the samples of the next feed start moving -- from host memory (pinned for speed: each
+ *   member's slice over its own PCIe link) or from device memory of member 0 (an RCCL scatter: grouped ncclSend / ncclRecv
+ *   from member 0 to every other member) -- into the landing buffers the current feed does not use, together with each
+ *   chunk's overlap (the samples in front of it that burst windows and the reference's stale ring reads reach back to:
+ *   the tail of the previous member's landing buffer, GPU to GPU).  Returns at once; n_samples <= n_gpus *
+ *   max_chunk_samples, chunks of max_chunk_samples except the last of the stream.  Calling it before the previous
+ *   irdm_group_feed puts the scatter under that feed's compute.
+ * irdm_group_feed_host / _device: stages (unless exactly this buffer was staged) and runs the super-step: K1 of every
+ *   chunk at once, then the detector's chain member by member -- ncclRecv of the previous member's state head, import, scan
+ *   (round 0 while the 512-frame history is still arriving), export, ncclSend to the next member -- and every chunk's
+ *   per-burst chain enqueued behind its scan (irdm_advance): the chains overlap the other members' scans and the next
+ *   super-step.  Returns the number of chunks fed, -1 on error.
+ * irdm_group_flush: everything in flight completes.
+ * irdm_group_poll_*: the members' records merged in STREAM order (chunk by chunk, as one context would have queued them);
+ *   a chunk's records come out once every earlier chunk is complete.
+ * irdm_group_set_option: an option of every member ("group_loopback" 1: a group of one member runs the whole protocol --
+ *   overlap seed, state export, ncclSend / ncclRecv to itself, import -- for tests on one GPU).
+ * irdm_group_get_stat: "hops", "hop_bytes", "scatter_bytes", "overlap_bytes", "chunks", "late_history", "tagged" (sum of
+ *   the members' burst counts), any other key: the sum over the members. */
+typedef struct irdm_group irdm_group_t;
+irdm_group_t *irdm_group_create(const irdm_config_t *cfg, int n_gpus, const int *devices);
+void irdm_group_destroy(irdm_group_t *g);
+int irdm_group_size(const irdm_group_t *g);
+irdm_pipeline_t *irdm_group_member(irdm_group_t *g, int i);
+int irdm_group_set_option(irdm_group_t *g, const char *key, int value);
+int64_t irdm_group_get_stat(const irdm_group_t *g, const char *key);
+int irdm_group_stage_host(irdm_group_t *g, const void *h_iq, size_t n_samples);
+int irdm_group_stage_device(irdm_group_t *g, const void *d_iq, size_t n_samples);
+int irdm_group_feed_host(irdm_group_t *g, const void *h_iq, size_t n_samples);
+int irdm_group_feed_device(irdm_group_t *g, const void *d_iq, size_t n_samples);
+int irdm_group_flush(irdm_group_t *g);
+int irdm_group_poll_bursts(irdm_group_t *g, irdm_burst_t *out, int max);
+int irdm_group_poll_frames(irdm_group_t *g, irdm_frame_info_t *out, float *samples_out /* max*2*4440 or NULL */, int max);
+int irdm_group_poll_demods(irdm_group_t *g, irdm_demod_t *out, int max);
+int irdm_group_poll_demods_packed(irdm_group_t *g, irdm_demod_packed_t *out, int max);
+int irdm_group_poll_decoded(irdm_group_t *g, irdm_decoded_t *out, int max);
+int irdm_group_poll_ida(irdm_group_t *g, irdm_ida_t *out, int max);
+/* what the group rests on in a single context: the marks (option "chunk_marks") and the number of chunks whose records
+ * are all in the queues */
+int irdm_poll_chunk_marks(irdm_pipeline_t *p, irdm_chunk_mark_t *out, int max);
+uint64_t irdm_chunks_complete(const irdm_pipeline_t *p);
 
 /* Options: "decode_frames" / "decode_ida" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded /
  * irdm_poll_ida),

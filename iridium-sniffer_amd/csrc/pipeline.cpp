@@ -415,6 +415,11 @@ struct irdm_pipeline {
     std::deque<irdm_demod_t> q_demods;
     std::deque<irdm_demod_packed_t> q_packed;
     int packed_records;         // option: queue irdm_demod_packed_t records only
+    // option "chunk_marks": one mark per batch of records pushed to the queues above -- which chunk (in the order fed)
+    // they belong to and how many records went to each queue -- for a caller that merges the records of several contexts
+    // in stream order (group.cpp)
+    std::deque<irdm_chunk_mark_t> q_marks;
+    int chunk_marks;
 
     uint64_t total_samples, tagged, start_time_ns;
     bool stream_closed;
@@ -1023,6 +1028,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     p->last_frames = 0;
     p->last_chunk = nullptr;
     p->keep_frame_samples = 0;
+    p->chunk_marks = 0;
     p->scan_mode = 0;
     p->mc_updaters = 7;         // + the leader = 8 workgroups: the scan stream's 8 reserved CUs (pipeline_depth 1)
     {
@@ -1084,6 +1090,25 @@ extern "C" int irdm_sincosf_probe(int device, const float *x, size_t n, float *r
 }
 
 extern "C" uint64_t irdm_tagged_bursts(const irdm_pipeline_t *p) { return p ? p->tagged : 0; }
+extern "C" size_t irdm_max_chunk_samples(const irdm_pipeline_t *p) { return p ? p->max_chunk : 0; }
+extern "C" size_t irdm_bytes_per_sample(const irdm_pipeline_t *p) { return p ? p->bps : 0; }
+// Samples a context that takes over a stream at some position must be given from in front of it (irdm_seed_history*): the
+// reference's ring -- stale-slot reads reach one ring length back (burst_detect.c:292-296, :401-422) -- plus the longest
+// burst window.
+extern "C" size_t irdm_required_overlap(const irdm_pipeline_t *p)
+{
+    if (!p) return 0;
+    return (size_t)(p->ref_ring + (uint64_t)p->P.max_len + (uint64_t)p->P.post_len + (uint64_t)p->P.pre_len + 2 * (uint64_t)p->P.n);
+}
+// K1 and the history-ring copy of every chunk handed over so far have read their input: the caller may write the buffers
+// again.  (Host wait on the ingest stream; the detector and the per-burst chains are not waited for.)
+extern "C" int irdm_wait_ingest(irdm_pipeline_t *p)
+{
+    if (!p) return -1;
+    pipeline_enter(p);
+    IRDM_HIP_CHECK(hipStreamSynchronize(p->fstream));
+    return 0;
+}
 extern "C" uint64_t irdm_sample_count(const irdm_pipeline_t *p) { return p ? p->total_samples : 0; }
 extern "C" int irdm_fft_size(const irdm_pipeline_t *p) { return p ? p->P.n : -1; }
 extern "C" uint64_t irdm_start_time_ns(const irdm_pipeline_t *p) { return p ? p->start_time_ns : 0; }
@@ -1624,8 +1649,30 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     return launch_kclk_fold(p->kclk_fir((int)(&b - p->bc)), st);
 }
 
+static int bursts_finish_records(irdm_pipeline *p, BatchCtx &b);
+
 // returns the number of bursts whose records were emitted, -1 on error
 static int bursts_finish(irdm_pipeline *p, BatchCtx &b)
+{
+    if (!p->chunk_marks || b.n == 0) return bursts_finish_records(p, b);
+    const size_t before[6] = { p->q_bursts.size(), p->q_frames.size(), p->q_demods.size(), p->q_packed.size(),
+                               p->q_decoded.size(), p->q_ida.size() };
+    const uint64_t chunk = b.chunk_no;
+    const int rc = bursts_finish_records(p, b);
+    if (rc < 0) return rc;
+    irdm_chunk_mark_t m;
+    m.chunk = chunk;
+    m.n_bursts = (uint32_t)(p->q_bursts.size() - before[0]);
+    m.n_frames = (uint32_t)(p->q_frames.size() - before[1]);
+    m.n_demods = (uint32_t)(p->q_demods.size() - before[2]);
+    m.n_packed = (uint32_t)(p->q_packed.size() - before[3]);
+    m.n_decoded = (uint32_t)(p->q_decoded.size() - before[4]);
+    m.n_ida = (uint32_t)(p->q_ida.size() - before[5]);
+    p->q_marks.push_back(m);
+    return rc;
+}
+
+static int bursts_finish_records(irdm_pipeline *p, BatchCtx &b)
 {
     const int nb = b.n;
     const int fs = p->cfg.sample_rate;
@@ -2713,6 +2760,25 @@ static int drain(std::deque<T> &q, T *out, int max)
     return n;
 }
 
+extern "C" int irdm_poll_chunk_marks(irdm_pipeline_t *p, irdm_chunk_mark_t *out, int max)
+{
+    if (!p || !out || max < 0) return -1;
+    return drain(p->q_marks, out, max);
+}
+
+// chunks (in the order fed, counted from 0) below this number have all their records in the queues: nothing of theirs is
+// in a scan in flight, a pending burst list or a batch context
+extern "C" uint64_t irdm_chunks_complete(const irdm_pipeline_t *p)
+{
+    if (!p) return 0;
+    uint64_t w = p->chunk_no;
+    if (p->fl_active) w = std::min<uint64_t>(w, p->fl_no);
+    if (p->has_pending) w = std::min<uint64_t>(w, p->pend_no);
+    for (int i = 0; i < p->n_bc; i++)
+        if (p->bc[i].n > 0) w = std::min<uint64_t>(w, p->bc[i].chunk_no);
+    return w;
+}
+
 extern "C" int irdm_poll_demods_packed(irdm_pipeline_t *p, irdm_demod_packed_t *out, int max)
 {
     if (!p || !out || max < 0) return -1;
@@ -3204,6 +3270,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!p || !key) return -1;
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "packed_records")) { p->packed_records = value; return 0; }
+    if (!strcmp(key, "chunk_marks")) { p->chunk_marks = value ? 1 : 0; if (!value) p->q_marks.clear(); return 0; }
     if (!strcmp(key, "host_cfo")) { p->dev_cfo = p->dev_cfo_ok && value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
     if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
     if (!strcmp(key, "scan_updaters")) { if (value < 1 || value > 32) return -1; p->mc_updaters = value; return 0; }

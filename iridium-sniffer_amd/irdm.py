@@ -174,6 +174,35 @@ def lib():
         L.irdm_kernel_clock.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int]
         L.irdm_format_raw.argtypes = [C.POINTER(Demod), C.c_char_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
         L.irdm_version.restype = C.c_char_p
+        # a group: one stream across several GPUs of this process (csrc/group.cpp)
+        L.irdm_group_create.restype = C.c_void_p
+        L.irdm_group_create.argtypes = [C.POINTER(Config), C.c_int, C.POINTER(C.c_int)]
+        L.irdm_group_destroy.argtypes = [C.c_void_p]
+        L.irdm_group_destroy.restype = None
+        L.irdm_group_size.argtypes = [C.c_void_p]
+        L.irdm_group_member.argtypes = [C.c_void_p, C.c_int]
+        L.irdm_group_member.restype = C.c_void_p
+        L.irdm_group_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.irdm_group_get_stat.argtypes = [C.c_void_p, C.c_char_p]
+        L.irdm_group_get_stat.restype = C.c_int64
+        for name in ("irdm_group_stage_host", "irdm_group_stage_device", "irdm_group_feed_host", "irdm_group_feed_device"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.irdm_group_flush.argtypes = [C.c_void_p]
+        L.irdm_group_poll_bursts.argtypes = [C.c_void_p, C.POINTER(Burst), C.c_int]
+        L.irdm_group_poll_frames.argtypes = [C.c_void_p, C.POINTER(FrameInfo), C.POINTER(C.c_float), C.c_int]
+        L.irdm_group_poll_demods.argtypes = [C.c_void_p, C.POINTER(Demod), C.c_int]
+        L.irdm_group_poll_demods_packed.argtypes = [C.c_void_p, C.POINTER(DemodPacked), C.c_int]
+        L.irdm_group_poll_decoded.argtypes = [C.c_void_p, C.POINTER(Decoded), C.c_int]
+        L.irdm_group_poll_ida.argtypes = [C.c_void_p, C.POINTER(Ida), C.c_int]
+        L.irdm_chunks_complete.argtypes = [C.c_void_p]
+        L.irdm_chunks_complete.restype = C.c_uint64
+        L.irdm_required_overlap.argtypes = [C.c_void_p]
+        L.irdm_required_overlap.restype = C.c_size_t
+        L.irdm_max_chunk_samples.argtypes = [C.c_void_p]
+        L.irdm_max_chunk_samples.restype = C.c_size_t
+        L.irdm_bytes_per_sample.argtypes = [C.c_void_p]
+        L.irdm_bytes_per_sample.restype = C.c_size_t
+        L.irdm_wait_ingest.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -541,6 +570,114 @@ class Pipeline:
         if self.h:
             self.L.irdm_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Group:
+    """irdm_group_*: ONE stream across n_gpus GPUs of this process, chunk k on member k mod n_gpus, the detector's state
+    handed from member to member with RCCL (csrc/group.cpp).  The polls return the members' records merged in stream
+    order -- what one Pipeline fed with the same samples returns."""
+    _poll = Pipeline._poll            # (fn(self.h, buffer, max): the group's polls have the pipeline's shape)
+
+    def __init__(self, sample_rate, n_gpus, devices=None, fmt=FMT_CF32, center_frequency=1622000000.0, threshold_db=0.0,
+                 feed_block=0, use_gardner=1, start_time_ns=1700000000 * 10**9, max_chunk_samples=0,
+                 max_bursts_per_chunk=0, pipeline_depth=1):
+        self.L = lib()
+        self.cfg = Config(center_frequency, int(sample_rate), threshold_db, fmt, feed_block, use_gardner, start_time_ns, 0,
+                          max_chunk_samples, max_bursts_per_chunk, pipeline_depth)
+        devs = (C.c_int * n_gpus)(*devices) if devices is not None else None
+        self.g = self.L.irdm_group_create(C.byref(self.cfg), n_gpus, devs)
+        if not self.g:
+            raise RuntimeError("irdm_group_create failed (devices, RCCL, or bad config)")
+        self.h = self.g                   # (Pipeline's poll helpers call fn(self.h, ...))
+        self.fmt = fmt
+        self.n_gpus = n_gpus
+        self.fft_size = self.L.irdm_fft_size(self.L.irdm_group_member(self.g, 0))
+        self.chunk = int(self.L.irdm_max_chunk_samples(self.L.irdm_group_member(self.g, 0)))
+
+    def member(self, i):
+        return self.L.irdm_group_member(self.g, i)
+
+    def set_option(self, key, value):
+        if self.L.irdm_group_set_option(self.g, key.encode(), int(value)) != 0:
+            raise ValueError("option %r refused" % key)
+
+    def stat(self, key):
+        return int(self.L.irdm_group_get_stat(self.g, key.encode()))
+
+    def _samples(self, iq):
+        return len(iq) if self.fmt == FMT_CF32 else len(iq) // 2
+
+    def stage_host(self, iq):
+        if self.L.irdm_group_stage_host(self.g, iq.ctypes.data_as(C.c_void_p), self._samples(iq)) != 0:
+            raise RuntimeError("irdm_group_stage_host failed")
+
+    def feed_host(self, iq):
+        """iq: a C-contiguous array of at most n_gpus chunks; it must stay alive until the call returns (and, if it was
+        staged first, from the stage call on)"""
+        rc = self.L.irdm_group_feed_host(self.g, iq.ctypes.data_as(C.c_void_p), self._samples(iq))
+        if rc < 0:
+            raise RuntimeError("irdm_group_feed_host failed")
+        return rc
+
+    def stage_device(self, ptr, n_samples):
+        if self.L.irdm_group_stage_device(self.g, C.c_void_p(ptr), n_samples) != 0:
+            raise RuntimeError("irdm_group_stage_device failed")
+
+    def feed_device(self, ptr, n_samples, stream=None):
+        rc = self.L.irdm_group_feed_device(self.g, C.c_void_p(ptr), n_samples)
+        if rc < 0:
+            raise RuntimeError("irdm_group_feed_device failed")
+        return rc
+
+    def flush(self):
+        rc = self.L.irdm_group_flush(self.g)
+        if rc < 0:
+            raise RuntimeError("irdm_group_flush failed")
+        return rc
+
+    def poll_bursts(self):
+        return self._poll(self.L.irdm_group_poll_bursts, Burst)
+
+    def poll_demods(self):
+        return self._poll(self.L.irdm_group_poll_demods, Demod)
+
+    def poll_demods_packed(self):
+        return self._poll(self.L.irdm_group_poll_demods_packed, DemodPacked)
+
+    def poll_decoded(self):
+        return self._poll(self.L.irdm_group_poll_decoded, Decoded)
+
+    def poll_ida(self):
+        return self._poll(self.L.irdm_group_poll_ida, Ida)
+
+    def poll_frames(self, chunk=64):
+        infos, samples = [], []
+        buf = (FrameInfo * chunk)()
+        sb = np.zeros((chunk, 2 * MAX_FRAME_SAMPLES), np.float32)
+        while True:
+            n = self.L.irdm_group_poll_frames(self.g, buf, _fp(sb), chunk)
+            if n <= 0:
+                break
+            for i in range(n):
+                fi = FrameInfo.from_buffer_copy(buf[i])
+                infos.append(fi)
+                samples.append(sb[i, :2 * fi.num_samples].copy().view(np.complex64))
+        return infos, samples
+
+    @property
+    def tagged(self):
+        return self.stat("tagged")
+
+    def close(self):
+        if self.g:
+            self.L.irdm_group_destroy(self.g)
+            self.g = self.h = None
 
     def __del__(self):
         try:

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE: builds tests/_build/libirdm_emul.so -- the product's sources (every kernel file, csrc/pipeline.cpp,
-csrc/host_design.cpp, csrc/compat.cpp: the whole C-ABI of include/irdm_hip.h) compiled with g++ against the HIP emulation
-of tests/hip_emul/hip/hip_runtime.h, so that the `-m "not gpu"` tests can drive the product end to end without a GPU
+csrc/group.cpp, csrc/host_design.cpp, csrc/compat.cpp: the whole C-ABI of include/irdm_hip.h) compiled with g++ against the
+HIP emulation of tests/hip_emul/hip/hip_runtime.h (and, for group.cpp, the emulated RCCL of tests/hip_emul/rccl/rccl.h), so that the `-m "not gpu"` tests can drive the product end to end without a GPU
 (tests/test_pipeline_emul.py).  Never loaded by the product: iridium-sniffer_amd/irdm.py loads libirdm_hip.so unless a
 test points IRDM_LIB elsewhere.
 
@@ -24,7 +24,7 @@ EMUL = os.path.join(ROOT, "tests", "hip_emul")
 OUT = os.path.join(ROOT, "tests", "_build", "emul")
 SO = os.path.join(ROOT, "tests", "_build", "libirdm_emul.so")
 SOURCES = ["detect.hip", "scan_fast.hip", "scan_band.hip", "downmix.hip", "fir_reg.hip", "demod.hip", "bitlayer.hip",
-           "pipeline.cpp", "host_design.cpp", "compat.cpp"]
+           "pipeline.cpp", "group.cpp", "host_design.cpp", "compat.cpp"]
 
 
 def transform(name, text):
@@ -55,6 +55,7 @@ def build(force=False, sanitize=False):
         SO = os.path.join(ROOT, "tests", "_build", "libirdm_emul_asan.so")
         OUT = os.path.join(ROOT, "tests", "_build", "emul_asan")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(EMUL, "hip", "hip_runtime.h"),
+                                                                os.path.join(EMUL, "rccl", "rccl.h"),
                                                                 os.path.join(EMUL, "fir_mac.inc"), os.path.join(EMUL, "fft_bfly.inc"),
                                                                 os.path.join(EMUL, "fir_fma.inc"),
                                                                 os.path.abspath(__file__)]

@@ -159,6 +159,30 @@ def main():
         ref16 = orc.run_stream(x, fs, fmt=irdm.FMT_CI16)
         res["ci16_chunked_depth1"] = parity.compare(
             parity.run_gpu(x, fs, fmt=irdm.FMT_CI16, chunks=chunks_of(len(iq), 2), depth=1), ref16)
+    elif case == "group":
+        # ONE stream across the members of a group (irdm_group_*, csrc/group.cpp), every "device" the emulation and RCCL the
+        # emulated send / receive pairs of tests/hip_emul/rccl/rccl.h: four chunks with a burst across every chunk boundary
+        # (the stream of the two-rank time-shard tests).  2 members: two super-steps, the state goes round; 3 members: a
+        # super-step of three chunks and one of one; 1 member with "group_loopback": overlap seed, export, send to itself,
+        # import; staged ahead; fed from "device" memory of member 0 (the scatter); 1 member, no loopback: the plain path
+        import test_gpu_timeshard as G
+        fs = G.CASES["2mhz"][0]
+        iq, chunk, ov = G._stream("2mhz")
+        ref = orc.run_stream(iq, fs)
+        for name, kw in (("two_members", dict(n_gpus=2)),
+                         ("three_members_staged_ahead", dict(n_gpus=3, staged_ahead=True)),
+                         ("two_members_scatter_from_member_0", dict(n_gpus=2, feed="device", staged_ahead=True, depth=2)),
+                         ("one_member_loopback", dict(n_gpus=1, options={"group_loopback": 1})),
+                         ("one_member", dict(n_gpus=1))):
+            got = parity.run_group(iq, fs, chunk=chunk, **kw)
+            res[name] = parity.compare(got, ref)
+            res[name].update({k: got["stats"][k] for k in ("hops", "chunks", "overlap_bytes", "scatter_bytes")})
+            assert got["stats"]["chunks"] == 4 and got["chunks_fed"] == 4, got["stats"]
+            assert got["stats"]["overlap_samples"] == ov, (got["stats"], ov)
+            proto = kw["n_gpus"] > 1 or "options" in kw
+            assert got["stats"]["hops"] == (4 if proto else 0), got["stats"]
+            assert got["stats"]["overlap_bytes"] == (3 * ov * 8 if proto else 0), got["stats"]
+            assert got["stats"]["scatter_bytes"] == len(iq) * 8, got["stats"]
     else:
         raise SystemExit("unknown case")
     print("RESULT " + json.dumps(res))

@@ -85,6 +85,59 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
     return res
 
 
+def run_group(iq, fs, n_gpus, chunk, fmt=irdm.FMT_CF32, depth=1, feed="host", staged_ahead=False, options=None, devices=None):
+    """The same stream through a group of n_gpus members (irdm_group_*, csrc/group.cpp) in super-steps of n_gpus chunks of
+    `chunk` samples: chunk k on member k mod n_gpus, the records merged by the library.  feed "host": irdm_group_feed_host;
+    "device": the super-step uploaded to member 0's device and scattered from there.  staged_ahead: super-step s + 1 is
+    staged before super-step s is fed."""
+    import ctypes as C
+    n = len(iq) if fmt == irdm.FMT_CF32 else len(iq) // 2
+    per = 1 if fmt == irdm.FMT_CF32 else 2
+    g = irdm.Group(fs, n_gpus, devices=devices, fmt=fmt, max_chunk_samples=chunk, max_bursts_per_chunk=1024, pipeline_depth=depth)
+    g.set_option("keep_frame_samples", 1)
+    for k, v in (options or {}).items():
+        g.set_option(k, v)
+    step = n_gpus * chunk
+    parts = [np.ascontiguousarray(iq[o * per:min(o + step, n) * per]) for o in range(0, n, step)]
+    held = []
+
+    def handle(part):
+        if feed == "host":
+            return part
+        ptr = irdm.device_buffer(part, device=(devices[0] if devices else 0))
+        held.append(ptr)
+        return (ptr, len(part) // per)
+
+    def stage(h):
+        if feed == "host":
+            g.stage_host(h)
+        else:
+            g.stage_device(*h)
+
+    def run(h):
+        return g.feed_host(h) if feed == "host" else g.feed_device(*h)
+
+    handles = [handle(p) for p in parts]
+    fed = 0
+    if staged_ahead and handles:
+        stage(handles[0])
+    for i, h in enumerate(handles):
+        if staged_ahead and i + 1 < len(handles):
+            stage(handles[i + 1])
+        fed += run(h)
+    g.flush()
+    bursts = g.poll_bursts()
+    infos, samples = g.poll_frames()
+    demods = g.poll_demods()
+    res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, tagged=g.tagged, chunks_fed=fed,
+               stats={k: g.stat(k) for k in ("hops", "hop_bytes", "scatter_bytes", "overlap_bytes", "late_history", "chunks",
+                                             "overlap_samples", "scan_fallbacks", "band_aborts", "band_chunks")})
+    g.close()
+    for ptr in held:
+        irdm.device_free(ptr)
+    return res
+
+
 def compare(gpu, ref, exact_frames=True):
     """ref: orc.StreamResult.  Returns a small summary dict; asserts on any mismatch."""
     assert gpu["tagged"] == ref.n_tagged, (gpu["tagged"], ref.n_tagged)

@@ -77,3 +77,13 @@ def test_whole_path_12mhz(emul_lib):
     res = run_case(emul_lib, "12mhz", timeout=2400)
     for name in ("default", "ci16_chunked_depth1"):
         assert res[name]["bursts"] >= 3 and res[name]["frames"] >= 2, res
+
+
+def test_group_of_members_equals_one_context(emul_lib):
+    """irdm_group_*: one stream over 2 and 3 members, a member handing the detector state to itself, super-steps staged
+    ahead, the scatter from member 0 -- every record equal to the oracle's for the whole stream, in stream order"""
+    res = run_case(emul_lib, "group", timeout=1800)
+    assert set(res) == {"two_members", "three_members_staged_ahead", "two_members_scatter_from_member_0", "one_member_loopback",
+                        "one_member"}
+    for name, s in res.items():
+        assert s["bursts"] >= 36 and s["demods"] >= 30, (name, s)
