@@ -124,6 +124,14 @@ static void *reader_main(void *arg)
     return NULL;
 }
 
+/* --gpus N: the stream goes through a group (irdm_group_*: chunk k on GPU k mod N, records merged in stream order by the
+ * library); the polls below then read the group's queues */
+static irdm_group_t *g_group;
+#define irdm_poll_demods_packed(p, o, m) (g_group ? irdm_group_poll_demods_packed(g_group, o, m) : irdm_poll_demods_packed(p, o, m))
+#define irdm_poll_demods(p, o, m) (g_group ? irdm_group_poll_demods(g_group, o, m) : irdm_poll_demods(p, o, m))
+#define irdm_poll_bursts(p, o, m) (g_group ? irdm_group_poll_bursts(g_group, o, m) : irdm_poll_bursts(p, o, m))
+#define irdm_poll_frames(p, o, s, m) (g_group ? irdm_group_poll_frames(g_group, o, s, m) : irdm_poll_frames(p, o, s, m))
+
 static void drain(irdm_pipeline_t *p, irdm_demod_t *d, const char *file_info, uint64_t *t0, char *line, size_t cap)
 {
     int n;
@@ -172,6 +180,8 @@ int main(int argc, char **argv)
     size_t chunk = (size_t)16 << 20;
     int depth = 1;
     int read_threads = 6;       /* pread() helpers per chunk of a regular file (0: one fread thread) */
+    int gpus = 0;               /* --gpus N: one stream across N GPUs of this process (0: one context on device 0) */
+    int chunk_given = 0, loopback = 0;
     const char *save_dir = NULL;
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i];
@@ -182,7 +192,9 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-d") || !strcmp(a, "--threshold")) db = atof(NEXT());
         else if (!strcmp(a, "--format")) format = NEXT();
         else if (!strcmp(a, "--file-info")) file_info = NEXT();
-        else if (!strcmp(a, "--chunk")) chunk = (size_t)atoll(NEXT());
+        else if (!strcmp(a, "--chunk")) { chunk = (size_t)atoll(NEXT()); chunk_given = 1; }
+        else if (!strcmp(a, "--gpus")) gpus = atoi(NEXT());         /* the reference's thread layout for N > 1 (main.c:667-694) */
+        else if (!strcmp(a, "--group-loopback")) loopback = 1;      /* test aid: --gpus 1 hands the detector state to itself over RCCL */
         else if (!strcmp(a, "--no-gardner")) gardner = 0;
         else if (!strcmp(a, "--save-bursts")) save_dir = NEXT();   /* options.c --save-bursts: IQ + .meta per downmixed frame */
         else if (!strcmp(a, "--read-threads")) read_threads = atoi(NEXT());
@@ -199,7 +211,7 @@ int main(int argc, char **argv)
         }
     }
     if (!file || rate <= 0) {
-        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR] [--no-simd] [--save-bursts DIR]\n", argv[0]);
+        fprintf(stderr, "usage: %s -f FILE -r RATE [-c FREQ] [--format ci8|ci16|cf32] [-d DB] [--file-info STR] [--no-simd] [--save-bursts DIR] [--gpus N]\n", argv[0]);
         return 2;
     }
     if (!format) format = ext_of(file);              /* autodetect by extension, options.c:533-544 */
@@ -216,25 +228,47 @@ int main(int argc, char **argv)
     c.format = fmt;
     c.feed_block = 32768;
     c.use_gardner = gardner;
+    /* (several GPUs: a chunk must hold the samples a member is given from in front of its chunk -- 2 s of signal, the
+     * reference's ring -- so the default grows with the rate) */
+    if (gpus > 1 && !chunk_given) chunk = (size_t)(2.75 * rate);
     chunk = chunk / 32768 * 32768;
     if (chunk == 0) chunk = 32768;
     c.max_chunk_samples = chunk;
     c.pipeline_depth = depth;
-    irdm_pipeline_t *p = irdm_create(&c);
-    if (!p) {
-        fprintf(stderr, "irdm_create failed (no MI355X / bad parameters)\n");
-        return 1;
+    if (gpus < 0 || gpus > 64) { fprintf(stderr, "--gpus %d\n", gpus); return 2; }
+    irdm_pipeline_t *p;
+    if (gpus > 0) {
+        g_group = irdm_group_create(&c, gpus, NULL);
+        if (!g_group) {
+            fprintf(stderr, "irdm_group_create failed (%d MI355X asked for / RCCL / bad parameters)\n", gpus);
+            return 1;
+        }
+        if (loopback && irdm_group_set_option(g_group, "group_loopback", 1) != 0) {
+            fprintf(stderr, "--group-loopback: refused (chunk smaller than the overlap, or no RCCL)\n");
+            return 1;
+        }
+        p = irdm_group_member(g_group, 0);
+    } else {
+        p = irdm_create(&c);
+        if (!p) {
+            fprintf(stderr, "irdm_create failed (no MI355X / bad parameters)\n");
+            return 1;
+        }
     }
+#define SET_OPTION(key, v) (g_group ? irdm_group_set_option(g_group, key, v) : irdm_set_option(p, key, v))
     /* --no-simd: the reference points its eleven dispatched kernels at simd_generic.c instead of simd_avx2.c
      * (simd_generic.c:33-57); here the same switch selects the kernels that follow the generic file's operation order */
-    if (no_simd && irdm_set_option(p, "fir_order", 0) != 0) {
+    if (no_simd && SET_OPTION("fir_order", 0) != 0) {
         fprintf(stderr, "--no-simd: the library refused fir_order 0\n");
         return 1;
     }
-    if (save_dir) irdm_set_option(p, "keep_frame_samples", 1);
-    else irdm_set_option(p, "packed_records", 1);
+    if (save_dir) SET_OPTION("keep_frame_samples", 1);
+    else SET_OPTION("packed_records", 1);
     g_save_dir = save_dir;
-    if (verbose) fprintf(stderr, "%s: fft_size=%d chunk=%zu samples\n", irdm_version(), irdm_fft_size(p), chunk);
+    if (verbose) fprintf(stderr, "%s: fft_size=%d chunk=%zu samples, %d GPU%s\n", irdm_version(), irdm_fft_size(p), chunk,
+                         gpus > 0 ? gpus : 1, gpus > 1 ? "s" : "");
+    /* a group is fed a super-step at a time: one chunk per member */
+    const size_t step = chunk * (size_t)(gpus > 0 ? gpus : 1);
 
     FILE *f = strcmp(file, "-") ? fopen(file, "rb") : stdin;
     if (!f) { perror(file); return 1; }
@@ -245,9 +279,9 @@ int main(int argc, char **argv)
     memset(&rd, 0, sizeof(rd));
     rd.f = f;
     rd.bps = bps;
-    rd.chunk = chunk;
+    rd.chunk = step;
     for (int i = 0; i < 2; i++) {
-        rd.buf[i] = irdm_host_alloc(chunk * bps);
+        rd.buf[i] = irdm_host_alloc(step * bps);
         if (!rd.buf[i]) { fprintf(stderr, "irdm_host_alloc failed\n"); return 1; }
     }
     sem_init(&rd.filled, 0, 0);
@@ -276,14 +310,14 @@ int main(int argc, char **argv)
         sem_wait(&rd.filled);
         const size_t r = rd.n[k];
         if (r == 0) break;                          /* end of file */
-        if (rc == 0 && irdm_feed_host(p, rd.buf[k], r) < 0) {
+        if (rc == 0 && (g_group ? irdm_group_feed_host(g_group, rd.buf[k], r) : irdm_feed_host(p, rd.buf[k], r)) < 0) {
             fprintf(stderr, "burst_detect: GPU processing failed\n");
             rc = 1;
         }
         fed += r;
         sem_post(&rd.empty);                        /* irdm_feed_host has consumed the buffer when it returns */
         if (rc == 0) drain(p, d, file_info, &t0, line, sizeof line);
-        if (r < chunk) { rd.stop = 1; sem_post(&rd.empty); break; }   /* ragged last chunk = end of stream */
+        if (r < step) { rd.stop = 1; sem_post(&rd.empty); break; }    /* ragged last chunk = end of stream */
     }
     rd.stop = 1;
     sem_post(&rd.empty);
@@ -293,7 +327,7 @@ int main(int argc, char **argv)
         sem_post(&rd.sl[i].go);
         pthread_join(rd.sl[i].th, NULL);
     }
-    if (rc == 0 && irdm_flush(p) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; }
+    if (rc == 0 && (g_group ? irdm_group_flush(g_group) : irdm_flush(p)) < 0) { fprintf(stderr, "burst_detect: GPU processing failed\n"); rc = 1; }
     drain(p, d, file_info, &t0, line, sizeof line);
     fflush(stdout);
     if (timing) {
@@ -301,8 +335,10 @@ int main(int argc, char **argv)
         fprintf(stderr, "irdm timing: startup %.3f s (HIP initialisation + device context), stream %.3f s for %llu samples = %.1f Msamples/s\n",
                 t_ready - t_main, t_done - t_ready, fed, t_done > t_ready ? fed / (t_done - t_ready) / 1e6 : 0.0);
     }
-    fprintf(stderr, "burst_detect: tagged %lu bursts total\n", (unsigned long)irdm_tagged_bursts(p));
-    irdm_destroy(p);
+    fprintf(stderr, "burst_detect: tagged %lu bursts total\n",
+            (unsigned long)(g_group ? (uint64_t)irdm_group_get_stat(g_group, "tagged") : irdm_tagged_bursts(p)));
+    if (g_group) irdm_group_destroy(g_group);
+    else irdm_destroy(p);
     irdm_host_free(rd.buf[0]);
     irdm_host_free(rd.buf[1]);
     free(d);

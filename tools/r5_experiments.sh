@@ -302,6 +302,12 @@ print("cfg4_n1", json.load(open(sys.argv[1] + "/cfg4_n1.json"))["value"], "first
 P
 }
 
+# l: the group API on the real library and the real RCCL (one member handing its state to itself), the C binary's --gpus
+exp_l() {
+  timeout 1200 python -m pytest tests/test_gpu_group.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 25 "$OUT/tests.log"
+}
+
 exp_$EXP
 
 # one line per bench result of the call
