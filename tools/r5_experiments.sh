@@ -308,6 +308,52 @@ exp_l() {
   tail -n 25 "$OUT/tests.log"
 }
 
+# m: rot_phase's stores through an LDS transpose: parity tests, the default line twice, every stage serial; what the group
+# protocol costs on one GPU (tools/group_bench.py); does RCCL write to the C binary's stdout?
+exp_m() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_group.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run c3
+  run c3_b
+  run c3_d0 --depth 0
+  run c5 --density 40 --sample-rate 12000000
+  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-samples 0 --file-run 0 2>/dev/null | tail -1 > "$OUT/b_alone.json"
+  python - "$OUT" <<'P'
+import json, sys
+d = json.load(open(sys.argv[1] + "/b_alone.json"))
+def find(o, k):
+    if isinstance(o, dict):
+        if k in o: return o[k]
+        for v in o.values():
+            r = find(v, k)
+            if r is not None: return r
+    return None
+print("alone", find(d, "stage_ms_alone"))
+P
+  timeout 400 python tools/group_bench.py > "$OUT/group_bench.json" 2>"$OUT/group_bench.err"
+  cat "$OUT/group_bench.json"; tail -n 3 "$OUT/group_bench.err"
+  timeout 300 python tools/group_bench.py --sample-rate 10000000 --depth 3 > "$OUT/group_bench_10mhz.json" 2>>"$OUT/group_bench.err"
+  cat "$OUT/group_bench_10mhz.json"
+  # the C binary with a loopback group: anything but RAW lines on stdout?
+  python - <<'P' > "$OUT/cli_stdout.txt" 2>&1
+import os, subprocess, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "iridium-sniffer_amd")
+import numpy as np
+import test_gpu_timeshard as G
+iq, chunk, ov = G._stream("2mhz")
+np.ascontiguousarray(iq).tofile("/tmp/g.cf32")
+out = subprocess.run(["iridium-sniffer_amd/iridium-sniffer-hip", "-f", "/tmp/g.cf32", "-r", "2000000", "--gpus", "1", "--group-loopback",
+                      "--chunk", str(chunk), "--timing"], capture_output=True, text=True)
+lines = out.stdout.splitlines()
+print("rc", out.returncode, "stdout lines", len(lines), "not RAW:", [l for l in lines if not l.startswith("RAW:")][:10])
+print("stderr:", out.stderr[-600:])
+P
+  cat "$OUT/cli_stdout.txt"
+}
+
 exp_$EXP
 
 # one line per bench result of the call
