@@ -400,7 +400,9 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  *   chunk's overlap (the samples in front of it that burst windows and the reference's stale ring reads reach back to:
  *   the tail of the previous member's landing buffer, GPU to GPU).  Returns at once; n_samples <= n_gpus *
  *   max_chunk_samples, chunks of max_chunk_samples except the last of the stream.  Calling it before the previous
- *   irdm_group_feed puts the scatter under that feed's compute.
+ *   irdm_group_feed puts the scatter under that feed's compute (two super-steps may be staged at most: the one being fed
+ *   and the one behind it).  The buffer must be complete when the call is made and stay unchanged until the
+ *   irdm_group_feed_* that consumes it has returned.
  * irdm_group_feed_host / _device: stages (unless exactly this buffer was staged) and runs the super-step: K1 of every
  *   chunk at once, then the detector's chain member by member -- ncclRecv of the previous member's state head, import, scan
  *   (round 0 while the 512-frame history is still arriving), export, ncclSend to the next member -- and every chunk's
@@ -411,8 +413,11 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  *   a chunk's records come out once every earlier chunk is complete.
  * irdm_group_set_option: an option of every member ("group_loopback" 1: a group of one member runs the whole protocol --
  *   overlap seed, state export, ncclSend / ncclRecv to itself, import -- for tests on one GPU).
- * irdm_group_get_stat: "hops", "hop_bytes", "scatter_bytes", "overlap_bytes", "chunks", "late_history", "tagged" (sum of
- *   the members' burst counts), any other key: the sum over the members. */
+ * irdm_group_get_stat: "hops", "hop_bytes", "scatter_bytes", "overlap_bytes", "overlap_samples", "chunks", "late_history"
+ *   (scans that took their history behind round 0), "tagged" (the stream's burst count: it travels with the detector
+ *   state), any other key: the sum of irdm_get_stat over the members.
+ * One thread drives a group.  Feeding or polling a member directly (irdm_group_member) is not allowed; options, statistics
+ * and kernel clocks of a member are. */
 typedef struct irdm_group irdm_group_t;
 irdm_group_t *irdm_group_create(const irdm_config_t *cfg, int n_gpus, const int *devices);
 void irdm_group_destroy(irdm_group_t *g);

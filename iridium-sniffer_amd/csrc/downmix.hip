@@ -1439,95 +1439,53 @@ __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ w
 {
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x * 64 + threadIdx.x;
-    const bool live = b < n_bursts;
-    int w_drop = 1, w_dec_len = 0, w_start = 0;
-    float inc_re = 1.0f, inc_im = 0.0f;
-    if (live) {
-        BurstWork &w = work[b];
-        if (cfo.on_device) {
-            const float rel = (w.center_bin - cfo.n_fft / 2) / (float)cfo.n_fft;
-            double cf = cfo.center_frequency;
-            cf += rel * cfo.sample_rate;                                        // burst_downmix.c:663-671 (float product)
-            if (!w.drop_reason) {
-                const float phase_inc = -2.0f * 3.14159274101257324f * w.center_offset;       // -2.0f * (float)M_PI * offset
-                float re, im;
-                if (libm_cexpf_i<true>(phase_inc, &re, &im) != 0) {
-                    // (outside the restated domain: cannot happen, |offset| <= 1/4; drop rather than be wrong)
-                    w.drop_reason = 9;
-                    re = 1.0f;
-                    im = 0.0f;
-                }
-                w.incr_re = re;
-                w.incr_im = im;
-                cf += w.center_offset * cfo.out_rate;
+    if (b >= n_bursts) return;
+    BurstWork &w = work[b];
+    if (cfo.on_device) {
+        const float rel = (w.center_bin - cfo.n_fft / 2) / (float)cfo.n_fft;
+        double cf = cfo.center_frequency;
+        cf += rel * cfo.sample_rate;                                        // burst_downmix.c:663-671 (float product)
+        if (!w.drop_reason) {
+            const float phase_inc = -2.0f * 3.14159274101257324f * w.center_offset;       // -2.0f * (float)M_PI * offset
+            float re, im;
+            if (libm_cexpf_i<true>(phase_inc, &re, &im) != 0) {
+                // (outside the restated domain: cannot happen, |offset| <= 1/4; drop rather than be wrong)
+                w.drop_reason = 9;
+                re = 1.0f;
+                im = 0.0f;
             }
-            w.simplex = cf > 1626000000 ? 1 : 0;                                // iridium.h:18
-        } else if (hp_work) {
-            // what the host's fine-CFO step left in the mapped pinned record (system-scope loads: the wait kernel in front
-            // of this one has seen the helper thread's sequence number)
-            w.incr_re = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_re), __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_SYSTEM));
-            w.incr_im = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_im), __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_SYSTEM));
-            w.simplex = __hip_atomic_load(&hp_work[b].simplex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            w.incr_re = re;
+            w.incr_im = im;
+            cf += w.center_offset * cfo.out_rate;
         }
-        w_drop = w.drop_reason;
-        w_dec_len = w.dec_len;
-        w_start = w.start_idx;
-        inc_re = w.incr_re;
-        inc_im = w.incr_im;
+        w.simplex = cf > 1626000000 ? 1 : 0;                                // iridium.h:18
+    } else if (hp_work) {
+        // what the host's fine-CFO step left in the mapped pinned record (system-scope loads: the wait kernel in front
+        // of this one has seen the helper thread's sequence number)
+        w.incr_re = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_re), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+        w.incr_im = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_im), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+        w.simplex = __hip_atomic_load(&hp_work[b].simplex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // The chain: phase_{k+1} = phase_k * incr, one lane per burst, kRotTile steps at a time.  With every lane storing
-    // into its own row a store instruction touched 64 cache lines, and their number, not the multiply chain, set the
-    // pace (27 ns per step against the chain's 14).  The phases of a tile go through LDS instead -- lane b writes its
-    // kRotTile phases to row b of the tile -- and leave as rows: eight lanes per burst, 16 bytes each, one store
-    // instruction = eight bursts x 128 contiguous bytes.  Every lane runs to the wavefront's longest frame (the extra
-    // products are never stored); a burst's length gates the stores of ITS row, whichever lanes make them.
-    constexpr int kRotTile = 16;                         // steps per tile: 128 bytes of a row
-    constexpr int kRotPitch = kRotTile + 1;              // float2 per LDS row (+1: rows start on different banks)
-    __shared__ float2 s_tile[64 * kRotPitch];
-    __shared__ int s_len[64];
-    const int lane = (int)threadIdx.x;
-    int L = 0;
-    if (live && w_drop == 0) {
-        const int frame_len = w_dec_len - w_start;
-        L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
-        if (L < 0) L = 0;
-    }
-    s_len[lane] = L;
-    int Lmax = L;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(Lmax, d);
-        Lmax = o > Lmax ? o : Lmax;
-    }
-    __syncthreads();
-    const float2 inc = make_float2(inc_re, inc_im);
+    if (w.drop_reason != 0) return;
+    const int frame_len = w.dec_len - w.start_idx;
+    const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+    const float2 inc = make_float2(w.incr_re, w.incr_im);
     float2 ph = make_float2(1.0f, 0.0f);
-    static_assert(kFrameNeed % 2 == 0 && kRotTile % 2 == 0, "rows start 16-byte aligned, two phases per store");
-    const int wg0 = (int)blockIdx.x * 64;
-    for (int k0 = 0; k0 < Lmax; k0 += kRotTile) {
-#pragma unroll
-        for (int j = 0; j < kRotTile; j++) {
-            s_tile[lane * kRotPitch + j] = ph;
-            ph = cmul(ph, inc);
-        }
-        __syncthreads();
-        // lane -> (burst of this pass, pair of phases): 8 lanes x 2 phases = one 128-byte piece of a row
-        const int part = lane & 7;
-#pragma unroll
-        for (int pass = 0; pass < 8; pass++) {
-            const int lb = pass * 8 + (lane >> 3);       // burst within the workgroup
-            const int Lb = s_len[lb];
-            const int k = k0 + 2 * part;
-            if (k < Lb) {
-                const float2 p0 = s_tile[lb * kRotPitch + 2 * part], p1 = s_tile[lb * kRotPitch + 2 * part + 1];
-                float2 *r = rrc_ws + (size_t)(wg0 + lb) * kFrameNeed + k;
-                if (k + 1 < Lb) *reinterpret_cast<float4 *>(r) = make_float4(p0.x, p0.y, p1.x, p1.y);
-                else *r = p0;
-            }
-        }
-        __syncthreads();
+    float2 *r = rrc_ws + (size_t)b * kFrameNeed;
+    // two phases per 16-byte store: every lane writes its own row, so a store instruction touches 64 cache lines and
+    // their number, not the multiply chain, set the pace with one phase per store (0.24 ms against 0.11 ms)
+    static_assert(kFrameNeed % 2 == 0, "rows start 16-byte aligned");
+    int k = 0;
+    for (; k + 2 <= L; k += 2) {
+        const float2 p0 = ph;
+        ph = cmul(ph, inc);
+        const float2 p1 = ph;
+        ph = cmul(ph, inc);
+        *reinterpret_cast<float4 *>(r + k) = make_float4(p0.x, p0.y, p1.x, p1.y);
     }
+    if (k < L) r[k] = ph;
 }
 
 // ---------------------------------------------------------------------------

@@ -354,6 +354,10 @@ P
   cat "$OUT/cli_stdout.txt"
 }
 
+# n: exp_m again after rot_phase went back to its direct stores (the LDS transpose measured slower: post stage alone 0.34 ->
+# 0.62 ms), the group's same-device copies by kernel, librccl's banner kept off stdout
+exp_n() { exp_m; }
+
 exp_$EXP
 
 # one line per bench result of the call
