@@ -461,7 +461,10 @@ uint64_t irdm_chunks_complete(const irdm_pipeline_t *p);
  * "band_first" (default 0 = as many band-scan rounds up front as the previous chunk needed; n = always n; test hook),
  * kernel-variant switches for A/B runs and tests: "fir_layout" (3 register-resident decimator -- default at M = 40 / 48; 2 persistent LDS decimator, 1 / 0 one tile per
  *   workgroup, column-major / polyphase rows), "fir_budget" (tiles per workgroup of the persistent decimator, default 4),
- *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof".
+ *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof", "rot_store" (1, default: the rotator's
+ *   phase rows leave through LDS as rows; 0: every lane stores into its own row), "chunk_marks" (see irdm_chunk_mark_t),
+ *   "band_sum_restart" (1, default: later rounds' sums passes restart behind the update steps they share with the round
+ *   before).
  * Stats (irdm_get_stat): "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks", "band_rounds",
  * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "host_us_0".."host_us_9", "rot_rows",
  * "rot_rows_cap", "rot_blocks", "rot_blocks_cap", "rot_builds", "rot_runs", "rot_ckpts", "rot_grows" (rotator checkpoints:

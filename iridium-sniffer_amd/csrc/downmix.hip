@@ -1402,6 +1402,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
 }
 
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
+int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
 
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
@@ -1433,49 +1434,74 @@ int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
 // tools/check_sincosf.cpp, tools/check_sincosf_gpu.hip) and the reference's own mixed float / double expression for
 // the frequency.  The chain then never leaves the GPU (before: event -> helper thread -> sequence number -> a kernel
 // spinning on pinned memory, 0.4 ms per chunk in run).
+typedef unsigned rot_u32x4 __attribute__((vector_size(16)));
+
+// what the chain of a burst starts from: the libm step (or the host's results), then the burst's record fields
+struct RotStart {
+    bool live;
+    int drop, dec_len, start;
+    float inc_re, inc_im;
+};
+__device__ __forceinline__ RotStart rot_phase_start(BurstWork *__restrict__ work, int n_bursts, const BurstWork *__restrict__ hp_work,
+                                                    const CfoStep &cfo)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const bool live = b < n_bursts;
+    int w_drop = 1, w_dec_len = 0, w_start = 0;
+    float inc_re = 1.0f, inc_im = 0.0f;
+    if (live) {
+        BurstWork &w = work[b];
+        if (cfo.on_device) {
+            const float rel = (w.center_bin - cfo.n_fft / 2) / (float)cfo.n_fft;
+            double cf = cfo.center_frequency;
+            cf += rel * cfo.sample_rate;                                        // burst_downmix.c:663-671 (float product)
+            if (!w.drop_reason) {
+                const float phase_inc = -2.0f * 3.14159274101257324f * w.center_offset;       // -2.0f * (float)M_PI * offset
+                float re, im;
+                if (libm_cexpf_i<true>(phase_inc, &re, &im) != 0) {
+                    // (outside the restated domain: cannot happen, |offset| <= 1/4; drop rather than be wrong)
+                    w.drop_reason = 9;
+                    re = 1.0f;
+                    im = 0.0f;
+                }
+                w.incr_re = re;
+                w.incr_im = im;
+                cf += w.center_offset * cfo.out_rate;
+            }
+            w.simplex = cf > 1626000000 ? 1 : 0;                                // iridium.h:18
+        } else if (hp_work) {
+            // what the host's fine-CFO step left in the mapped pinned record (system-scope loads: the wait kernel in front
+            // of this one has seen the helper thread's sequence number)
+            w.incr_re = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_re), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_SYSTEM));
+            w.incr_im = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_im), __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_SYSTEM));
+            w.simplex = __hip_atomic_load(&hp_work[b].simplex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        w_drop = w.drop_reason;
+        w_dec_len = w.dec_len;
+        w_start = w.start_idx;
+        inc_re = w.incr_re;
+        inc_im = w.incr_im;
+    }
+    return RotStart{ live, w_drop, w_dec_len, w_start, inc_re, inc_im };
+}
+
+// rot_store 0: every lane stores into its own row, two phases per 16-byte store (one phase per store: the number of cache
+// lines a store instruction touches, 64, set the pace: 0.24 ms against 0.11)
 __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ work, int n_bursts,
                                                        float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
                                                        CfoStep cfo)
 {
-    __builtin_amdgcn_s_setprio(3);
+    const RotStart s0 = rot_phase_start(work, n_bursts, hp_work, cfo);
+    if (!s0.live || s0.drop != 0) return;
     const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= n_bursts) return;
-    BurstWork &w = work[b];
-    if (cfo.on_device) {
-        const float rel = (w.center_bin - cfo.n_fft / 2) / (float)cfo.n_fft;
-        double cf = cfo.center_frequency;
-        cf += rel * cfo.sample_rate;                                        // burst_downmix.c:663-671 (float product)
-        if (!w.drop_reason) {
-            const float phase_inc = -2.0f * 3.14159274101257324f * w.center_offset;       // -2.0f * (float)M_PI * offset
-            float re, im;
-            if (libm_cexpf_i<true>(phase_inc, &re, &im) != 0) {
-                // (outside the restated domain: cannot happen, |offset| <= 1/4; drop rather than be wrong)
-                w.drop_reason = 9;
-                re = 1.0f;
-                im = 0.0f;
-            }
-            w.incr_re = re;
-            w.incr_im = im;
-            cf += w.center_offset * cfo.out_rate;
-        }
-        w.simplex = cf > 1626000000 ? 1 : 0;                                // iridium.h:18
-    } else if (hp_work) {
-        // what the host's fine-CFO step left in the mapped pinned record (system-scope loads: the wait kernel in front
-        // of this one has seen the helper thread's sequence number)
-        w.incr_re = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_re), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_SYSTEM));
-        w.incr_im = __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(&hp_work[b].incr_im), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_SYSTEM));
-        w.simplex = __hip_atomic_load(&hp_work[b].simplex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (w.drop_reason != 0) return;
-    const int frame_len = w.dec_len - w.start_idx;
+    const int frame_len = s0.dec_len - s0.start;
     const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
-    const float2 inc = make_float2(w.incr_re, w.incr_im);
+    const float2 inc = make_float2(s0.inc_re, s0.inc_im);
     float2 ph = make_float2(1.0f, 0.0f);
     float2 *r = rrc_ws + (size_t)b * kFrameNeed;
-    // two phases per 16-byte store: every lane writes its own row, so a store instruction touches 64 cache lines and
-    // their number, not the multiply chain, set the pace with one phase per store (0.24 ms against 0.11 ms)
     static_assert(kFrameNeed % 2 == 0, "rows start 16-byte aligned");
     int k = 0;
     for (; k + 2 <= L; k += 2) {
@@ -1486,6 +1512,125 @@ __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ w
         *reinterpret_cast<float4 *>(r + k) = make_float4(p0.x, p0.y, p1.x, p1.y);
     }
     if (k < L) r[k] = ph;
+}
+
+// rot_store 1 (default): the phases leave as rows
+__global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restrict__ work, int n_bursts,
+                                                            float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
+                                                            CfoStep cfo)
+{
+    const RotStart s0 = rot_phase_start(work, n_bursts, hp_work, cfo);
+    const bool live = s0.live;
+    const int w_drop = s0.drop, w_dec_len = s0.dec_len, w_start = s0.start;
+    const float inc_re = s0.inc_re, inc_im = s0.inc_im;
+    // The chain: phase_{k+1} = phase_k * incr, one lane per burst.  With every lane storing into its own row a store
+    // instruction touched 64 cache lines, and their number, not the multiply chain, set the pace (27 ns per step against
+    // the chain's 14).  Here a tile of kRotTile steps goes through LDS -- lane b writes its phases to row b of the tile
+    // -- and leaves as rows: eight lanes per burst, 16 bytes each, one store instruction = eight bursts x 128 contiguous
+    // bytes.  A first version of this (two workgroup barriers and eight read-then-store passes per tile, in line with the
+    // chain) took 0.44 ms instead of 0.16: the passes' LDS round trips were added to the chain.  Now the loop is skewed by
+    // one tile and has no barrier: an iteration issues the sixteen LDS reads of tile t - 1, runs the chain of tile t into
+    // the OTHER tile buffer, and stores tile t - 1 behind it -- a wavefront's LDS instructions complete in order, the
+    // wavefront is the workgroup, so a wave barrier (an ordering point for the compiler, no instruction) is all the reads
+    // need behind the writes.  Every lane runs to the wavefront's longest frame (the extra products are never stored); a
+    // burst's length gates the stores of ITS row, whichever lanes make them; a pair of phases is stored whole where its
+    // first element is in the frame (the second lands inside the row, behind the frame: kFrameNeed is even).
+    constexpr int kRotTile = 16;                         // steps per tile: 128 bytes of a row
+    constexpr int kRotPitch = kRotTile + 1;              // float2 per LDS row (+1: rows start on different banks)
+    __shared__ float2 s_tile[2][64 * kRotPitch];
+    __shared__ int s_len[64];
+    static_assert(kFrameNeed % 2 == 0 && kRotTile % 2 == 0, "rows start 16-byte aligned, two phases per store");
+    const int lane = (int)threadIdx.x;
+    int L = 0;
+    if (live && w_drop == 0) {
+        const int frame_len = w_dec_len - w_start;
+        L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+        if (L < 0) L = 0;
+    }
+    s_len[lane] = L;
+    int Lmax = L;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(Lmax, d);
+        Lmax = o > Lmax ? o : Lmax;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane -> (burst of pass p, pair of phases): 8 lanes x 2 phases = one 128-byte piece of a row.  The rows leave as
+    // buffer stores over this workgroup's 64 rows (fewer in the last workgroup: rows behind the batch are out of range):
+    // a store whose pair lies behind its burst's frame gets an out-of-range offset and is dropped by the address
+    // check -- no branch, so the stores sit in the chain's basic block.
+    const int part = lane & 7;
+    int len_of[8], off_of[8];
+    const int wg0 = (int)blockIdx.x * 64;
+    const int rows = n_bursts - wg0 < 64 ? n_bursts - wg0 : 64;
+    const __amdgpu_buffer_rsrc_t r_rows = __builtin_amdgcn_make_buffer_rsrc(rrc_ws + (size_t)wg0 * kFrameNeed, 0,
+                                                                            rows * kFrameNeed * (int)sizeof(float2), 0x00020000);
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int lb = p * 8 + (lane >> 3);
+        len_of[p] = s_len[lb];
+        off_of[p] = (lb * kFrameNeed + 2 * part) * (int)sizeof(float2);
+    }
+    const float2 inc = make_float2(inc_re, inc_im);
+    float2 ph = make_float2(1.0f, 0.0f);
+    const int n_tiles = (Lmax + kRotTile - 1) / kRotTile;
+    float2 q0[8], q1[8];
+    // tile u out of its buffer: sixteen LDS reads, in flight while whatever follows runs
+    auto fetch = [&](int u) {
+        const float2 *src = s_tile[u & 1];
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int lb = p * 8 + (lane >> 3);
+            q0[p] = src[lb * kRotPitch + 2 * part];
+            q1[p] = src[lb * kRotPitch + 2 * part + 1];
+        }
+    };
+    // the chain of tile u into its buffer
+    auto chain = [&](int u) {
+        float2 *dst = s_tile[u & 1];
+#pragma unroll
+        for (int j = 0; j < kRotTile; j++) {
+            dst[lane * kRotPitch + j] = ph;
+            ph = cmul(ph, inc);
+        }
+    };
+    // tile u (fetched) to its rows
+    auto store = [&](int u) {
+        const int k = u * kRotTile + 2 * part;
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                   r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
+                                                   u * kRotTile * (int)sizeof(float2), 0);
+    };
+    auto order = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (n_tiles > 0) {
+        chain(0);
+        order();
+        for (int t = 1; t < n_tiles; t++) {     // one basic block: the reads, the chain and the stores of an iteration
+            fetch(t - 1);
+            // (chain(t) and store(t - 1) written into each other: a store pass in the gap behind every other step)
+            float2 *dst = s_tile[t & 1];
+            const int k = (t - 1) * kRotTile + 2 * part;
+#pragma unroll
+            for (int j = 0; j < kRotTile; j++) {
+                dst[lane * kRotPitch + j] = ph;
+                ph = cmul(ph, inc);
+                if (j & 1) {
+                    const int p = j >> 1;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                           r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
+                                                           (t - 1) * kRotTile * (int)sizeof(float2), 0);
+                }
+            }
+            order();
+        }
+        fetch(n_tiles - 1);
+        store(n_tiles - 1);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1662,7 +1807,10 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    if (g_rot_store)
+        hipLaunchKernelGGL(rot_phase_rows_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    else
+        hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     if (rrc_ntaps == 51 && !g_post_generic) {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

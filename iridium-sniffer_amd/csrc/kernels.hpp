@@ -192,6 +192,7 @@ int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hip
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
                         float2 *out, hipStream_t stream);
 extern int g_post_generic;        // 1: runtime-tap-count instances of post1 / post2 (test hook)
+extern int g_rot_store;           // rot_phase: 1 (default) rows through LDS, 0 a row per lane
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,

@@ -55,6 +55,13 @@ def main():
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=4, feed="ingest_lookahead"), ref)
         res["chunked_depth3_two_ahead"] = parity.compare(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=3, feed="lookahead2"), ref)
+        # the rotator's phase rows a row per lane (rot_store 0; the default sends them through LDS and stores rows)
+        try:
+            res["rot_store_per_lane"] = parity.compare(parity.run_gpu(iq, fs, options={"rot_store": 0}), ref)
+        finally:
+            pz = irdm.Pipeline(fs, max_chunk_samples=65536, max_bursts_per_chunk=64)
+            pz.set_option("rot_store", 1)
+            pz.close()
         x = siggen.to_ci8(iq)
         ref8 = orc.run_stream(x, fs, fmt=irdm.FMT_CI8)
         res["ci8"] = parity.compare(parity.run_gpu(x, fs, fmt=irdm.FMT_CI8), ref8)

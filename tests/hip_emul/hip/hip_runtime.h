@@ -407,8 +407,10 @@ inline hip_emul::u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsr
     memcpy(&v, r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, 16);
     return v;
 }
-inline void __builtin_amdgcn_raw_buffer_store_b128(hip_emul::u32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+// (V: any 16-byte value -- the emulation's u32x4 or a GCC vector of four words)
+template <typename V> inline void __builtin_amdgcn_raw_buffer_store_b128(V v, __amdgpu_buffer_rsrc_t r, int voff, int soff, int)
 {
+    static_assert(sizeof(V) == 16, "a 128-bit store");
     if ((uint32_t)voff + 16u > r.num) return;
     memcpy(r.base + (size_t)(uint32_t)voff + (size_t)(uint32_t)soff, &v, 16);
 }

@@ -184,8 +184,9 @@ def test_detect_only_mode_emits_the_same_bursts():
 
 def test_kernel_variants_agree():
     """The runtime-M decimator and the radix-2 FFT kernels (fallbacks for sizes without a specialised kernel), the
-    one-tile-per-workgroup decimators (row-major and column-major tile) and the persistent decimator with one resident
-    grid / the smallest tile budget give the same records as the default kernels and the oracle."""
+    one-tile-per-workgroup decimators (row-major and column-major tile), the persistent decimator with one resident
+    grid / the smallest tile budget and the rotator's phase rows stored a row per lane (rot_store 0) give the same records
+    as the default kernels and the oracle."""
     fs, iq = _scene_2m(seed=19, n_bursts=6, secs=2.0)
     ref = orc.run_stream(iq, fs)
     try:
@@ -193,8 +194,8 @@ def test_kernel_variants_agree():
         ref0 = orc.run_stream(iq, fs)
     finally:
         orc.set_fir_order(1)
-    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0, "fir_order": 1}
-    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"post_generic": 1}, {"fir_order": 0},
+    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0, "fir_order": 1, "rot_store": 1}
+    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"post_generic": 1}, {"fir_order": 0}, {"rot_store": 0},
                  {"fir_order": 0, "fir_generic": 1}, {"fir_order": 0, "fir_layout": 0}, {"fir_order": 0, "fir_layout": 1},
                  {"fir_order": 0, "fir_layout": 2}, {"fir_order": 0, "fir_budget": 0}, {"fir_order": 0, "fir_budget": 2}):
         p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)

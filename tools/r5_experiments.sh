@@ -358,6 +358,28 @@ P
 # 0.62 ms), the group's same-device copies by kernel, librccl's banner kept off stdout
 exp_n() { exp_m; }
 
+# o: rot_phase with its phases leaving as rows through LDS, skewed by a tile and without barriers (rot_store 1) against the
+# direct stores (rot_store 0), alternating on one box; the group bench with the wide copy kernel
+exp_o() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_group.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run rs1
+  run rs0 --opt rot_store=0
+  run rs1_b
+  run rs0_b --opt rot_store=0
+  run rs1_d0 --depth 0
+  run rs0_d0 --depth 0 --opt rot_store=0
+  run rs1_c
+  run rs0_c --opt rot_store=0
+  run rs1_c5 --density 40 --sample-rate 12000000
+  run rs0_c5 --density 40 --sample-rate 12000000 --opt rot_store=0
+  timeout 400 python tools/group_bench.py > "$OUT/group_bench.txt" 2>"$OUT/group_bench.err"
+  cat "$OUT/group_bench.txt"
+}
+
 exp_$EXP
 
 # one line per bench result of the call
