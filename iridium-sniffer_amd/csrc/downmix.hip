@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
 }
 
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
-int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
+int g_rot_store = 0;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
 
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,

@@ -380,6 +380,34 @@ exp_o() {
   cat "$OUT/group_bench.txt"
 }
 
+# p: where the frames differ with rot_store 1 on the hardware (tools/rot_store_debug.py); the PLL's cosf / sinf as glibc's
+# polynomial: the parity tests and the default line, every stage serial, with the demod stage alone
+exp_p() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  timeout 300 python tools/rot_store_debug.py > "$OUT/rot_store_debug.txt" 2>&1
+  cat "$OUT/rot_store_debug.txt" | cut -c1-260
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_libm.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run c3
+  run c3_b
+  run c3_d0 --depth 0
+  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-samples 0 --file-run 0 2>/dev/null | tail -1 > "$OUT/b_alone.json"
+  python - "$OUT" <<'P'
+import json, sys
+d = json.load(open(sys.argv[1] + "/b_alone.json"))
+def find(o, k):
+    if isinstance(o, dict):
+        if k in o: return o[k]
+        for v in o.values():
+            r = find(v, k)
+            if r is not None: return r
+    return None
+print("alone", find(d, "stage_ms_alone"))
+P
+}
+
 exp_$EXP
 
 # one line per bench result of the call
