@@ -2,15 +2,12 @@
 // per-symbol recurrences (<= 448 steps) run one frame per lane, the per-symbol independent work one symbol per lane.
 //
 // Numerics: float32 in the reference's operation order.  cabsf is reproduced
-// exactly (double sqrt); the PLL's cosf / sinf are glibc's (libm_port.hpp: the
-// argument is 0.2 * an angle, |x| <= 0.63 < pi/4 -- the polynomial branch, no
-// reduction); cargf / atan2f come from the device libm and may differ from
-// glibc in the last ulp -> soft outputs (level, LLR, refined frequency) are
-// compared with tolerance 1e-4, hard bits exactly.
+// exactly (double sqrt); cargf/atan2f, cosf, sinf come from the device libm and
+// may differ from glibc in the last ulp -> soft outputs (level, LLR, refined
+// frequency) are compared with tolerance 1e-4, hard bits exactly.
 #include "common.hpp"
 #include "types.hpp"
 #include "kernels.hpp"
-#include "libm_port.hpp"
 
 namespace irdm {
 
@@ -97,18 +94,10 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
         const float2 unit = make_float2(er.x / em, er.y / em);
         const float ang = atan2f(unit.y, unit.x);
         const float sa = 0.2f * ang;
-        // cosf(sa), sinf(sa) (:184) as glibc evaluates them (s_sincosf.h: promoted to double, two polynomials, rounded
-        // to float): |sa| <= 0.2 * pi is inside the branch that needs no reduction, so this is 14 double-precision
-        // operations instead of the device libm's ~100 single-precision ones with their large-argument path
+        // (glibc's own polynomial for this range -- libm_port.hpp, 14 double-precision operations, bit for bit the host's
+        // cosf / sinf -- was tried in place of the device libm's single-precision routine: exact, and 0.03 ms slower)
         float sn, cs;
-        {
-            const double xd = (double)sa;
-            double sd, cd;
-            libm_sincosf_poly<true>(xd, xd * xd, 0, &sd, &cd);
-            const bool tiny = ((__float_as_uint(sa) >> 20) & 0x7ff) < 0x398;      // |sa| < 2^-12: sinf = x, cosf = 1
-            sn = tiny ? sa : (float)sd;
-            cs = tiny ? 1.0f : (float)cd;
-        }
+        sincosf(sa, &sn, &cs);          // one shared argument reduction for cosf(sa), sinf(sa) (:184)
         const float2 corr = make_float2(cs, sn);
         const float tp = total_phase + sa;
         const float2 p1 = cmul(make_float2(corr.x, -corr.y), phi);

@@ -1514,7 +1514,9 @@ __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ w
     if (k < L) r[k] = ph;
 }
 
-// rot_store 1 (default): the phases leave as rows
+// rot_store 1: the phases leave as rows (2, 3: variants for tracking a mismatch on the hardware down -- LDS rows
+// 16-byte aligned / plain stores under a branch)
+template <int PITCH, bool BUF>
 __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restrict__ work, int n_bursts,
                                                             float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
                                                             CfoStep cfo)
@@ -1536,7 +1538,7 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
     // burst's length gates the stores of ITS row, whichever lanes make them; a pair of phases is stored whole where its
     // first element is in the frame (the second lands inside the row, behind the frame: kFrameNeed is even).
     constexpr int kRotTile = 16;                         // steps per tile: 128 bytes of a row
-    constexpr int kRotPitch = kRotTile + 1;              // float2 per LDS row (+1: rows start on different banks)
+    constexpr int kRotPitch = PITCH;                     // float2 per LDS row (17: rows start on different banks)
     __shared__ float2 s_tile[2][64 * kRotPitch];
     __shared__ int s_len[64];
     static_assert(kFrameNeed % 2 == 0 && kRotTile % 2 == 0, "rows start 16-byte aligned, two phases per store");
@@ -1599,9 +1601,13 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
         const int k = u * kRotTile + 2 * part;
 #pragma unroll
         for (int p = 0; p < 8; p++)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                   r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
-                                                   u * kRotTile * (int)sizeof(float2), 0);
+            if (BUF)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                       r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
+                                                       u * kRotTile * (int)sizeof(float2), 0);
+            else if (k < len_of[p])
+                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rrc_ws + (size_t)wg0 * kFrameNeed) + off_of[p] +
+                                            u * kRotTile * (int)sizeof(float2)) = make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y);
     };
     auto order = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1621,9 +1627,13 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
                 ph = cmul(ph, inc);
                 if (j & 1) {
                     const int p = j >> 1;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                           r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
-                                                           (t - 1) * kRotTile * (int)sizeof(float2), 0);
+                    if (BUF)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                               r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
+                                                               (t - 1) * kRotTile * (int)sizeof(float2), 0);
+                    else if (k < len_of[p])
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rrc_ws + (size_t)wg0 * kFrameNeed) + off_of[p] +
+                                                    (t - 1) * kRotTile * (int)sizeof(float2)) = make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y);
                 }
             }
             order();
@@ -1807,8 +1817,12 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    if (g_rot_store)
-        hipLaunchKernelGGL(rot_phase_rows_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    if (g_rot_store == 1)
+        hipLaunchKernelGGL((rot_phase_rows_kernel<17, true>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    else if (g_rot_store == 2)
+        hipLaunchKernelGGL((rot_phase_rows_kernel<18, true>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    else if (g_rot_store == 3)
+        hipLaunchKernelGGL((rot_phase_rows_kernel<17, false>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     else
         hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     if (rrc_ntaps == 51 && !g_post_generic) {

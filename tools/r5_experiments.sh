@@ -408,6 +408,13 @@ print("alone", find(d, "stage_ms_alone"))
 P
 }
 
+# q: the rows kernel's variants on the hardware (rot_store 1: LDS pitch 17 + buffer stores, 2: pitch 18, 3: pitch 17 + plain
+# stores under a branch) against the per-lane stores
+exp_q() {
+  timeout 300 python tools/rot_store_debug.py > "$OUT/rot_store_debug.txt" 2>&1
+  grep -c same "$OUT/rot_store_debug.txt"; grep "rot_store\|DIFF" "$OUT/rot_store_debug.txt" | cut -c1-200
+}
+
 exp_$EXP
 
 # one line per bench result of the call
