@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
 }
 
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
-int g_rot_store = 0;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
+int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
 
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
                          float2 *lpf, const float *noise_taps, int noise_ntaps,
@@ -1514,8 +1514,8 @@ __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ w
     if (k < L) r[k] = ph;
 }
 
-// rot_store 1: the phases leave as rows (2, 3: variants for tracking a mismatch on the hardware down -- LDS rows
-// 16-byte aligned / plain stores under a branch)
+// rot_store 1 (default): the phases leave as rows; 3: the same with plain stores under a branch instead of buffer stores
+// (what told the store hazard below from an LDS problem)
 template <int PITCH, bool BUF>
 __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restrict__ work, int n_bursts,
                                                             float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
@@ -1560,7 +1560,13 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
     // lane -> (burst of pass p, pair of phases): 8 lanes x 2 phases = one 128-byte piece of a row.  The rows leave as
     // buffer stores over this workgroup's 64 rows (fewer in the last workgroup: rows behind the batch are out of range):
     // a store whose pair lies behind its burst's frame gets an out-of-range offset and is dropped by the address
-    // check -- no branch, so the stores sit in the chain's basic block.
+    // check -- no branch, so the stores sit in the chain's basic block.  The tile's offset is part of the VECTOR offset,
+    // the scalar offset is the constant 0: with the tile's offset in an SGPR the compiler scheduled the chain's next
+    // packed multiply -- which overwrites two of the store's four data registers -- directly behind the 128-bit store
+    // (LLVM takes a buffer store with a register in the scalar-offset field to be free of the "store wider than 64 bits,
+    // then a VALU write of its data registers" hazard), and on gfx950 the rows of every other burst arrived with the
+    // NEXT step's products in them (tools/rot_store_debug.py; lanes 8-15, 24-31, ... of the store).  Without a register
+    // there the hazard recognizer separates the two.
     const int part = lane & 7;
     int len_of[8], off_of[8];
     const int wg0 = (int)blockIdx.x * 64;
@@ -1603,8 +1609,8 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
         for (int p = 0; p < 8; p++)
             if (BUF)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                       r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
-                                                       u * kRotTile * (int)sizeof(float2), 0);
+                                                       r_rows, k < len_of[p] ? off_of[p] + u * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
+                                                       0, 0);
             else if (k < len_of[p])
                 *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rrc_ws + (size_t)wg0 * kFrameNeed) + off_of[p] +
                                             u * kRotTile * (int)sizeof(float2)) = make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y);
@@ -1629,8 +1635,8 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
                     const int p = j >> 1;
                     if (BUF)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                               r_rows, k < len_of[p] ? off_of[p] : 0x7ffffff0,
-                                                               (t - 1) * kRotTile * (int)sizeof(float2), 0);
+                                                               r_rows, k < len_of[p] ? off_of[p] + (t - 1) * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
+                                                               0, 0);
                     else if (k < len_of[p])
                         *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rrc_ws + (size_t)wg0 * kFrameNeed) + off_of[p] +
                                                     (t - 1) * kRotTile * (int)sizeof(float2)) = make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y);
@@ -1819,8 +1825,6 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
     if (g_rot_store == 1)
         hipLaunchKernelGGL((rot_phase_rows_kernel<17, true>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
-    else if (g_rot_store == 2)
-        hipLaunchKernelGGL((rot_phase_rows_kernel<18, true>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     else if (g_rot_store == 3)
         hipLaunchKernelGGL((rot_phase_rows_kernel<17, false>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     else

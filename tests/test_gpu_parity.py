@@ -194,8 +194,8 @@ def test_kernel_variants_agree():
         ref0 = orc.run_stream(iq, fs)
     finally:
         orc.set_fir_order(1)
-    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0, "fir_order": 1, "rot_store": 0}
-    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"post_generic": 1}, {"fir_order": 0},
+    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0, "fir_order": 1, "rot_store": 1}
+    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"post_generic": 1}, {"fir_order": 0}, {"rot_store": 0}, {"rot_store": 3},
                  {"fir_order": 0, "fir_generic": 1}, {"fir_order": 0, "fir_layout": 0}, {"fir_order": 0, "fir_layout": 1},
                  {"fir_order": 0, "fir_layout": 2}, {"fir_order": 0, "fir_budget": 0}, {"fir_order": 0, "fir_budget": 2}):
         p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)

@@ -415,6 +415,28 @@ exp_q() {
   grep -c same "$OUT/rot_store_debug.txt"; grep "rot_store\|DIFF" "$OUT/rot_store_debug.txt" | cut -c1-200
 }
 
+# r: the rows kernel with the tile's offset in the vector offset (no register in the scalar-offset field: the hazard
+# recognizer keeps the chain's next multiply off the store's data registers): debug script, parity tests, A/B against rot_store 0
+exp_r() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  timeout 300 python tools/rot_store_debug.py > "$OUT/rot_store_debug.txt" 2>&1
+  grep -c same "$OUT/rot_store_debug.txt"; grep "rot_store\|DIFF" "$OUT/rot_store_debug.txt" | cut -c1-200
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scenes.py tests/test_gpu_ingest.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run rs1
+  run rs0 --opt rot_store=0
+  run rs1_b
+  run rs0_b --opt rot_store=0
+  run rs1_c
+  run rs0_c --opt rot_store=0
+  run rs1_d0 --depth 0
+  run rs0_d0 --depth 0 --opt rot_store=0
+  run rs1_c5 --density 40 --sample-rate 12000000
+  run rs0_c5 --density 40 --sample-rate 12000000 --opt rot_store=0
+}
+
 exp_$EXP
 
 # one line per bench result of the call
