@@ -47,6 +47,7 @@
 #include <unistd.h>
 
 #include "../../include/irdm_hip.h"
+#include "kernels.hpp"
 
 namespace {
 
@@ -183,30 +184,15 @@ namespace {
 
 bool full_protocol(const irdm_group *g) { return g->n > 1 || g->loopback; }
 
-// a member's own slice from the caller's buffer into its landing buffer: 16 bytes per lane, the whole chip.  (Not
-// hipMemcpyAsync: device to device on these streams it ran at 77 GB/s -- 6.9 ms for a 64 Mi-sample chunk.)
-__global__ __launch_bounds__(256) void group_copy_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
-{
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
-
 // one point-to-point transfer between two members' streams (src == dst: a plain device copy)
 int transfer(irdm_group *g, std::vector<ncclComm_t> &comms, int src, const void *from, hipStream_t s_src, int dst, void *to,
              hipStream_t s_dst, size_t bytes)
 {
     if (bytes == 0) return 0;
     if (src == dst && !g->loopback) {
+        // (by kernel: a device-to-device hipMemcpyAsync of this size ran at 75-110 GB/s on these streams)
         GRP_HIP(hipSetDevice(g->m[dst].dev));
-        if (bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(to) | reinterpret_cast<uintptr_t>(from)) % 16 == 0) {
-            const size_t n16 = bytes / 16;
-            const int grid = (int)std::min<size_t>((n16 + 255) / 256, 8192);
-            hipLaunchKernelGGL(group_copy_kernel, dim3(grid), dim3(256), 0, s_dst, static_cast<uint4 *>(to),
-                               static_cast<const uint4 *>(from), n16);
-            GRP_HIP(hipGetLastError());
-            return 0;
-        }
-        GRP_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s_dst));
-        return 0;
+        return irdm::launch_copy_wide(to, from, bytes, s_dst);
     }
     Rccl *r = rccl();
     GRP_NCCL(r->GroupStart());

@@ -1167,9 +1167,9 @@ static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t
     while (a0 < c1) {
         const uint64_t pos = a0 % p->ring_len;
         const uint64_t run = std::min<uint64_t>(c1 - a0, p->ring_len - pos);
-        IRDM_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(p->d_ring) + pos * p->bps,
-                                      static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
-                                      run * p->bps, hipMemcpyDeviceToDevice, st));
+        if (launch_copy_wide(static_cast<char *>(p->d_ring) + pos * p->bps, static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
+                             run * p->bps, st) != 0)
+            return -1;
         a0 += run;
     }
     return 0;
@@ -3286,6 +3286,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "band_first")) { p->band_first = value < 0 ? 0 : value > kBandRounds ? kBandRounds : value; return 0; }
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "rot_store")) { irdm::g_rot_store = value; return 0; }
+    if (!strcmp(key, "copy_wide")) { irdm::g_copy_wide = value ? 1 : 0; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }

@@ -437,6 +437,23 @@ exp_r() {
   run rs0_c5 --density 40 --sample-rate 12000000 --opt rot_store=0
 }
 
+# s: chunks NOT fed in place (--ingest 0: every chunk is copied into the history ring): the ring copy by kernel (copy_wide 1,
+# default) against hipMemcpyAsync (0); the group bench again
+exp_s() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run i0_w1 --ingest 0
+  run i0_w0 --ingest 0 --opt copy_wide=0
+  run i0_w1_b --ingest 0
+  run i0_w0_b --ingest 0 --opt copy_wide=0
+  run i1
+  timeout 400 python tools/group_bench.py > "$OUT/group_bench.txt" 2>"$OUT/group_bench.err"
+  cat "$OUT/group_bench.txt"
+  timeout 300 python -m pytest tests/test_gpu_group.py tests/test_gpu_ingest.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 3 "$OUT/tests.log"
+}
+
 exp_$EXP
 
 # one line per bench result of the call
