@@ -1090,14 +1090,16 @@ int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t st
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// A device-to-device copy of a chunk's size by kernel: 16 bytes per lane over the whole chip.  (hipMemcpyAsync device to
-// device on the pipeline's non-blocking streams went through the DMA engines: 512 MB in 4.8-6.9 ms, 75-110 GB/s.)
+// A device-to-device copy of a chunk's size by kernel: 16 bytes per lane over the whole chip -- option copy_wide 1.  The
+// default (0) stays hipMemcpyAsync: it goes through the DMA engines (a 512 MB chunk in ~5 ms, ~100 GB/s) BESIDE the
+// kernels, and in a pipelined run that is the better place for a copy nobody waits for: chunks not fed in place
+// (bench.py --ingest 0) 64.7-65.4 Gsamples/s with it against 60.7-61.0 with this kernel taking the CUs.
 __global__ __launch_bounds__(256) void copy_wide_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
 {
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-int g_copy_wide = 1;        // 0: hipMemcpyAsync for the history-ring copies (A/B)
+int g_copy_wide = 0;        // 1: the history-ring copies by kernel instead of hipMemcpyAsync (A/B: slower in run)
 int launch_copy_wide(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
     if (bytes == 0) return 0;

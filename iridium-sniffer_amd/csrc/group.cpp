@@ -190,7 +190,7 @@ int transfer(irdm_group *g, std::vector<ncclComm_t> &comms, int src, const void 
 {
     if (bytes == 0) return 0;
     if (src == dst && !g->loopback) {
-        // (by kernel: a device-to-device hipMemcpyAsync of this size ran at 75-110 GB/s on these streams)
+        // (hipMemcpyAsync, i.e. the DMA engines, unless option copy_wide asks for the copy kernel)
         GRP_HIP(hipSetDevice(g->m[dst].dev));
         return irdm::launch_copy_wide(to, from, bytes, s_dst);
     }

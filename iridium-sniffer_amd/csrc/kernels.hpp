@@ -188,8 +188,8 @@ int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t st
 int launch_copy2_to_host(void *dst_a, const void *src_a, size_t bytes_a, void *dst_b, const void *src_b, size_t bytes_b,
                          hipStream_t stream);
 int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream);   // bytes % 4 == 0
-int launch_copy_wide(void *dst, const void *src, size_t bytes, hipStream_t stream);    // device to device, chunk-sized: by kernel
-extern int g_copy_wide;           // 0: hipMemcpyAsync instead (A/B)
+int launch_copy_wide(void *dst, const void *src, size_t bytes, hipStream_t stream);    // device to device, chunk-sized: DMA (default) or kernel
+extern int g_copy_wide;           // 1: by kernel instead of hipMemcpyAsync (A/B)
 int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hipStream_t stream);
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
                         float2 *out, hipStream_t stream);

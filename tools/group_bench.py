@@ -45,20 +45,36 @@ def main():
         t0 = None
         total = args.warmup + args.steps
         g.stage_device(ptr, n)
+        tt = {"stage": 0.0, "feed": 0.0, "poll": 0.0}
+        h0 = None
+        names = ("k1_ring", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync", "settle_wait_scan",
+                 "settle_counters", "settle_records", "build_records")
         for s in range(total):
             if s == args.warmup:
                 t0 = time.perf_counter()
+                tt = {k: 0.0 for k in tt}
+                h0 = [g.stat("host_us_%d" % i) for i in range(10)]
+            a = time.perf_counter()
             if s + 1 < total:
                 g.stage_device(ptr, n)         # (the same buffer again: the stream repeats, the detector carries on)
+            b = time.perf_counter()
             g.feed_device(ptr, n)
+            c = time.perf_counter()
             frames += len(g.poll_demods_packed())
             g.poll_bursts()
+            d = time.perf_counter()
+            tt["stage"] += b - a
+            tt["feed"] += c - b
+            tt["poll"] += d - c
+        h1 = [g.stat("host_us_%d" % i) for i in range(10)]
         g.flush()
         frames += len(g.poll_demods_packed())
         dt = time.perf_counter() - t0
         st = {k: g.stat(k) for k in ("hops", "hop_bytes", "overlap_bytes", "scatter_bytes", "late_history", "chunks")}
         out.append({"mode": mode, "Msamples_per_s": round(args.steps * n / dt / 1e6, 1), "ms_per_chunk": round(dt / args.steps * 1e3, 3),
                     "frames": frames, "per_chunk_MB": {k: round(st[k] / max(st["chunks"], 1) / 1e6, 1) for k in ("hop_bytes", "overlap_bytes", "scatter_bytes")},
+                    "call_ms_per_chunk": {k: round(v / args.steps * 1e3, 3) for k, v in tt.items()},
+                    "member_host_us_per_chunk": {k: round((b_ - a_) / args.steps) for k, a_, b_ in zip(names, h0, h1)},
                     "hops": st["hops"], "late_history": st["late_history"], "sample_rate": fs, "chunk_samples": n, "pipeline_depth": args.depth})
         print(json.dumps(out[-1]), flush=True)
         g.close()

@@ -454,6 +454,12 @@ exp_s() {
   tail -n 3 "$OUT/tests.log"
 }
 
+# t: where a chunk's 4.4 ms go in the group's plain mode (timers in tools/group_bench.py)
+exp_t() {
+  timeout 400 python tools/group_bench.py > "$OUT/group_bench.txt" 2>"$OUT/group_bench.err"
+  cat "$OUT/group_bench.txt"; tail -n 2 "$OUT/group_bench.err"
+}
+
 exp_$EXP
 
 # one line per bench result of the call
