@@ -135,6 +135,7 @@ struct Member {
     hipStream_t xs = nullptr;            // IQ samples: uploads, scatter and overlap transfers
     hipStream_t hs = nullptr;            // detector state blobs
     void *land[2] = { nullptr, nullptr };
+    void *chunk_at[2] = { nullptr, nullptr };   // where the staged chunk's samples are: behind the overlap in land[], or in the ring
     void *blob_out = nullptr, *blob_in = nullptr;
     hipEvent_t ev_head = nullptr, ev_hist = nullptr;      // on hs: the previous member's head / history has arrived in blob_in
     hipEvent_t ev_land[2] = { nullptr, nullptr };         // on xs: the landing buffer holds its chunk and overlap
@@ -327,6 +328,16 @@ int stage(irdm_group *g, const void *src, size_t n_samples, bool host)
         char *land = static_cast<char *>(mb.land[mb.staged & 1]);
         char *dst = land + g->ov * g->bps;
         const size_t bytes = lens[i] * g->bps;
+        if (!full_protocol(g)) {
+            // one member, no hand-off: the stream is continuous in its context, so the chunk goes straight to its place in
+            // the history ring (irdm_ingest_ptr's arithmetic for a chunk that is up to two ahead of the one being fed: the
+            // ring is sized for exactly that) and irdm_feed_begin finds it there -- no landing buffer, no ring copy
+            uint64_t ring_len = 0;
+            char *ring = static_cast<char *>(irdm_ring_ptr(mb.p, &ring_len));
+            const uint64_t pos = ring_len ? g->abs_staged % ring_len : 0;
+            if (ring && pos + lens[i] <= ring_len) dst = ring + pos * g->bps;
+        }
+        mb.chunk_at[mb.staged & 1] = dst;
         GRP_HIP(hipSetDevice(mb.dev));
         // the buffer held the member's chunk before last: K1 and the ring copy that read it are long over, but nothing
         // orders this stream behind them (returns at once: that chunk's scan has settled since)
@@ -385,7 +396,7 @@ int run_super_step(irdm_group *g)
             fprintf(stderr, "irdm_hip group: irdm_seed_history_device failed (member %d, chunk %llu)\n", r, (unsigned long long)gno);
             return -1;
         }
-        if (irdm_feed_begin(mb.p, land + g->ov * g->bps, len, nullptr) != 0) return -1;
+        if (irdm_feed_begin(mb.p, mb.chunk_at[mb.fed & 1], len, nullptr) != 0) return -1;
         abs += len;
     }
     // ---- the detector's chain, member by member ----
