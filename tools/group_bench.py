@@ -68,13 +68,16 @@ def main():
             tt["poll"] += d - c
         h1 = [g.stat("host_us_%d" % i) for i in range(10)]
         t_loop = time.perf_counter() - t0
+        in_loop = frames
         g.flush()
+        t_flush = time.perf_counter() - t0 - t_loop
         frames += len(g.poll_demods_packed())
         dt = time.perf_counter() - t0
         st = {k: g.stat(k) for k in ("hops", "hop_bytes", "overlap_bytes", "scatter_bytes", "late_history", "chunks")}
         out.append({"mode": mode, "Msamples_per_s": round(args.steps * n / dt / 1e6, 1), "ms_per_chunk": round(dt / args.steps * 1e3, 3),
                     "frames": frames, "per_chunk_MB": {k: round(st[k] / max(st["chunks"], 1) / 1e6, 1) for k in ("hop_bytes", "overlap_bytes", "scatter_bytes")},
-                    "loop_ms_per_chunk": round(t_loop / args.steps * 1e3, 3), "final_flush_ms": round((dt - t_loop) * 1e3, 3),
+                    "loop_ms_per_chunk": round(t_loop / args.steps * 1e3, 3), "final_flush_ms": round(t_flush * 1e3, 3),
+                    "final_poll_ms": round((dt - t_loop - t_flush) * 1e3, 3), "frames_polled_in_loop": in_loop,
                     "call_ms_per_chunk": {k: round(v / args.steps * 1e3, 3) for k, v in tt.items()},
                     "member_host_us_per_chunk": {k: round((b_ - a_) / args.steps) for k, a_, b_ in zip(names, h0, h1)},
                     "hops": st["hops"], "late_history": st["late_history"], "sample_rate": fs, "chunk_samples": n, "pipeline_depth": args.depth})
