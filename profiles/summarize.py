@@ -135,6 +135,17 @@ if tl:
         print(k, v["Msamples_per_s"], "scan", v["scan_stage_ms"], "dur", round(sum(x[0] for x in p.values())), "gap",
               round(sum(x[1] for x in p.values())))
 
+# what the group protocol costs on one GPU (tools/group_bench.py: one JSON line per mode)
+gb = f"{src}/group_bench.txt"
+if os.path.exists(gb) and os.path.getsize(gb) > 10:
+    runs = [json.loads(l) for l in open(gb) if l.startswith("{")]
+    json.dump({"what": "tools/group_bench.py on one MI355X: a group of one member over a 12 MHz stream in 64 Mi-sample chunks, device-resident, "
+                       "the next super-step staged ahead -- plain (chunks straight into the member's ring, no hand-off) and with "
+                       "group_loopback (slice and overlap through the landing buffers, state export -> ncclSend / ncclRecv to itself -> "
+                       "import in front of every chunk)", "runs": runs}, open(f"profiles/{tag}_group_bench.json", "w"), indent=1)
+    for r in runs:
+        print("group", r["mode"], r["Msamples_per_s"], r["ms_per_chunk"])
+
 for f in (f"profiles/{tag}_kernel_stats.csv", f"profiles/{tag}_kernel_stats_depth0.csv",
           f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40.csv", f"profiles/{tag}_kernel_stats_cfg5_12mhz_d40_depth0.csv"):
     if os.path.exists(f):

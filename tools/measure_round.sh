@@ -10,13 +10,16 @@ Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
 D12="--density 40 --sample-rate 12000000"
 timeout 600 python bench.py --steps 20 --warmup 5 2>"$OUT/b.err" | tail -1 > "$OUT/b.json"
 timeout 90 python bench.py --steps 20 --warmup 5 --depth 0 $Q 2>/dev/null | tail -1 > "$OUT/b0.json"
-timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 2 2>/dev/null | tail -1 > "$OUT/d2.json"
-timeout 90 python bench.py --steps 10 --warmup 3 $Q --density 40 2>/dev/null | tail -1 > "$OUT/d40.json"
-timeout 120 python bench.py --steps 10 --warmup 3 $Q --alone-steps 3 $D12 2>/dev/null | tail -1 > "$OUT/cfg5_12mhz_d40.json"
+# (20 steps behind 6 of warm-up, as the driver's line: over 10 steps behind 3 the dense and the sparse scene read 10-15 % lower)
+timeout 90 python bench.py --steps 20 --warmup 6 $Q --density 2 2>/dev/null | tail -1 > "$OUT/d2.json"
+timeout 120 python bench.py --steps 20 --warmup 6 $Q --density 40 2>/dev/null | tail -1 > "$OUT/d40.json"
+timeout 150 python bench.py --steps 20 --warmup 6 $Q --alone-steps 3 $D12 2>/dev/null | tail -1 > "$OUT/cfg5_12mhz_d40.json"
 timeout 90 python bench.py --steps 20 --warmup 5 $Q --alone-steps 3 --opt fir_order=0 2>/dev/null | tail -1 > "$OUT/scalar_fir.json"
 timeout 120 python bench.py --shard time --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/cfg4_n1.json"
 # (the first eight chunks of that stream: every chunk brings centre bins never seen before -- rotator checkpoint builds)
 timeout 120 python bench.py --shard time --steps 6 --warmup 2 2>/dev/null | tail -1 > "$OUT/cfg4_n1_first8chunks.json"
+# what the group protocol costs on one GPU (one member plain / handing its state to itself over RCCL)
+timeout 300 python tools/group_bench.py > "$OUT/group_bench.txt" 2>/dev/null
 # the detector scan's own device timeline (option band_timeline: first workgroup's start / last one's end per pass), in
 # run and alone, both scenes
 timeout 90 python bench.py $Q --opt band_timeline=1 2>/dev/null | tail -1 > "$OUT/tl.json"
