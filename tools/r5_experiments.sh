@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round 5's experiment runs on the GPU box, one function per gpurun call (tools/r5_experiments.sh <a..h> [out-dir]); the
-# condensed results are the profiles/r5_*.json files named in DESIGN.md.  (tools/measure_round.sh is the round-end measurement.)
+# condensed results (profiles/condense_runs.py) are the profiles/r5_*.json files named in DESIGN.md.  (tools/measure_round.sh is the round-end measurement.)
 set -u
-EXP=${1:?which experiment: a .. i}
+EXP=${1:?which experiment: a .. u}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${2:-r5_$EXP}
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
@@ -458,6 +458,21 @@ exp_s() {
 exp_t() {
   timeout 400 python tools/group_bench.py > "$OUT/group_bench.txt" 2>"$OUT/group_bench.err"
   cat "$OUT/group_bench.txt"; tail -n 2 "$OUT/group_bench.err"
+}
+
+# u: the batch contexts again at the round's last commit (the chains got shorter: does the best depth move?)
+exp_u() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run d3
+  run d4 --depth 4
+  run d2 --depth 2
+  run d3_b
+  run d4_b --depth 4
+  run d5 --depth 5
+  run d3_c5 --density 40 --sample-rate 12000000
+  run d4_c5 --density 40 --sample-rate 12000000 --depth 4
 }
 
 exp_$EXP
