@@ -40,6 +40,7 @@ namespace irdm {
 #include "fir_mac.inc"
 
 int g_fir_strip = 3;           // double blocks (128 columns) per strip: a strip yields 128*g_fir_strip - NR outputs
+int g_chain_cus = 0;           // CUs the per-burst chains' streams may use (0: all of them)
 int g_fir_grid = -1;           // > 0: at most this many single-wavefront workgroups in flight, each walking strips; 0: one per
                                // strip; -1 (default): fir_decimate_kernel_f seven per CU, fir_decimate_kernel_r one per strip
 int g_fir_slice = 0;           // > 0: strips per launch (the chunk's strips as several launches); 0: one launch
@@ -542,7 +543,11 @@ static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
             if (n_cu <= 0) n_cu = 256;
         }
-        if (7 * n_cu < n_tiles) grid = 7 * n_cu;
+        // (the per-burst chains' streams may be masked off some CUs -- IRDM_CHAIN_CU_RESERVE --: the resident grid is
+        // seven per CU THEY may use; sized for the whole device, the workgroups that found no slot ran as a second round
+        // and doubled the kernel's time: what round 5's first CU-mask measurement, 0.61 ms, had measured)
+        const int cus = g_chain_cus > 0 && g_chain_cus < n_cu ? g_chain_cus : n_cu;
+        if (7 * cus < n_tiles) grid = 7 * cus;
     }
     if (next_tile != nullptr) {
         if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);

@@ -153,6 +153,7 @@ extern int g_fir_budget;          // persistent kernel: tiles per workgroup befo
 extern int g_fir_reserve_cus;     // persistent kernel: CUs left free for the other streams
 // fir_reg.hip: the register-resident decimator (M = 40, 48)
 extern int g_fir_strip;           // double blocks of 128 columns per strip
+extern int g_chain_cus;           // CUs the chains' streams may use (IRDM_CHAIN_CU_RESERVE; 0: all)
 extern int g_fir_grid;            // workgroups of the register-resident decimator (0: one per strip)
 extern int g_fir_slice;           // strips per launch of the register-resident decimator (0: all in one launch)
 extern thread_local int g_fir_order;           // 1 (default): the decimating FIR in the order of the reference's AVX2 kernel (simd_avx2.c:62-108),

@@ -598,6 +598,7 @@ static bool chain_stream_create(irdm_pipeline *p, hipStream_t *out, int prio)
             }
             if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) {
                 p->chain_cu_reserved = reserve;
+                irdm::g_chain_cus = n_cu - reserve;         // (the decimator's resident grid: seven per CU it may use)
                 return true;
             }
         }

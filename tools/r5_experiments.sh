@@ -2,7 +2,7 @@
 # Round 5's experiment runs on the GPU box, one function per gpurun call (tools/r5_experiments.sh <a..h> [out-dir]); the
 # condensed results (profiles/condense_runs.py) are the profiles/r5_*.json files named in DESIGN.md.  (tools/measure_round.sh is the round-end measurement.)
 set -u
-EXP=${1:?which experiment: a .. u}
+EXP=${1:?which experiment: a .. v}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${2:-r5_$EXP}
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
@@ -473,6 +473,26 @@ exp_u() {
   run d5 --depth 5
   run d3_c5 --density 40 --sample-rate 12000000
   run d4_c5 --density 40 --sample-rate 12000000 --depth 4
+}
+
+# v: IRDM_CHAIN_CU_RESERVE again, with the decimator's resident grid sized for the CUs its stream may use (the first
+# measurement, exp_g, launched 7 x 256 workgroups onto 256 - R CUs: a second round, 0.61 ms): r<R>_d<pipeline_depth>
+exp_v() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  run() { local name=$1 r=$2; shift 2
+    IRDM_CHAIN_CU_RESERVE=$r timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run r0_d3 0
+  run r8_d3 8
+  run r16_d3 16
+  run r32_d3 32
+  run r8_d4 8 --depth 4
+  run r16_d4 16 --depth 4
+  run r16_d5 16 --depth 5
+  run r0_d3_b 0
+  run r8_d3_b 8
+  run r16_d3_b 16
+  run r16_c5 16 --density 40 --sample-rate 12000000
+  run r0_c5 0 --density 40 --sample-rate 12000000
 }
 
 exp_$EXP
