@@ -3119,6 +3119,8 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     p->decode_frames = 0;
     p->decode_ida = 0;
     p->detect_only = 0;          // a stage-B call on a detect-only context still runs stage B
+    const int marks = p->chunk_marks;
+    p->chunk_marks = 0;          // (the records go to private queues: no chunk mark for them)
     const uint64_t tagged = p->tagged;
     std::vector<irdm_burst_t> last; last.swap(p->last_bursts);
     p->keep_frame_samples = 1;
@@ -3134,6 +3136,7 @@ extern "C" int irdm_downmix_burst(irdm_pipeline_t *p, const irdm_burst_t *info, 
     }
     p->q_bursts.swap(qb); p->q_frames.swap(qf); p->q_frame_samples.swap(qs); p->q_demods.swap(qd);
     p->keep_frame_samples = keep;
+    p->chunk_marks = marks;
     p->detect_only = det;
     p->decode_frames = dec;
     p->decode_ida = dec_ida;
