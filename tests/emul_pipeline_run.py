@@ -190,6 +190,13 @@ def main():
             assert got["stats"]["hops"] == (4 if proto else 0), got["stats"]
             assert got["stats"]["overlap_bytes"] == (3 * ov * 8 if proto else 0), got["stats"]
             assert got["stats"]["scatter_bytes"] == len(iq) * 8, got["stats"]
+        # the stream ends inside a chunk (and not on a feed-block boundary): two members, the last super-step's second
+        # chunk short; a further feed is refused
+        cut = len(iq) - 3 * 32768 - 777
+        ref_cut = orc.run_stream(iq[:cut], fs)
+        got = parity.run_group(iq[:cut], fs, n_gpus=2, chunk=chunk, staged_ahead=True)
+        res["two_members_ragged_end"] = parity.compare(got, ref_cut)
+        assert got["stats"]["chunks"] == 4 and got["stats"]["hops"] == 4, got["stats"]
     else:
         raise SystemExit("unknown case")
     print("RESULT " + json.dumps(res))
