@@ -1069,8 +1069,9 @@ int launch_copy2_to_host(void *dst_a, const void *src_a, size_t bytes_a, void *d
     }
     const size_t n = (bytes_a + bytes_b) / 16;
     if (!n) return 0;
-    const int grid = (int)std::min<size_t>((n + 255) / 256, 512);
-    hipLaunchKernelGGL(copy2_to_host_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint4 *>(dst_a),
+    const size_t wg = (size_t)g_small_wg;
+    const int grid = (int)std::min<size_t>((n + wg - 1) / wg, 512 * 256 / wg);
+    hipLaunchKernelGGL(copy2_to_host_kernel, dim3(grid), dim3((unsigned)wg), 0, stream, static_cast<uint4 *>(dst_a),
                        static_cast<const uint4 *>(src_a), bytes_a / 16, static_cast<uint4 *>(dst_b),
                        static_cast<const uint4 *>(src_b), bytes_b / 16);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1083,8 +1084,9 @@ int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t st
         return launch_copy_words(dst, src, bytes, stream);
     const size_t n16 = bytes / 16;
     const int n_tail = (int)((bytes - n16 * 16) / 4);
-    const int grid = (int)std::min<size_t>((n16 + 255) / 256 + 1, 512);
-    hipLaunchKernelGGL(copy_to_host_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint4 *>(dst),
+    const size_t wg = (size_t)g_small_wg;
+    const int grid = (int)std::min<size_t>((n16 + wg - 1) / wg + 1, 512 * 256 / wg);
+    hipLaunchKernelGGL(copy_to_host_kernel, dim3(grid), dim3((unsigned)wg), 0, stream, static_cast<uint4 *>(dst),
                        static_cast<const uint4 *>(src), n16, reinterpret_cast<uint32_t *>(static_cast<char *>(dst) + n16 * 16),
                        reinterpret_cast<const uint32_t *>(static_cast<const char *>(src) + n16 * 16), n_tail);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1116,8 +1118,9 @@ int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stre
 {
     if (bytes == 0) return 0;
     const size_t n = bytes / 4;
-    const int grid = (int)std::min<size_t>((n + 255) / 256, 256);
-    hipLaunchKernelGGL(copy_words_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint32_t *>(dst),
+    const size_t wg = (size_t)g_small_wg;
+    const int grid = (int)std::min<size_t>((n + wg - 1) / wg, 256 * 256 / wg);
+    hipLaunchKernelGGL(copy_words_kernel, dim3(grid), dim3((unsigned)wg), 0, stream, static_cast<uint32_t *>(dst),
                        static_cast<const uint32_t *>(src), n);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1423,6 +1426,9 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     }
 }
 
+int g_small_wg = 64;        // threads per workgroup of the chain's little copy / threshold kernels: a single wavefront finds a
+                            // slot beside the decimator's resident grid (seven of a CU's eight), a 256-thread workgroup
+                            // needs one on all four SIMDs of a CU and waits for the grid to drain (option small_wg 256: as before)
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
 int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
 

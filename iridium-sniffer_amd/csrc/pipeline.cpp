@@ -3291,6 +3291,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
     if (!strcmp(key, "rot_store")) { irdm::g_rot_store = value; return 0; }
     if (!strcmp(key, "copy_wide")) { irdm::g_copy_wide = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "small_wg")) { if (value != 64 && value != 128 && value != 256) return -1; irdm::g_small_wg = value; return 0; }
     if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
     if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
     if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }

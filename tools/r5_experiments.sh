@@ -2,7 +2,7 @@
 # Round 5's experiment runs on the GPU box, one function per gpurun call (tools/r5_experiments.sh <a..h> [out-dir]); the
 # condensed results (profiles/condense_runs.py) are the profiles/r5_*.json files named in DESIGN.md.  (tools/measure_round.sh is the round-end measurement.)
 set -u
-EXP=${1:?which experiment: a .. v}
+EXP=${1:?which experiment: a .. w}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${2:-r5_$EXP}
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
@@ -493,6 +493,26 @@ exp_v() {
   run r16_d3_b 16
   run r16_c5 16 --density 40 --sample-rate 12000000
   run r0_c5 0 --density 40 --sample-rate 12000000
+}
+
+# w: the chain's little copy / threshold kernels as single-wavefront workgroups (small_wg 64, default) against 256 threads
+exp_w() {
+  Q="--cpu-samples 0 --host-steps 0 --alone-steps 0 --detect-steps 0 --file-run 0"
+  D12="--density 40 --sample-rate 12000000"
+  timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ingest.py -x -q -m gpu > "$OUT/tests.log" 2>&1
+  tail -n 2 "$OUT/tests.log"
+  run() { local name=$1; shift
+    timeout 150 python bench.py --steps 20 --warmup 6 $Q "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/$name.json"; }
+  run w64
+  run w256 --opt small_wg=256
+  run w64_b
+  run w256_b --opt small_wg=256
+  run w64_c5 $D12
+  run w256_c5 $D12 --opt small_wg=256
+  run w64_c5_b $D12
+  run w256_c5_b $D12 --opt small_wg=256
+  run w64_d0 --depth 0
+  run w256_d0 --depth 0 --opt small_wg=256
 }
 
 exp_$EXP
