@@ -1426,9 +1426,10 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     }
 }
 
-int g_small_wg = 64;        // threads per workgroup of the chain's little copy / threshold kernels: a single wavefront finds a
-                            // slot beside the decimator's resident grid (seven of a CU's eight), a 256-thread workgroup
-                            // needs one on all four SIMDs of a CU and waits for the grid to drain (option small_wg 256: as before)
+int g_small_wg = 256;       // threads per workgroup of the chain's little copy / threshold kernels.  Option small_wg 64: a single
+                            // wavefront finds a slot beside the decimator's resident grid where a 256-thread workgroup needs one
+                            // on all four SIMDs of a CU -- measured: nothing in run (71.1 / 71.9 against 72.5 / 71.1 Gsamples/s,
+                            // 12 MHz dense 25.5 / 25.5 against 26.0 / 25.5), every stage serial 1.82 against 1.88 ms
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
 int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
 

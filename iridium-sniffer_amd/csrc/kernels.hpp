@@ -194,7 +194,7 @@ extern int g_copy_wide;           // 1: by kernel instead of hipMemcpyAsync (A/B
 int launch_wait_host_flag(const uint32_t *flag, uint32_t seq, uint32_t *err, hipStream_t stream);
 int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_end, int n,
                         float2 *out, hipStream_t stream);
-extern int g_small_wg;            // threads per workgroup of the little copy / threshold kernels (64; 256 as before)
+extern int g_small_wg;            // threads per workgroup of the little copy / threshold kernels (256; option small_wg 64)
 extern int g_post_generic;        // 1: runtime-tap-count instances of post1 / post2 (test hook)
 extern int g_rot_store;           // rot_phase: 1 (default) rows through LDS, 0 a row per lane
 int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
