@@ -124,6 +124,70 @@ __device__ __forceinline__ void fft_lds_radix2(float2 *s, const float2 *__restri
     }
 }
 
+// One butterfly of the pinned FFT (the body of fft_lds_radix2's inner loop): stage twiddle index tix of N points.
+template <int N, int DIR>
+__device__ __forceinline__ void fft_bfly2(float2 &a, float2 &v, int tix, const float2 *__restrict__ tw)
+{
+    float2 t;
+    if (tix == 0) {
+        t = v;
+    } else if (tix == N / 4) {
+        t = DIR < 0 ? make_float2(v.y, -v.x) : make_float2(-v.y, v.x);
+    } else {
+        float2 w = tw[tix];
+        if (DIR > 0) w.y = -w.y;
+        t = cmul(w, v);
+    }
+    const float2 a0 = a;
+    a = make_float2(a0.x + t.x, a0.y + t.y);
+    v = make_float2(a0.x - t.x, a0.y - t.y);
+}
+
+// The same transform from stage FIRST on (the stages before it done by the caller), TWO stages per barrier: a thread
+// takes the four points base + {0, h, 2h, 3h} (h = the first stage's butterfly span) through stage st -- (0, h) and
+// (2h, 3h), one twiddle -- and stage st + 1 -- (0, 2h) and (h, 3h) -- in registers: the same butterflies on the same
+// operands as fft_lds_radix2, half the LDS round trips and barriers.  NA arrays side by side (s + a * pitch): the two
+// backward transforms of the sync correlation share their barriers.  An odd number of stages ends with a single one.
+template <int LOGN, int NT, int DIR, int FIRST, int NA = 1>
+__device__ __forceinline__ void fft_lds_radix2x2(float2 *s, const float2 *__restrict__ tw, int pitch = 0)
+{
+    constexpr int N = 1 << LOGN;
+    const int tid = threadIdx.x;
+    int st = FIRST;
+#pragma unroll 1
+    for (; st + 1 <= LOGN; st += 2) {
+        const int h = 1 << (st - 1);
+        const int sh = LOGN - st;
+        for (int g = tid; g < NA * (N / 4); g += NT) {
+            float2 *sa = s + (g / (N / 4)) * pitch;
+            const int q = g % (N / 4);
+            const int j = q & (h - 1);
+            const int i0 = ((q >> (st - 1)) << (st + 1)) + j;
+            float2 e0 = sa[i0], e1 = sa[i0 + h], e2 = sa[i0 + 2 * h], e3 = sa[i0 + 3 * h];
+            fft_bfly2<N, DIR>(e0, e1, j << sh, tw);
+            fft_bfly2<N, DIR>(e2, e3, j << sh, tw);
+            fft_bfly2<N, DIR>(e0, e2, j << (sh - 1), tw);
+            fft_bfly2<N, DIR>(e1, e3, (j + h) << (sh - 1), tw);
+            sa[i0] = e0; sa[i0 + h] = e1; sa[i0 + 2 * h] = e2; sa[i0 + 3 * h] = e3;
+        }
+        __syncthreads();
+    }
+    if (st <= LOGN) {
+        const int half = 1 << (st - 1);
+        const int sh = LOGN - st;
+        for (int g = tid; g < NA * (N / 2); g += NT) {
+            float2 *sa = s + (g / (N / 2)) * pitch;
+            const int b = g % (N / 2);
+            const int j = b & (half - 1);
+            const int i0 = ((b >> (st - 1)) << st) + j;
+            float2 a = sa[i0], v = sa[i0 + half];
+            fft_bfly2<N, DIR>(a, v, j << sh, tw);
+            sa[i0] = a; sa[i0 + half] = v;
+        }
+        __syncthreads();
+    }
+}
+
 __host__ __device__ __forceinline__ unsigned bitrev(unsigned v, int bits)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

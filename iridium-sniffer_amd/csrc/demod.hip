@@ -166,8 +166,50 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
     out[b].total_phase = total_phase;
 }
 
+// Export (packed_records): with hp_packed != nullptr the wavefront writes its burst's DemodPacked record -- the six scalars
+// and the hard bits 8 per byte, MSB first, exactly what demod_pack_kernel makes of the DemodOut -- and the burst's work record
+// straight into pinned host memory (34 + 22 words, one store instruction each), and leaves the DemodOut's bits and LLRs
+// unwritten: the chain ends with this kernel instead of demod_pack_kernel and a copy kernel behind it.
+__device__ __forceinline__ void demod_export(const BurstWork *__restrict__ w, int lane, int ok, int direction, int confidence, int ns, float level,
+                                             float total_phase, const int *s_sym, DemodPacked *__restrict__ hp_packed,
+                                             BurstWork *__restrict__ hp_work, int b)
+{
+    uint32_t *dst = reinterpret_cast<uint32_t *>(hp_packed + b);
+    static_assert(sizeof(DemodPacked) == 4 * 34 && kMaxBits / 8 == 4 * 28, "six scalars and 28 words of bits");
+    uint32_t v = 0;
+    if (lane == 0) v = (uint32_t)ok;
+    else if (lane == 1) v = (uint32_t)direction;
+    else if (lane == 2) v = (uint32_t)confidence;
+    else if (lane == 3) v = (uint32_t)ns;
+    else if (lane == 4) v = __float_as_uint(level);
+    else if (lane == 5) v = __float_as_uint(total_phase);
+    else if (lane < 34 && ok) {
+        // word lane - 6 = bytes 4 (lane - 6) .. + 3 = symbols 16 (lane - 6) .. + 15, two bits each, MSB first within a byte
+        const int dq[4] = { 0, 2, 3, 1 };
+        const int s0 = 16 * (lane - 6);
+#pragma unroll
+        for (int byte = 0; byte < 4; byte++) {
+            uint32_t bv = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = s0 + 4 * byte + k;
+                if (i < ns) {
+                    const int sq = s_sym[i] & 3, old = i > 0 ? (s_sym[i - 1] & 3) : 0;
+                    bv |= (uint32_t)dq[(sq - old + 4) % 4] << (6 - 2 * k);
+                }
+            }
+            v |= bv << (8 * byte);
+        }
+    }
+    if (lane < 34) dst[lane] = v;
+    static_assert(sizeof(BurstWork) == 4 * 22, "the work record as 22 words");
+    if (lane < 22) reinterpret_cast<uint32_t *>(hp_work + b)[lane] = reinterpret_cast<const uint32_t *>(w)[lane];
+    __threadfence_system();
+}
+
 __global__ __launch_bounds__(64) void demod_par_kernel(const BurstWork *__restrict__ work, int n_bursts,
-                                                       const float2 *__restrict__ ws, DemodOut *__restrict__ out)
+                                                       const float2 *__restrict__ ws, DemodOut *__restrict__ out,
+                                                       DemodPacked *__restrict__ hp_packed, BurstWork *__restrict__ hp_work)
 {
     __shared__ float2 s_po[kMaxSymbols];
     __shared__ float s_mag[kMaxSymbols];      // sqrtf(re^2 + im^2) of the PLL output (:205, :231)
@@ -183,6 +225,7 @@ __global__ __launch_bounds__(64) void demod_par_kernel(const BurstWork *__restri
     const BurstWork w = work[b];
     if (w.drop_reason != 0) {
         if (lane == 0) o.ok = 0;
+        if (hp_packed) demod_export(work + b, lane, 0, 0, 0, 0, 0.0f, 0.0f, s_sym, hp_packed, hp_work, b);
         return;
     }
     const int n = o.n_symbols;
@@ -293,6 +336,10 @@ __global__ __launch_bounds__(64) void demod_par_kernel(const BurstWork *__restri
         o.level = s_resf[0];
         o.total_phase = s_resf[1];
     }
+    if (hp_packed) {
+        demod_export(work + b, lane, ok, s_res[1], s_res[3], ns, s_resf[0], s_resf[1], s_sym, hp_packed, hp_work, b);
+        return;
+    }
     if (!ok) return;
     // steps 5-7: decode_dqpsk (:264-273), bits MSB first (:329-335), LLR (:498-503): per-symbol independent
     const float scale = s_resf[2];
@@ -342,12 +389,12 @@ int launch_demod_pack(const DemodOut *in, int n_bursts, DemodPacked *out, hipStr
 }
 
 int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,
-                 float sps, float2 *ws, DemodOut *out, hipStream_t stream)
+                 float sps, float2 *ws, DemodOut *out, hipStream_t stream, DemodPacked *hp_packed, BurstWork *hp_work)
 {
     if (n_bursts <= 0) return 0;
     hipLaunchKernelGGL(demod_seq_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts,
                        frames, use_gardner, sps, ws, out);
-    hipLaunchKernelGGL(demod_par_kernel, dim3(n_bursts), dim3(64), 0, stream, work, n_bursts, ws, out);
+    hipLaunchKernelGGL(demod_par_kernel, dim3(n_bursts), dim3(64), 0, stream, work, n_bursts, ws, out, hp_packed, hp_work);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -1006,9 +1006,8 @@ int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stre
 
 // kernel clock (common.hpp): fold the per-slot entry / exit stamps of the launch that has just ended into the record's
 // sums and re-arm the slots
-__global__ __launch_bounds__(64) void kclk_fold_kernel(unsigned long long *__restrict__ k)
+__device__ __forceinline__ void kclk_fold_wave(unsigned long long *__restrict__ k, int l)
 {
-    const int l = threadIdx.x;
     unsigned long long lo = k[l], hi = k[64 + l];
     k[l] = ~0ull;
     k[64 + l] = 0ull;
@@ -1025,6 +1024,8 @@ __global__ __launch_bounds__(64) void kclk_fold_kernel(unsigned long long *__res
         k[130] = hi - lo;
     }
 }
+
+__global__ __launch_bounds__(64) void kclk_fold_kernel(unsigned long long *__restrict__ k) { kclk_fold_wave(k, (int)threadIdx.x); }
 
 int launch_kclk_fold(unsigned long long *kclk, hipStream_t stream)
 {
@@ -1426,6 +1427,229 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// post1 as TWO launches (round 6).  The one-workgroup-per-burst kernel above walks a burst tile by tile -- seven rounds of
+// load - barrier - filter - barrier - box filter - barrier for a 6700-sample burst, each round mostly the latency of its
+// loads -- and then runs a 12-stage radix-2 transform with a barrier per stage: 87 us alone for 36 MB of data, every
+// workgroup's latency end to end, and it holds the chip that long.
+//   post_tiles_kernel  grid (tiles of the longest burst, bursts): ONE tile of kPostTile outputs per workgroup -- steps 2b
+//                      and 3's box filter for all tiles of all bursts at once (the same loops on the same operands as
+//                      above); the start filter's outputs go to a row of floats of their own (`box`: the tiles of a burst
+//                      run side by side, the alias into `dec` would be read while it is written), the burst's maximum is
+//                      an atomic max over its tiles (the outputs are sums of products of non-negative numbers: their
+//                      bits order like unsigned integers).
+//   post_cfo_kernel    one workgroup per burst: threshold search, burst start, drop rule, fine CFO.  The 4096-point
+//                      transform of 256 samples: the first four stages of the pinned radix-2 transform combine x[i] with
+//                      x[i + 2048 .. 256] = 0 -- a + W * 0 = a, a - W * 0 = a, exactly -- so they are a copy: position
+//                      16 q + r holds x[bitrev8(q)] after them; stages 5..12 run two per barrier (fft_lds_radix2x2).
+// ---------------------------------------------------------------------------
+template <int NT, int SN>
+__global__ __launch_bounds__(kPostThreads) void post_tiles_kernel(
+    BurstWork *__restrict__ work, const float2 *__restrict__ dec, float2 *__restrict__ lpf, float *__restrict__ box,
+    const float *__restrict__ noise_taps, int noise_ntaps_rt, const float *__restrict__ start_taps, int start_ntaps_rt,
+    int search_depth, int order, unsigned long long *__restrict__ kclk)
+{
+    __shared__ __attribute__((aligned(16))) float2 xs[kPostTile + 2 * kPostMaxTaps];
+    __shared__ float m2[kPostTile + kPostMaxTaps];
+    __shared__ float redf[4];
+    __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x;
+    // (kernel clock: the decimator in front of this launch has ended -- its stamps are folded here instead of by a launch
+    // of their own at the chain's end)
+    if (kclk && blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) kclk_fold_wave(kclk, tid);
+    BurstWork &w = work[blockIdx.y];
+    if (w.drop_reason != 0) return;
+    const int dec_len = w.dec_len;
+    const int B = (int)blockIdx.x * kPostTile;
+    if (B >= dec_len) return;
+    const int noise_ntaps = NT ? NT : noise_ntaps_rt;
+    const int start_ntaps = SN ? SN : start_ntaps_rt;
+    const float2 *x = dec + (size_t)w.dec_off;
+    float2 *y = lpf + (size_t)w.dec_off;
+    float *fscr = box + (size_t)w.dec_off;
+
+    // step 3 geometry (burst_downmix.c:441-478)
+    int search = search_depth < dec_len ? search_depth : dec_len;
+    int mag_len = search + start_ntaps - 1;
+    if (mag_len > dec_len) mag_len = dec_len;
+    int flen = mag_len - start_ntaps + 1;
+    if (flen > search) flen = search;
+
+    const bool do_lpf = dec_len - noise_ntaps + 1 > 0;       // burst_downmix.c:683-698
+    const int half = (noise_ntaps - 1) / 2;
+    const int span_y = kPostTile + start_ntaps - 1;          // LPF outputs a tile's start filter needs
+    const int span_x = span_y + noise_ntaps - 1;
+    const int lpf_vec = order ? (dec_len & ~3) : 0;          // avx2_fir_ccf over dec_len outputs (burst_downmix.c:693)
+    const int mag_vec = order ? (mag_len & ~3) : 0;          // avx2_mag_squared over mag_len (burst_downmix.c:450)
+    const int box_vec = order ? (flen > 0 ? (flen & ~7) : 0) : 0;   // avx2_fir_fff over flen outputs (burst_downmix.c:458)
+    for (int q = tid; q < span_x; q += kPostThreads) {
+        const int j = B - half + q;
+        xs[q] = (j >= 0 && j < dec_len) ? x[j] : make_float2(0.0f, 0.0f);
+    }
+    __syncthreads();
+    // step 2b: centred LPF over the zero-padded burst, outputs B .. B + span_y
+    for (int p = tid; p < span_y; p += kPostThreads) {
+        if (B + p >= dec_len) break;
+        float2 v;
+        if (do_lpf) {
+            float ar = 0.0f, ai = 0.0f;
+            if (B + p < lpf_vec) {
+#pragma unroll
+                for (int k = 0; k < (NT ? NT : 1); k++) {
+                    if (NT) {
+                        const float2 u = xs[p + k];
+                        const float t = noise_taps[k];
+                        ar = __builtin_fmaf(t, u.x, ar);
+                        ai = __builtin_fmaf(t, u.y, ai);
+                    }
+                }
+                if (!NT) {
+                    for (int k = 0; k < noise_ntaps; k++) {
+                        const float2 u = xs[p + k];
+                        const float t = noise_taps[k];
+                        ar = __builtin_fmaf(t, u.x, ar);
+                        ai = __builtin_fmaf(t, u.y, ai);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < (NT ? NT : 1); k++) {
+                    if (NT) {
+                        const float2 u = xs[p + k];
+                        const float t = noise_taps[k];
+                        ar += t * u.x;
+                        ai += t * u.y;
+                    }
+                }
+                if (!NT) {
+                    for (int k = 0; k < noise_ntaps; k++) {
+                        const float2 u = xs[p + k];
+                        const float t = noise_taps[k];
+                        ar += t * u.x;
+                        ai += t * u.y;
+                    }
+                }
+            }
+            v = make_float2(ar, ai);
+        } else {
+            v = xs[p + half];
+        }
+        if (p < kPostTile) y[B + p] = v;
+        m2[p] = B + p < mag_vec ? mag2_fma(v) : mag2(v);
+    }
+    __syncthreads();
+    // step 3, first half: the box filter over |y|^2
+    float mx = -1.0f;                                        // (no output of this thread yet; the outputs are >= 0)
+    for (int o = tid; o < kPostTile && B + o < flen; o += kPostThreads) {
+        float acc = 0.0f;
+        if (B + o < box_vec) {
+#pragma unroll
+            for (int k = 0; k < (SN ? SN : 1); k++)
+                if (SN) acc = __builtin_fmaf(start_taps[k], m2[o + k], acc);
+            if (!SN)
+                for (int k = 0; k < start_ntaps; k++) acc = __builtin_fmaf(start_taps[k], m2[o + k], acc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < (SN ? SN : 1); k++)
+                if (SN) acc += start_taps[k] * m2[o + k];
+            if (!SN)
+                for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[o + k];
+        }
+        fscr[B + o] = acc;
+        mx = acc > mx ? acc : mx;
+    }
+    mx = block_max(mx, redf);
+    // (`if (v > max) max = v` from -1e30 over outputs that are never negative: the largest output, +0 at least)
+    if (tid == 0 && mx >= 0.0f) atomicMax(&w.box_max, __float_as_uint(mx));
+}
+
+template <int SN>
+__global__ __launch_bounds__(kPostThreads) void post_cfo_kernel(
+    BurstWork *__restrict__ work, const float2 *__restrict__ lpf, const float *__restrict__ box, int start_ntaps_rt,
+    int search_depth, int pre_start, const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096,
+    BurstWork *__restrict__ hp_work)
+{
+    __shared__ __attribute__((aligned(16))) float2 s[kCfoTotal];
+    __shared__ float redf[4];
+    __shared__ int redi[4];
+    __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x;
+    BurstWork &w = work[blockIdx.x];
+    if (w.drop_reason != 0) return;
+    const int start_ntaps = SN ? SN : start_ntaps_rt;
+    const int dec_len = w.dec_len;
+    const float2 *y = lpf + (size_t)w.dec_off;
+    const float *fscr = box + (size_t)w.dec_off;
+    int search = search_depth < dec_len ? search_depth : dec_len;
+    int mag_len = search + start_ntaps - 1;
+    if (mag_len > dec_len) mag_len = dec_len;
+    int flen = mag_len - start_ntaps + 1;
+    if (flen > search) flen = search;
+
+    int start = 0;
+    if (flen > 0) {
+        const float thr = 0.45f * __uint_as_float(w.box_max);          // START_THRESHOLD
+        int first = flen;
+        for (int i = tid; i < flen; i += kPostThreads) {
+            if (fscr[i] >= thr) { first = i; break; }
+        }
+        start = block_min_int(first, redi);
+        if (start > 0) {
+            start = start + (start_ntaps - 1) / 2 - pre_start;
+            if (start < 0) start = 0;
+        }
+    }
+    if (start >= dec_len - 100) {                           // burst_downmix.c:702-705
+        if (tid == 0) {
+            w.start_idx = start;
+            w.drop_reason = 3;
+            if (hp_work) post1_publish(hp_work[blockIdx.x], w);
+        }
+        return;
+    }
+    const int frame_len = dec_len - start;
+
+    // step 4 (burst_downmix.c:482-535): x^2 * blackman(256), zero-padded 4096-pt FFT -- entered behind its first four
+    // stages: sixteen copies of x[bitrev8(q)] at positions 16 q .. 16 q + 15
+    static_assert(kCfoTotal == 4096 && kCfoN == 256 && kPostThreads == 256, "the pruned transform's geometry");
+    const int n = kCfoN < frame_len ? kCfoN : frame_len;
+    {
+        const int i = (int)bitrev((unsigned)tid, 8);
+        float2 v = make_float2(0.0f, 0.0f);
+        if (i < n) {
+            const float2 sv = y[start + i];
+            const float2 sq = cmul(sv, sv);                 // simd_csquare_window: (s*s)*w
+            const float wv = cfo_window[i];
+            v = make_float2(sq.x * wv, sq.y * wv);
+        }
+        float4 *d4 = reinterpret_cast<float4 *>(s + 16 * tid);
+        const float4 vv = make_float4(v.x, v.y, v.x, v.y);
+#pragma unroll
+        for (int r = 0; r < 8; r++) d4[r] = vv;
+    }
+    __syncthreads();
+    fft_lds_radix2x2<12, kPostThreads, -1, 5>(s, tw4096);
+    float bm = 0.0f;
+    int bi = 0;
+    for (int i = tid; i < kCfoTotal; i += kPostThreads) {
+        const float m = mag2(s[i]);
+        if (m > bm) { bm = m; bi = i; }
+    }
+    block_argmax(bm, bi, redf, redi);
+    if (tid == 0) {
+        const int idx = bi >= kCfoTotal / 2 ? bi - kCfoTotal : bi;
+        float corr = 0.0f;
+        if (bi > 0 && bi < kCfoTotal - 1) {
+            const int im1 = idx - 1 < 0 ? idx - 1 + kCfoTotal : idx - 1;
+            const int ip1 = idx + 1 < 0 ? idx + 1 + kCfoTotal : idx + 1;
+            corr = parabolic(mag2(s[im1]), bm, mag2(s[ip1]));
+        }
+        w.start_idx = start;
+        w.center_offset = ((float)idx + corr) / (float)kCfoTotal / 2.0f;
+        if (hp_work) post1_publish(hp_work[blockIdx.x], w);
+    }
+}
+
 int g_small_wg = 256;       // threads per workgroup of the chain's little copy / threshold kernels.  Option small_wg 64: a single
                             // wavefront finds a slot beside the decimator's resident grid where a 256-thread workgroup needs one
                             // on all four SIMDs of a CU -- measured: nothing in run (71.1 / 71.9 against 72.5 / 71.1 Gsamples/s,
@@ -1433,14 +1657,40 @@ int g_small_wg = 256;       // threads per workgroup of the chain's little copy 
 int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
 int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
 
-int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
-                         float2 *lpf, const float *noise_taps, int noise_ntaps,
+int g_post_split = 1;       // post1: 1 = post_tiles_kernel + post_cfo_kernel (a tile per workgroup, the pruned transform), 0 = one
+                            // workgroup per burst (downmix_post1_kernel)
+
+int launch_downmix_post1(BurstWork *work, int n_bursts, int max_dec_len, float2 *dec,
+                         float2 *lpf, float *box, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
-                         const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream)
+                         const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream,
+                         unsigned long long *kclk)
 {
     if (n_bursts <= 0) return 0;
     if (noise_ntaps > kPostMaxTaps || start_ntaps > kPostMaxTaps) return -1;
-    if (noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic)
+    const bool fixed = noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic;
+    if (g_post_split) {
+        const dim3 grid((unsigned)((max_dec_len + kPostTile - 1) / kPostTile), (unsigned)n_bursts);
+        if (grid.x > 0) {
+            if (fixed)
+                hipLaunchKernelGGL((post_tiles_kernel<25, 20>), grid, dim3(kPostThreads), 0, stream, work, dec, lpf, box, noise_taps,
+                                   noise_ntaps, start_taps, start_ntaps, search_depth, g_fir_order, kclk);
+            else
+                hipLaunchKernelGGL((post_tiles_kernel<0, 0>), grid, dim3(kPostThreads), 0, stream, work, dec, lpf, box, noise_taps,
+                                   noise_ntaps, start_taps, start_ntaps, search_depth, g_fir_order, kclk);
+        } else if (launch_kclk_fold(kclk, stream) != 0) {
+            return -1;
+        }
+        if (fixed)
+            hipLaunchKernelGGL((post_cfo_kernel<20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, lpf, box, start_ntaps,
+                               search_depth, pre_start, cfo_window, tw4096, hp_work);
+        else
+            hipLaunchKernelGGL((post_cfo_kernel<0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, lpf, box, start_ntaps,
+                               search_depth, pre_start, cfo_window, tw4096, hp_work);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (launch_kclk_fold(kclk, stream) != 0) return -1;
+    if (fixed)
         hipLaunchKernelGGL((downmix_post1_kernel<25, 20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
                            lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
                            pre_start, cfo_window, tw4096, hp_work, g_fir_order);
@@ -1468,16 +1718,23 @@ typedef unsigned rot_u32x4 __attribute__((vector_size(16)));
 // what the chain of a burst starts from: the libm step (or the host's results), then the burst's record fields
 struct RotStart {
     bool live;
-    int drop, dec_len, start;
+    int drop, dec_len, start, simplex;
     float inc_re, inc_im;
 };
+// Decimated samples behind `start` that can reach the output frame of a burst: the unique word starts at most 889 samples in
+// (the correlation peak lies in the first 840 samples, burst_downmix.c:565-586, :633-636: 839 - 271 + 1 + 320), the frame
+// is at most 1910 / 4440 samples long (normal / simplex, iridium.h:23-27), and the 51-tap RRC filter reads 25 samples past
+// its output: 2824 / 5354, rounded up.  The class is known behind the fine CFO (BurstWork::simplex).
+constexpr int kFrameNeedNormal = 2832;
+static_assert(kFrameNeed >= 889 + kMaxFrameSamples + 25 && kFrameNeedNormal >= 889 + 1910 + 25, "frame need");
+__device__ __forceinline__ int frame_need(int simplex) { return simplex ? kFrameNeed : kFrameNeedNormal; }
 __device__ __forceinline__ RotStart rot_phase_start(BurstWork *__restrict__ work, int n_bursts, const BurstWork *__restrict__ hp_work,
                                                     const CfoStep &cfo)
 {
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x * 64 + threadIdx.x;
     const bool live = b < n_bursts;
-    int w_drop = 1, w_dec_len = 0, w_start = 0;
+    int w_drop = 1, w_dec_len = 0, w_start = 0, w_simplex = 0;
     float inc_re = 1.0f, inc_im = 0.0f;
     if (live) {
         BurstWork &w = work[b];
@@ -1511,10 +1768,11 @@ __device__ __forceinline__ RotStart rot_phase_start(BurstWork *__restrict__ work
         w_drop = w.drop_reason;
         w_dec_len = w.dec_len;
         w_start = w.start_idx;
+        w_simplex = w.simplex;
         inc_re = w.incr_re;
         inc_im = w.incr_im;
     }
-    return RotStart{ live, w_drop, w_dec_len, w_start, inc_re, inc_im };
+    return RotStart{ live, w_drop, w_dec_len, w_start, w_simplex, inc_re, inc_im };
 }
 
 // rot_store 0: every lane stores into its own row, two phases per 16-byte store (one phase per store: the number of cache
@@ -1527,7 +1785,7 @@ __global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ w
     if (!s0.live || s0.drop != 0) return;
     const int b = blockIdx.x * 64 + threadIdx.x;
     const int frame_len = s0.dec_len - s0.start;
-    const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+    const int L = frame_len < frame_need(s0.simplex) ? frame_len : frame_need(s0.simplex);
     const float2 inc = make_float2(s0.inc_re, s0.inc_im);
     float2 ph = make_float2(1.0f, 0.0f);
     float2 *r = rrc_ws + (size_t)b * kFrameNeed;
@@ -1575,7 +1833,8 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
     int L = 0;
     if (live && w_drop == 0) {
         const int frame_len = w_dec_len - w_start;
-        L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+        const int need = frame_need(s0.simplex);
+        L = frame_len < need ? frame_len : need;
         if (L < 0) L = 0;
     }
     s_len[lane] = L;
@@ -1704,7 +1963,7 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
     if (w.drop_reason != 0) return;
     const int start = w.start_idx;
     const int frame_len = w.dec_len - start;
-    const int L = frame_len < kFrameNeed ? frame_len : kFrameNeed;
+    const int L = frame_len < frame_need(w.simplex) ? frame_len : frame_need(w.simplex);
     const float2 *x = lpf + (size_t)w.dec_off + start;
     float2 *r = rrc_ws + (size_t)blockIdx.x * kFrameNeed;
 
@@ -1763,10 +2022,16 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
 
     // step 7 (burst_downmix.c:539-639)
     const int sl = kSyncSearch < frame_len ? kSyncSearch : frame_len;
-    for (int i = tid; i < kCorrN; i += kPostThreads)
-        fa[bitrev((unsigned)i, 11)] = i < sl ? r[i] : make_float2(0.0f, 0.0f);
+    // (the forward transform behind its first stage: the inputs 1024 .. 2047 are zero, so the stage's butterflies a + 0,
+    // a - 0 are copies -- positions 2 m and 2 m + 1 hold x[bitrev10(m)]; stages 2..11 two per barrier)
+    static_assert(kSyncSearch <= kCorrN / 2 && kCorrN == 2048, "the pruned forward transform");
+    for (int m = tid; m < kCorrN / 2; m += kPostThreads) {
+        const int i = (int)bitrev((unsigned)m, 10);
+        const float2 v = i < sl ? r[i] : make_float2(0.0f, 0.0f);
+        *reinterpret_cast<float4 *>(fa + 2 * m) = make_float4(v.x, v.y, v.x, v.y);
+    }
     __syncthreads();
-    fft_lds_radix2<11, kPostThreads, -1>(fa, tw2048);
+    fft_lds_radix2x2<11, kPostThreads, -1, 2>(fa, tw2048);
     for (int i = tid; i < kCorrN; i += kPostThreads) {
         const float2 v = fa[i];
         const unsigned br = bitrev((unsigned)i, 11);
@@ -1774,8 +2039,8 @@ __global__ __launch_bounds__(kPostThreads) void downmix_post2_kernel(
         fu[br] = cmul(v, ul_fft[i]);
     }
     __syncthreads();
-    fft_lds_radix2<11, kPostThreads, +1>(fd, tw2048);
-    fft_lds_radix2<11, kPostThreads, +1>(fu, tw2048);
+    // (both backward transforms side by side: they share their barriers)
+    fft_lds_radix2x2<11, kPostThreads, +1, 1, 2>(fd, tw2048, kCorrN);
     float mdl = 0.0f, mul = 0.0f;
     int odl = 0, oul = 0;
     for (int i = tid; i < sl; i += kPostThreads) {

@@ -197,10 +197,12 @@ int launch_gather_burst(const SampleSource &src, uint64_t start, uint64_t avail_
 extern int g_small_wg;            // threads per workgroup of the little copy / threshold kernels (256; option small_wg 64)
 extern int g_post_generic;        // 1: runtime-tap-count instances of post1 / post2 (test hook)
 extern int g_rot_store;           // rot_phase: 1 (default) rows through LDS, 0 a row per lane
-int launch_downmix_post1(BurstWork *work, int n_bursts, float2 *dec,
-                         float2 *lpf, const float *noise_taps, int noise_ntaps,
+extern int g_post_split;          // post1 as post_tiles_kernel + post_cfo_kernel (1, default) or one workgroup per burst (0)
+int launch_downmix_post1(BurstWork *work, int n_bursts, int max_dec_len, float2 *dec,
+                         float2 *lpf, float *box, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
-                         const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream);
+                         const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream,
+                         unsigned long long *kclk);      // kclk: the decimator's kernel-clock record, folded here (nullptr: none)
 // the fine-CFO libm step of the per-burst chain (rot_phase_kernel): on the device, or taken from the host's records
 struct CfoStep {
     int on_device;
@@ -221,7 +223,10 @@ int launch_ida_decode(const DemodOut *frames, int n_frames, const int2 *syn_da, 
 int launch_frame_decode(const DemodOut *frames, int n_frames, const int2 *syn_ra, const int2 *syn_hdr, int use_llr,
                         const int *n_bits, DecodedOut *out, hipStream_t stream);
 int launch_demod_pack(const DemodOut *in, int n_bursts, DemodPacked *out, hipStream_t stream);
+// hp_packed / hp_work != nullptr (packed_records): demod_par_kernel writes the DemodPacked and work records straight into
+// pinned host memory -- the chain's last launch
 int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,
-                 float sps, float2 *ws, DemodOut *out, hipStream_t stream);
+                 float sps, float2 *ws, DemodOut *out, hipStream_t stream, DemodPacked *hp_packed = nullptr,
+                 BurstWork *hp_work = nullptr);
 
 }  // namespace irdm

@@ -184,6 +184,10 @@ struct irdm_pipeline;
 // latency divided by three -- the feeding thread spent 0.6 ms of every 1.05 ms step waiting for the oldest chain
 // (profiles/r5_spec_ab.json, host_us "wait_older_chain") -- and nothing done to the scan or the decimator moved it.
 constexpr int kMaxBc = 6;
+// the low-passed scratch of a batch context holds `cap` float2 outputs and, behind them, `cap` floats: the start filter's
+// outputs (post_tiles_kernel -> post_cfo_kernel)
+static inline size_t lpf_alloc(size_t cap) { return cap + cap / 2 + 8; }
+static inline float *box_of(float2 *lpf, size_t cap) { return reinterpret_cast<float *>(lpf + cap); }
 // Feed slots: chunks that may be between irdm_feed_begin and the settling of their scan -- the one being scanned, the one
 // whose scan is chained behind it, and TWO begun ahead (round 5: one more than before, so that K1 of chunk k + 2 is on the GPU
 // a period early and runs in the stretches where the chains in flight are in their lane-per-burst kernels instead of in
@@ -819,7 +823,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     // grown by doubling when a batch needs more (bursts_enqueue)
     p->scratch_init = std::max<size_t>((size_t)p->burst_cap * p->dec_stride / 16, (size_t)4 * p->dec_stride);
     AL(p->d_dec, float2, p->scratch_init);
-    AL(p->d_lpf, float2, p->scratch_init);
+    AL(p->d_lpf, float2, lpf_alloc(p->scratch_init));
     AL(p->d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
     AL(p->d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
     AL(p->d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
@@ -953,7 +957,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
             AL(b.d_work, BurstWork, (size_t)p->burst_cap);
             AL(b.d_tiles, FirTile, (b.tiles_cap + 1) * kFirTileUnits);
             AL(b.d_dec, float2, p->scratch_init);
-            AL(b.d_lpf, float2, p->scratch_init);
+            AL(b.d_lpf, float2, lpf_alloc(p->scratch_init));
             AL(b.d_rrc_ws, float2, (size_t)p->burst_cap * kFrameNeed);
             AL(b.d_frames, float2, (size_t)p->burst_cap * kMaxFrameSamples);
             AL(b.d_demod_ws, float2, (size_t)p->burst_cap * 2 * kMaxSymbols);
@@ -1465,6 +1469,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     b.n = nb;
     b.recs.assign(nb, irdm_burst_t());
     size_t n_tiles = 0, dec_need = 0;
+    int max_dec_len = 0;         // the longest decimated burst of the batch: the tile grid of post_tiles_kernel
     // (the register-resident decimator also needs the chunk to start at a multiple of 8 samples: a caller's burst window
     // presented as a chunk -- irdm_downmix_burst -- may not; such sources take the LDS kernel)
     const int fir_aligned = p->ring_len % 8 == 0 && p->ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
@@ -1509,6 +1514,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         w.tile_base = (int32_t)n_tiles;
         w.dec_off = (int32_t)dec_need;
         if (!w.drop_reason) {
+            max_dec_len = std::max(max_dec_len, w.dec_len);
             n_tiles += (size_t)(w.dec_len + tile_out - 1) / tile_out;
             dec_need += ((size_t)w.dec_len + 15) & ~(size_t)15;           // rows start on 128-byte lines
         }
@@ -1537,7 +1543,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
             fprintf(stderr, "irdm_hip: %zu decimated samples in a batch of %d bursts\n", dec_need, nb);
             return -1;
         }
-        float2 *d2 = dev_alloc<float2>(cap2), *l2 = dev_alloc<float2>(cap2);
+        float2 *d2 = dev_alloc<float2>(cap2), *l2 = dev_alloc<float2>(lpf_alloc(cap2));
         if (!d2 || !l2) {
             if (d2) (void)hipFree(d2);
             if (l2) (void)hipFree(l2);
@@ -1589,9 +1595,10 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
                             p->kclk_fir((int)(&b - p->bc)), p->d_rot_slot) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
-    if (launch_downmix_post1(b.d_work, nb, b.d_dec, b.d_lpf, p->d_noise_taps,
+    if (launch_downmix_post1(b.d_work, nb, max_dec_len, b.d_dec, b.d_lpf, box_of(b.d_lpf, b.dec_cap), p->d_noise_taps,
                              p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
-                             p->pre_start, p->d_cfo_window, p->d_tw4096, p->dev_cfo ? nullptr : b.hp_work_dev, st) != 0)
+                             p->pre_start, p->d_cfo_window, p->d_tw4096, p->dev_cfo ? nullptr : b.hp_work_dev, st,
+                             p->kclk_fir((int)(&b - p->bc))) != 0)
         return -1;
     // host libm step, ordered on the stream: post1 has stored what the step reads into the burst's record in the mapped
     // pinned buffer (system scope), the helper thread runs behind this event and publishes a sequence number, a one-lane
@@ -1620,9 +1627,14 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
                              b.d_rrc_ws, b.d_frames, p->dev_cfo ? nullptr : b.hp_work_dev, cfo, st) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[2], st));
-    if (launch_demod(b.d_work, nb, b.d_frames, p->cfg.use_gardner, p->sps, b.d_demod_ws, b.d_demod, st) != 0)
+    // the chain's results: work records and demodulator output.  packed_records (136 bytes per burst instead of 4.5 KB: hard
+    // bits 8 per byte, no LLRs): written into pinned host memory by the demodulator's last kernel itself
+    b.packed = p->packed_records && !p->decode_frames && !p->decode_ida && !p->keep_frame_samples;
+    if (launch_demod(b.d_work, nb, b.d_frames, p->cfg.use_gardner, p->sps, b.d_demod_ws, b.d_demod, st,
+                     b.packed ? b.hp_packed : nullptr, b.packed ? b.hp_work_dev : nullptr) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[3], st));
+    if (b.packed) return 0;
     if (p->decode_frames) {
         // post-demod bit layer on the demodulator's device-resident output (frames that failed the unique word
         // have ok = 0 and decode to FRAME_UNKNOWN)
@@ -1634,20 +1646,8 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
                               b.d_ida, st) != 0)
             return -1;
     }
-    // the chain's results: work records and demodulator output, one launch
-    b.packed = p->packed_records && !p->decode_frames && !p->decode_ida && !p->keep_frame_samples;
-    if (b.packed) {
-        // (136 bytes per burst instead of 4.5 KB: hard bits 8 per byte, no LLRs)
-        if (launch_demod_pack(b.d_demod, nb, b.d_packed, st) != 0) return -1;
-        if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_packed, b.d_packed,
-                                 sizeof(DemodPacked) * nb, st) != 0)
-            return -1;
-        return launch_kclk_fold(p->kclk_fir((int)(&b - p->bc)), st);
-    }
-    if (launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_demod, b.d_demod, sizeof(DemodOut) * nb,
-                             st) != 0)
-        return -1;
-    return launch_kclk_fold(p->kclk_fir((int)(&b - p->bc)), st);
+    // full records: one copy launch for both
+    return launch_copy2_to_host(b.hp_work_dev, b.d_work, sizeof(BurstWork) * nb, b.hp_demod, b.d_demod, sizeof(DemodOut) * nb, st);
 }
 
 static int bursts_finish_records(irdm_pipeline *p, BatchCtx &b);
@@ -3289,6 +3289,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
     if (!strcmp(key, "k1_lists")) { p->k1_lists = value; return 0; }
     if (!strcmp(key, "band_first")) { p->band_first = value < 0 ? 0 : value > kBandRounds ? kBandRounds : value; return 0; }
     if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
+    if (!strcmp(key, "post_split")) { irdm::g_post_split = value ? 1 : 0; return 0; }
     if (!strcmp(key, "rot_store")) { irdm::g_rot_store = value; return 0; }
     if (!strcmp(key, "copy_wide")) { irdm::g_copy_wide = value ? 1 : 0; return 0; }
     if (!strcmp(key, "small_wg")) { if (value != 64 && value != 128 && value != 256) return -1; irdm::g_small_wg = value; return 0; }
@@ -3321,7 +3322,7 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
         IRDM_HIP_CHECK(hipDeviceSynchronize());
         for (int i = 0; i < p->n_bc; i++) {
             BatchCtx &b = p->bc[i];
-            float2 *d2 = dev_alloc<float2>((size_t)value), *l2 = dev_alloc<float2>((size_t)value);
+            float2 *d2 = dev_alloc<float2>((size_t)value), *l2 = dev_alloc<float2>(lpf_alloc((size_t)value));
             if (!d2 || !l2) return -1;
             (void)hipFree(b.d_dec);
             (void)hipFree(b.d_lpf);

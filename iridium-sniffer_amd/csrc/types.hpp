@@ -139,7 +139,7 @@ struct BurstWork {
     float uw_corr, corr_re, corr_im;
     int32_t tile_base;       // index of the burst's first decimator tile (host; the persistent decimator's geometry pass)
     int32_t dec_off;         // the burst's row in the decimated / low-passed scratch (float2 units; host: rows by actual length)
-    int32_t pad_;
+    uint32_t box_max;        // bits of the start filter's largest output (post_tiles_kernel: atomic max over the burst's tiles; >= 0)
 };
 static_assert(sizeof(BurstWork) == 88, "BurstWork is mirrored word by word between device and pinned host memory");
 

@@ -257,10 +257,11 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, A... ar
             lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
             std::swap(seq[i - 1], seq[(unsigned)((lcg >> 33) % i)]);
         }
-    for (unsigned k = 0; k < grid.x; k++) {
-        m.block = Idx3{ seq[k], 0, 0 };
-        run_workgroup((int)block.x, [&]() { kernel(args...); });
-    }
+    for (unsigned ky = 0; ky < grid.y; ky++)
+        for (unsigned k = 0; k < grid.x; k++) {
+            m.block = Idx3{ seq[k], (order && order[0] == 'r') ? grid.y - 1 - ky : ky, 0 };
+            run_workgroup((int)block.x, [&]() { kernel(args...); });
+        }
 }
 
 // ---- wavefront-level exchanges (lanes of the calling thread's wavefront) ----
