@@ -660,12 +660,20 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    K = max(args.steps, 1)
+    # what a SCALE record can be checked with: the size of the group the collectives really ran over (RCCL when the backend
+    # is nccl) and every rank's own rate over its own clock (the job's rate divides by the slowest rank's time)
+    group_world = dist.get_world_size() if world > 1 else 1
+    rank_rates = [n * K / dt / 1e6]
     if world > 1:
+        mine = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_rates = [n * K / float(t.item()) / 1e6 for t in every]
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    K = max(args.steps, 1)
     ms = {k: v / K for k, v in stage.items()}
     value = world * n * K / dt / 1e6
 
@@ -981,6 +989,10 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # ranks the collectives ran over and the backend that carried them ("nccl" = RCCL); per-rank Msamples/s
+            "rccl_world": group_world if backend == "nccl" else 0, "collective_backend": backend if world > 1 else None,
+            "collective_world": group_world,
+            "rank_Msamples_per_s": {"min": round(min(rank_rates), 2), "max": round(max(rank_rates), 2)},
             "config": {"workload": "cfg3: %d MHz %s full pipeline (detect + downmix/FIR/CFO + Gardner DQPSK), "
                                    "%d-pt detect, %d samples/GPU/step resident in HBM, %.0f bursts/Msample"
                                    % (fs // 1_000_000, args.format, pipe.fft_size, n, args.density),

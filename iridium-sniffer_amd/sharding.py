@@ -68,6 +68,60 @@ def gather_records(dist, records, rec_size, cap, device=None):
     return res
 
 
+class RecordGather:
+    """The streams-mode record gather of bench.py (BASELINE config 5 / the headline metric at N > 1): every rank sends the
+    compact frame records of a step -- fixed-size messages of a count word + `cap` records of `rec_bytes` -- to rank 0 with an
+    asynchronous dist.gather, double-buffered so that the collective of step i runs beside the detector scan of step i + 1.
+    Nothing is ever dropped silently: more records than the message holds is an error, and rank 0 counts what arrived from
+    the messages' count words (`gathered`), which the caller compares with what the ranks produced and sent."""
+
+    def __init__(self, dist, torch, rank, world, cap, rec_bytes, device, pin=True):
+        self.dist, self.torch, self.rank, self.world, self.cap, self.rec = dist, torch, rank, world, cap, rec_bytes
+        self.msg = 8 + cap * rec_bytes
+        mk = lambda dev=None: torch.zeros((self.msg,), dtype=torch.uint8, device=dev)          # noqa: E731
+        self.host = [mk().pin_memory() if pin else mk() for _ in range(2)]
+        self.bufs = [mk(device) for _ in range(2)]
+        self.lists = [[mk(device) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+        self.work = [None, None]
+        self.gathered = torch.zeros((1,), dtype=torch.int64, device=device)      # rank 0: records received
+        self.step = 0
+        self.sent = 0
+
+    def wait(self, slot):
+        if self.work[slot] is None:
+            return
+        self.work[slot].wait()
+        self.work[slot] = None
+        if self.rank == 0:
+            self.gathered.add_(self.torch.stack([l[:8] for l in self.lists[slot]]).view(self.torch.int64).sum())
+
+    def send(self, records):
+        """records: uint8 [k, rec_bytes] (numpy).  Returns k."""
+        slot = self.step & 1
+        self.step += 1
+        self.wait(slot)
+        k = len(records)
+        if k > self.cap:
+            raise SystemExit("record gather: %d records in one step exceed the message (%d)" % (k, self.cap))
+        hb = self.host[slot].numpy()
+        hb[:8] = np.array([k], dtype=np.int64).view(np.uint8)
+        if k:
+            hb[8:8 + k * self.rec] = np.ascontiguousarray(records, np.uint8).reshape(-1)
+        self.bufs[slot].copy_(self.host[slot], non_blocking=True)
+        self.work[slot] = self.dist.gather(self.bufs[slot], self.lists[slot], dst=0, async_op=True)
+        self.sent += k
+        return k
+
+    def finish(self):
+        for slot in (0, 1):
+            self.wait(slot)
+
+    def reset_counts(self):
+        self.finish()
+        self.gathered.zero_()
+        self.sent = 0
+
+
 def max_over_ranks(dist, value, device=None):
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)

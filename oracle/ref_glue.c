@@ -32,6 +32,74 @@ int acars_enabled = 0;
 
 void ref_set_use_gardner(int v) { use_gardner = v; }
 
+/* --save-bursts (main.c sets the global from options.c): qpsk_demod then calls its static save_burst_iq (qpsk_demod.c:339-389,
+ * :441-444, :468-470) */
+void ref_set_save_bursts_dir(const char *dir)
+{
+    free(save_bursts_dir);
+    save_bursts_dir = dir ? strdup(dir) : NULL;
+}
+
+/* qpsk_demod with every downmix_frame_t field the .meta file prints (qpsk_demod.c:376-385); returns its return value and
+ * the direction it left in the input frame (what the file name and the "direction:" line carry) */
+int ref_qpsk_demod_save(const float *samples, int num_samples, float sample_rate, float samples_per_symbol, int direction,
+                        double center_frequency, uint64_t id, uint64_t timestamp, float magnitude, float noise, float uw_start,
+                        int *direction_left)
+{
+    downmix_frame_t in;
+    memset(&in, 0, sizeof(in));
+    in.id = id;
+    in.timestamp = timestamp;
+    in.center_frequency = center_frequency;
+    in.sample_rate = sample_rate;
+    in.samples_per_symbol = samples_per_symbol;
+    in.direction = (ir_direction_t)direction;
+    in.magnitude = magnitude;
+    in.noise = noise;
+    in.uw_start = uw_start;
+    in.num_samples = (size_t)num_samples;
+    in.samples = malloc(sizeof(float complex) * (size_t)num_samples);
+    memcpy(in.samples, samples, sizeof(float complex) * (size_t)num_samples);
+    demod_frame_t *out = NULL;
+    const int r = qpsk_demod(&in, &out);
+    *direction_left = (int)in.direction;
+    free(in.samples);
+    if (r) {
+        free(out->bits);
+        free(out->llr);
+        free(out);
+    }
+    return r;
+}
+
+/* sizeof / offsetof of the reference's stage-level structs as its own headers declare them (burst_downmix.h:31-53,
+ * qpsk_demod.h:24-38), for tests/test_ref_pins.py: name, value pairs */
+#include <stddef.h>
+#define REF_LAY(T, F) { #T "." #F, (long)offsetof(T, F) }
+#define REF_SZ(T) { "sizeof " #T, (long)sizeof(T) }
+static const struct { const char *name; long value; } ref_layout_tab[] = {
+    REF_SZ(downmix_frame_t), REF_LAY(downmix_frame_t, id), REF_LAY(downmix_frame_t, timestamp),
+    REF_LAY(downmix_frame_t, center_frequency), REF_LAY(downmix_frame_t, sample_rate),
+    REF_LAY(downmix_frame_t, samples_per_symbol), REF_LAY(downmix_frame_t, direction), REF_LAY(downmix_frame_t, magnitude),
+    REF_LAY(downmix_frame_t, noise), REF_LAY(downmix_frame_t, uw_start), REF_LAY(downmix_frame_t, num_samples),
+    REF_LAY(downmix_frame_t, samples),
+    REF_SZ(downmix_config_t), REF_LAY(downmix_config_t, output_sample_rate), REF_LAY(downmix_config_t, search_depth),
+    REF_LAY(downmix_config_t, handle_multiple_frames),
+    REF_SZ(demod_frame_t), REF_LAY(demod_frame_t, id), REF_LAY(demod_frame_t, timestamp),
+    REF_LAY(demod_frame_t, center_frequency), REF_LAY(demod_frame_t, direction), REF_LAY(demod_frame_t, magnitude),
+    REF_LAY(demod_frame_t, noise), REF_LAY(demod_frame_t, confidence), REF_LAY(demod_frame_t, level),
+    REF_LAY(demod_frame_t, n_symbols), REF_LAY(demod_frame_t, n_payload_symbols), REF_LAY(demod_frame_t, bits),
+    REF_LAY(demod_frame_t, llr), REF_LAY(demod_frame_t, n_bits),
+    REF_SZ(ir_direction_t), { "DIR_UNDEF", DIR_UNDEF }, { "DIR_DOWNLINK", DIR_DOWNLINK }, { "DIR_UPLINK", DIR_UPLINK },
+};
+int ref_layout(int i, const char **name, long *value)
+{
+    if (i < 0 || i >= (int)(sizeof(ref_layout_tab) / sizeof(ref_layout_tab[0]))) return 0;
+    *name = ref_layout_tab[i].name;
+    *value = ref_layout_tab[i].value;
+    return 1;
+}
+
 /* frame_output_print (frame_output.c:160-199) writes the RAW line to stdout; this shim hands it the fields through a
  * demod_frame_t and returns what it printed (fd 1 is pointed at a temporary file for the duration of the call).
  * frame_output.c keeps file_info and t0 in statics set by the FIRST frame of the process: call frame_output_init

@@ -50,6 +50,10 @@ def main():
         res["chunked_depth1"] = parity.compare(parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 4), depth=1), ref)
         res["chunked_depth2_in_place_lookahead"] = parity.compare(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead"), ref)
+        # the compact records the bench polls, written to pinned memory by the demodulator's last kernel itself (demod_export)
+        res["packed_depth3_in_place_lookahead"] = parity.compare_packed(
+            parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 7), depth=3, feed="ingest_lookahead", packed=True), ref)
+        res["packed_depth0"] = parity.compare_packed(parity.run_gpu(iq, fs, packed=True), ref)
         # five batch contexts (pipeline_depth 4): records five chunks late, same records, same order
         res["chunked_depth4_in_place_lookahead"] = parity.compare(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=4, feed="ingest_lookahead"), ref)

@@ -11,16 +11,20 @@ def bits_of(x):
     return np.float32(x).view(np.uint32)
 
 
-def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="host", options=None, **kw):
+def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="host", options=None, packed=False, **kw):
     """Feed `iq` through the HIP pipeline in the given chunk sizes (samples).
 
     feed: "host" irdm_feed_host per chunk; "ingest" every chunk written in place (irdm_ingest_ptr) and fed from there;
-    "lookahead" device buffers, irdm_feed_begin(k+1) before irdm_feed_end(k); "ingest_lookahead" both."""
+    "lookahead" device buffers, irdm_feed_begin(k+1) before irdm_feed_end(k); "ingest_lookahead" both.
+    packed: option packed_records -- the compact frame records only (gpu["packed"]; no frame samples, no LLRs)."""
     n = len(iq) if fmt == irdm.FMT_CF32 else len(iq) // 2
     max_chunk = max(chunks) if chunks else n
     p = irdm.Pipeline(fs, fmt=fmt, max_chunk_samples=max_chunk, max_bursts_per_chunk=1024,
                       pipeline_depth=depth, **kw)
-    p.set_option("keep_frame_samples", 1)
+    if packed:
+        p.set_option("packed_records", 1)
+    else:
+        p.set_option("keep_frame_samples", 1)
     p.set_option("scan_mode", scan_mode)
     for k, v in (options or {}).items():
         p.set_option(k, v)
@@ -75,7 +79,8 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
     bursts = p.poll_bursts()
     infos, samples = p.poll_frames()
     demods = p.poll_demods()
-    res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, tagged=p.tagged,
+    packed_recs = p.poll_demods_packed() if packed else []
+    res = dict(bursts=bursts, infos=infos, samples=samples, demods=demods, packed=packed_recs, tagged=p.tagged,
                n_samples=p.sample_count, timings=p.timings(),
                stats={k: p.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks",
                                              "band_rounds", "band_retries", "band_aborts", "band_last_flags", "k1_lists", "band_extra",
@@ -216,3 +221,33 @@ def compare_records(bursts, demods, ref):
         assert bits_of(g.magnitude) == bits_of(r.magnitude) and bits_of(g.noise) == bits_of(r.noise)
     assert max_soft <= SOFT_TOL
     return dict(bursts=len(bursts), demods=len(demods), max_soft=max_soft)
+
+
+def compare_packed(gpu, ref):
+    """A packed_records run (run_gpu(..., packed=True)) against the oracle: burst records as in compare(); the compact frame
+    records -- everything frame_output_print reads -- ids, timestamps, direction, symbol counts, hard bits (8 per byte, MSB
+    first, zero behind n_bits), confidence and the dB fields exact; level within SOFT_TOL, the refined frequency within
+    0.05 Hz."""
+    assert gpu["tagged"] == ref.n_tagged, (gpu["tagged"], ref.n_tagged)
+    assert len(gpu["bursts"]) == len(ref.bursts)
+    for g, r in zip(gpu["bursts"], ref.bursts):
+        for f in ("id", "start", "stop", "last_active", "center_bin", "num_samples", "avail_end"):
+            assert getattr(g, f) == getattr(r, f), (f, g.id, getattr(g, f), getattr(r, f))
+        for f in ("magnitude", "noise", "peak_rel", "base_sum"):
+            assert bits_of(getattr(g, f)) == bits_of(getattr(r, f)), (f, g.id)
+    assert gpu["demods"] == [] and len(gpu["infos"]) == 0                 # the packed mode queues nothing else
+    assert len(gpu["packed"]) == len(ref.demods), (len(gpu["packed"]), len(ref.demods))
+    max_soft = 0.0
+    for q, r in zip(gpu["packed"], ref.demods):
+        assert q.id == r.id and q.timestamp == r.timestamp, (q.id, r.id)
+        assert (q.direction, q.n_symbols, q.n_payload_symbols, q.n_bits, q.ok) == \
+               (r.direction, r.n_symbols, r.n_payload_symbols, r.n_bits, 1), q.id
+        allbits = np.unpackbits(np.frombuffer(bytes(q.bits), np.uint8))
+        assert bytes(allbits[:q.n_bits]) == bytes(r.bits[:r.n_bits]), q.id
+        assert not allbits[q.n_bits:].any(), q.id
+        assert q.confidence == r.confidence, (q.id, q.confidence, r.confidence)
+        assert abs(q.level - r.level) <= SOFT_TOL
+        max_soft = max(max_soft, abs(q.level - r.level))
+        assert abs(q.center_frequency - r.center_frequency) <= 0.05
+        assert bits_of(q.magnitude) == bits_of(r.magnitude) and bits_of(q.noise) == bits_of(r.noise)
+    return dict(bursts=len(ref.bursts), demods=len(ref.demods), max_soft=max_soft)

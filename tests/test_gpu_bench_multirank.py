@@ -43,6 +43,9 @@ def test_streams_mode_two_ranks_gathers_every_record():
     rec = out["config"]["records"]
     assert rec["produced"] == rec["sent"] == rec["gathered_on_rank0"] > 0, rec
     assert out["config"]["scan"]["scan_fallbacks"] == 0
+    # what a SCALE record is checked with: the group's real size, the backend that carried it (gloo here: rccl_world 0)
+    assert out["collective_world"] == 2 and out["collective_backend"] == "gloo" and out["rccl_world"] == 0
+    assert 0 < out["rank_Msamples_per_s"]["min"] <= out["rank_Msamples_per_s"]["max"]
 
 
 def test_time_shard_mode_two_ranks():

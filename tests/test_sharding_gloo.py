@@ -110,3 +110,57 @@ def test_chunk_plan_properties():
             assert b == c and a % 32768 == 0 and h <= a
         assert all((b - a) % 32768 == 0 for a, b, _ in plan[:-1])
     assert sharding.required_overlap(10_000_000, 8192) == 20_000_000 + 900_000 + 160_000 + 16384 + 16384
+
+
+def _gather8_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec, cap, steps = 176, 64, 7
+        g = sharding.RecordGather(dist, torch, rank, world, cap, rec, torch.device("cpu"), pin=False)
+        rng = np.random.default_rng(100 + rank)
+        produced = 0
+        for step in range(steps):
+            k = int(rng.integers(0, cap + 1)) if (step + rank) % 3 else 0       # some steps bring nothing
+            recs = np.full((k, rec), (rank * 16 + step) & 255, np.uint8)
+            produced += k
+            g.send(recs)
+        g.finish()
+        counts = torch.tensor([produced, g.sent], dtype=torch.int64)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        rates = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(rates, torch.tensor([1.0 + rank], dtype=torch.float64))
+        if rank == 0:
+            # the last two messages of every rank are still in the receive lists: their payload is what that rank sent
+            last = [bytes(t[8:8 + rec].numpy()) for t in g.lists[(steps - 1) & 1]]
+            q.put((int(counts[0]), int(counts[1]), int(g.gathered.item()), dist.get_world_size(), [float(r.item()) for r in rates], last))
+        try:
+            g.send(np.zeros((cap + 1, rec), np.uint8))
+            over = False
+        except SystemExit:
+            over = True
+        assert over                                       # never a silent truncation
+    finally:
+        dist.destroy_process_group()
+
+
+def test_streams_mode_gather_world_size_8():
+    """bench.py --gpus 8's record gather (sharding.RecordGather) with eight gloo ranks on the CPU: every record a rank produces
+    is sent and arrives on rank 0 (produced = sent = gathered), over seven double-buffered steps incl. empty ones."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_gather8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    produced, sent, gathered, gw, rates, last = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert produced == sent == gathered > 0 and gw == 8
+    assert rates == [1.0 + r for r in range(8)]
+    assert len(last) == 8
