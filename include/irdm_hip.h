@@ -419,6 +419,8 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  * One thread drives a group.  Feeding or polling a member directly (irdm_group_member) is not allowed; options, statistics
  * and kernel clocks of a member are. */
 typedef struct irdm_group irdm_group_t;
+int irdm_device_count(void);                           /* GPUs this process sees (0: none, or no HIP runtime) */
+/* EXPERIMENTAL for n_gpus > 1 (a warning says so once): run on emulated devices and as ranks sharing one GPU only */
 irdm_group_t *irdm_group_create(const irdm_config_t *cfg, int n_gpus, const int *devices);
 void irdm_group_destroy(irdm_group_t *g);
 int irdm_group_size(const irdm_group_t *g);

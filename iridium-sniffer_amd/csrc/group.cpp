@@ -166,6 +166,8 @@ struct irdm_group {
     size_t prev_len = 0;                 // length of the last staged chunk (where its tail is)
     std::deque<Staged> staged;           // at most two: the super-step being fed and the one behind it
     bool closed = false;
+    bool broken = false;                 // a transfer or a staging step failed midway: the counters of the chunks staged so far
+                                         // may be ahead of what was fed -- every later stage / feed / flush call fails cleanly
     int loopback = 0, keep_samples = 0;
     // merged output
     std::map<uint64_t, ChunkRecords> store;
@@ -197,14 +199,17 @@ int transfer(irdm_group *g, std::vector<ncclComm_t> &comms, int src, const void 
     }
     Rccl *r = rccl();
     GRP_NCCL(r->GroupStart());
-    GRP_HIP(hipSetDevice(g->m[src].dev));
-    ncclResult_t e1 = r->Send(from, bytes, ncclUint8, dst, comms[src], s_src);
-    GRP_HIP(hipSetDevice(g->m[dst].dev));
-    ncclResult_t e2 = r->Recv(to, bytes, ncclUint8, src, comms[dst], s_dst);
-    ncclResult_t e3 = r->GroupEnd();
-    if (e1 != ncclSuccess || e2 != ncclSuccess || e3 != ncclSuccess) {
+    // (whatever fails between GroupStart and GroupEnd, the group is closed again: an open one would swallow every later call)
+    ncclResult_t e1 = ncclSuccess, e2 = ncclSuccess;
+    const bool d1 = hipSetDevice(g->m[src].dev) == hipSuccess;
+    if (d1) e1 = r->Send(from, bytes, ncclUint8, dst, comms[src], s_src);
+    const bool d2 = d1 && hipSetDevice(g->m[dst].dev) == hipSuccess;
+    if (d2) e2 = r->Recv(to, bytes, ncclUint8, src, comms[dst], s_dst);
+    const ncclResult_t e3 = r->GroupEnd();
+    if (!d1 || !d2 || e1 != ncclSuccess || e2 != ncclSuccess || e3 != ncclSuccess) {
         fprintf(stderr, "irdm_hip group: ncclSend / ncclRecv %d -> %d failed: %s\n", src, dst,
-                r->GetErrorString(e1 != ncclSuccess ? e1 : e2 != ncclSuccess ? e2 : e3));
+                !d1 || !d2 ? "hipSetDevice" : r->GetErrorString(e1 != ncclSuccess ? e1 : e2 != ncclSuccess ? e2 : e3));
+        g->broken = true;
         return -1;
     }
     return 0;
@@ -303,7 +308,23 @@ int cut(const irdm_group *g, size_t n_samples, std::vector<size_t> &lens)
     return 0;
 }
 
+static int stage_chunks(irdm_group *g, const void *src, size_t n_samples, bool host);
+
+// (a staging step that fails after some of its chunks were counted leaves the per-member counters ahead of g->staged: the
+// group is latched broken instead of mis-numbering the chunks of the next feed)
 int stage(irdm_group *g, const void *src, size_t n_samples, bool host)
+{
+    if (g->broken) {
+        fprintf(stderr, "irdm_hip group: an earlier transfer failed; the group cannot go on\n");
+        return -1;
+    }
+    const uint64_t before = g->next_stage;
+    const int rc = stage_chunks(g, src, n_samples, host);
+    if (rc != 0 && g->next_stage != before) g->broken = true;
+    return rc;
+}
+
+static int stage_chunks(irdm_group *g, const void *src, size_t n_samples, bool host)
 {
     if (g->staged.size() >= 2) {
         fprintf(stderr, "irdm_hip group: two super-steps are already staged; feed one first\n");
@@ -464,7 +485,7 @@ int run_super_step(irdm_group *g)
 
 int feed(irdm_group *g, const void *src, size_t n_samples, bool host)
 {
-    if (!g || (!src && n_samples)) return -1;
+    if (!g || (!src && n_samples) || g->broken) return -1;
     if (!g->staged.empty()) {
         const Staged &st = g->staged.front();
         if (st.src != src || st.n != n_samples || st.host != host) {
@@ -597,9 +618,24 @@ static int group_comms(irdm_group *g)
     return 0;
 }
 
+extern "C" int irdm_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" irdm_group_t *irdm_group_create(const irdm_config_t *cfg, int n_gpus, const int *devices)
 {
     if (!cfg || n_gpus < 1 || n_gpus > 64) return nullptr;
+#ifndef IRDM_RCCL_EMULATED
+    if (n_gpus > 1) {
+        // (honesty clause: groups of two and more members have run on the CPU emulation of the devices and of RCCL and as two
+        // ranks sharing one GPU, never yet on two real GPUs -- tests/test_gpu_group.py skips there)
+        static bool warned = false;
+        if (!warned) fprintf(stderr, "irdm_hip group: %d members -- EXPERIMENTAL: the multi-GPU group protocol has not run on multi-GPU hardware yet\n", n_gpus);
+        warned = true;
+    }
+#endif
     irdm_group *g = new (std::nothrow) irdm_group();
     if (!g) return nullptr;
     g->n = n_gpus;
@@ -677,7 +713,7 @@ extern "C" int irdm_group_feed_device(irdm_group_t *g, const void *d_iq, size_t 
 
 extern "C" int irdm_group_flush(irdm_group_t *g)
 {
-    if (!g) return -1;
+    if (!g || g->broken) return -1;
     if (!g->staged.empty()) {
         fprintf(stderr, "irdm_hip group: a staged super-step was never fed\n");
         return -1;

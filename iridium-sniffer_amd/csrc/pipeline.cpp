@@ -445,6 +445,14 @@ struct irdm_pipeline {
     uint32_t rot_gen[kMaxBc] = {}, rot_done_gen[kMaxBc] = {};   // per context: builds enqueued / known to be complete (its stream was waited for)
     std::vector<float2 *> rot_retired;      // outgrown pools
     uint64_t stat_rot_builds = 0, stat_rot_rows = 0, stat_rot_ckpts = 0, stat_rot_grows = 0, stat_band_steps = 0;
+    // rot_prebuild (default where pipeline_depth >= 1): every centre bin's row, as far as an ordinary burst needs it, built by
+    // ONE background launch behind create instead of by the chains that first meet the bin (a stream's first chunks bring
+    // hundreds of new bins each: 2.4-3.9 ms of checkpoint recurrence in front of a chain, 11.5 ms at 12 MHz dense)
+    hipStream_t stream_rot_pre = nullptr;
+    hipEvent_t ev_rot_pre = nullptr;
+    int4 *d_rot_pre_news = nullptr;
+    bool rot_pre_pending = false;           // chains wait for ev_rot_pre until the host has seen it complete
+    int rot_pre_runs = 0;                   // runs of kRotRun checkpoints every bin's row was prebuilt with (0: none)
     size_t scratch_init = 0;                 // outputs the decimated / low-passed scratch of a context holds to begin with
     std::vector<float2 *> scratch_retired;   // outgrown scratch (freed when the context is closed, like the rotator pools)
     std::vector<void *> tiles_retired, tiles_host_retired;   // outgrown strip lists (device / pinned host): likewise
@@ -473,6 +481,7 @@ struct irdm_pipeline {
 // and 10.9 GB at 12 MHz, built at create in rounds 1-3 -- is the arena's upper bound: it grows by doubling; an arena that
 // has been outgrown stays allocated until the context is closed (chains in flight still read it).
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st);
+static int rot_prebuild(irdm_pipeline *p);
 
 // Every C-ABI entry that enqueues work for a pipeline: the calling thread is put on the pipeline's device and the
 // arithmetic-order switch the launch helpers read (irdm::g_fir_order, thread-local) is set to THIS pipeline's -- two
@@ -551,6 +560,9 @@ static void pipeline_free(irdm_pipeline *p)
     for (void *q : p->tiles_retired) (void)hipFree(q);
     for (void *q : p->tiles_host_retired) (void)hipHostFree(q);
     if (p->d_rot_slot) (void)hipFree(p->d_rot_slot);
+    if (p->stream_rot_pre) { (void)hipStreamSynchronize(p->stream_rot_pre); (void)hipStreamDestroy(p->stream_rot_pre); }
+    if (p->ev_rot_pre) (void)hipEventDestroy(p->ev_rot_pre);
+    if (p->d_rot_pre_news) (void)hipFree(p->d_rot_pre_news);
     if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
     if (p->stream_spec) (void)hipStreamDestroy(p->stream_spec);
     if (p->ev_sums1) (void)hipEventDestroy(p->ev_sums1);
@@ -1019,6 +1031,12 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     ok = ok && hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)P.n * p->rot_runs) == hipSuccess;
     p->rot_build_ctx.assign((size_t)P.n, -1);
     p->rot_build_gen.assign((size_t)P.n, 0);
+#ifndef IRDM_HIP_EMULATED
+    // (a throughput context: the rows of all bins in the background, now.  Not fatal: without the memory for it the rows
+    // come on demand.  The CPU emulation runs the launch to completion on enqueue -- seconds per context -- and asks for it
+    // by option where it tests it.)
+    if (ok && p->depth >= 1 && !getenv("IRDM_NO_ROT_PREBUILD")) (void)rot_prebuild(p);
+#endif
     mark("rotator row pool");
     if (!ok) {
         fprintf(stderr, "irdm_hip: device initialisation failed\n");
@@ -1363,8 +1381,73 @@ static void cfo_helper_main(irdm_pipeline *p)
     }
 }
 
+// Back to an empty on-demand arena of `blocks` blocks (create's state; also what the test hook rot_pool_rows asks for):
+// only while no chain has built or read a row.
+static int rot_arena_reset(irdm_pipeline *p, long long blocks)
+{
+    if (p->stat_rot_builds != 0) return -1;
+    if (p->stream_rot_pre) IRDM_HIP_CHECK(hipStreamSynchronize(p->stream_rot_pre));
+    p->rot_pre_pending = false;
+    p->rot_pre_runs = 0;
+    float2 *pool = dev_alloc<float2>((size_t)blocks * kRotRun);
+    if (!pool) return -1;
+    (void)hipFree(p->d_rot_table);
+    p->d_rot_table = pool;
+    p->rot_blocks_cap = (int)blocks;
+    p->rot_blocks_used = 0;
+    p->rot_rows_used = 0;
+    std::fill(p->rot_len_h.begin(), p->rot_len_h.end(), 0);
+    std::fill(p->rot_want.begin(), p->rot_want.end(), 0);
+    std::fill(p->rot_build_ctx.begin(), p->rot_build_ctx.end(), -1);
+    IRDM_HIP_CHECK(hipMemset(p->d_rot_slot, 0xff, sizeof(int) * (size_t)p->P.n * p->rot_runs));
+    return 0;
+}
+
+// Every centre bin's row as far as a burst of ordinary length needs it (window = 2 pre + post + 12 ms of signal: Iridium's
+// frames are 8.3 ms, simplex 20.3 ms -- longer bursts extend their bin's row on demand as before), one lane per bin, ONE
+// launch on a stream of its own behind create; the chains wait for its event until the host has seen it complete.  The
+// arena holds these blocks (bin b: blocks b * runs ..) plus the on-demand margin it had.  Footprint: n bins x runs x 16 KB --
+// 0.07 GB at 2 MHz, 1.3 GB at 10 MHz, 3.2 GB at 12 MHz (of 288) -- against 3-4 ms per chain in a stream's first seconds.
+static int rot_prebuild(irdm_pipeline *p)
+{
+    if (p->stat_rot_builds != 0 || p->rot_rows_used != 0 || p->rot_pre_runs != 0) return -1;
+    const DetParams &P = p->P;
+    const long long window = 2ll * P.pre_len + P.post_len + (long long)(0.012 * p->cfg.sample_rate);
+    int runs = (int)((window / kRotSeg + 8 + kRotRun - 1) / kRotRun);
+    if (runs > p->rot_runs) runs = p->rot_runs;
+    if (runs < 1) return -1;
+    const long long blocks = (long long)P.n * runs;
+    const long long cap = blocks + (long long)std::min(P.n, 256) * p->rot_runs;
+    if (cap > 0x7fffffffll / 2) return -1;
+    if (!p->stream_rot_pre && hipStreamCreateWithFlags(&p->stream_rot_pre, hipStreamNonBlocking) != hipSuccess) return -1;
+    if (!p->ev_rot_pre && hipEventCreateWithFlags(&p->ev_rot_pre, hipEventDisableTiming) != hipSuccess) return -1;
+    if (!p->d_rot_pre_news && !(p->d_rot_pre_news = dev_alloc<int4>((size_t)P.n))) return -1;
+    float2 *pool = dev_alloc<float2>((size_t)cap * kRotRun);
+    if (!pool) return -1;                                   // (no memory for it: rows on demand, as without the option)
+    (void)hipFree(p->d_rot_table);
+    p->d_rot_table = pool;
+    p->rot_blocks_cap = (int)cap;
+    std::vector<int4> news((size_t)P.n);
+    for (int b = 0; b < P.n; b++) news[(size_t)b] = int4{ b, 0, runs * kRotRun, b * runs };
+    IRDM_HIP_CHECK(hipMemcpy(p->d_rot_pre_news, news.data(), sizeof(int4) * news.size(), hipMemcpyHostToDevice));
+    if (launch_rotator_rows(p->d_rot_incr, p->d_rot_table, p->rot_runs, p->d_rot_pre_news, P.n, p->d_rot_slot, p->stream_rot_pre) != 0)
+        return -1;
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_rot_pre, p->stream_rot_pre));
+    std::fill(p->rot_len_h.begin(), p->rot_len_h.end(), runs * kRotRun);
+    p->rot_blocks_used = (int)blocks;
+    p->rot_rows_used = P.n;
+    p->rot_pre_runs = runs;
+    p->rot_pre_pending = true;
+    return 0;
+}
+
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st)
 {
+    if (p->rot_pre_pending) {
+        // (the prebuilt rows: this chain reads them -- and may continue or, growing the arena, copy them)
+        IRDM_HIP_CHECK(hipStreamWaitEvent(st, p->ev_rot_pre, 0));
+        if (hipEventQuery(p->ev_rot_pre) == hipSuccess) p->rot_pre_pending = false;
+    }
     // A row is built as far as the bursts on its bin have needed it so far (a window of n samples restores checkpoints
     // 0 .. n / 16), in runs of kRotRun checkpoints -- a block of the arena each --, and continued from its last
     // checkpoint when a longer burst comes: the recurrence is sequential, 9 ns a sample -- 12 ms for a whole row at
@@ -2910,9 +2993,15 @@ extern "C" long long irdm_export_state(irdm_pipeline_t *p, void *buf, size_t cap
     return (long long)irdm_state_bytes(p);
 }
 
+// A detector state may only be replaced while no scan that ran on the OLD state is ahead of the caller: with two chunks begun
+// ahead, or with the next chunk's scan already chained behind the one in flight (scan_chain_early), that scan has read -- or
+// committed against -- the state the import is about to overwrite, and irdm_feed_end would book its results as the
+// imported stream's.  The time-sharded callers begin one chunk ahead at most and import before its irdm_feed_end.
+static inline bool import_allowed(const irdm_pipeline *p) { return !p->chain_pending && p->begin_no <= p->end_no + 1; }
+
 extern "C" int irdm_import_state(irdm_pipeline_t *p, const void *buf, size_t n)
 {
-    if (!p || !buf || n < irdm_state_bytes(p) || quiesce(p) != 0) return -1;
+    if (!p || !buf || n < irdm_state_bytes(p) || !import_allowed(p) || quiesce(p) != 0) return -1;
     pipeline_enter(p);
     const char *i = static_cast<const char *>(buf);
     StateHeader h;
@@ -2956,7 +3045,7 @@ extern "C" long long irdm_export_state_device(irdm_pipeline_t *p, void *d_buf, s
 
 extern "C" int irdm_import_state_device(irdm_pipeline_t *p, const void *d_buf, size_t n)
 {
-    if (!p || !d_buf || n < irdm_state_bytes(p)) return -1;
+    if (!p || !d_buf || n < irdm_state_bytes(p) || !import_allowed(p)) return -1;
     pipeline_enter(p);
     if (settle(p) != 0 || hist_fence(p) != 0) return -1;
     const char *i = static_cast<const char *>(d_buf);
@@ -2991,7 +3080,7 @@ extern "C" size_t irdm_state_head_bytes(const irdm_pipeline_t *p)
 
 extern "C" int irdm_import_state_head_device(irdm_pipeline_t *p, const void *d_buf, size_t n)
 {
-    if (!p || !d_buf || n < irdm_state_head_bytes(p)) return -1;
+    if (!p || !d_buf || n < irdm_state_head_bytes(p) || !import_allowed(p)) return -1;
     pipeline_enter(p);
     if (settle(p) != 0) return -1;
     const char *i = static_cast<const char *>(d_buf);
@@ -3304,14 +3393,16 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
         return 0;
     }
     if (!strcmp(key, "rot_pool_rows")) {
-        // (test hook) the rotator checkpoint pool with `value` rows to begin with; only before the first burst
-        if (p->rot_rows_used != 0 || value < 1 || value > p->P.n) return -1;
-        float2 *pool = dev_alloc<float2>((size_t)value * p->rot_runs * kRotRun);
-        if (!pool) return -1;
-        (void)hipFree(p->d_rot_table);
-        p->d_rot_table = pool;
-        p->rot_blocks_cap = value * p->rot_runs;
-        return 0;
+        // (test hook) an empty on-demand rotator checkpoint arena with room for `value` whole rows (a prebuilt one is given
+        // up); only before the first burst
+        if (value < 1 || value > p->P.n) return -1;
+        return rot_arena_reset(p, (long long)value * p->rot_runs);
+    }
+    if (!strcmp(key, "rot_prebuild")) {
+        // 1: every centre bin's row in one background launch now (the default of a context with pipeline_depth >= 1);
+        // 0: rows on demand only (the default otherwise); only before the first burst
+        if (value) return p->rot_pre_runs ? 0 : rot_prebuild(p);
+        return p->rot_pre_runs ? rot_arena_reset(p, (long long)std::min(p->P.n, 1024) * p->rot_runs) : 0;
     }
     if (!strcmp(key, "scratch_outputs")) {
         // (test hook) the decimated / low-passed scratch of every context with room for `value` outputs to begin with;
@@ -3386,6 +3477,7 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
         return i >= 0 && i < 16 ? (int64_t)p->stat_plan_tp[i] : -1;
     }
     if (!strcmp(key, "rot_rows")) return (int64_t)p->rot_rows_used;
+    if (!strcmp(key, "rot_prebuilt_runs")) return (int64_t)p->rot_pre_runs;
     if (!strcmp(key, "rot_rows_cap")) return (int64_t)(p->rot_blocks_cap / p->rot_runs);      // (in whole rows)
     if (!strcmp(key, "rot_blocks")) return (int64_t)p->rot_blocks_used;
     if (!strcmp(key, "rot_blocks_cap")) return (int64_t)p->rot_blocks_cap;

@@ -236,6 +236,10 @@ int main(int argc, char **argv)
     c.max_chunk_samples = chunk;
     c.pipeline_depth = depth;
     if (gpus < 0 || gpus > 64) { fprintf(stderr, "--gpus %d\n", gpus); return 2; }
+    if (gpus > irdm_device_count()) {
+        fprintf(stderr, "--gpus %d: this host has %d GPU%s\n", gpus, irdm_device_count(), irdm_device_count() == 1 ? "" : "s");
+        return 2;
+    }
     irdm_pipeline_t *p;
     if (gpus > 0) {
         g_group = irdm_group_create(&c, gpus, NULL);

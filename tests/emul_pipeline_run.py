@@ -54,6 +54,11 @@ def main():
         res["packed_depth3_in_place_lookahead"] = parity.compare_packed(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 7), depth=3, feed="ingest_lookahead", packed=True), ref)
         res["packed_depth0"] = parity.compare_packed(parity.run_gpu(iq, fs, packed=True), ref)
+        # every centre bin's checkpoint row prebuilt by one launch behind create (rot_prebuild; the default on the GPU for
+        # pipeline_depth >= 1, asked for by option here): no build on any chain, same records
+        pre = parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 5), depth=2, feed="ingest_lookahead", options={"rot_prebuild": 1})
+        res["rows_prebuilt"] = parity.compare(pre, ref)
+        assert pre["stats"]["rot_rows"] == 2048 and pre["stats"]["rot_ckpts"] == 0, pre["stats"]
         # five batch contexts (pipeline_depth 4): records five chunks late, same records, same order
         res["chunked_depth4_in_place_lookahead"] = parity.compare(
             parity.run_gpu(iq, fs, chunks=chunks_of(len(iq), 9), depth=4, feed="ingest_lookahead"), ref)

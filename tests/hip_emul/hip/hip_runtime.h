@@ -10,6 +10,7 @@
 // streams, events and memory fences are no-ops and atomics are plain operations.  __shared__ variables are statics
 // (one workgroup at a time); dynamic LDS is one 160 KB buffer (hip_emul::dyn_lds()).
 #pragma once
+#define IRDM_HIP_EMULATED 1   /* the product compiled against this header: the CPU emulation (tests/emul_build.py) */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -148,3 +148,18 @@ def test_save_burst_writes_the_reference_file_pair(tmp_path):
     assert irdm.save_burst(f, x, d) == 0 and os.path.exists(base[:-2] + "UN.meta")
     f.drop_reason = 3
     assert irdm.save_burst(f, x, d) == -1
+
+
+def test_cli_refuses_more_gpus_than_the_host_has(tmp_path):
+    """iridium-sniffer-hip --gpus N on a host with fewer devices: exit code 2 and a message that says how many there are (here:
+    none without a GPU, one on the GPU box) -- before any context or communicator is built."""
+    import subprocess
+    irdm.build()
+    exe = os.path.join(os.path.dirname(irdm.LIB_PATH), "iridium-sniffer-hip")
+    f = tmp_path / "x.cf32"
+    f.write_bytes(b"\0" * 8 * 32768)
+    n_dev = irdm.lib().irdm_device_count()
+    out = subprocess.run([exe, "-f", str(f), "-r", "2000000", "--gpus", str(n_dev + 1)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2, (out.returncode, out.stderr)
+    assert "--gpus %d: this host has %d GPU" % (n_dev + 1, n_dev) in out.stderr, out.stderr
+    assert out.stdout == ""

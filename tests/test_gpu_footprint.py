@@ -87,6 +87,7 @@ def test_rotator_rows_are_built_as_far_as_needed_and_extended():
     n = len(iq)
     for chunks in ([n // 2 // 32768 * 32768, n - n // 2 // 32768 * 32768],):
         p = irdm.Pipeline(fs, max_chunk_samples=n, max_bursts_per_chunk=64, pipeline_depth=1 if chunks else 0)
+        p.set_option("rot_prebuild", 0)               # rows on demand (a pipeline_depth >= 1 context prebuilds them by default)
         p.set_option("keep_frame_samples", 1)
         off = 0
         for c in (chunks or [n]):
@@ -124,10 +125,58 @@ def test_burst_scratch_rows_by_length_and_growth():
 def test_context_footprint_10mhz():
     """a 10 MHz context for 16 Mi-sample chunks: no table of a row per FFT bin (4.5 GB in rounds 1-3), an arena of
     checkpoint blocks (0.57 GB to begin with) instead; no decimated / low-passed scratch for 4096 bursts of the longest length per chain (3 x 1.8 GB
-    up to round 4), 1/16 of that to begin with"""
+    up to round 4), 1/16 of that to begin with; since round 6 plus every bin's row prebuilt as far as an ordinary burst needs it
+    (rot_prebuild: 8192 bins x 10 runs x 16 KB = 1.3 GB instead of the 0.57 GB the empty arena had)"""
     u0 = _used()
     p = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=2)
     u1 = _used()
     p.close()
-    assert u1 - u0 < 4.5e9, u1 - u0        # (8.8 GB with full-length scratch rows; rounds 1-3: 6.1 GB + the 4.5 GB table)
+    assert u1 - u0 < 5.0e9, u1 - u0        # (8.8 GB with full-length scratch rows; rounds 1-3: 6.1 GB + the 4.5 GB table)
+    u0 = _used()
+    p = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=2)
+    p.set_option("rot_prebuild", 0)
+    u2 = _used()
+    p.close()
+    assert u2 - u0 < 4.2e9, u2 - u0        # rows on demand: as in round 5
+    print("10 MHz context, rows on demand: %.2f GB" % ((u2 - u0) / 1e9))
     print("10 MHz context, 16 Mi-sample chunks, depth 2: %.2f GB" % ((u1 - u0) / 1e9))
+
+
+def test_rotator_rows_prebuilt_in_the_background():
+    """rot_prebuild (the default of a context with pipeline_depth >= 1): one background launch behind create builds every
+    centre bin's row as far as a burst of ordinary length needs it -- a stream's first chunks then bring no checkpoint build in
+    front of their chains (bursts of ordinary length: no build at all; a 54 ms burst extends its bin's row on demand) -- at
+    n bins x runs x 16 KB of device memory; same records as the oracle, and as with the rows on demand."""
+    fs = 2_000_000
+    n = int(0.9 * fs) // 32768 * 32768
+    iq, _ = siggen.standard_scene(fs, n, 9, seed=5)
+    ref = orc.run_stream(iq, fs)
+    c = (n // 5) // 32768 * 32768
+    chunks = [c, c, c, c, n - 4 * c]
+    before = _used()
+    p = irdm.Pipeline(fs, max_chunk_samples=max(chunks), max_bursts_per_chunk=256, pipeline_depth=2)
+    runs = p.stat("rot_prebuilt_runs")
+    assert runs >= 2 and p.stat("rot_rows") == 2048 and p.stat("rot_blocks") == 2048 * runs
+    p.close()
+    got = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead")
+    parity.compare(got, ref)
+    assert got["stats"]["rot_rows"] == 2048 and got["stats"]["rot_ckpts"] == 0 and got["stats"]["rot_grows"] == 0, got["stats"]
+    off = parity.run_gpu(iq, fs, chunks=chunks, depth=2, feed="ingest_lookahead", options={"rot_prebuild": 0})
+    parity.compare(off, ref)
+    assert off["stats"]["rot_rows"] == len({b.center_bin for b in ref.bursts}) and off["stats"]["rot_ckpts"] > 0, off["stats"]
+    # long bursts: their rows are continued from the prebuilt part
+    fs2, iq2 = _short_then_long()
+    ref2 = orc.run_stream(iq2, fs2)
+    half = len(iq2) // 2 // 32768 * 32768
+    got = parity.run_gpu(iq2, fs2, chunks=[half, len(iq2) - half], depth=1)
+    parity.compare(got, ref2)
+    assert got["stats"]["rot_rows"] == 2048 and got["stats"]["rot_ckpts"] >= 2048, got["stats"]
+    # footprint at 10 MHz: 8192 bins x 10 runs x 16 KB on top of the on-demand margin
+    base = _used()
+    q = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=3)
+    r10 = q.stat("rot_prebuilt_runs")
+    with_pre = _used() - base
+    q.close()
+    assert 8 <= r10 <= 12
+    assert with_pre < 9.0e9, with_pre            # (four batch contexts + ring + the prebuilt rows)
+    del before

@@ -38,7 +38,7 @@ def test_whole_path_2mhz(emul_lib):
     res = run_case(emul_lib, "2mhz")
     assert set(res) == {"whole", "chunked_depth1", "chunked_depth2_in_place_lookahead", "ci8", "sequential_scan", "scratch_growth",
                         "rotator_row_extension", "rotator_arena_growth", "chunked_depth4_in_place_lookahead", "chunked_depth3_two_ahead",
-                        "rot_store_per_lane"}
+                        "rot_store_per_lane", "packed_depth3_in_place_lookahead", "packed_depth0", "rows_prebuilt"}
     assert res["scratch_growth"]["grows"] >= 1
     for name, s in res.items():
         assert s["bursts"] >= 4 and s["demods"] >= 3, (name, s)
