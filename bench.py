@@ -374,7 +374,12 @@ def bench_time_shard(args, torch, dist, irdm, rank, world, local, device, cdev, 
                                            **{k: round(v / max(ts.steps_timed, 1) * 1e3, 3) for k, v in ts.t.items()}}
                                           if ts is not None else None),
                        "ring_waits": pipe.stat("ring_waits"),
-                       "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")}},
+                       "scan": {k: pipe.stat(k) for k in ("scan_fast_chunks", "scan_fallbacks", "band_chunks", "band_rounds", "band_aborts")},
+                       # rotator checkpoint rows: prebuilt runs per bin (0: on demand), builds / checkpoints chains had to make
+                       "rot": {k: pipe.stat(k) for k in ("rot_prebuilt_runs", "rot_builds", "rot_ckpts", "rot_grows", "scratch_grows", "tiles_grows")},
+                       "host_us": {k: pipe.stat("host_us_%d" % i) for i, k in enumerate(
+                           ("k1_ring_enqueue", "settle", "chain_enqueue", "scan_enqueue", "wait_older_chain", "final_sync",
+                            "settle_wait_scan", "settle_counters", "settle_records", "build_records"))}},
             "roofline": {"bound": "hbm", "kernel": "fir_decimate_kernel_f", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None, "traffic": None, "stage_ms_rank0_last_step": {k: round(v, 4) for k, v in t.items()}},
             "cpu_baseline": None,
@@ -451,8 +456,7 @@ def main():
                     help="pipeline_depth >= 1: 1 = the chunk lives in its slot of the history ring (irdm_ingest_ptr; the ring is "
                          "filled with the synthetic chunk before the timed region), 0 = fed from a separate buffer and copied")
     ap.add_argument("--lookahead", type=int, default=1,
-                    help="pipeline_depth >= 1: 1 = irdm_feed_begin(k+1) before irdm_feed_end(k); 2 = two chunks begun ahead "
-                         "(K1 of chunk k+2 on the GPU a period early); 0 = irdm_feed_device")
+                    help="pipeline_depth >= 1: 1 = irdm_feed_begin(k+1) before irdm_feed_end(k); 0 = irdm_feed_device")
     ap.add_argument("--host-steps", type=int, default=6,
                     help="extra, separately timed steps fed from pinned HOST memory (PCIe-inclusive rate; 0 = skip)")
     args = ap.parse_args()
@@ -566,7 +570,7 @@ def main():
             return pipe.feed_device(ptr, n, stream)
         pipe.feed_begin(ptr, n, stream)
         pending[0] += 1
-        if pending[0] > min(max(args.lookahead, 1), 2):          # (chunks begun ahead of the one that is ended: 1 or 2)
+        if pending[0] > 1:          # (one chunk begun ahead of the one that is ended)
             pending[0] -= 1
             return pipe.feed_end()
         return 0
@@ -687,12 +691,10 @@ def main():
     }
     opts = dict((kv.split("=", 1)[0], int(kv.split("=", 1)[1])) for kv in args.opt)
     # (the kernels the library picks for this configuration: DESIGN.md section 5; options fir_order / k1_kernel)
-    fir_name = "fir_decimate_kernel_w"
-    if decim in (40, 48):
+    fir_name = "fir_decimate_kernel"                   # (the any-M kernel: 2 / 4 MHz)
+    if decim in (40, 48) and not opts.get("fir_generic", 0):
         fir_name = "fir_decimate_kernel_f" if opts.get("fir_order", 1) else "fir_decimate_kernel_r"
-        if opts.get("fir_layout", 3) == 4 and opts.get("fir_order", 1):
-            fir_name = "fir_decimate_kernel_x"           # (the same arithmetic on the matrix cores: v_mfma_f32_16x16x4_f32)
-    k1_name = "fft_mag_p32_kernel" if opts.get("k1_kernel", 1) and pipe.fft_size >= 8192 else "fft_mag_r16_kernel"
+    k1_name = "fft_mag_p32_kernel" if pipe.fft_size >= 8192 else "fft_mag_r16_kernel" if pipe.fft_size == 4096 else "fft_mag_kernel"
     kernels = {"fft_mag": k1_name, "scan": "band_* (scan_band.hip passes)", "fir": fir_name}
     # the dominant KERNEL: the scan is a chain of ~25 short launches of six kernels (its stage time is their sum plus
     # what they wait for each other), so it is reported in stage_ms / stage_GBps but not as "the" kernel
@@ -706,7 +708,7 @@ def main():
     for which, key in ((0, "fir"), (1, "fft_mag")):
         sm, nl, _ = pipe.kernel_clock(which)
         kclk[key] = {"ms": sm / nl if nl else 0.0, "launches": nl}
-    has_clock = kernels["fir"] != "fir_decimate_kernel_w" and kclk["fir"]["launches"] > 0
+    has_clock = kernels["fir"] != "fir_decimate_kernel" and kclk["fir"]["launches"] > 0
     if has_clock:
         dom = "fir" if kclk["fir"]["ms"] >= kclk["fft_mag"]["ms"] else "fft_mag"
     else:
@@ -999,7 +1001,7 @@ def main():
                        "samples_per_step_per_gpu": n, "bursts_per_step": totals["bursts"] / K,
                        "raw_frames_per_step": totals["demods"] / K, "parallelism": "streams x%d" % world,
                        "job_bursts_per_step": (int(counts[0].item()) / K) if world > 1 else totals["bursts"] / K,
-                       "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": (min(max(args.lookahead, 1), 2) if look else 0),
+                       "pipeline_depth": args.depth, "ingest_in_place": ingest, "lookahead": (1 if look else 0),
                        "packed_records": packed,      # the timed context returns 176-byte frame records (what frame_output_print reads: no LLRs)
                        "records": ({"produced": int(counts[1].item()), "sent": int(counts[2].item()),
                                     "gathered_on_rank0": int(gathered.item())} if world > 1 else None),

@@ -68,15 +68,10 @@ struct BandParams {
                                  // bit 3 the wavefront walk without its 64-frame look-ahead (band_wave.hpp: skim),
                                  // bit 4 the plan pass without its LDS (through the workspace arrays, wavefront boundary test),
                                  // bit 5 the speculation pass's guess spoilt in one late frame (a round more, its sums pass restarted)
-    int32_t ahead = 0;           // 1: the plan passes of this launch are launched ahead on a second stream and wait for
-                                 // the walk pass's workgroups to count themselves done (BandWork::bar[8])
     int32_t tl_sel = -1;         // >= 0: the passes stamp their first workgroup's start and last one's end into half tl_sel of
                                  // BandWork::tl (diagnostic, option band_timeline)
     int32_t chained = 0;         // 1: enqueued behind a band scan whose verdict the host had not seen: valid only if that
                                  // scan committed (BandWork::bar[4]), else every pass of this launch returns untouched
-    int32_t tail = 0;            // 1: the launch-saving form (scan_band.hip, g_band_tail): pair list, plan pass in the walk pass's
-                                 // last workgroup, history on a side stream
-    uint32_t seq = 0;            // tail: number of the SCAN this launch belongs to (HistJob::seq)
     int32_t sum_restart = 1;     // 1: a later round's sums pass restarts at the last stored state in front of the first frame whose u
                                  // changed (a snapshot every 64 update steps); 0: every sums pass walks all steps (option band_sum_restart)
     int32_t spec_in = 0;         // 1: this scan has no round 0 of its own -- a speculation pass on a second workspace, run beside

@@ -354,40 +354,6 @@ __global__ __launch_bounds__(64) void demod_par_kernel(const BurstWork *__restri
     }
 }
 
-// DemodOut -> DemodPacked: a lane per output byte
-__global__ __launch_bounds__(128) void demod_pack_kernel(const DemodOut *__restrict__ in, int n_bursts, DemodPacked *__restrict__ out)
-{
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (b >= n_bursts) return;
-    const DemodOut &d = in[b];
-    DemodPacked &o = out[b];
-    if (t < kMaxBits / 8) {
-        const int nbits = d.ok ? 2 * d.n_symbols : 0;
-        unsigned v = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int i = 8 * t + k;
-            v |= (unsigned)((i < nbits ? d.bits[i] : 0) & 1) << (7 - k);
-        }
-        o.bits[t] = (uint8_t)v;
-    }
-    if (t == 127) {
-        o.ok = d.ok;
-        o.direction = d.direction;
-        o.confidence = d.confidence;
-        o.n_symbols = d.n_symbols;
-        o.level = d.level;
-        o.total_phase = d.total_phase;
-    }
-}
-
-int launch_demod_pack(const DemodOut *in, int n_bursts, DemodPacked *out, hipStream_t stream)
-{
-    if (n_bursts <= 0) return 0;
-    hipLaunchKernelGGL(demod_pack_kernel, dim3(n_bursts), dim3(128), 0, stream, in, n_bursts, out);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int use_gardner,
                  float sps, float2 *ws, DemodOut *out, hipStream_t stream, DemodPacked *hp_packed, BurstWork *hp_work)
 {

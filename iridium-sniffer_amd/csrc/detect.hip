@@ -527,14 +527,10 @@ __global__ __launch_bounds__((1 << LOGN) / 32, 4) void fft_mag_p32_kernel(const 
     kclk_leave(kclk);
 }
 
-thread_local int g_fir_order = 1;          // the form of the reference's dispatched kernels the product follows: 1 simd_avx2.c, 0 simd_generic.c (downmix.hip)
-int g_fft_kernel = 1;         // 1 (default): the 32-points-per-lane streaming kernel where it applies (N = 8192, 16384); 0: radix-16 kernel
-int g_fft_force_radix2 = 0;   // test hook: 1 = always use the radix-2 LDS kernel
-
 template <int LOGN, bool LISTS>
 static int launch_p32(int fmt, const void *iq, const float *window, const float2 *tw, float *mag, int n_frames,
                       const float *pre, unsigned *counts, ListEntry *entries, int cap, unsigned long long *kclk,
-                      hipStream_t stream)
+                      hipStream_t stream, int order)
 {
     const size_t lds = P32<LOGN>::LDS;
     const dim3 grid(n_frames), block(P32<LOGN>::T);
@@ -543,7 +539,7 @@ static int launch_p32(int fmt, const void *iq, const float *window, const float2
         (void)hipFuncSetAttribute((const void *)fft_mag_p32_kernel<LOGN, F, LISTS>,                      \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
         hipLaunchKernelGGL((fft_mag_p32_kernel<LOGN, F, LISTS>), grid, block, lds, stream, iq, window, tw, mag, \
-                           n_frames, pre, counts, entries, cap, kclk, g_fir_order);                                \
+                           n_frames, pre, counts, entries, cap, kclk, order);                            \
     } while (0)
     if (fmt == 2) IRDM_LAUNCH_P32(2);
     else if (fmt == 1) IRDM_LAUNCH_P32(1);
@@ -552,61 +548,58 @@ static int launch_p32(int fmt, const void *iq, const float *window, const float2
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// K1 with the candidate lists of the band scan (see fft_mag_r16_kernel); 1 if this FFT size has no such kernel
-int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window, const float2 *tw, float *mag,
-                         int n_frames, const float *pre, unsigned *counts, ListEntry *entries, int cap,
-                         hipStream_t stream, unsigned long long *kclk)
+// Which K1 a frame size takes: 8192 / 16384 points (10 / 12 MHz) fft_mag_p32_kernel, 4096 fft_mag_r16_kernel, 256 .. 2048
+// (2 MHz, the plug point's small sizes) fft_mag_kernel -- the same butterflies on the same operands in all three.
+// `order`: fftshift_mag in the reference's AVX2 form (1: fma(re, re, im * im)) or its generic form (0), see mag2_simd.
+template <int LOGN, bool LISTS>
+static int launch_r16(int fmt, const void *iq, const float *window, const float2 *tw, float *mag, int n_frames,
+                      const float *pre, unsigned *counts, ListEntry *entries, int cap, hipStream_t stream, int order)
 {
-    if (n_frames <= 0) return 0;
-    if (fmt < 0 || fmt > 2 || log_n < 12 || log_n > 14 || g_fft_force_radix2) return 1;
-    if (g_fft_kernel == 1 && log_n == 13)
-        return launch_p32<13, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, kclk, stream);
-    if (g_fft_kernel == 1 && log_n == 14)
-        return launch_p32<14, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, kclk, stream);
-#define IRDM_LAUNCH_R16L_F(LOGN, F)                                                            \
-    do {                                                                                       \
-        constexpr int NB_ = 1 << (LOGN - 8);                                                   \
-        size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN)           \
-                                           ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));   \
-        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F, true>,             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, true>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
-                           stream, iq, window, tw, mag, n_frames, pre, counts, entries, cap, g_fir_order);  \
+    constexpr int NB_ = 1 << (LOGN - 8);
+    const size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN) ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));
+#define IRDM_LAUNCH_R16(F)                                                                               \
+    do {                                                                                                 \
+        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F, LISTS>,                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, LISTS>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
+                           stream, iq, window, tw, mag, n_frames, pre, counts, entries, cap, order);     \
     } while (0)
-#define IRDM_LAUNCH_R16L(LOGN)                                                                 \
-    do {                                                                                       \
-        if (fmt == 2) IRDM_LAUNCH_R16L_F(LOGN, 2);                                             \
-        else if (fmt == 1) IRDM_LAUNCH_R16L_F(LOGN, 1);                                        \
-        else IRDM_LAUNCH_R16L_F(LOGN, 0);                                                      \
-    } while (0)
-    switch (log_n) {
-    case 12: IRDM_LAUNCH_R16L(12); break;
-    case 13: IRDM_LAUNCH_R16L(13); break;
-    default: IRDM_LAUNCH_R16L(14); break;
-    }
-#undef IRDM_LAUNCH_R16L
-#undef IRDM_LAUNCH_R16L_F
+    if (fmt == 2) IRDM_LAUNCH_R16(2);
+    else if (fmt == 1) IRDM_LAUNCH_R16(1);
+    else IRDM_LAUNCH_R16(0);
+#undef IRDM_LAUNCH_R16
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
-                   float *mag, int n_frames, hipStream_t stream, unsigned long long *kclk)
+// K1 with the candidate lists of the band scan (see fft_mag_r16_kernel); 1 if this FFT size has no such kernel
+int launch_fft_mag_lists(int log_n, int fmt, const void *iq, const float *window, const float2 *tw, float *mag,
+                         int n_frames, const float *pre, unsigned *counts, ListEntry *entries, int cap,
+                         hipStream_t stream, unsigned long long *kclk, int order)
 {
     if (n_frames <= 0) return 0;
-    int grid = n_frames < 4096 ? n_frames : 4096;
+    if (fmt < 0 || fmt > 2 || log_n < 12 || log_n > 14) return 1;
+    if (log_n == 13) return launch_p32<13, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, kclk, stream, order);
+    if (log_n == 14) return launch_p32<14, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, kclk, stream, order);
+    return launch_r16<12, true>(fmt, iq, window, tw, mag, n_frames, pre, counts, entries, cap, stream, order);
+}
+
+int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, const float2 *tw,
+                   float *mag, int n_frames, hipStream_t stream, unsigned long long *kclk, int order)
+{
+    if (n_frames <= 0) return 0;
+    const int grid = n_frames < 4096 ? n_frames : 4096;
     const int f = fmt;
     if (f < 0 || f > 2) return -1;
-    if (g_fft_kernel == 1 && !g_fft_force_radix2 && log_n == 13)
-        return launch_p32<13, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, kclk, stream);
-    if (g_fft_kernel == 1 && !g_fft_force_radix2 && log_n == 14)
-        return launch_p32<14, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, kclk, stream);
+    if (log_n == 13) return launch_p32<13, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, kclk, stream, order);
+    if (log_n == 14) return launch_p32<14, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, kclk, stream, order);
+    if (log_n == 12) return launch_r16<12, false>(fmt, iq, window, tw, mag, n_frames, nullptr, nullptr, nullptr, 0, stream, order);
 #define IRDM_LAUNCH_FFT_F(LOGN, NT, F)                                                         \
     do {                                                                                       \
         size_t lds = sizeof(float2) << LOGN;                                                   \
         (void)hipFuncSetAttribute((const void *)fft_mag_kernel<LOGN, NT, F>,                   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((fft_mag_kernel<LOGN, NT, F>), dim3(grid), dim3(NT), lds,           \
-                           stream, iq, window, tw, mag, n_frames, g_fir_order);                \
+                           stream, iq, window, tw, mag, n_frames, order);                      \
     } while (0)
 #define IRDM_LAUNCH_FFT(LOGN, NT)                                                              \
     do {                                                                                       \
@@ -614,41 +607,11 @@ int launch_fft_mag(int log_n, int fmt, const void *iq, const float *window, cons
         else if (f == 1) IRDM_LAUNCH_FFT_F(LOGN, NT, 1);                                       \
         else IRDM_LAUNCH_FFT_F(LOGN, NT, 0);                                                   \
     } while (0)
-#define IRDM_LAUNCH_R16_F(LOGN, F)                                                             \
-    do {                                                                                       \
-        constexpr int NB_ = 1 << (LOGN - 8);                                                   \
-        size_t lds = sizeof(float2) * ((size_t)256 * (NB_ + 1) > ((size_t)1 << LOGN)           \
-                                           ? (size_t)256 * (NB_ + 1) : ((size_t)1 << LOGN));   \
-        (void)hipFuncSetAttribute((const void *)fft_mag_r16_kernel<LOGN, F, false>,            \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
-        hipLaunchKernelGGL((fft_mag_r16_kernel<LOGN, F, false>), dim3(n_frames), dim3((1 << LOGN) / 16), lds, \
-                           stream, iq, window, tw, mag, n_frames, (const float *)nullptr,      \
-                           (unsigned *)nullptr, (ListEntry *)nullptr, 0, g_fir_order);         \
-    } while (0)
-#define IRDM_LAUNCH_R16(LOGN)                                                                  \
-    do {                                                                                       \
-        if (f == 2) IRDM_LAUNCH_R16_F(LOGN, 2);                                                \
-        else if (f == 1) IRDM_LAUNCH_R16_F(LOGN, 1);                                           \
-        else IRDM_LAUNCH_R16_F(LOGN, 0);                                                       \
-    } while (0)
-    if (!g_fft_force_radix2) {
-        switch (log_n) {
-        case 12: IRDM_LAUNCH_R16(12); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 13: IRDM_LAUNCH_R16(13); return hipGetLastError() == hipSuccess ? 0 : -1;
-        case 14: IRDM_LAUNCH_R16(14); return hipGetLastError() == hipSuccess ? 0 : -1;
-        default: break;
-        }
-    }
-#undef IRDM_LAUNCH_R16
-#undef IRDM_LAUNCH_R16_F
     switch (log_n) {
     case 8:  IRDM_LAUNCH_FFT(8, 64); break;
     case 9:  IRDM_LAUNCH_FFT(9, 128); break;
     case 10: IRDM_LAUNCH_FFT(10, 256); break;
     case 11: IRDM_LAUNCH_FFT(11, 256); break;
-    case 12: IRDM_LAUNCH_FFT(12, 512); break;
-    case 13: IRDM_LAUNCH_FFT(13, 512); break;
-    case 14: IRDM_LAUNCH_FFT(14, 1024); break;
     default: return -1;
     }
 #undef IRDM_LAUNCH_FFT

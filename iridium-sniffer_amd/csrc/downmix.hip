@@ -256,285 +256,12 @@ __global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel(
     }
 }
 
-// Same kernel with the decimation factor as a compile-time constant (M = 8 / 16 / 40 / 48 at 2 / 4 / 10 / 12 MHz):
-//   * polyphase slot of tap k = (k % M, k / M) -> the LDS byte offset of tap r*M + p is  r*8 + p*ROW*8, the second
-//     term an instruction immediate (< 64 KB), so the tap loop has no address arithmetic and no offset table;
-//   * the 801 taps are staged into LDS once and read four at a time as one broadcast ds_read_b128: no scalar loads in
-//     the loop (SMEM returns out of order and shares lgkmcnt with LDS, i.e. every tap fetch forced a full
-//     lgkmcnt(0) drain of the sample reads in flight);
-//   * one unrolled row of M taps per iteration: M sample reads in flight ahead of the dependent mul/add (hipcc packs
-//     the re/im chains into v_pk_mul_f32 + v_pk_add_f32: two VALU instructions per tap, still one rounding each).
-// Accumulation order is unchanged (k ascending, two independent chains).
-// Measured (10 MHz, 167 M window samples per chunk): 0.91 ms vs 1.04 ms for the runtime-M kernel; staging alone (loads,
-// rotation, polyphase scatter) is 0.47 ms of it, the tap loop 0.43 ms -- both instruction-issue bound on the same
-// SIMDs (PMC: 48 % of wave cycles issuing, 45 % waiting with 1.5 waves per SIMD), so they add rather than overlap.
-// Taps through scalar loads instead of LDS, or all staging loads issued up front, measured the same or worse.
-constexpr int fir_tile_row_c(int decim)
-{
-    // odd row length (staging writes of neighbouring lanes land in different banks), no further padding: at M = 40
-    // tile + taps = 51.5 KB, so three workgroups share a CU's 160 KB (161-sample rows would leave room for two)
-    return (kFirTileOut + kFirTaps / decim + 2) | 1;
-}
-
-template <int M>
-__global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_m(
-    SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
-    const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec,
-    const int *__restrict__ rot_slot)
-{
-    constexpr int ROW = fir_tile_row_c(M);
-    constexpr int NR = kFirTaps / M;               // full rows of M taps
-    constexpr int REM = kFirTaps - NR * M;         // taps of the last, partial row
-    static_assert(M % 4 == 0, "taps are fetched four at a time");
-    static_assert((size_t)(M - 1) * ROW * 8 + 8 < 65536, "polyphase offsets must fit the DS immediate");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2 *s = reinterpret_cast<float2 *>(smem_raw);
-    float *s_taps = reinterpret_cast<float *>(s + (size_t)ROW * M);      // 16-byte aligned: ROW*M*8 is a multiple of 16
-    const int tid = threadIdx.x;
-    const FirTile tile = tiles[blockIdx.x];
-    const BurstWork w = work[tile.burst];
-    const int o0 = tile.first_out;
-    int n_out = w.dec_len - o0;
-    if (n_out > kFirTileOut) n_out = kFirTileOut;
-    const int span = (n_out - 1) * M + kFirTaps;
-    const int s0 = o0 * M;                           // multiple of kRotSeg
-    const float2 inc = rot_incr[w.center_bin];
-    const RotCk ck(rot_table, rot_slot, n_ckpt, w.center_bin, s0 / kRotSeg);
-    const int n_seg = (span + kRotSeg - 1) / kRotSeg;
-
-    for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
-    for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
-        float2 ph = ck.at(seg);
-        const int k0 = seg * kRotSeg;
-        int p = k0 % M, q = k0 / M;
-        const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
-        float2 x[kRotSeg];
-        // (a segment that runs past the tile's span is loaded whole as long as its samples exist: the slots past the
-        // span are never read by a tap, and the tile has room for them)
-        const bool whole = a0 + kRotSeg <= w.avail_end;
-        if (whole && a0 >= src.chunk_start) {
-            // the whole segment lies in the chunk being fed: 16-byte loads, all in flight (cf32 8, ci16 4, ci8 2 of them)
-            load_seg16(src.fmt, src.chunk, (size_t)(a0 - src.chunk_start), x);
-        } else if (whole && a0 + kRotSeg <= src.chunk_start) {
-            // same from the history ring: ring_len is a multiple of 16 and a0 is too, so no wrap inside
-            load_seg16(src.fmt, src.ring, (size_t)(a0 % src.ring_len), x);
-        } else {
-#pragma unroll
-            for (int u = 0; u < kRotSeg; u++)
-                x[u] = (k0 + u < span) ? burst_sample(src, w.start, w.avail_end, s0 + k0 + u)
-                                       : make_float2(0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int u = 0; u < kRotSeg; u++) {
-            if (k0 + u < span) {
-                s[p * ROW + q] = cmul(x[u], ph);     // out[i] = in[i] * phase (rotator.h:38)
-                ph = cmul(ph, inc);                  // phase *= incr          (rotator.h:39)
-            }
-            if (++p == M) { p = 0; q++; }
-        }
-    }
-    __syncthreads();
-
-    if (tid < n_out) {
-        float ar = 0.0f, ai = 0.0f;
-        const float2 *col = s + tid;
-#pragma unroll 1
-        for (int r = 0; r < NR; r++) {
-            const float2 *c = col + r;
-            const float4 *t4 = reinterpret_cast<const float4 *>(s_taps + r * M);
-            float2 v[M];
-            float4 t[M / 4];
-#pragma unroll
-            for (int p = 0; p < M; p++) v[p] = c[p * ROW];
-#pragma unroll
-            for (int p = 0; p < M / 4; p++) t[p] = t4[p];
-#pragma unroll
-            for (int p = 0; p < M / 4; p++) {
-                ar += t[p].x * v[4 * p].x;     ai += t[p].x * v[4 * p].y;
-                ar += t[p].y * v[4 * p + 1].x; ai += t[p].y * v[4 * p + 1].y;
-                ar += t[p].z * v[4 * p + 2].x; ai += t[p].z * v[4 * p + 2].y;
-                ar += t[p].w * v[4 * p + 3].x; ai += t[p].w * v[4 * p + 3].y;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < REM; p++) {
-            const float2 v = col[p * ROW + NR];
-            const float t = s_taps[NR * M + p];
-            ar += t * v.x;
-            ai += t * v.y;
-        }
-        dec[(size_t)w.dec_off + o0 + tid] = make_float2(ar, ai);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// The same decimator with the tile stored COLUMN-MAJOR: the M rotated samples that output column q needs for one row of
-// taps (k = r*M .. r*M+M-1 -> samples (q+r)*M .. (q+r)*M+M-1) are contiguous, CS = M*8 + 16 bytes per column.
-//   * tap loop: one ds_read_b128 brings the samples of TWO taps (M/2 reads per row instead of M ds_read_b64): per tap
-//     and wavefront 0.5 + 0.25 LDS instructions + 2 VALU = 2.75 instead of 3.25 -- the loop is bound by instruction
-//     issue (DESIGN.md "The decimator");
-//   * the 16-byte pad makes the lane stride CS/4 = 2M+4 dwords: the lanes of a 16-lane ds_read_b128 group start in
-//     different banks for every M used here (8, 16, 40, 48);
-//   * staging: a lane's 16 consecutive rotated samples are contiguous in a column (or split once, at a multiple of 8
-//     samples, between two columns): eight ds_write_b128 instead of sixteen ds_write_b64 with per-sample addressing.
-// Accumulation order is unchanged (k ascending, two independent chains).
-// ---------------------------------------------------------------------------
-template <int M>
-struct FirCol {
-    static constexpr int NR = kFirTaps / M;                  // full rows of M taps
-    static constexpr int REM = kFirTaps - NR * M;            // taps of the last, partial row
-    static constexpr int COLS = kFirTileOut + NR + 1;        // columns a full tile touches
-    static constexpr int CS = M * 8 + 16;                    // column stride, bytes
-    static constexpr size_t LDS = (size_t)COLS * CS + sizeof(float) * (kFirTaps + 3);
-    static_assert(M % 8 == 0, "a 16-sample segment splits between columns only at a multiple of 8 samples");
-};
-
-template <int M>
-__global__ __launch_bounds__(kFirTileOut) void fir_decimate_kernel_c(
-    SampleSource src, const BurstWork *__restrict__ work, const FirTile *__restrict__ tiles,
-    const float *__restrict__ taps, const float2 *__restrict__ rot_incr,
-    const float2 *__restrict__ rot_table, int n_ckpt, float2 *__restrict__ dec,
-    const int *__restrict__ rot_slot)
-{
-    using C = FirCol<M>;
-    constexpr int NR = C::NR, REM = C::REM, CS = C::CS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char *s = smem_raw;
-    float *s_taps = reinterpret_cast<float *>(s + (size_t)C::COLS * CS);     // 16-byte aligned: CS is a multiple of 16
-    const int tid = threadIdx.x;
-    const FirTile tile = tiles[blockIdx.x];
-    const BurstWork w = work[tile.burst];
-    const int o0 = tile.first_out;
-    int n_out = w.dec_len - o0;
-    if (n_out > kFirTileOut) n_out = kFirTileOut;
-    const int span = (n_out - 1) * M + kFirTaps;
-    const int s0 = o0 * M;                           // multiple of kRotSeg
-    const float2 inc = rot_incr[w.center_bin];
-    const RotCk ck(rot_table, rot_slot, n_ckpt, w.center_bin, s0 / kRotSeg);
-    const int n_seg = (span + kRotSeg - 1) / kRotSeg;
-
-    for (int i = tid; i < kFirTaps + 3; i += kFirTileOut) s_taps[i] = i < kFirTaps ? taps[i] : 0.0f;
-    for (int seg = tid; seg < n_seg; seg += kFirTileOut) {
-        float2 ph = ck.at(seg);
-        const int k0 = seg * kRotSeg;
-        const uint64_t a0 = w.start + (uint64_t)(s0 + k0);
-        float2 x[kRotSeg];
-        // (a segment that runs past the tile's span is loaded whole as long as its samples exist: the slots past the
-        // span are never read by a tap, and the tile has room for them)
-        const bool whole = a0 + kRotSeg <= w.avail_end;
-        if (whole && a0 >= src.chunk_start) {
-            load_seg16(src.fmt, src.chunk, (size_t)(a0 - src.chunk_start), x);
-        } else if (whole && a0 + kRotSeg <= src.chunk_start) {
-            load_seg16(src.fmt, src.ring, (size_t)(a0 % src.ring_len), x);
-        } else {
-#pragma unroll
-            for (int u = 0; u < kRotSeg; u++)
-                x[u] = (k0 + u < span) ? burst_sample(src, w.start, w.avail_end, s0 + k0 + u)
-                                       : make_float2(0.0f, 0.0f);
-        }
-        // rotate (rotator.h:38-39); samples past the tile's span are never read by a tap, their slots may hold anything
-        float2 y[kRotSeg];
-#pragma unroll
-        for (int u = 0; u < kRotSeg; u++) {
-            y[u] = cmul(x[u], ph);
-            ph = cmul(ph, inc);
-        }
-        // samples k0 .. k0+7 and k0+8 .. k0+15: each half lies inside one column (k0 and M are multiples of 8)
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int k = k0 + 8 * h;
-            float4 *dst = reinterpret_cast<float4 *>(s + (size_t)(k / M) * CS + (size_t)(k % M) * 8);
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                dst[u] = make_float4(y[8 * h + 2 * u].x, y[8 * h + 2 * u].y, y[8 * h + 2 * u + 1].x, y[8 * h + 2 * u + 1].y);
-        }
-    }
-    __syncthreads();
-
-    if (tid < n_out) {
-        float ar = 0.0f, ai = 0.0f;
-        const unsigned char *col = s + (size_t)tid * CS;
-#pragma unroll 1
-        for (int r = 0; r < NR; r++) {
-            const float4 *c4 = reinterpret_cast<const float4 *>(col + (size_t)r * CS);
-            const float4 *t4 = reinterpret_cast<const float4 *>(s_taps + r * M);
-            float4 v[M / 2];
-            float4 t[M / 4];
-#pragma unroll
-            for (int j = 0; j < M / 2; j++) v[j] = c4[j];
-#pragma unroll
-            for (int j = 0; j < M / 4; j++) t[j] = t4[j];
-#pragma unroll
-            for (int j = 0; j < M / 4; j++) {
-                ar += t[j].x * v[2 * j].x;     ai += t[j].x * v[2 * j].y;
-                ar += t[j].y * v[2 * j].z;     ai += t[j].y * v[2 * j].w;
-                ar += t[j].z * v[2 * j + 1].x; ai += t[j].z * v[2 * j + 1].y;
-                ar += t[j].w * v[2 * j + 1].z; ai += t[j].w * v[2 * j + 1].w;
-            }
-        }
-        {
-            const float2 *c2 = reinterpret_cast<const float2 *>(col + (size_t)NR * CS);
-#pragma unroll
-            for (int p = 0; p < REM; p++) {
-                const float2 v = c2[p];
-                const float t = s_taps[NR * M + p];
-                ar += t * v.x;
-                ai += t * v.y;
-            }
-        }
-        dec[(size_t)w.dec_off + o0 + tid] = make_float2(ar, ai);
-    }
-}
-
-
-// ---------------------------------------------------------------------------
-// The column-major decimator as a PERSISTENT kernel: the workgroups that fit the chip's LDS walk tiles blockIdx.x,
-// blockIdx.x + gridDim.x, ... of TO outputs each.  What that buys over one tile per workgroup (measured there at the
-// bench's 667 bursts: staging alone 0.43 ms, tap loop alone 0.51 ms, together 0.80 ms):
-//   * the raw samples of the NEXT tile are requested before the tap loop of the current one and wait in registers
-//     (3 segments of 16 samples per lane at M = 40: 96 VGPRs), so the HBM latency of staging is covered by the tap loop;
-//   * the tap loop is software-pipelined by hand: the LDS reads of step s+1 are issued before the multiplies of step s;
-//   * the taps come through the scalar cache into SGPRs instead of as LDS broadcast reads -- a broadcast ds_read_b128
-//     still costs its 4 LDS cycles, a third of the loop's LDS time (MI355X_MICROARCH.md, LDS table);
-//   * one FirGeom record per tile (fir_geom_kernel) replaces the tile -> burst -> rotator-table pointer chase;
-//   * larger tiles shrink the share of the 801-tap halo that is staged twice (21 of TO + 21 columns at M = 40).
-// The loop is bound by the multiply-add chain, not by memory: v_pk_mul_f32 / v_pk_add_f32 issue once per ~7.4 cycles per
-// SIMD (tools/ubench/valu_chain.hip: no faster with two wavefronts per SIMD, and plain v_mul/v_add at 4 cycles each
-// cost the same per complex tap), a dependent v_pk_add_f32 can issue ~23 cycles after its producer, and the reference
-// rounds the product before the add (no FMA): 16 SIMD-cycles per complex tap and wavefront = 0.36 ms for the bench's
-// 4.4 M outputs, before staging.  Two wavefronts per SIMD (or two outputs per lane) are needed to cover the chain, and
-// the tile's LDS footprint allows six per CU.  Forming the product of tap q + 4 ahead of the add of tap q halved the
-// tap loop's cycle count (s_memtime) but cost 8 % wall time (register copies at the loop edge, SGPR spills); tiles of
-// 256 / 448 outputs measured 0.84 / 0.70 ms against 0.66 ms.
-// Values and accumulation order are those of fir_decimate_kernel_c.
-// ---------------------------------------------------------------------------
-template <int M, int TO>
-struct FirW {
-    static constexpr int NR = kFirTaps / M;
-    static constexpr int REM = kFirTaps - NR * M;
-    static constexpr int COLS = TO + NR + 1;
-    static constexpr int CS = M * 8 + 16;
-    static constexpr size_t LDS = (size_t)COLS * CS + 16;     // + the word the claimed tile index is broadcast through
-    static constexpr int SPAN_MAX = (TO - 1) * M + kFirTaps;
-    static constexpr int SEG_MAX = (SPAN_MAX + kRotSeg - 1) / kRotSeg;
-    static constexpr int SLOTS = (SEG_MAX + TO - 1) / TO;
-    // taps per pipeline step: a divisor of M, multiple of 4, at most 24
-    static constexpr int T = (M % 24 == 0) ? 24 : (M % 20 == 0) ? 20 : (M % 16 == 0) ? 16 : 8;
-    static constexpr int SPR = M / T;                 // steps per row
-    static constexpr int NS = NR * SPR;               // pipeline steps
-    static_assert(M % 8 == 0 && M % T == 0 && T % 4 == 0 && NS % 2 == 0, "step size");
-    static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
-};
-
 // one lane per tile: everything the decimator's workgroups need, in one record
 __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts, int n_tiles, int M,
                                 int tile_out, uint64_t ring_len, uint64_t ref_ring, const float2 *__restrict__ rot_incr, int n_ckpt,
-                                FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile,
-                                const int *__restrict__ rot_slot)
+                                FirGeom *__restrict__ geom, const int *__restrict__ rot_slot)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t == 0) *next_tile = 0;
     if (t >= n_tiles) return;
     // the burst whose tiles include t: the last one with tile_base <= t among those that have tiles (bursts without --
     // dropped before the decimator -- carry the tile_base of the next one, so the LAST burst with tile_base <= t is it)
@@ -581,185 +308,6 @@ __global__ void fir_geom_kernel(const BurstWork *__restrict__ work, int n_bursts
     geom[t] = g;
 }
 
-__device__ unsigned long long g_fir_prof_dev[8];
-#define FIR_PROF_MARK(i)                                                         \
-    do {                                                                         \
-        if (PROF) {                                                              \
-            const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
-            prof[i] += now_ - tlast;                                             \
-            tlast = now_;                                                        \
-        }                                                                        \
-    } while (0)
-
-#include "fir_mac.inc"
-
-template <int M, int FMT, int TO, bool PROF = false>
-__global__ __launch_bounds__(TO) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_w(
-    SampleSource src, const FirGeom *__restrict__ geom, unsigned *__restrict__ next_tile, int n_tiles, int budget,
-    const float *__restrict__ taps, const float2 *__restrict__ rot_table, float2 *__restrict__ dec)
-{
-    using W = FirW<M, TO>;
-    constexpr int NR = W::NR, REM = W::REM, CS = W::CS, SLOTS = W::SLOTS, T = W::T, SPR = W::SPR, NS = W::NS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char *s = smem_raw;
-    const int tid = threadIdx.x;
-
-    float2 x[SLOTS][kRotSeg];
-    float2 ph0[SLOTS];
-    // request the raw samples of tile `g`: whole segments inside the chunk or the ring; the others are read in consume()
-    auto prefetch = [&](const FirGeom &g) {
-#pragma unroll
-        for (int j = 0; j < SLOTS; j++) {
-            const int seg = tid + TO * j;
-            const int k0 = seg * kRotSeg;
-            const uint64_t a0 = g.a_tile + (uint64_t)k0;
-            const bool whole = seg < g.n_seg && a0 + kRotSeg <= g.avail_end;      // (may run past the span: never read)
-            const bool in_chunk = whole && a0 >= src.chunk_start;
-            const bool in_ring = whole && a0 + kRotSeg <= src.chunk_start;
-            uint64_t rp = g.ring_pos + (uint64_t)k0;
-            if (rp >= src.ring_len) rp -= src.ring_len;
-            // (segments that are not loaded here read the start of the ring: always mapped, never used)
-            const void *base = in_chunk ? src.chunk : src.ring;
-            const size_t idx = in_chunk ? (size_t)(a0 - src.chunk_start) : in_ring ? (size_t)rp : 0;
-            load_seg16(FMT, base, idx, x[j]);
-            ph0[j] = rot_table[fir_ck(g, seg < g.n_seg ? seg : 0)];
-        }
-    };
-    // rotate the samples of tile `g` (rotator.h:38-39) and store them in the tile
-    auto consume = [&](const FirGeom &g) {
-#pragma unroll
-        for (int j = 0; j < SLOTS; j++) {
-            const int seg = tid + TO * j;
-            if (seg >= g.n_seg) continue;
-            const int k0 = seg * kRotSeg;
-            const uint64_t a0 = g.a_tile + (uint64_t)k0;
-            const bool whole = a0 + kRotSeg <= g.avail_end;
-            const bool fast = whole && (a0 >= src.chunk_start || a0 + kRotSeg <= src.chunk_start);
-            float2 ph = ph0[j];
-            const float2 inc = make_float2(g.inc_re, g.inc_im);
-            if (!fast) {
-                // a segment across the chunk / ring / availability boundary: sample by sample
-#pragma unroll 1
-                for (int u = 0; u < kRotSeg; u++) {
-                    const int k = k0 + u;
-                    const float2 xs = (k < g.span) ? burst_sample(src, g.burst_start, g.avail_end, g.s0 + k)
-                                                   : make_float2(0.0f, 0.0f);
-                    *reinterpret_cast<float2 *>(s + (size_t)(k / M) * CS + (size_t)(k % M) * 8) = cmul(xs, ph);
-                    ph = cmul(ph, inc);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int k = k0 + 8 * h;
-                float4 *dst = reinterpret_cast<float4 *>(s + (size_t)(k / M) * CS + (size_t)(k % M) * 8);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float2 y0 = cmul(x[j][8 * h + 2 * u], ph);
-                    ph = cmul(ph, inc);
-                    const float2 y1 = cmul(x[j][8 * h + 2 * u + 1], ph);
-                    ph = cmul(ph, inc);
-                    dst[u] = make_float4(y0.x, y0.y, y1.x, y1.y);
-                }
-            }
-        }
-    };
-
-    unsigned long long prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    unsigned long long tlast = PROF ? __builtin_amdgcn_s_memtime() : 0;
-    // Tiles are claimed dynamically (the workgroups do not run at the same speed: a wavefront alone on its SIMD is
-    // faster than two that share one, and the last tile of a burst is short): the first two tiles of a workgroup are
-    // blockIdx.x and blockIdx.x + gridDim.x, every further one comes from the counter fir_geom_kernel zeroed.  A
-    // workgroup retires after `budget` tiles: its LDS and registers go back to the dispatcher, which hands them to the
-    // high-priority detector stream first -- a grid that stayed resident for the whole launch kept the other streams'
-    // kernels out of every CU (measured: the band scan of the next chunk took 1.15 ms instead of 0.86 ms).
-    unsigned *s_claim = reinterpret_cast<unsigned *>(s + (size_t)W::COLS * CS);
-    int t = blockIdx.x;
-    int t1 = t + (int)gridDim.x;
-    int n_claimed = 2;
-    FirGeom g = geom[t];
-    prefetch(g);
-    FIR_PROF_MARK(0);
-    for (;;) {
-        const bool more = t1 < n_tiles;
-        // the last round requests its own tile again (no branch around the loads: a join would wait for them)
-        const FirGeom gn = geom[more ? t1 : t];
-        unsigned claimed = 0x7fffffffu;
-        if (tid == 0 && n_claimed < budget) claimed = atomicAdd(next_tile, 1u) + 2u * gridDim.x;
-        n_claimed++;
-        consume(g);
-        if (tid == 0) *s_claim = claimed;
-        FIR_PROF_MARK(1);
-        __syncthreads();
-        FIR_PROF_MARK(2);
-        prefetch(gn);
-        const int t2 = (int)*s_claim;
-        FIR_PROF_MARK(3);
-
-        if (tid < g.n_out) {
-            const unsigned char *col = s + (size_t)tid * CS;
-            // the multiply-add groups are inline asm (fir_mac.inc): taps straight from SGPR pairs, products one tap ahead
-            v2f acc = { 0.0f, 0.0f };
-            v4f va[T / 2], vb[T / 2];
-            uint64_t ta[T / 2], tb[T / 2];
-            const uint64_t *taps64 = reinterpret_cast<const uint64_t *>(taps);      // (T is even: pairs never straddle a step)
-            auto issue = [&](int st, v4f (&v)[T / 2], uint64_t (&tt)[T / 2]) {
-                const v4f *c4 = reinterpret_cast<const v4f *>(col + (size_t)(st / SPR) * CS + (size_t)(st % SPR) * (T * 8));
-#pragma unroll
-                for (int q = 0; q < T / 2; q++) v[q] = c4[q];
-#pragma unroll
-                for (int q = 0; q < T / 2; q++) tt[q] = taps64[(st * T) / 2 + q];
-            };
-            issue(0, va, ta);
-#pragma unroll 1
-            for (int st = 0; st < NS; st += 2) {
-                // the first tap pair of a step comes before the next step's requests: whatever the step waits for was
-                // requested a whole step ago (scalar loads return out of order, so the wait is for everything)
-                fir_mac<1>(acc, va, ta);
-                __builtin_amdgcn_sched_barrier(0);
-                issue(st + 1, vb, tb);
-                __builtin_amdgcn_sched_barrier(0);
-                fir_mac<T / 2 - 1>(acc, va + 1, ta + 1);
-                fir_mac<1>(acc, vb, tb);
-                __builtin_amdgcn_sched_barrier(0);
-                issue(st + 2 < NS ? st + 2 : 0, va, ta);       // (the last round's request is not used)
-                __builtin_amdgcn_sched_barrier(0);
-                fir_mac<T / 2 - 1>(acc, vb + 1, tb + 1);
-            }
-            float ar = acc.x, ai = acc.y;
-            {
-                const float2 *c2 = reinterpret_cast<const float2 *>(col + (size_t)NR * CS);
-#pragma unroll
-                for (int q = 0; q < REM; q++) {
-                    const float2 v = c2[q];
-                    const float tq = taps[NR * M + q];
-                    ar += tq * v.x;
-                    ai += tq * v.y;
-                }
-            }
-            dec[g.out_base + tid] = make_float2(ar, ai);
-        }
-        FIR_PROF_MARK(4);
-        __syncthreads();
-        FIR_PROF_MARK(5);
-        if (PROF) prof[6] += 1;
-        if (!more) break;
-        t = t1;
-        t1 = t2;
-        g = gn;
-    }
-    if (PROF && (tid & 63) == 0) {
-        for (int i = 0; i < 7; i++) atomicAdd(&g_fir_prof_dev[i], prof[i]);
-        atomicAdd(&g_fir_prof_dev[7], 1ull);
-    }
-}
-
-int g_fir_force_generic = 0;   // test hook: 1 = always use the runtime-M kernel
-int g_fir_layout = 3;          // 3: register-resident columns, travelling accumulators (fir_reg.hip; M = 40 / 48, else 2),
-                               // 2: persistent column-major LDS kernel (fir_decimate_kernel_w), 1: column-major, one tile per
-                               // workgroup (fir_decimate_kernel_c), 0: polyphase rows (fir_decimate_kernel_m)
-int g_fir_prof = 0;
-
 int fir_tile_row(int decim)
 {
     int r = kFirTileOut + kFirTaps / decim + 2;
@@ -767,206 +315,51 @@ int fir_tile_row(int decim)
     return r;
 }
 
-int g_fir_reserve_cus = 0;     // persistent kernel: CUs left to the other streams' kernels
-int g_fir_budget = 4;          // persistent kernel: tiles per workgroup before it retires (0: one resident grid)
+// Which decimator a batch takes (DESIGN.md "The decimator"):
+//   M = 40 / 48 (10 / 12 MHz), the source's ring lengths multiples of 8 samples (`aligned`: fir_reg.hip fetches columns in
+//   pieces of 8): the register-resident kernels of fir_reg.hip -- fir_decimate_kernel_f in the reference's AVX2 order
+//   (simd_avx2.c:62-108: four accumulators, fused multiply-adds; order 1), fir_decimate_kernel_r in its scalar order
+//   (simd_generic.c:86-96: one accumulator, every product and sum rounded; order 0, --no-simd);
+//   anything else (2 / 4 MHz, a caller's burst window presented as a chunk, the test hook `generic`): fir_decimate_kernel
+//   above, any M, either order, one tile of kFirTileOut outputs per workgroup from the FirTile list.
+// `order`: which of the reference's two forms of its dispatched kernels the product follows (simd_kernels.h; option
+// "fir_order", alias "simd_order"; per pipeline).  The other dispatched kernels with two forms (fir_ccf, fir_fff,
+// fftshift_mag, mag_squared) follow the same switch in post_tiles / post2 / K1.
+static bool fir_reg_path(int decim, int aligned, int generic) { return !generic && aligned && fir_reg_supported(decim); }
 
-// Which of the reference's two forms of its dispatched kernels (simd_kernels.h) the kernels follow (DESIGN.md "Arithmetic
-// contract"; option "fir_order", alias "simd_order"; defined in detect.hip):
-//   1 (default)  simd_avx2.c -- what the reference runs on x86 unless --no-simd is given.  avx2_fir_ccf_dec (:62-108): four
-//                accumulators, fused multiply-adds (fir_decimate_kernel_f at M = 40 / 48; the runtime-M kernel otherwise);
-//                avx2_fir_ccf (:28-55) / avx2_fir_fff (:115-138): a fused multiply-add per tap for the outputs of the vector
-//                body, the generic form for the last n % 4 / n % 8 outputs (post1's noise filter and start filter, post2's RRC
-//                filter); avx2_mag_squared (:304-323) / avx2_fftshift_mag (:177-221): fma(re, re, im*im) (post1, K1)
-//   0            simd_generic.c (--no-simd, every non-x86 host): one accumulator, every product and sum rounded
-//                (fir_decimate_kernel_r / _w / _c / _m)
-// (the other dispatched kernels are the same operations in both forms: tests/test_oracle_vs_ref.py)
-
-// `aligned`: the pipeline's ring lengths are multiples of 8 samples (fir_reg.hip fetches columns in pieces of 8)
-// fir_layout 4 (fir_order 1 only): the AVX2 order on the matrix cores
-static bool fir_mfma_ok(int decim, int aligned)
-{
-    return !g_fir_force_generic && g_fir_order == 1 && g_fir_layout == 4 && aligned && fir_reg_supported(decim);
-}
-
-static bool fir_fma_ok(int decim, int aligned)
-{
-    return !g_fir_force_generic && g_fir_order == 1 && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
-}
-
-static bool fir_reg_ok(int decim, int aligned)
-{
-    return !g_fir_force_generic && g_fir_order == 0 && g_fir_layout == 3 && aligned && fir_reg_supported(decim);
-}
-
-static bool fir_wide_ok(int decim, int aligned)
-{
-    return !g_fir_force_generic && g_fir_order == 0 && (g_fir_layout == 2 || (g_fir_layout == 3 && !fir_reg_ok(decim, aligned))) &&
-           (decim == 8 || decim == 16 || decim == 40 || decim == 48);
-}
-
-static int fir_wide_tile(int)
-{
-    // 256 outputs (one workgroup per CU, a wavefront per SIMD) and 448 (seven wavefronts, the whole LDS) measured
-    // 0.84 and 0.70 ms against 0.66 ms for three workgroups of 128 per CU
-    return 128;
-}
-
-// 1: launch_fir_decimate() reads the FirTile list (the one-tile-per-workgroup kernels); 0: only BurstWork::tile_base
-int fir_needs_tile_list(int decim, int aligned)
-{
-    return fir_wide_ok(decim, aligned) || fir_reg_ok(decim, aligned) || fir_fma_ok(decim, aligned) || fir_mfma_ok(decim, aligned) ? 0 : 1;
-}
+// 1: launch_fir_decimate() reads the FirTile list (the one-tile-per-workgroup kernel); 0: only BurstWork::tile_base
+int fir_needs_tile_list(int decim, int aligned, int generic) { return fir_reg_path(decim, aligned, generic) ? 0 : 1; }
 
 // outputs per FirTile for the kernel launch_fir_decimate() will pick
-int fir_tile_out(int decim, int aligned)
+int fir_tile_out(int decim, int aligned, int generic, int order)
 {
-    if (fir_mfma_ok(decim, aligned)) return fir_mfma_tile_out(decim);
-    if (fir_fma_ok(decim, aligned)) return fir_fma_tile_out(decim);
-    if (fir_reg_ok(decim, aligned)) return fir_reg_tile_out(decim);
-    return fir_wide_ok(decim, aligned) ? fir_wide_tile(decim) : kFirTileOut;
-}
-
-template <int M, int FMT, int TO>
-static int launch_fir_w(const SampleSource &src, const FirGeom *geom, unsigned *next_tile, int n_tiles, const float *taps,
-                         const float2 *rot_table, float2 *dec, int n_cu, hipStream_t stream)
-{
-    using W = FirW<M, TO>;
-    int slots = (n_cu - g_fir_reserve_cus) * (int)((160 * 1024) / W::LDS);
-    if (slots < 1) slots = 1;
-    // budget tiles per workgroup (at least 2: the two static ones); a budget of 0 keeps one resident grid
-    int budget = g_fir_budget >= 2 ? g_fir_budget : 0x3fffffff;
-    int grid = n_tiles < slots ? n_tiles : slots;
-    if (g_fir_budget >= 2 && (n_tiles + budget - 1) / budget > grid) grid = (n_tiles + budget - 1) / budget;
-    if constexpr (M == 40 && FMT == 2) if (g_fir_prof) {
-        unsigned long long z[8] = { 0 };
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fir_prof_dev), z, sizeof(z));
-        (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_w<M, FMT, TO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipStreamSynchronize(stream);
-        (void)hipEventRecord(e0, stream);
-        hipLaunchKernelGGL((fir_decimate_kernel_w<M, FMT, TO, true>), dim3(grid), dim3(TO), W::LDS, stream, src, geom, next_tile, n_tiles, budget, taps, rot_table, dec);
-        (void)hipEventRecord(e1, stream);
-        (void)hipStreamSynchronize(stream);
-        float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        fprintf(stderr, "fir prof kernel %.4f ms; ", ms);
-        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_fir_prof_dev), sizeof(z));
-        const double w = z[7] ? (double)z[7] : 1.0;
-        fprintf(stderr, "fir prof TO=%d (cycles per wave, %llu waves, %.1f tiles/wave): prologue %.0f consume %.0f barrierA %.0f prefetch %.0f taps %.0f barrierB %.0f\n",
-                TO, z[7], z[6] / w, z[0] / w, z[1] / w, z[2] / w, z[3] / w, z[4] / w, z[5] / w);
-        return 0;
-    }
-    (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_w<M, FMT, TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS);
-    hipLaunchKernelGGL((fir_decimate_kernel_w<M, FMT, TO>), dim3(grid), dim3(TO), W::LDS, stream, src, geom, next_tile, n_tiles, budget, taps, rot_table, dec);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-template <int M, int TO>
-static int launch_fir_w_fmt(const SampleSource &src, const FirGeom *geom, unsigned *next_tile, int n_tiles, const float *taps,
-                            const float2 *rot_table, float2 *dec, int n_cu, hipStream_t stream)
-{
-    if (src.fmt == 2) return launch_fir_w<M, 2, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
-    if (src.fmt == 1) return launch_fir_w<M, 1, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
-    return launch_fir_w<M, 0, TO>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
+    if (!fir_reg_path(decim, aligned, generic)) return kFirTileOut;
+    return order ? fir_fma_tile_out(decim) : fir_reg_tile_out(decim);
 }
 
 int launch_fir_decimate(const SampleSource &src, const BurstWork *work, int n_bursts, FirTile *tiles, size_t tiles_cap,
                         int n_tiles, int decim, const float *taps, const int *tap_off, const float2 *rot_incr,
                         const float2 *rot_table, int n_ckpt, float2 *dec,
-                        hipStream_t stream, unsigned long long *kclk, const int *rot_slot)
+                        hipStream_t stream, unsigned long long *kclk, const int *rot_slot, int order, int generic)
 {
     if (n_tiles <= 0) return 0;
-#define IRDM_LAUNCH_FIR_M(MM)                                                                                  \
-    do {                                                                                                       \
-        const size_t lds_m = sizeof(float2) * (size_t)fir_tile_row_c(MM) * MM + sizeof(float) * (kFirTaps + 3);  \
-        (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_m<MM>,                                     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m);                     \
-        hipLaunchKernelGGL(fir_decimate_kernel_m<MM>, dim3(n_tiles), dim3(kFirTileOut), lds_m, stream, src,    \
-                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, rot_slot);                   \
-        return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
-    } while (0)
-#define IRDM_LAUNCH_FIR_C(MM)                                                                                  \
-    do {                                                                                                       \
-        (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_c<MM>,                                     \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)FirCol<MM>::LDS);           \
-        hipLaunchKernelGGL(fir_decimate_kernel_c<MM>, dim3(n_tiles), dim3(kFirTileOut), FirCol<MM>::LDS, stream, src, \
-                           work, tiles, taps, rot_incr, rot_table, n_ckpt, dec, rot_slot);                   \
-        return hipGetLastError() == hipSuccess ? 0 : -1;                                                       \
-    } while (0)
     const int aligned = src.ring_len % 8 == 0 && src.ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
-    if (fir_mfma_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
+    if (fir_reg_path(decim, aligned, generic) && tiles_cap >= (size_t)n_tiles) {
+        // strip geometry (one FirGeom record per strip, behind the FirTile array), then the register-resident decimator
         FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
-        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
         hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_mfma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
-        return launch_fir_mfma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
+                           order ? fir_fma_tile_out(decim) : fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt,
+                           geom, rot_slot);
+        return (order ? launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk)
+                      : launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk)) == 0 ? 0 : -1;
     }
-    if (fir_fma_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
-        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
-        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
-        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_fma_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
-        return launch_fir_fma(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk, next_tile) == 0 ? 0 : -1;
-    }
-    if (fir_reg_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
-        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
-        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);
-        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           fir_reg_tile_out(decim), src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
-        return launch_fir_reg(src, geom, n_tiles, decim, taps, rot_table, dec, stream, kclk) == 0 ? 0 : -1;
-    }
-    if (fir_wide_ok(decim, aligned) && tiles_cap >= (size_t)n_tiles) {
-        FirGeom *geom = reinterpret_cast<FirGeom *>(tiles + tiles_cap);
-        unsigned *next_tile = reinterpret_cast<unsigned *>(geom + tiles_cap);      // (one spare record behind the last)
-        const int to = fir_wide_tile(decim);
-        hipLaunchKernelGGL(fir_geom_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, work, n_bursts, n_tiles, decim,
-                           to, src.ring_len, src.ref_ring, rot_incr, n_ckpt, geom, next_tile, rot_slot);
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-            if (n_cu <= 0) n_cu = 256;
-        }
-        switch (decim) {
-        case 8: return launch_fir_w_fmt<8, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
-        case 16: return launch_fir_w_fmt<16, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
-        case 48: return launch_fir_w_fmt<48, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
-        case 40: return launch_fir_w_fmt<40, 128>(src, geom, next_tile, n_tiles, taps, rot_table, dec, n_cu, stream);
-        default: break;
-        }
-    }
-    if (!g_fir_force_generic && g_fir_order == 0 && g_fir_layout == 1) {
-        switch (decim) {
-        case 8: IRDM_LAUNCH_FIR_C(8);
-        case 16: IRDM_LAUNCH_FIR_C(16);
-        case 40: IRDM_LAUNCH_FIR_C(40);
-        case 48: IRDM_LAUNCH_FIR_C(48);
-        default: break;
-        }
-    }
-#undef IRDM_LAUNCH_FIR_C
-    if (!g_fir_force_generic && g_fir_order == 0) {
-        switch (decim) {
-        case 8: IRDM_LAUNCH_FIR_M(8);
-        case 16: IRDM_LAUNCH_FIR_M(16);
-        case 40: IRDM_LAUNCH_FIR_M(40);
-        case 48: IRDM_LAUNCH_FIR_M(48);
-        default: break;
-        }
-    }
-#undef IRDM_LAUNCH_FIR_M
     const int row = fir_tile_row(decim);
     const size_t lds = sizeof(float2) * (size_t)row * decim;
     if (lds > 160 * 1024) return -1;
     (void)hipFuncSetAttribute((const void *)fir_decimate_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(fir_decimate_kernel, dim3(n_tiles), dim3(kFirTileOut), lds, stream, src, work,
-                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, g_fir_order, rot_slot);
+                       tiles, decim, row, taps, tap_off, rot_incr, rot_table, n_ckpt, dec, order, rot_slot);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1070,7 +463,7 @@ int launch_copy2_to_host(void *dst_a, const void *src_a, size_t bytes_a, void *d
     }
     const size_t n = (bytes_a + bytes_b) / 16;
     if (!n) return 0;
-    const size_t wg = (size_t)g_small_wg;
+    const size_t wg = 256;
     const int grid = (int)std::min<size_t>((n + wg - 1) / wg, 512 * 256 / wg);
     hipLaunchKernelGGL(copy2_to_host_kernel, dim3(grid), dim3((unsigned)wg), 0, stream, static_cast<uint4 *>(dst_a),
                        static_cast<const uint4 *>(src_a), bytes_a / 16, static_cast<uint4 *>(dst_b),
@@ -1085,7 +478,7 @@ int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t st
         return launch_copy_words(dst, src, bytes, stream);
     const size_t n16 = bytes / 16;
     const int n_tail = (int)((bytes - n16 * 16) / 4);
-    const size_t wg = (size_t)g_small_wg;
+    const size_t wg = 256;
     const int grid = (int)std::min<size_t>((n16 + wg - 1) / wg + 1, 512 * 256 / wg);
     hipLaunchKernelGGL(copy_to_host_kernel, dim3(grid), dim3((unsigned)wg), 0, stream, static_cast<uint4 *>(dst),
                        static_cast<const uint4 *>(src), n16, reinterpret_cast<uint32_t *>(static_cast<char *>(dst) + n16 * 16),
@@ -1093,33 +486,11 @@ int launch_copy_to_host(void *dst, const void *src, size_t bytes, hipStream_t st
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// A device-to-device copy of a chunk's size by kernel: 16 bytes per lane over the whole chip -- option copy_wide 1.  The
-// default (0) stays hipMemcpyAsync: it goes through the DMA engines (a 512 MB chunk in ~5 ms, ~100 GB/s) BESIDE the
-// kernels, and in a pipelined run that is the better place for a copy nobody waits for: chunks not fed in place
-// (bench.py --ingest 0) 64.7-65.4 Gsamples/s with it against 60.7-61.0 with this kernel taking the CUs.
-__global__ __launch_bounds__(256) void copy_wide_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
-{
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
-
-int g_copy_wide = 0;        // 1: the history-ring copies by kernel instead of hipMemcpyAsync (A/B: slower in run)
-int launch_copy_wide(void *dst, const void *src, size_t bytes, hipStream_t stream)
-{
-    if (bytes == 0) return 0;
-    if (!g_copy_wide || bytes % 16 != 0 || (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 != 0 ||
-        bytes < (1u << 20))
-        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream) == hipSuccess ? 0 : -1;
-    const size_t n16 = bytes / 16;
-    const int grid = (int)std::min<size_t>((n16 + 255) / 256, 8192);
-    hipLaunchKernelGGL(copy_wide_kernel, dim3(grid), dim3(256), 0, stream, static_cast<uint4 *>(dst), static_cast<const uint4 *>(src), n16);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
 int launch_copy_words(void *dst, const void *src, size_t bytes, hipStream_t stream)
 {
     if (bytes == 0) return 0;
     const size_t n = bytes / 4;
-    const size_t wg = (size_t)g_small_wg;
+    const size_t wg = 256;
     const int grid = (int)std::min<size_t>((n + wg - 1) / wg, 256 * 256 / wg);
     hipLaunchKernelGGL(copy_words_kernel, dim3(grid), dim3((unsigned)wg), 0, stream, static_cast<uint32_t *>(dst),
                        static_cast<const uint32_t *>(src), n);
@@ -1224,18 +595,11 @@ __device__ __forceinline__ float parabolic(float alpha, float beta, float gamma)
 constexpr int kPostThreads = 256;
 
 // ---------------------------------------------------------------------------
-// post1: one workgroup per burst.  Steps 2b and 3 walk the burst in tiles of kPostTile outputs staged in LDS (four per
-// thread: a burst of 6000 decimated samples is six rounds of load - barrier - filter - barrier - box filter - barrier
-// instead of twenty-four; each round is mostly the latency of its loads): the
-// noise filter reads its 25 neighbours and the start filter its 20 from LDS with unrolled loops (the first version read
-// them from HBM/L2 one dependent load per tap: 0.5 ms for 667 bursts).  The start filter's outputs are kept in the
-// burst's row of `dec` (as floats, behind the part of the row the tiles still read) for the threshold pass.
-// NT / SN: compile-time tap counts (25 / 20 at every supported rate), 0 = the runtime values.
+// post1 (steps 2b, 3, 4): post_tiles_kernel + post_cfo_kernel below.  NT / SN: compile-time tap counts (25 / 20 at every
+// supported rate), 0 = the runtime values.
 // ---------------------------------------------------------------------------
 constexpr int kPostMaxTaps = 64;
 constexpr int kPostTile = 4 * kPostThreads;
-static_assert(sizeof(float2) * (kPostTile + 2 * kPostMaxTaps) + sizeof(float) * (kPostTile + kPostMaxTaps) <= sizeof(float2) * kCfoTotal,
-              "the tile buffers live in the CFO transform's LDS");
 
 // what the host's fine-CFO step reads, stored straight into the burst's record in mapped pinned memory (system scope):
 // the helper thread is released by an event behind this kernel, no copy pass in between
@@ -1248,190 +612,11 @@ __device__ __forceinline__ void post1_publish(BurstWork &hp, const BurstWork &w)
     __threadfence_system();
 }
 
-template <int NT, int SN>
-__global__ __launch_bounds__(kPostThreads) void downmix_post1_kernel(
-    BurstWork *__restrict__ work, float2 *__restrict__ dec,
-    float2 *__restrict__ lpf, const float *__restrict__ noise_taps, int noise_ntaps_rt,
-    const float *__restrict__ start_taps, int start_ntaps_rt, int search_depth, int pre_start,
-    const float *__restrict__ cfo_window, const float2 *__restrict__ tw4096, BurstWork *__restrict__ hp_work, int order)
-{
-    __shared__ __attribute__((aligned(16))) float2 s[kCfoTotal];
-    __shared__ float redf[4];
-    __shared__ int redi[4];
-    __builtin_amdgcn_s_setprio(2);      // latency-bound, next to the decimator of the next chunk
-    const int tid = threadIdx.x;
-    BurstWork &w = work[blockIdx.x];
-    if (w.drop_reason != 0) return;
-    const int noise_ntaps = NT ? NT : noise_ntaps_rt;
-    const int start_ntaps = SN ? SN : start_ntaps_rt;
-    const int dec_len = w.dec_len;
-    float2 *x = dec + (size_t)w.dec_off;
-    float *fscr = reinterpret_cast<float *>(x);         // start-filter outputs: float i aliases x[i / 2], read long before
-    float2 *y = lpf + (size_t)w.dec_off;
-
-    // step 3 geometry (burst_downmix.c:441-478)
-    int search = search_depth < dec_len ? search_depth : dec_len;
-    int mag_len = search + start_ntaps - 1;
-    if (mag_len > dec_len) mag_len = dec_len;
-    int flen = mag_len - start_ntaps + 1;
-    if (flen > search) flen = search;
-
-    // the tile buffers live in the FFT's LDS (not in use yet)
-    float2 *xs = s;                                          // kPostTile + 2 * kPostMaxTaps samples
-    float *m2 = reinterpret_cast<float *>(s + kPostTile + 2 * kPostMaxTaps);         // kPostTile + kPostMaxTaps
-    const bool do_lpf = dec_len - noise_ntaps + 1 > 0;       // burst_downmix.c:683-698
-    const int half = (noise_ntaps - 1) / 2;
-    const int span_y = kPostTile + start_ntaps - 1;          // LPF outputs a tile's start filter needs
-    const int span_x = span_y + noise_ntaps - 1;
-    // option "fir_order" 1: the reference's AVX2 forms (simd_avx2.c) -- the outputs of a kernel's vector body take a fused
-    // multiply-add per tap, its last n % 4 (fir_ccf, mag_squared) / n % 8 (fir_fff) outputs the generic form
-    const int lpf_vec = order ? (dec_len & ~3) : 0;          // avx2_fir_ccf over dec_len outputs (burst_downmix.c:693)
-    const int mag_vec = order ? (mag_len & ~3) : 0;          // avx2_mag_squared over mag_len (burst_downmix.c:450)
-    const int box_vec = order ? (flen > 0 ? (flen & ~7) : 0) : 0;   // avx2_fir_fff over flen outputs (burst_downmix.c:458)
-    float mx = -1e30f;
-    for (int B = 0; B < dec_len; B += kPostTile) {
-        for (int q = tid; q < span_x; q += kPostThreads) {
-            const int j = B - half + q;
-            xs[q] = (j >= 0 && j < dec_len) ? x[j] : make_float2(0.0f, 0.0f);
-        }
-        __syncthreads();
-        // step 2b: centred LPF over the zero-padded burst, outputs B .. B + span_y
-        for (int p = tid; p < span_y; p += kPostThreads) {
-            if (B + p >= dec_len) break;
-            float2 v;
-            if (do_lpf) {
-                float ar = 0.0f, ai = 0.0f;
-                if (B + p < lpf_vec) {
-#pragma unroll
-                    for (int k = 0; k < (NT ? NT : 1); k++) {
-                        if (NT) {
-                            const float2 u = xs[p + k];
-                            const float t = noise_taps[k];
-                            ar = __builtin_fmaf(t, u.x, ar);
-                            ai = __builtin_fmaf(t, u.y, ai);
-                        }
-                    }
-                    if (!NT) {
-                        for (int k = 0; k < noise_ntaps; k++) {
-                            const float2 u = xs[p + k];
-                            const float t = noise_taps[k];
-                            ar = __builtin_fmaf(t, u.x, ar);
-                            ai = __builtin_fmaf(t, u.y, ai);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < (NT ? NT : 1); k++) {
-                        if (NT) {
-                            const float2 u = xs[p + k];
-                            const float t = noise_taps[k];
-                            ar += t * u.x;
-                            ai += t * u.y;
-                        }
-                    }
-                    if (!NT) {
-                        for (int k = 0; k < noise_ntaps; k++) {
-                            const float2 u = xs[p + k];
-                            const float t = noise_taps[k];
-                            ar += t * u.x;
-                            ai += t * u.y;
-                        }
-                    }
-                }
-                v = make_float2(ar, ai);
-            } else {
-                v = xs[p + half];
-            }
-            if (p < kPostTile) y[B + p] = v;
-            m2[p] = B + p < mag_vec ? mag2_fma(v) : mag2(v);
-        }
-        __syncthreads();
-        // step 3, first half: the box filter over |y|^2
-        for (int o = tid; o < kPostTile && B + o < flen; o += kPostThreads) {
-            float acc = 0.0f;
-            if (B + o < box_vec) {
-#pragma unroll
-                for (int k = 0; k < (SN ? SN : 1); k++)
-                    if (SN) acc = __builtin_fmaf(start_taps[k], m2[o + k], acc);
-                if (!SN)
-                    for (int k = 0; k < start_ntaps; k++) acc = __builtin_fmaf(start_taps[k], m2[o + k], acc);
-            } else {
-#pragma unroll
-                for (int k = 0; k < (SN ? SN : 1); k++)
-                    if (SN) acc += start_taps[k] * m2[o + k];
-                if (!SN)
-                    for (int k = 0; k < start_ntaps; k++) acc += start_taps[k] * m2[o + k];
-            }
-            fscr[B + o] = acc;
-            mx = acc > mx ? acc : mx;
-        }
-        __syncthreads();
-    }
-
-    int start = 0;
-    if (flen > 0) {
-        mx = block_max(mx, redf);
-        const float thr = 0.45f * mx;                       // START_THRESHOLD
-        int first = flen;
-        for (int i = tid; i < flen; i += kPostThreads) {
-            if (fscr[i] >= thr) { first = i; break; }
-        }
-        start = block_min_int(first, redi);
-        if (start > 0) {
-            start = start + (start_ntaps - 1) / 2 - pre_start;
-            if (start < 0) start = 0;
-        }
-    }
-    if (start >= dec_len - 100) {                           // burst_downmix.c:702-705
-        if (tid == 0) {
-            w.start_idx = start;
-            w.drop_reason = 3;
-            if (hp_work) post1_publish(hp_work[blockIdx.x], w);
-        }
-        return;
-    }
-    const int frame_len = dec_len - start;
-
-    // step 4 (burst_downmix.c:482-535): x^2 * blackman(256), zero-padded 4096-pt FFT
-    int n = kCfoN < frame_len ? kCfoN : frame_len;
-    for (int i = tid; i < kCfoTotal; i += kPostThreads) {
-        float2 v = make_float2(0.0f, 0.0f);
-        if (i < n) {
-            const float2 sv = y[start + i];
-            const float2 sq = cmul(sv, sv);                 // simd_csquare_window: (s*s)*w
-            const float wv = cfo_window[i];
-            v = make_float2(sq.x * wv, sq.y * wv);
-        }
-        s[bitrev((unsigned)i, 12)] = v;
-    }
-    __syncthreads();
-    fft_lds_radix2<12, kPostThreads, -1>(s, tw4096);
-    float bm = 0.0f;
-    int bi = 0;
-    for (int i = tid; i < kCfoTotal; i += kPostThreads) {
-        const float m = mag2(s[i]);
-        if (m > bm) { bm = m; bi = i; }
-    }
-    block_argmax(bm, bi, redf, redi);
-    if (tid == 0) {
-        const int idx = bi >= kCfoTotal / 2 ? bi - kCfoTotal : bi;
-        float corr = 0.0f;
-        if (bi > 0 && bi < kCfoTotal - 1) {
-            const int im1 = idx - 1 < 0 ? idx - 1 + kCfoTotal : idx - 1;
-            const int ip1 = idx + 1 < 0 ? idx + 1 + kCfoTotal : idx + 1;
-            corr = parabolic(mag2(s[im1]), bm, mag2(s[ip1]));
-        }
-        w.start_idx = start;
-        w.center_offset = ((float)idx + corr) / (float)kCfoTotal / 2.0f;
-        if (hp_work) post1_publish(hp_work[blockIdx.x], w);
-    }
-}
-
 // ---------------------------------------------------------------------------
-// post1 as TWO launches (round 6).  The one-workgroup-per-burst kernel above walks a burst tile by tile -- seven rounds of
+// post1 as TWO launches (round 6).  One workgroup per burst (rounds 1-5) walked a burst tile by tile -- seven rounds of
 // load - barrier - filter - barrier - box filter - barrier for a 6700-sample burst, each round mostly the latency of its
-// loads -- and then runs a 12-stage radix-2 transform with a barrier per stage: 87 us alone for 36 MB of data, every
-// workgroup's latency end to end, and it holds the chip that long.
+// loads -- and then ran a 12-stage radix-2 transform with a barrier per stage: 87 us alone for 36 MB of data, every
+// workgroup's latency end to end, holding the chip that long.  Now 38 + 30 us:
 //   post_tiles_kernel  grid (tiles of the longest burst, bursts): ONE tile of kPostTile outputs per workgroup -- steps 2b
 //                      and 3's box filter for all tiles of all bursts at once (the same loops on the same operands as
 //                      above); the start filter's outputs go to a row of floats of their own (`box`: the tiles of a burst
@@ -1650,54 +835,32 @@ __global__ __launch_bounds__(kPostThreads) void post_cfo_kernel(
     }
 }
 
-int g_small_wg = 256;       // threads per workgroup of the chain's little copy / threshold kernels.  Option small_wg 64: a single
-                            // wavefront finds a slot beside the decimator's resident grid where a 256-thread workgroup needs one
-                            // on all four SIMDs of a CU -- measured: nothing in run (71.1 / 71.9 against 72.5 / 71.1 Gsamples/s,
-                            // 12 MHz dense 25.5 / 25.5 against 26.0 / 25.5), every stage serial 1.82 against 1.88 ms
-int g_post_generic = 0;     // test hook: 1 = the runtime-tap-count instance of post1 / post2
-int g_rot_store = 1;        // rot_phase: 1 = the phases leave as rows through LDS (rot_phase_rows_kernel), 0 = a row per lane
-
-int g_post_split = 1;       // post1: 1 = post_tiles_kernel + post_cfo_kernel (a tile per workgroup, the pruned transform), 0 = one
-                            // workgroup per burst (downmix_post1_kernel)
-
 int launch_downmix_post1(BurstWork *work, int n_bursts, int max_dec_len, float2 *dec,
                          float2 *lpf, float *box, const float *noise_taps, int noise_ntaps,
                          const float *start_taps, int start_ntaps, int search_depth, int pre_start,
                          const float *cfo_window, const float2 *tw4096, BurstWork *hp_work, hipStream_t stream,
-                         unsigned long long *kclk)
+                         unsigned long long *kclk, int order, int generic)
 {
     if (n_bursts <= 0) return 0;
     if (noise_ntaps > kPostMaxTaps || start_ntaps > kPostMaxTaps) return -1;
-    const bool fixed = noise_ntaps == 25 && start_ntaps == 20 && !g_post_generic;
-    if (g_post_split) {
-        const dim3 grid((unsigned)((max_dec_len + kPostTile - 1) / kPostTile), (unsigned)n_bursts);
-        if (grid.x > 0) {
-            if (fixed)
-                hipLaunchKernelGGL((post_tiles_kernel<25, 20>), grid, dim3(kPostThreads), 0, stream, work, dec, lpf, box, noise_taps,
-                                   noise_ntaps, start_taps, start_ntaps, search_depth, g_fir_order, kclk);
-            else
-                hipLaunchKernelGGL((post_tiles_kernel<0, 0>), grid, dim3(kPostThreads), 0, stream, work, dec, lpf, box, noise_taps,
-                                   noise_ntaps, start_taps, start_ntaps, search_depth, g_fir_order, kclk);
-        } else if (launch_kclk_fold(kclk, stream) != 0) {
-            return -1;
-        }
+    const bool fixed = noise_ntaps == 25 && start_ntaps == 20 && !generic;
+    const dim3 grid((unsigned)((max_dec_len + kPostTile - 1) / kPostTile), (unsigned)n_bursts);
+    if (grid.x > 0) {
         if (fixed)
-            hipLaunchKernelGGL((post_cfo_kernel<20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, lpf, box, start_ntaps,
-                               search_depth, pre_start, cfo_window, tw4096, hp_work);
+            hipLaunchKernelGGL((post_tiles_kernel<25, 20>), grid, dim3(kPostThreads), 0, stream, work, dec, lpf, box, noise_taps,
+                               noise_ntaps, start_taps, start_ntaps, search_depth, order, kclk);
         else
-            hipLaunchKernelGGL((post_cfo_kernel<0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, lpf, box, start_ntaps,
-                               search_depth, pre_start, cfo_window, tw4096, hp_work);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
+            hipLaunchKernelGGL((post_tiles_kernel<0, 0>), grid, dim3(kPostThreads), 0, stream, work, dec, lpf, box, noise_taps,
+                               noise_ntaps, start_taps, start_ntaps, search_depth, order, kclk);
+    } else if (launch_kclk_fold(kclk, stream) != 0) {
+        return -1;
     }
-    if (launch_kclk_fold(kclk, stream) != 0) return -1;
     if (fixed)
-        hipLaunchKernelGGL((downmix_post1_kernel<25, 20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
-                           lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                           pre_start, cfo_window, tw4096, hp_work, g_fir_order);
+        hipLaunchKernelGGL((post_cfo_kernel<20>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, lpf, box, start_ntaps,
+                           search_depth, pre_start, cfo_window, tw4096, hp_work);
     else
-        hipLaunchKernelGGL((downmix_post1_kernel<0, 0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, dec,
-                           lpf, noise_taps, noise_ntaps, start_taps, start_ntaps, search_depth,
-                           pre_start, cfo_window, tw4096, hp_work, g_fir_order);
+        hipLaunchKernelGGL((post_cfo_kernel<0>), dim3(n_bursts), dim3(kPostThreads), 0, stream, work, lpf, box, start_ntaps,
+                           search_depth, pre_start, cfo_window, tw4096, hp_work);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1775,35 +938,9 @@ __device__ __forceinline__ RotStart rot_phase_start(BurstWork *__restrict__ work
     return RotStart{ live, w_drop, w_dec_len, w_start, w_simplex, inc_re, inc_im };
 }
 
-// rot_store 0: every lane stores into its own row, two phases per 16-byte store (one phase per store: the number of cache
-// lines a store instruction touches, 64, set the pace: 0.24 ms against 0.11)
-__global__ __launch_bounds__(64) void rot_phase_kernel(BurstWork *__restrict__ work, int n_bursts,
-                                                       float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
-                                                       CfoStep cfo)
-{
-    const RotStart s0 = rot_phase_start(work, n_bursts, hp_work, cfo);
-    if (!s0.live || s0.drop != 0) return;
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    const int frame_len = s0.dec_len - s0.start;
-    const int L = frame_len < frame_need(s0.simplex) ? frame_len : frame_need(s0.simplex);
-    const float2 inc = make_float2(s0.inc_re, s0.inc_im);
-    float2 ph = make_float2(1.0f, 0.0f);
-    float2 *r = rrc_ws + (size_t)b * kFrameNeed;
-    static_assert(kFrameNeed % 2 == 0, "rows start 16-byte aligned");
-    int k = 0;
-    for (; k + 2 <= L; k += 2) {
-        const float2 p0 = ph;
-        ph = cmul(ph, inc);
-        const float2 p1 = ph;
-        ph = cmul(ph, inc);
-        *reinterpret_cast<float4 *>(r + k) = make_float4(p0.x, p0.y, p1.x, p1.y);
-    }
-    if (k < L) r[k] = ph;
-}
-
-// rot_store 1 (default): the phases leave as rows; 3: the same with plain stores under a branch instead of buffer stores
-// (what told the store hazard below from an LDS problem)
-template <int PITCH, bool BUF>
+// the phases leave as rows (a row per lane -- rounds 2-4 -- touched 64 cache lines per store instruction: 0.24 ms against 0.11;
+// the same rows with plain stores under a branch instead of buffer stores told the store hazard below from an LDS problem)
+template <int PITCH>
 __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restrict__ work, int n_bursts,
                                                             float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
                                                             CfoStep cfo)
@@ -1895,13 +1032,9 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
         const int k = u * kRotTile + 2 * part;
 #pragma unroll
         for (int p = 0; p < 8; p++)
-            if (BUF)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                       r_rows, k < len_of[p] ? off_of[p] + u * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
-                                                       0, 0);
-            else if (k < len_of[p])
-                *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rrc_ws + (size_t)wg0 * kFrameNeed) + off_of[p] +
-                                            u * kRotTile * (int)sizeof(float2)) = make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                   r_rows, k < len_of[p] ? off_of[p] + u * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
+                                                   0, 0);
     };
     auto order = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1921,13 +1054,9 @@ __global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restric
                 ph = cmul(ph, inc);
                 if (j & 1) {
                     const int p = j >> 1;
-                    if (BUF)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                               r_rows, k < len_of[p] ? off_of[p] + (t - 1) * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
-                                                               0, 0);
-                    else if (k < len_of[p])
-                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(rrc_ws + (size_t)wg0 * kFrameNeed) + off_of[p] +
-                                                    (t - 1) * kRotTile * (int)sizeof(float2)) = make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                           r_rows, k < len_of[p] ? off_of[p] + (t - 1) * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
+                                                           0, 0);
                 }
             }
             order();
@@ -2113,28 +1242,23 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
                          const float *rrc_taps, int rrc_ntaps, const float2 *tw2048,
                          const float2 *dl_fft, const float2 *ul_fft, int dl_len, int ul_len,
                          float sps, float2 *rrc_ws, float2 *frames, const BurstWork *hp_work, const CfoStep &cfo,
-                         hipStream_t stream)
+                         hipStream_t stream, int order, int generic)
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    if (g_rot_store == 1)
-        hipLaunchKernelGGL((rot_phase_rows_kernel<17, true>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
-    else if (g_rot_store == 3)
-        hipLaunchKernelGGL((rot_phase_rows_kernel<17, false>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
-    else
-        hipLaunchKernelGGL(rot_phase_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
-    if (rrc_ntaps == 51 && !g_post_generic) {
+    hipLaunchKernelGGL((rot_phase_rows_kernel<17>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    if (rrc_ntaps == 51 && !generic) {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((downmix_post2_kernel<51>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
                            rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
-                           rrc_ws, frames, g_fir_order);
+                           rrc_ws, frames, order);
     } else {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<0>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((downmix_post2_kernel<0>), dim3(n_bursts), dim3(kPostThreads), lds, stream, work, lpf,
                            rrc_taps, rrc_ntaps, tw2048, dl_fft, ul_fft, dl_len, ul_len, sps,
-                           rrc_ws, frames, g_fir_order);
+                           rrc_ws, frames, order);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

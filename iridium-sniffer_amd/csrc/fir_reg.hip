@@ -39,11 +39,7 @@ namespace irdm {
 
 #include "fir_mac.inc"
 
-int g_fir_strip = 3;           // double blocks (128 columns) per strip: a strip yields 128*g_fir_strip - NR outputs
-int g_chain_cus = 0;           // CUs the per-burst chains' streams may use (0: all of them)
-int g_fir_grid = -1;           // > 0: at most this many single-wavefront workgroups in flight, each walking strips; 0: one per
-                               // strip; -1 (default): fir_decimate_kernel_f seven per CU, fir_decimate_kernel_r one per strip
-int g_fir_slice = 0;           // > 0: strips per launch (the chunk's strips as several launches); 0: one launch
+constexpr int kFirStrip = 3;   // double blocks (128 columns) per strip of fir_decimate_kernel_r: a strip yields 128 * kFirStrip - NR outputs
 
 template <int M>
 struct FirR {
@@ -55,11 +51,7 @@ struct FirR {
 int fir_reg_supported(int decim) { return decim == 40 || decim == 48; }
 
 // outputs per strip (= FirTile unit of the host's tile count)
-int fir_reg_tile_out(int decim)
-{
-    int s = g_fir_strip < 1 ? 1 : (g_fir_strip > 64 ? 64 : g_fir_strip);
-    return 128 * s - kFirTaps / decim;
-}
+int fir_reg_tile_out(int decim) { return 128 * kFirStrip - kFirTaps / decim; }
 
 // 8 consecutive samples (16-byte aligned in every format), converted exactly as load_iq does
 template <int FMT>
@@ -378,11 +370,10 @@ __device__ __forceinline__ void fir_fetch_column(const SampleSource &src, const 
     }
 }
 
-template <int M, int FMT, bool CLAIM = false>
+template <int M, int FMT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_decimate_kernel_f(
     SampleSource src, const FirGeom *__restrict__ geom, const float *__restrict__ taps,
-    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk,
-    unsigned *__restrict__ next_tile)
+    const float2 *__restrict__ rot_table, float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk)
 {
     using R = FirR<M>;
     constexpr int NR = R::NR, REM = R::REM;
@@ -391,21 +382,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     static_assert(M % 4 == 0 && VT % 8 == 0 && (kFirTaps - 1) % 4 == 0, "tap k -> accumulator k % 4 = (k % M) % 4; one tap left over");
     const int lane = threadIdx.x;
     kclk_enter(kclk);
-    // Strips: fixed shares (tile += gridDim.x), or -- option fir_claim, off: measured slower -- the workgroup's first strip
-    // its index and every further one CLAIMED from a counter (next_tile, zeroed by fir_geom_kernel): a resident grid with
-    // fixed shares ends when its slowest wavefront does, and in run the wavefronts that share a SIMD with the lane-per-burst
-    // kernels of the other chains fall behind (0.46 ms in run against 0.33 alone at four contexts); the claim for the strip
-    // after this one is made before this one's work.
-    // (a template parameter: the claim's few registers cost the fixed-share kernel a 20-byte spill when both lived in one body)
-    const bool claim = CLAIM && next_tile != nullptr && (int)gridDim.x < n_tiles;
+    // Strips in fixed shares (tile += gridDim.x) of a resident grid.  (Strips claimed from a counter -- a resident grid with
+    // fixed shares ends when its slowest wavefront does -- measured slower, 0.54 against 0.33 ms alone: the strip index
+    // reached the geometry record's scalar loads through an atomic and a v_readfirstlane at every strip,
+    // profiles/r5_fir_claim.json.)
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < n_tiles;) {
-        int tile_next = tile + (int)gridDim.x;
-        if (CLAIM && claim) {
-            unsigned c = 0;
-            if (lane == 0) c = atomicAdd(next_tile, 1u);
-            tile_next = (int)gridDim.x + (int)__builtin_amdgcn_readfirstlane((int)c);
-        }
+        const int tile_next = tile + (int)gridDim.x;
         const FirGeom g = geom[tile];
         tile = tile_next;
         const int n_cols = g.n_out + NR;                     // columns that feed a stored output (<= 128)
@@ -517,57 +500,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     kclk_leave(kclk);
 }
 
-int g_fir_claim = 0;           // 1: the resident grid of fir_decimate_kernel_f claims its strips from a counter; 0 (default): fixed shares.
-                               // Measured (profiles/r5_fir_claim.json): with the claim the kernel takes 0.54 ms ALONE against 0.33 -- the strip
-                               // index reaches the geometry record's scalar loads through an atomic and a v_readfirstlane at every strip --
-                               // and 58-59 Gsamples/s against 68.5-70.2 in run: fixed shares stay.
-
 template <int M>
 static int launch_fir_f_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
-                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk, unsigned *next_tile)
+                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
 {
-    if (!g_fir_claim) next_tile = nullptr;
-    // Workgroups: by default a resident grid of seven single-wavefront workgroups per CU that walk the strips, i.e. seven
-    // of a CU's eight 256-register slots (two per SIMD) -- the eighth is where the waves of K1, the scan's passes and
-    // the per-burst filters of the other streams live while this kernel runs.  Measured (10 MHz, in run, six / seven per
-    // CU): the decimator's own span 0.55 -> 0.41 / 0.40 ms, the step 1.09 -> 1.06-1.09 / 1.08 ms against one workgroup
-    // per strip, whose short-lived waves (40 000 per chunk) lose every freed slot to the higher-priority streams (12 MHz
-    // dense, six: 2.7 -> 2.2 ms, step 3.13 -> 2.96 ms).  Option fir_grid: n > 0 workgroups, 0 one per strip.
-    int grid = n_tiles;
-    if (g_fir_grid > 0) grid = g_fir_grid < n_tiles ? g_fir_grid : n_tiles;
-    else if (g_fir_grid < 0) {
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-            if (n_cu <= 0) n_cu = 256;
-        }
-        // (the per-burst chains' streams may be masked off some CUs -- IRDM_CHAIN_CU_RESERVE --: the resident grid is
-        // seven per CU THEY may use; sized for the whole device, the workgroups that found no slot ran as a second round
-        // and doubled the kernel's time: what round 5's first CU-mask measurement, 0.61 ms, had measured)
-        const int cus = g_chain_cus > 0 && g_chain_cus < n_cu ? g_chain_cus : n_cu;
-        if (7 * cus < n_tiles) grid = 7 * cus;
+    // A resident grid of seven single-wavefront workgroups per CU that walk the strips, i.e. seven of a CU's eight
+    // 256-register slots (two per SIMD) -- the eighth is where the waves of K1, the scan's passes and the per-burst filters of
+    // the other streams live while this kernel runs.  Measured (10 MHz, in run, six / seven per CU): the decimator's own span
+    // 0.55 -> 0.41 / 0.40 ms, the step 1.09 -> 1.06-1.09 / 1.08 ms against one workgroup per strip, whose short-lived waves
+    // (40 000 per chunk) lose every freed slot to the higher-priority streams; five and six per CU again in round 6: 70.2 /
+    // 72.7 against 74.1-74.4 Gsamples/s (profiles/r6_option_ab.json).
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
     }
-    if (next_tile != nullptr) {
-        if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
-        else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
-        else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0, true>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
-        return hipGetLastError() == hipSuccess ? 0 : -1;
-    }
-    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
-    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
-    else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk, next_tile);
+    const int grid = 7 * n_cu < n_tiles ? 7 * n_cu : n_tiles;
+    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_f<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    else hipLaunchKernelGGL((fir_decimate_kernel_f<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int launch_fir_fma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
-                   const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk, unsigned *next_tile)
+                   const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
 {
     if (src.ring_len % 8 != 0 || src.ref_ring % 8 != 0 || (src.chunk_start != ~0ull && src.chunk_start % 8 != 0)) return 1;
     switch (decim) {
-    case 40: return launch_fir_f_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk, next_tile);
-    case 48: return launch_fir_f_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk, next_tile);
+    case 40: return launch_fir_f_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
+    case 48: return launch_fir_f_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
     default: return 1;
     }
 }
@@ -576,20 +539,10 @@ template <int M>
 static int launch_fir_r_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
                             const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
 {
-    // Slices (option fir_slice): the strips of a chunk as several launches of `g_fir_slice` strips each.  A wavefront of
-    // this kernel owns half a SIMD's registers for its whole life and the dispatcher refills a freed slot from the SAME
-    // launch: next to one launch of 12 000 strips a pass of the detector scan (another stream, higher priority) that
-    // arrives after the first generation of wavefronts waits until the launch has drained (measured: passes of 60-90 us
-    // stretched to 350-390 us).  The strips of a generation end together anyway (equal lengths), so a launch boundary per
-    // generation costs a dispatch (~2 us) and lets everything that is waiting in.
-    const int slice = g_fir_slice > 0 && g_fir_grid <= 0 ? g_fir_slice : n_tiles;
-    for (int t0 = 0; t0 < n_tiles; t0 += slice) {
-        const int cnt = n_tiles - t0 < slice ? n_tiles - t0 : slice;
-        const int grid = g_fir_grid > 0 && g_fir_grid < cnt ? g_fir_grid : cnt;
-        if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 2>), dim3(grid), dim3(64), 0, stream, src, geom + t0, taps, rot_table, dec, cnt, kclk);
-        else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 1>), dim3(grid), dim3(64), 0, stream, src, geom + t0, taps, rot_table, dec, cnt, kclk);
-        else hipLaunchKernelGGL((fir_decimate_kernel_r<M, 0>), dim3(grid), dim3(64), 0, stream, src, geom + t0, taps, rot_table, dec, cnt, kclk);
-    }
+    // one single-wavefront workgroup per strip
+    if (src.fmt == 2) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 2>), dim3(n_tiles), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    else if (src.fmt == 1) hipLaunchKernelGGL((fir_decimate_kernel_r<M, 1>), dim3(n_tiles), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
+    else hipLaunchKernelGGL((fir_decimate_kernel_r<M, 0>), dim3(n_tiles), dim3(64), 0, stream, src, geom, taps, rot_table, dec, n_tiles, kclk);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -607,230 +560,6 @@ int launch_fir_reg(const SampleSource &src, const FirGeom *geom, int n_tiles, in
     switch (decim) {
     case 40: return launch_fir_r_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
     case 48: return launch_fir_r_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
-    default: return 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The decimator on the matrix cores (option fir_layout 4; fir_order 1 only): avx2_fir_ccf_dec's arithmetic as a
-// Toeplitz-taps x samples product on v_mfma_f32_16x16x4_f32.
-//
-// fir_decimate_kernel_f above issues one v_pk_fma_f32 per tap and output pair and is bound by that instruction's issue
-// rate (42 TFLOP/s useful at 53 % of the HBM roofline, beside a K1 that wants the same pipe).  The f32-input MFMA is an
-// fmaf chain in k order, bit for bit (tools/ubench/mfma_fir.hip -> profiles/r5_mfma_fir.txt: the instruction against
-// fma(a[k], b[k], acc), k = 0..3, on 512 000 values with zeros, -0, large and small operands; the whole filter against the
-// host's loop on 262 144 outputs, M = 40 and 48: no differing bit), and fma(0, y, acc) == acc: for ONE polyphase j
-//
-//   D[i][n] += sum_k A[i][k] * B[k][n]     i   16 consecutive outputs q0 + i of a strip (the row group)
-//                                          n   16 real streams: (re, im) of 8 strips filtered side by side
-//                                          k   4 consecutive positions u = 4 s + kk of the sequence y_j[u] = y[q0 M + 4 u + j]
-//   A[i][k] = t[4 (u - (M/4) i) + j], zero outside taps 0..799 (the Toeplitz band);  B[k][n] = y_j[u] of stream n
-//
-// with s ascending over the 88 (M = 40) / 96 (48) steps that a row group's positions take, every accumulator sees its taps
-// in ascending order: acc_j = fma(t[4m + j], y[qM + 4m + j], acc_j), the AVX2 kernel's four accumulators = the four
-// wavefronts of a workgroup, summed (a0 + a2) + (a1 + a3) + t[800] * y[qM + 800] by the VALU afterwards.  57 % of the
-// multiply-adds the instruction performs are the filter's (16 rows share a window of 350 positions of which 200 are a
-// row's own); the core sustains 64 TFLOP/s useful at two chains per SIMD, 50 at one (the ubench).
-//
-// A workgroup (4 wavefronts, wavefront j = polyphase j) walks an OCTET of strips (8 FirGeom tiles of kFirMfmaTile
-// outputs) 16 outputs at a time.  The rotated samples of the 8 strips live in LDS, de-interleaved by polyphase and
-// stream, S[j][n][position mod CP], a circular window: a step's chain reads WSEG segments (16 samples = 4 positions each)
-// while the M segments per strip the NEXT step adds are loaded (fir_fetch_column<16>: the ring, the stale tail, every
-// format, exactly as above), rotated from their checkpoint (a segment starts on one) and written behind the window --
-// WSEG + M segments = the buffer (128 at M = 40: 132 KB; 144 at 48: 148 KB).  Every sample is fetched and rotated ONCE
-// per tile (tiles overlap by the window's 88 segments per 256 outputs: 1.07 x the algorithmic bytes).  A operands: 88 / 96
-// VGPRs per lane, the same for every row group; B: one ds_read_b32 per MFMA, lane (kk, n) -> bank 4 n + kk.
-//
-// What the form costs in exactness: nothing for finite samples.  A NaN or infinity among the samples poisons the (up to
-// 15) outputs of its row group whose taps there are ZERO (0 x inf), where the reference's outputs further than 800 samples
-// away stay finite: cf32 input with non-finite samples is outside this kernel's contract (ci8 / ci16 cannot produce them).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kFirMfmaTile = 256;          // outputs per FirTile (16 row groups)
-int fir_mfma_tile_out(int) { return kFirMfmaTile; }
-
-typedef float f32x4_t __attribute__((vector_size(16)));
-
-template <int M>
-struct FirX {
-    static constexpr int Q = M / 4;                                     // positions of one polyphase per output
-    static constexpr int STEPS = ((15 * Q + 200 + 1) + 3) / 4;          // MFMA steps per row group: positions 0 .. 15 Q + 200 (the tail tap's)
-    static constexpr int WSEG = STEPS;                                  // segments (4 positions) a row group's window holds
-    static constexpr int ADV = M;                                       // segments a step adds: 16 outputs x M samples / 16
-    static constexpr int CSEG = WSEG + ADV;                             // the buffer, in segments
-    static constexpr int CP = 4 * CSEG;                                 // ... in positions
-    static constexpr int PITCH = (CP + 63) / 64 * 64 + 4;               // words per (polyphase, stream): == 4 (mod 64)
-    static constexpr size_t LDS = ((size_t)4 * 16 * PITCH + 4 * 16 * 16) * 4 + 8 * sizeof(FirGeom);
-    static_assert(M % 16 == 0 || M % 16 == 8, "geometry");
-    static_assert(LDS <= 160 * 1024, "the window does not fit the LDS");
-};
-
-template <int M, int FMT>
-__global__ __launch_bounds__(256) void fir_decimate_kernel_x(SampleSource src, const FirGeom *__restrict__ geom,
-                                                             const float *__restrict__ taps, const float2 *__restrict__ rot_table,
-                                                             float2 *__restrict__ dec, int n_tiles, unsigned long long *__restrict__ kclk)
-{
-    using X = FirX<M>;
-    constexpr int Q = X::Q, STEPS = X::STEPS, ADV = X::ADV, CSEG = X::CSEG, CP = X::CP, PITCH = X::PITCH;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fir_x_lds[];
-    float *S = reinterpret_cast<float *>(fir_x_lds);                            // [4 j][16 n][PITCH]
-    float *Cx = S + (size_t)4 * 16 * PITCH;                                     // [4 j][16 rows][16 cols]
-    FirGeom *G = reinterpret_cast<FirGeom *>(Cx + 4 * 16 * 16);                 // the octet's 8 tiles
-    const int tid = threadIdx.x, lane = tid & 63, j = tid >> 6;
-    const int kk = lane >> 4, col = lane & 15;
-    kclk_enter(kclk);
-
-    // this wavefront's A operands: lane (kk, i) of step s holds t[4 (4 s + kk - Q i) + j], zero outside taps 0..799
-    float a_reg[STEPS];
-#pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-        const int u = 4 * s + kk - Q * col;                 // (col doubles as the A operand's row index i = lane & 15)
-        a_reg[s] = (u >= 0 && u < 200) ? taps[4 * u + j] : 0.0f;
-    }
-    const float t_last = taps[kFirTaps - 1];
-
-    // one segment task: segment `seg` of strip `st` -> 16 raw samples (fetch), then rotate + write (finish)
-    auto fetch = [&](int st, int seg, v2f *y) {
-        const FirGeom g = G[st];
-        fir_fetch_column<16, FMT>(src, g, seg, g.n_seg, y);
-    };
-    auto finish = [&](int st, int seg, v2f *y) {
-        const FirGeom &g = G[st];
-        const int sg = seg < g.n_seg ? seg : 0;             // (a segment beyond the strip was fetched as segment 0: finite filler)
-        const float2 c = rot_table[fir_ck(g, sg)];
-        v2f ph = { c.x, c.y };
-        const v2f inc = { g.inc_re, g.inc_im };
-#pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const v2f r = cmul_pk(y[u], ph);                // out[i] = in[i] * phase (rotator.h:38)
-            ph = cmul_pk(ph, inc);                          // phase *= incr          (rotator.h:39)
-            y[u] = r;
-        }
-        // sample 16 seg + u: polyphase u & 3, position 4 seg + (u >> 2); four positions of a polyphase with one 16-byte store
-        const int p = 4 * (seg % CSEG);
-#pragma unroll
-        for (int jj = 0; jj < 4; jj++) {
-            float *re = S + ((size_t)(jj * 16 + 2 * st)) * PITCH + p;
-            *reinterpret_cast<float4 *>(re) = make_float4(y[jj].x, y[jj + 4].x, y[jj + 8].x, y[jj + 12].x);
-            *reinterpret_cast<float4 *>(re + PITCH) = make_float4(y[jj].y, y[jj + 4].y, y[jj + 8].y, y[jj + 12].y);
-        }
-    };
-
-    const int n_octets = (n_tiles + 7) / 8;
-#pragma unroll 1
-    for (int oc = blockIdx.x; oc < n_octets; oc += gridDim.x) {
-        __syncthreads();                                    // (the previous octet's last reads of G and S)
-        if (tid < 8) {
-            const int t = oc * 8 + tid;
-            FirGeom g = geom[t < n_tiles ? t : n_tiles - 1];
-            if (t >= n_tiles) {                             // (an octet's missing strips: nothing stored, filler samples)
-                g.n_out = 0;
-                g.n_seg = 0;
-            }
-            G[tid] = g;
-        }
-        __syncthreads();
-        int max_out = 0;
-#pragma unroll
-        for (int st = 0; st < 8; st++) max_out = max(max_out, G[st].n_out);
-        const int n_groups = (max_out + 15) / 16;
-        // ---- the first window: segments 0 .. WSEG - 1 of the 8 strips ----
-#pragma unroll 1
-        for (int t0 = 0; t0 < 8 * X::WSEG; t0 += 256) {
-            // (every lane fetches -- the fetch votes across the wavefront --, the lanes beyond the last task a task again)
-            const bool valid = t0 + tid < 8 * X::WSEG;
-            const int task = valid ? t0 + tid : 8 * X::WSEG - 1;
-            v2f y[16];
-            const int st = task / X::WSEG, seg = task % X::WSEG;
-            fetch(st, seg, y);
-            if (valid) finish(st, seg, y);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int g = 0; g < n_groups; g++) {
-            // ---- the segments the NEXT step adds: requested now, rotated and written behind this step's chain ----
-            const bool more = g + 1 < n_groups;
-            v2f ya[16], yb[16];
-            const int ta = tid, tb = 256 + tid;             // (8 ADV = 320 / 384 tasks: two rounds)
-            const int sta = ta / ADV, sega = X::WSEG + ADV * g + ta % ADV;
-            const int stb = tb / ADV, segb = X::WSEG + ADV * g + tb % ADV;
-            const bool has_b = tb < 8 * ADV;
-            if (more) {
-                fetch(sta, sega, ya);
-                if (has_b) fetch(stb, segb, yb);
-            }
-            // ---- the chain: STEPS dependent MFMAs, B from the circular window ----
-            f32x4_t acc = { 0.0f, 0.0f, 0.0f, 0.0f };
-            {
-                const float *bp = S + ((size_t)(j * 16 + col)) * PITCH;
-                int p = (4 * ADV * g + kk) % CP;
-#pragma unroll
-                for (int s = 0; s < STEPS; s++) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_reg[s], bp[p], acc, 0, 0, 0);
-                    p += 4;
-                    p = p >= CP ? p - CP : p;
-                }
-            }
-            if (more) {
-                finish(sta, sega, ya);
-                if (has_b) finish(stb, segb, yb);
-            }
-            // ---- combine the four accumulators, add the tail tap, store ----
-            // D: lane l, register r holds row 4 (l >> 4) + r, column l & 15
-#pragma unroll
-            for (int r = 0; r < 4; r++) Cx[((size_t)j * 16 + 4 * kk + r) * 16 + col] = acc[r];
-            __syncthreads();
-            {
-                // thread -> (strip, row, re | im): a strip's 16 x 2 values are 128 contiguous bytes of `dec`
-                const int st = tid >> 5, row = (tid >> 1) & 15, comp = tid & 1, n = 2 * st + comp;
-                const float *c = Cx + (size_t)row * 16 + n;
-                const float a0 = c[0], a1 = c[256], a2 = c[512], a3 = c[768];
-                int pt = (4 * ADV * g + Q * row + 200) % CP;             // sample (q0 + row) M + 800: polyphase 0
-                const float yt = S[(size_t)n * PITCH + pt];
-                const float v = ((a0 + a2) + (a1 + a3)) + t_last * yt;
-                const int q = 16 * g + row;
-                if (q < G[st].n_out) reinterpret_cast<float *>(dec + G[st].out_base + q)[comp] = v;
-            }
-            __syncthreads();
-        }
-    }
-    kclk_leave(kclk);
-}
-
-template <int M>
-static int launch_fir_x_fmt(const SampleSource &src, const FirGeom *geom, int n_tiles, const float *taps,
-                            const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
-{
-    using X = FirX<M>;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    // one workgroup per CU (the window takes most of the LDS), each walking octets of strips
-    const int n_octets = (n_tiles + 7) / 8;
-    int grid = g_fir_grid > 0 ? g_fir_grid : n_cu;
-    if (grid > n_octets) grid = n_octets;
-#define IRDM_LAUNCH_FIR_X(FMTv)                                                                                          \
-    {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void *)fir_decimate_kernel_x<M, FMTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X::LDS); \
-        hipLaunchKernelGGL((fir_decimate_kernel_x<M, FMTv>), dim3(grid), dim3(256), X::LDS, stream, src, geom, taps, rot_table, dec, n_tiles, kclk); \
-    }
-    if (src.fmt == 2) IRDM_LAUNCH_FIR_X(2)
-    else if (src.fmt == 1) IRDM_LAUNCH_FIR_X(1)
-    else IRDM_LAUNCH_FIR_X(0)
-#undef IRDM_LAUNCH_FIR_X
-    return hipGetLastError() == hipSuccess ? 0 : -1;
-}
-
-int launch_fir_mfma(const SampleSource &src, const FirGeom *geom, int n_tiles, int decim, const float *taps,
-                    const float2 *rot_table, float2 *dec, hipStream_t stream, unsigned long long *kclk)
-{
-    if (src.ring_len % 8 != 0 || src.ref_ring % 8 != 0 || (src.chunk_start != ~0ull && src.chunk_start % 8 != 0)) return 1;
-    switch (decim) {
-    case 40: return launch_fir_x_fmt<40>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
-    case 48: return launch_fir_x_fmt<48>(src, geom, n_tiles, taps, rot_table, dec, stream, kclk);
     default: return 1;
     }
 }

@@ -193,9 +193,10 @@ int transfer(irdm_group *g, std::vector<ncclComm_t> &comms, int src, const void 
 {
     if (bytes == 0) return 0;
     if (src == dst && !g->loopback) {
-        // (hipMemcpyAsync, i.e. the DMA engines, unless option copy_wide asks for the copy kernel)
+        // (hipMemcpyAsync, i.e. the DMA engines, beside the kernels)
         GRP_HIP(hipSetDevice(g->m[dst].dev));
-        return irdm::launch_copy_wide(to, from, bytes, s_dst);
+        GRP_HIP(hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, s_dst));
+        return 0;
     }
     Rccl *r = rccl();
     GRP_NCCL(r->GroupStart());

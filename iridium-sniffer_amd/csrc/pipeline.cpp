@@ -74,6 +74,7 @@ int ilog2(int n)
 // ===========================================================================
 struct gpu_burst_fft {
     int n, log_n, batch;
+    int order;                  // fftshift_mag in the reference's AVX2 form (1: what an x86 host with AVX2 computes) or its generic form (0)
     float *d_window;
     float2 *d_tw;
     float2 *d_in;
@@ -97,6 +98,7 @@ extern "C" gpu_burst_fft_t *gpu_burst_fft_create(int fft_size, int batch_size, c
     g->n = fft_size;
     g->log_n = lg;
     g->batch = batch_size;
+    g->order = getenv("IRDM_NO_SIMD") ? 0 : 1;          // (the plug point has no option call: the reference's --no-simd as an environment switch)
     std::vector<cfloat> tw = design_twiddles(fft_size);
     g->d_window = dev_upload(window, (size_t)fft_size);
     g->d_tw = reinterpret_cast<float2 *>(dev_upload(tw.data(), tw.size()));
@@ -156,7 +158,7 @@ extern "C" int gpu_burst_fft_process_device(gpu_burst_fft_t *g, const void *d_in
 {
     if (!g || !d_input || !d_output || batch_count <= 0) return -1;
     return launch_fft_mag(g->log_n, 2, d_input, g->d_window, g->d_tw, static_cast<float *>(d_output),
-                          batch_count, static_cast<hipStream_t>(stream));
+                          batch_count, static_cast<hipStream_t>(stream), nullptr, g->order);
 }
 
 extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, float *output,
@@ -166,7 +168,7 @@ extern "C" int gpu_burst_fft_process(gpu_burst_fft_t *g, const float *input, flo
     if (batch_count <= 0 || batch_count > g->batch) return -1;       // opencl/burst_fft.c:325-326
     const size_t ns = (size_t)g->n * batch_count;
     IRDM_HIP_CHECK(hipMemcpyAsync(g->d_in, input, ns * sizeof(float2), hipMemcpyHostToDevice, g->stream));
-    if (launch_fft_mag(g->log_n, 2, g->d_in, g->d_window, g->d_tw, g->d_out, batch_count, g->stream) != 0)
+    if (launch_fft_mag(g->log_n, 2, g->d_in, g->d_window, g->d_tw, g->d_out, batch_count, g->stream, nullptr, g->order) != 0)
         return -1;
     IRDM_HIP_CHECK(hipMemcpyAsync(output, g->d_out, ns * sizeof(float), hipMemcpyDeviceToHost, g->stream));
     IRDM_HIP_CHECK(hipStreamSynchronize(g->stream));
@@ -193,8 +195,8 @@ static inline float *box_of(float2 *lpf, size_t cap) { return reinterpret_cast<f
 // a period early and runs in the stretches where the chains in flight are in their lane-per-burst kernels instead of in
 // front of the decimator of every period, kernel trace in profiles/r5_kernel_trace_gantt.txt).  A slot owns a magnitude
 // buffer, K1's candidate lists with the levels they were built against, and the events of its K1 and ring copy.
-constexpr int kFeedSlots = 4;
-constexpr unsigned kLookAhead = 2;
+constexpr int kFeedSlots = 3;
+constexpr unsigned kLookAhead = 1;
 
 // One batch of finished bursts on its way through the per-burst stages K4..K7.  pipeline_depth 0 uses one context on the
 // detector's stream; pipeline_depth >= 1 alternates between two, each on a stream of its own, so that the FIR of one
@@ -216,7 +218,7 @@ struct BatchCtx {
     BurstWork *hp_work, *hp_work_dev;   // host / device view of the same mapped pinned buffer
     FirTile *hp_tiles;
     DemodOut *hp_demod;
-    DemodPacked *d_packed, *hp_packed;      // packed_records: the demodulator's result without LLRs, bits 8 per byte
+    DemodPacked *hp_packed;                 // packed_records: the demodulator's result without LLRs, bits 8 per byte (pinned; written by demod_par_kernel)
     uint32_t *hp_flag, *hp_flag_dev;    // [0] sequence number the helper publishes, [1] time-out flag of the waiting kernel
     int4 *hp_rot_new, *hp_rot_new_dev, *d_rot_new;   // (bin, row, from, to) of the checkpoint runs this batch has to build: mapped pinned / device
     uint32_t cfo_seq;
@@ -257,16 +259,8 @@ struct irdm_pipeline {
     hipStream_t sstream;     // detector scan kernels; pipeline_depth 1: a stream with CUs of its own (CU mask), so that the
                              // sequential leader wavefront is not slowed down by the per-burst kernels running beside it
     hipEvent_t ev_scan_in, ev_scan_out;
-    hipStream_t stream_side = nullptr;      // plan passes launched ahead (option band_plan_ahead)
-    hipEvent_t ev_plan_set[2][kBandRounds + 2] = {};
-    unsigned walk_launched = 0;             // BandWork::walk_host
-    // band_tail (scan_band.hip): the history copy of scan k runs on stream_side beside scan k + 1's round 0
-    hipEvent_t ev_hist_set[kFeedSlots] = {};   // recorded behind the history copy of the scan of chunk k: [k % kFeedSlots] (the magnitude buffer it reads)
-    hipEvent_t ev_hist_hop = nullptr;       // scan stream -> side stream
-    hipEvent_t ev_hist_last = nullptr;      // the latest history copy enqueued (nullptr: none): whatever touches the ring next waits for it
     // band_spec (scan_band.hip): round 0 of chunk k + 1 as a speculation pass on a second workspace and stream, beside chunk
     // k's scan; the scan of chunk k + 1 then opens with round 1
-    int chain_cu_reserved = 0;              // CUs the per-burst chains' streams are masked off (IRDM_CHAIN_CU_RESERVE)
     int band_spec_opt = 1;                  // option band_spec
     void *d_band_spec = nullptr;
     BandWork band_spec = {};
@@ -281,9 +275,10 @@ struct irdm_pipeline {
     uint32_t fl_seq = 0;                    // number of the scan in flight
     uint32_t chain_seq = 0;                 // ... of the chained launch (scan_chain_try), taken over by scan_launch
     uint64_t chain_no = 0;                  // the chunk the chained launch in flight (chain_pending) scans
-    int chain_early = 1;                    // option scan_chain_early: chain the NEXT chunk's scan before waiting for the oldest chain
-    int scan_events = 1;     // 0: no timing events around the band scan (stage time of the scan reads -1)
     int fir_order = 1;       // option fir_order / simd_order: 1 simd_avx2.c's operation order, 0 simd_generic.c's (--no-simd); per pipeline
+    int fir_generic = 0;     // test hook fir_generic: 1 = always the any-M decimator (what 2 / 4 MHz streams take)
+    int post_generic = 0;    // test hook post_generic: 1 = the runtime-tap-count instances of post_tiles / post_cfo / post2
+    irdm::BandTune band_tune;   // options band_selfcheck / band_timeline / band_sum_restart
     hipEvent_t ev_sk[2];     // bracket the scan kernel itself on sstream (last_timings[1], bench.py's roofline)
     hipEvent_t ev[10];   // 0 start,1 fft,2 scan,3 pre-fir,4 fir,5 post,6 demod,7 end,8 caller sync
 
@@ -375,7 +370,6 @@ struct irdm_pipeline {
     GoneBurst *hp_gone_set[2];
     hipEvent_t ev_sk_set[2][2], ev_end_set[2], ev_end;
     int out_sel;
-    int scan_chain;             // option (default 1): enqueue chunk k's band scan before waiting for chunk k-1's
     bool chain_pending;         // feed_end has enqueued this chunk's scan behind the previous one
     int chain_sel, chain_band_first;
     bool settle_clean;          // the scan settled last committed on its own (no continuation, retry or fallback)
@@ -406,7 +400,6 @@ struct irdm_pipeline {
     uint64_t begin_no, end_no;  // feeds begun / ended; slot = number % kFeedSlots
     uint64_t begun_samples;     // absolute index the next irdm_feed_begin starts at
     float *d_mag3;
-    float *d_mag4 = nullptr;
     double host_us[10];         // pipeline_depth >= 1, accumulated host time: K1+ring enqueue, settle, chain enqueue, scan enqueue, wait for the older chain, final sync
     std::vector<FirTile> h_tiles;
     std::vector<DemodOut> h_demod;
@@ -483,16 +476,10 @@ struct irdm_pipeline {
 static int rot_rows_prepare(irdm_pipeline *p, BatchCtx &b, int nb, hipStream_t st);
 static int rot_prebuild(irdm_pipeline *p);
 
-// Every C-ABI entry that enqueues work for a pipeline: the calling thread is put on the pipeline's device and the
-// arithmetic-order switch the launch helpers read (irdm::g_fir_order, thread-local) is set to THIS pipeline's -- two
-// contexts of one process may follow different orders (option fir_order; --no-simd of the host binary).
-static inline void pipeline_enter(const irdm_pipeline *p);
-
-static inline void pipeline_enter(const irdm_pipeline *p)
-{
-    (void)hipSetDevice(p->cfg.device);
-    irdm::g_fir_order = p->fir_order;
-}
+// Every C-ABI entry that enqueues work for a pipeline: the calling thread is put on the pipeline's device.  (Every switch a
+// launch helper reads -- the arithmetic order, the test hooks -- is a field of the pipeline and travels as an argument: two
+// contexts of one process may differ in all of them.)
+static inline void pipeline_enter(const irdm_pipeline *p) { (void)hipSetDevice(p->cfg.device); }
 
 static void pipeline_free(irdm_pipeline *p)
 {
@@ -503,8 +490,7 @@ static void pipeline_free(irdm_pipeline *p)
                      p->d_start_taps, p->d_rrc_taps, p->d_cfo_window, p->d_work, p->d_tiles, p->d_dec,
                      p->d_lpf, p->d_rrc_ws, p->d_frames, p->d_demod_ws, p->d_probe, p->d_demod, p->d_decoded, p->d_syn_ra,
                      p->d_syn_hdr, p->d_nbits, p->d_ida, p->d_syn_da, p->d_syn_l1, p->d_syn_l2, p->d_syn_l3, p->d_dirs,
-                     p->d_fir_off, p->d_mag2, p->d_mag3, p->d_mag4, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
-                     p->k1_pre[3], p->k1_counts[3], p->k1_entries[3],
+                     p->d_fir_off, p->d_mag2, p->d_mag3, p->k1_pre[1], p->k1_pre[2], p->k1_counts[1], p->k1_counts[2], p->k1_entries[1], p->k1_entries[2],
                      p->k1_pre[0] != p->d_pre ? p->k1_pre[0] : nullptr, p->k1_counts[0] != p->d_counts ? p->k1_counts[0] : nullptr,
                      p->k1_entries[0] != p->d_entries ? p->k1_entries[0] : nullptr, p->d_counts, p->d_entries, p->d_goff, p->d_compact, p->d_pre, p->d_sum_bak, p->d_hist_bak, p->d_state_bak,
                      p->d_status, p->d_mc_ops, p->d_mc_done, p->d_band, p->d_smin, p->d_kclk, p->d_state_spec };
@@ -538,7 +524,6 @@ static void pipeline_free(irdm_pipeline *p)
         if (b.hp_tiles) (void)hipHostFree(b.hp_tiles);
         if (b.hp_demod) (void)hipHostFree(b.hp_demod);
         if (b.hp_packed) (void)hipHostFree(b.hp_packed);
-        if (b.d_packed) (void)hipFree(b.d_packed);
         if (b.owns_buffers) {
             void *own[] = { b.d_work, b.d_tiles, b.d_dec, b.d_lpf, b.d_rrc_ws, b.d_frames, b.d_demod_ws, b.d_demod,
                             b.d_decoded, b.d_ida };
@@ -563,17 +548,10 @@ static void pipeline_free(irdm_pipeline *p)
     if (p->stream_rot_pre) { (void)hipStreamSynchronize(p->stream_rot_pre); (void)hipStreamDestroy(p->stream_rot_pre); }
     if (p->ev_rot_pre) (void)hipEventDestroy(p->ev_rot_pre);
     if (p->d_rot_pre_news) (void)hipFree(p->d_rot_pre_news);
-    if (p->stream_side) (void)hipStreamDestroy(p->stream_side);
     if (p->stream_spec) (void)hipStreamDestroy(p->stream_spec);
     if (p->ev_sums1) (void)hipEventDestroy(p->ev_sums1);
     if (p->ev_spec_done) (void)hipEventDestroy(p->ev_spec_done);
     if (p->d_band_spec) (void)hipFree(p->d_band_spec);
-    for (auto &set : p->ev_plan_set)
-        for (auto &e : set)
-            if (e) (void)hipEventDestroy(e);
-    for (auto &e : p->ev_hist_set)
-        if (e) (void)hipEventDestroy(e);
-    if (p->ev_hist_hop) (void)hipEventDestroy(p->ev_hist_hop);
     for (auto &e : p->ev)
         if (e) (void)hipEventDestroy(e);
     if (p->sstream && p->sstream != p->stream) (void)hipStreamDestroy(p->sstream);
@@ -594,31 +572,10 @@ static void cfo_helper_main(irdm_pipeline *p);
 // seven 256-register wavefronts per CU for 0.35-0.45 ms per chunk, on every CU it may use -- cannot hold ALL of them: a
 // 1024-thread workgroup (the scan's plan passes) needs a CU to itself and otherwise waits until the decimator's launch has
 // drained (kernel trace).  A masked stream has the default priority, not the chains' low one.
-static bool chain_stream_create(irdm_pipeline *p, hipStream_t *out, int prio)
+static bool chain_stream_create(irdm_pipeline *, hipStream_t *out, int prio)
 {
-    static const int reserve = [] {
-        const char *e = getenv("IRDM_CHAIN_CU_RESERVE");
-        const int r = e ? atoi(e) : 0;
-        return r < 0 ? 0 : r > 64 ? 64 : r;
-    }();
-    if (reserve > 0) {
-        hipDeviceProp_t prop;
-        int n_cu = hipGetDeviceProperties(&prop, p->cfg.device) == hipSuccess ? prop.multiProcessorCount : 0;
-        if (n_cu >= 64) {
-            const int words = (n_cu + 31) / 32;
-            std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
-            if (n_cu % 32) mask[(size_t)words - 1] = (1u << (n_cu % 32)) - 1u;
-            for (int r = 0; r < reserve; r++) {
-                const int w = r % words, bit = 31 - r / words;          // (one CU per mask word before a second one anywhere)
-                mask[(size_t)w] &= ~(1u << bit);
-            }
-            if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) {
-                p->chain_cu_reserved = reserve;
-                irdm::g_chain_cus = n_cu - reserve;         // (the decimator's resident grid: seven per CU it may use)
-                return true;
-            }
-        }
-    }
+    // (CU masks that keep the chains off 4-32 CUs -- hipExtStreamCreateWithCUMask -- were measured twice in round 5 and dropped:
+    // the decimator's resident grid on a masked stream took 0.61-0.67 ms, 64-66 against 71-72 Gsamples/s, profiles/r5_cu_reserve*.json)
     return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio) == hipSuccess;
 }
 
@@ -630,7 +587,6 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         fprintf(stderr, "irdm_hip: no HIP device -- there is no CPU fallback in this library\n");
         return nullptr;
     }
-    irdm::band_resolve_env();
     if (hipSetDevice(cfg->device) != hipSuccess) return nullptr;
     // IRDM_CREATE_DEBUG: where the time and the device memory of a context go (stderr)
     const bool dbg = getenv("IRDM_CREATE_DEBUG") != nullptr;
@@ -784,7 +740,6 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         if (ok) memset(p->h_pin_set[s], 0, sizeof(int) * 128);
     }
     p->out_sel = 0;
-    p->scan_chain = 1;
     p->chain_pending = false;
     p->settle_clean = true;
     p->h_pin = p->h_pin_set[0];
@@ -819,7 +774,6 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
     AL(p->d_mag, float, p->max_chunk);
     if (p->depth) AL(p->d_mag2, float, p->max_chunk);
     if (p->depth) AL(p->d_mag3, float, p->max_chunk);
-    if (p->depth) AL(p->d_mag4, float, p->max_chunk);
     AL(p->d_state, DetState, 1);
     AL(p->d_gone, GoneBurst, (size_t)p->gone_cap);
     AL(p->d_cand_a, PeakCand, (size_t)P.n);
@@ -920,15 +874,7 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         AL(p->d_smin, float, (size_t)P.n);
         if (ok) ok = hipMalloc(&p->d_band, band_work_bytes(P.n, p->max_chunk)) == hipSuccess;
         if (ok) band_work_carve(&p->band, p->d_band, P.n, p->max_chunk);
-        if (ok) {
-            p->band.walk_host = &p->walk_launched;
-            ok = hipStreamCreateWithPriority(&p->stream_side, hipStreamNonBlocking, prio_hi) == hipSuccess;
-            for (auto &set : p->ev_plan_set)
-                for (auto &e : set) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            for (auto &e : p->ev_hist_set) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            ok = ok && hipEventCreateWithFlags(&p->ev_hist_hop, hipEventDisableTiming) == hipSuccess;
-        }
-        if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // the cooperative kernel's grid barrier starts idle
+        if (ok) ok = hipMemset(p->band.bar, 0, 256) == hipSuccess;         // (no scan has committed, no launch is void)
         if (ok && p->depth) {
             // the speculation passes' workspace (one snapshot row; 0.27 GB at 64 Mi-sample chunks, most of it the sparse
             // relative-magnitude plane), carried-burst list, stream and events
@@ -983,7 +929,6 @@ extern "C" irdm_pipeline_t *irdm_create(const irdm_config_t *cfg)
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_tiles), sizeof(FirTile) * b.tiles_cap, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_demod), sizeof(DemodOut) * (size_t)p->burst_cap, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_packed), sizeof(DemodPacked) * (size_t)p->burst_cap, hipHostMallocDefault) == hipSuccess;
-        AL(b.d_packed, DemodPacked, (size_t)p->burst_cap);
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&b.hp_flag), 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
              hipHostGetDevicePointer(reinterpret_cast<void **>(&b.hp_flag_dev), b.hp_flag, 0) == hipSuccess;
         if (ok) memset(b.hp_flag, 0, 64);
@@ -1190,9 +1135,10 @@ static int ring_update(irdm_pipeline *p, const void *d_iq, uint64_t c0, uint64_t
     while (a0 < c1) {
         const uint64_t pos = a0 % p->ring_len;
         const uint64_t run = std::min<uint64_t>(c1 - a0, p->ring_len - pos);
-        if (launch_copy_wide(static_cast<char *>(p->d_ring) + pos * p->bps, static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
-                             run * p->bps, st) != 0)
-            return -1;
+        // (hipMemcpyAsync, i.e. the DMA engines, BESIDE the kernels: a copy kernel over the whole chip measured 60.7-61.0 against
+        // 64.7-65.4 Gsamples/s for chunks not fed in place, round 5)
+        IRDM_HIP_CHECK(hipMemcpyAsync(static_cast<char *>(p->d_ring) + pos * p->bps, static_cast<const char *>(d_iq) + (a0 - c0) * p->bps,
+                                      run * p->bps, hipMemcpyDeviceToDevice, st));
         a0 += run;
     }
     return 0;
@@ -1556,7 +1502,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     // (the register-resident decimator also needs the chunk to start at a multiple of 8 samples: a caller's burst window
     // presented as a chunk -- irdm_downmix_burst -- may not; such sources take the LDS kernel)
     const int fir_aligned = p->ring_len % 8 == 0 && p->ref_ring % 8 == 0 && (src.chunk_start == ~0ull || src.chunk_start % 8 == 0);
-    const int tile_out = fir_tile_out(p->decim, fir_aligned);
+    const int tile_out = fir_tile_out(p->decim, fir_aligned, p->fir_generic, p->fir_order);
     for (int i = 0; i < nb; i++) {
         const GoneBurst &g = gone_list[i];
         irdm_burst_t &r = b.recs[i];
@@ -1641,7 +1587,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
         if (!b.owns_buffers) { p->d_dec = d2; p->d_lpf = l2; }
         p->stat_scratch_grows++;
     }
-    const bool tile_list = fir_needs_tile_list(p->decim, fir_aligned) != 0;
+    const bool tile_list = fir_needs_tile_list(p->decim, fir_aligned, p->fir_generic) != 0;
     if (n_tiles > b.tiles_cap) {
         // (like the scratch above: no hipFree / hipHostFree here -- either waits for the whole device, and in the time-shard
         // flow a gated scan spins on the device until THIS thread has returned from irdm_feed_end and published the history:
@@ -1675,13 +1621,13 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     IRDM_HIP_CHECK(hipEventRecord(b.ev[0], st));
     if (launch_fir_decimate(src, b.d_work, nb, b.d_tiles, b.tiles_cap, (int)n_tiles, p->decim, p->d_in_taps,
                             p->d_fir_off, p->d_rot_incr, p->d_rot_table, p->rot_runs, b.d_dec, st,
-                            p->kclk_fir((int)(&b - p->bc)), p->d_rot_slot) != 0)
+                            p->kclk_fir((int)(&b - p->bc)), p->d_rot_slot, p->fir_order, p->fir_generic) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[1], st));
     if (launch_downmix_post1(b.d_work, nb, max_dec_len, b.d_dec, b.d_lpf, box_of(b.d_lpf, b.dec_cap), p->d_noise_taps,
                              p->noise_ntaps, p->d_start_taps, p->start_ntaps, p->search_depth,
                              p->pre_start, p->d_cfo_window, p->d_tw4096, p->dev_cfo ? nullptr : b.hp_work_dev, st,
-                             p->kclk_fir((int)(&b - p->bc))) != 0)
+                             p->kclk_fir((int)(&b - p->bc)), p->fir_order, p->post_generic) != 0)
         return -1;
     // host libm step, ordered on the stream: post1 has stored what the step reads into the burst's record in the mapped
     // pinned buffer (system scope), the helper thread runs behind this event and publishes a sequence number, a one-lane
@@ -1707,7 +1653,7 @@ static int bursts_enqueue(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
     }
     if (launch_downmix_post2(b.d_work, nb, b.d_lpf, p->d_rrc_taps, p->rrc_ntaps,
                              p->d_tw2048, p->d_dl_fft, p->d_ul_fft, p->dl_len, p->ul_len, p->sps,
-                             b.d_rrc_ws, b.d_frames, p->dev_cfo ? nullptr : b.hp_work_dev, cfo, st) != 0)
+                             b.d_rrc_ws, b.d_frames, p->dev_cfo ? nullptr : b.hp_work_dev, cfo, st, p->fir_order, p->post_generic) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(b.ev[2], st));
     // the chain's results: work records and demodulator output.  packed_records (136 bytes per burst instead of 4.5 KB: hard
@@ -1937,13 +1883,9 @@ static int process_bursts(irdm_pipeline *p, BatchCtx &b, const SampleSource &src
 // finished bursts into h_gone.  pipeline_depth 0 calls them back to back; pipeline_depth 1 calls scan_finish at the
 // start of the NEXT feed, so the detector of chunk k runs while the host returns, the caller produces chunk k+1 and
 // the FFT of chunk k+1 executes.
-// Whatever reads or writes the noise-floor history ring on the detector's stream outside a band scan (the sequential
-// scans, snapshots, state export / import) goes behind the history copy a band scan may have left on the side stream.
-static int hist_fence(irdm_pipeline *p)
-{
-    if (p->ev_hist_last) IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream, p->ev_hist_last, 0));
-    return 0;
-}
+// (every pass of a band scan, the sequential scans, snapshots and the state export / import run on the detector's one stream:
+// they are ordered by it)
+static int hist_fence(irdm_pipeline *) { return 0; }
 
 static uint32_t next_scan_seq(irdm_pipeline *p)
 {
@@ -2019,13 +1961,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
                                 uint64_t c0, const irdm_pipeline::FeedSlot *feed, int sel, int first, int chained,
                                 uint32_t seq, uint64_t chunk_no, bool use_spec = false)
 {
-    // (band_tail: this scan's history copy is recorded in the event of the magnitude buffer it reads; it waits for the latest
-    // one enqueued before -- the previous scan's, or this scan's own from an earlier launch)
-    hipEvent_t hist_done = p->ev_hist_set[chunk_no % kFeedSlots], hist_wait = p->ev_hist_last;
-    struct HistNote {
-        irdm_pipeline *p; hipEvent_t e;
-        ~HistNote() { if (irdm::g_band_tail || irdm::g_band_hist_side) p->ev_hist_last = e; }
-    } hist_note{ p, hist_done };
+    (void)seq; (void)chunk_no;
     const DetParams &P = p->P;
     const float *mag_rest = mag + (size_t)done * P.n;
     const uint64_t idx0 = c0 + (uint64_t)done * (uint64_t)P.n;           // chunks start on frame boundaries
@@ -2042,8 +1978,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
         // the first rounds left the verdict open: the remaining rounds, on the same lists and workspace
         return launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts, entries, pre,
                                 p->d_smin, p->d_gone, p->gone_cap, first, kBandRounds, hpg,
-                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, sel, p->stream, p->stream_side,
-                                p->ev_plan_set[sel], nullptr, 0, nullptr, nullptr, 0, seq, hist_wait, hist_done, p->ev_hist_hop);
+                                reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, 0, sel, p->stream, p->band_tune);
     }
     if (!from_k1 || retry) {
         if (launch_prefilter_lists(p->d_sum, P.threshold, pre, retry ? p->d_smin : nullptr, mag_rest, P.n, counts,
@@ -2052,7 +1987,7 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
     } else {
         p->stat_k1_lists++;
     }
-    if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][0], p->stream));
     const bool gate = p->gate_armed && !retry && p->hp_gate_dev;
     if (gate) {
         p->gate_armed = false;
@@ -2061,13 +1996,13 @@ static int scan_band_enqueue_at(irdm_pipeline *p, const float *mag, int n_frames
     // (use_spec: this chunk's round 0 was made by a speculation pass, spec_enqueue: the scan opens with round 1)
     if (launch_band_scan(P, p->band, p->d_state, p->d_sum, p->d_hist, mag_rest, n_frames - done, idx0, counts,
                          entries, pre, p->d_smin, p->d_gone, p->gone_cap, use_spec ? 1 : 0, first, hpg,
-                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream, p->stream_side,
-                         p->ev_plan_set[sel], gate ? p->hp_gate_dev : nullptr, p->gate_seq, gate ? p->hp_gate_dev + 1 : nullptr,
-                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n, seq, hist_wait, hist_done, p->ev_hist_hop,
+                         reinterpret_cast<uint32_t *>(pin + 64), pin + 96, p->hp_gone_cap, chained, sel, p->stream, p->band_tune,
+                         gate ? p->hp_gate_dev : nullptr, p->gate_seq, gate ? p->hp_gate_dev + 1 : nullptr,
+                         p->gate_src, sizeof(float) * (size_t)kHistory * P.n,
                          use_spec ? &p->band_spec : nullptr, p->ev_sums1) != 0)
         return -1;
     if (use_spec) p->stat_spec_scans++;
-    if (p->scan_events) IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
+    IRDM_HIP_CHECK(hipEventRecord(p->ev_sk_set[sel][1], p->stream));
     // (the control block reaches the host with the records: scan_export)
     return 0;
 }
@@ -2152,7 +2087,7 @@ static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f, uint64_t
     p->chain_pending = false;
     // (only with K1's own candidate lists: the prefilter pass that builds them otherwise writes the one set of buffers
     // the scan in front may still need for a continuation or a retry, and it runs before the chained launch's check)
-    if (!p->scan_chain || !p->fl_active || p->fl_mode != 2 || !p->fl_band_ran || !p->host_primed || scan_pick(p) != 2 ||
+    if (!p->fl_active || p->fl_mode != 2 || !p->fl_band_ran || !p->host_primed || scan_pick(p) != 2 ||
         f.frames < 1 || !f.lists)
         return 0;
     const int sel = p->out_sel ^ 1;
@@ -2180,15 +2115,13 @@ static int scan_chain_try(irdm_pipeline *p, irdm_pipeline::FeedSlot &f, uint64_t
 // tests against -- which is also behind that scan's plan pass, the one reader of the workspace this pass overwrites.
 static int spec_enqueue(irdm_pipeline *p, irdm_pipeline::FeedSlot &nx, uint64_t no)
 {
-    if (!p->band_spec_opt || !p->d_band_spec || !p->scan_chain || !p->host_primed || scan_pick(p) != 2 || nx.frames < 1 || !nx.lists ||
-        irdm::g_band_coop)
-        return 0;
+    if (!p->band_spec_opt || !p->d_band_spec || !p->host_primed || scan_pick(p) != 2 || nx.frames < 1 || !nx.lists) return 0;
     const int ls = (int)(&nx - p->fs);
     IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream_spec, nx.ev_k1, 0));
     IRDM_HIP_CHECK(hipStreamWaitEvent(p->stream_spec, p->ev_sums1, 0));
     const int have_prev = p->spec_for_no != ~0ull && p->spec_for_no + 1 == no;
     if (launch_band_spec(p->P, p->band_spec, p->d_state_spec, p->band.sum_new, nx.frames, nx.c0, p->k1_counts[ls], p->k1_entries[ls],
-                         have_prev, p->stream_spec) != 0)
+                         have_prev, p->stream_spec, p->band_tune) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(p->ev_spec_done, p->stream_spec));
     p->spec_for_no = no;
@@ -2309,7 +2242,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
         }
         p->stat_band_rounds += (uint64_t)ctl->rounds;
         p->stat_band_steps += (uint64_t)(ctl->n_upd > 0 ? ctl->n_upd : 0);      // (update steps of the last round: what the sums pass walked)
-        if (irdm::g_band_timeline && p->fl_band_ran) {
+        if (p->band_tune.timeline && p->fl_band_ran) {
             // (diagnostic) the passes' device timeline of this scan: durations, and the idle time in front of each pass
             unsigned long long tl[2 * kBandTlSlots];
             IRDM_HIP_CHECK(hipMemcpy(tl, p->band.tl + (size_t)p->out_sel * 2 * kBandTlSlots, sizeof(tl), hipMemcpyDeviceToHost));
@@ -2424,7 +2357,7 @@ static int scan_finish(irdm_pipeline *p, int *n_gone_out)
     tq1 = now_us(); p->host_us[8] += tq1 - tq0; tq0 = tq1;          // [8] the burst records' round trip
     float ms = 0;
     // the scan proper (band passes, the sparse kernel, or the dense one when it ran instead)
-    p->last_ms[1] = (p->scan_events || p->fl_mode != 2) && hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
+    p->last_ms[1] = hipEventElapsedTime(&ms, p->ev_sk[0], p->ev_sk[1]) == hipSuccess ? ms : -1.0f;
     p->last_frames = p->fl_frames;
     p->d_mag_last = p->fl_mag;
     // burst_detect.c:739: counted where the detector hands the burst over -- here, when the scan settles -- so that the
@@ -2595,14 +2528,8 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
     // K1 of this chunk.  pipeline_depth 1: on its own stream and into the other magnitude buffer, while the detector
     // scan of the previous chunk may still be running
     irdm_pipeline::FeedSlot &f = p->fs[p->begin_no % kFeedSlots];
-    float *const mags[kFeedSlots] = { p->d_mag, p->d_mag2, p->d_mag3, p->d_mag4 };
+    float *const mags[kFeedSlots] = { p->d_mag, p->d_mag2, p->d_mag3 };
     float *mag = p->depth ? mags[p->begin_no % kFeedSlots] : p->d_mag;
-    // (band_tail: the history copy of the scan that last read this magnitude buffer -- three chunks ago, one with
-    // pipeline_depth 0 -- ran on the side stream: long over, but nothing else orders K1 behind it)
-    if (p->band_ok) {
-        if (p->depth) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_set[p->begin_no % kFeedSlots]));
-        else if (p->ev_hist_last) IRDM_HIP_CHECK(hipEventSynchronize(p->ev_hist_last));
-    }
     // written in place (irdm_ingest_ptr)?  Then the ring already holds the chunk.
     const uint64_t pos = c0 % p->ring_len;
     const bool in_ring = p->depth && n_samples > 0 && pos + n_samples <= p->ring_len &&
@@ -2618,12 +2545,12 @@ extern "C" int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_sa
         if (launch_prefilter_threshold(p->d_sum, P.threshold, p->k1_pre[ls], P.n, p->fstream) != 0) return -1;
         const int rc = launch_fft_mag_lists(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->k1_pre[ls],
                                             p->k1_counts[ls], p->k1_entries[ls], band_list_cap(P.n), p->fstream,
-                                            p->kclk_rec(3 + ls % 3));
+                                            p->kclk_rec(3 + ls % 3), p->fir_order);
         if (rc < 0) return -1;
         f.lists = rc == 0;
     }
     if (!f.lists && launch_fft_mag(P.log_n, p->dev_fmt, d_iq, p->d_window, p->d_tw, mag, n_frames, p->fstream,
-                                   p->kclk_rec(3 + ls % 3)) != 0)
+                                   p->kclk_rec(3 + ls % 3), p->fir_order) != 0)
         return -1;
     IRDM_HIP_CHECK(hipEventRecord(f.ev_k1, p->fstream));
     if (n_frames > 0 && launch_kclk_fold(p->kclk_rec(3 + ls % 3), p->fstream) != 0) return -1;   // (behind the event the scan waits for)
@@ -2720,7 +2647,7 @@ extern "C" int irdm_feed_end(irdm_pipeline_t *p)
         //     the caller's polls and its next irdm_feed_begin -- took 0.4-0.8 ms, during which the scan's stream ran dry
         //     after every scan: the period was (that host time + a scan) / 2, not a scan.
         //     The same launch the next irdm_feed_end would make first thing -- it finds it done.
-        if (p->chain_early && p->begin_no > p->end_no + 1 && !p->chain_pending &&
+        if (p->begin_no > p->end_no + 1 && !p->chain_pending &&
             scan_chain_try(p, p->fs[(p->end_no + 1) % kFeedSlots], p->chunk_no + 1) != 0)
             return -1;
         // 4. results of the older batch: its context is the one the NEXT chunk's bursts will use
@@ -3361,48 +3288,37 @@ extern "C" int irdm_ida_decode_batch(irdm_pipeline_t *p, const irdm_demod_t *in,
 extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
 {
     if (!p || !key) return -1;
+    // ---- what a caller chooses (include/irdm_hip.h documents every key) ----
     if (!strcmp(key, "keep_frame_samples")) { p->keep_frame_samples = value; return 0; }
     if (!strcmp(key, "packed_records")) { p->packed_records = value; return 0; }
     if (!strcmp(key, "chunk_marks")) { p->chunk_marks = value ? 1 : 0; if (!value) p->q_marks.clear(); return 0; }
-    if (!strcmp(key, "host_cfo")) { p->dev_cfo = p->dev_cfo_ok && value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
-    if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
-    if (!strcmp(key, "scan_updaters")) { if (value < 1 || value > 32) return -1; p->mc_updaters = value; return 0; }
     if (!strcmp(key, "decode_frames")) { p->decode_frames = value; return 0; }
     if (!strcmp(key, "decode_ida")) { p->decode_ida = value; return 0; }
     if (!strcmp(key, "detect_only")) { p->detect_only = value; return 0; }
-    // kernel-variant hooks (process-wide; parity tests and A/B timing): generic runtime-M decimator, radix-2 FFT
-    if (!strcmp(key, "fir_generic")) { irdm::g_fir_force_generic = value; return 0; }
-    if (!strcmp(key, "fir_layout")) { irdm::g_fir_layout = value; return 0; }
-    if (!strcmp(key, "fir_prof")) { irdm::g_fir_prof = value; return 0; }
-    if (!strcmp(key, "k1_first")) { p->k1_first = value; return 0; }
-    if (!strcmp(key, "k1_lists")) { p->k1_lists = value; return 0; }
-    if (!strcmp(key, "band_first")) { p->band_first = value < 0 ? 0 : value > kBandRounds ? kBandRounds : value; return 0; }
-    if (!strcmp(key, "post_generic")) { irdm::g_post_generic = value; return 0; }
-    if (!strcmp(key, "post_split")) { irdm::g_post_split = value ? 1 : 0; return 0; }
-    if (!strcmp(key, "rot_store")) { irdm::g_rot_store = value; return 0; }
-    if (!strcmp(key, "copy_wide")) { irdm::g_copy_wide = value ? 1 : 0; return 0; }
-    if (!strcmp(key, "small_wg")) { if (value != 64 && value != 128 && value != 256) return -1; irdm::g_small_wg = value; return 0; }
-    if (!strcmp(key, "fir_budget")) { irdm::g_fir_budget = value; return 0; }
-    if (!strcmp(key, "fir_strip")) { irdm::g_fir_strip = value; return 0; }
-    if (!strcmp(key, "fir_grid")) { irdm::g_fir_grid = value; return 0; }
-    if (!strcmp(key, "fir_claim")) { irdm::g_fir_claim = value != 0; return 0; }
-    if (!strcmp(key, "fir_order") || !strcmp(key, "simd_order")) {
-        // (per pipeline; the calling thread's switch follows at once for the stage-level calls that take no pipeline)
-        p->fir_order = value ? 1 : 0;
-        irdm::g_fir_order = p->fir_order;
-        return 0;
-    }
-    if (!strcmp(key, "rot_pool_rows")) {
-        // (test hook) an empty on-demand rotator checkpoint arena with room for `value` whole rows (a prebuilt one is given
-        // up); only before the first burst
-        if (value < 1 || value > p->P.n) return -1;
-        return rot_arena_reset(p, (long long)value * p->rot_runs);
-    }
+    if (!strcmp(key, "fir_order") || !strcmp(key, "simd_order")) { p->fir_order = value ? 1 : 0; return 0; }
+    if (!strcmp(key, "host_cfo")) { p->dev_cfo = p->dev_cfo_ok && value == 0; return 0; }      // 1: the fine-CFO libm step on the helper thread
+    if (!strcmp(key, "scan_mode")) { p->scan_mode = value; return 0; }
+    if (!strcmp(key, "kernel_clock")) { p->kernel_clock = value != 0; return 0; }
     if (!strcmp(key, "rot_prebuild")) {
         // 1: every centre bin's row in one background launch now (the default of a context with pipeline_depth >= 1);
         // 0: rows on demand only (the default otherwise); only before the first burst
         if (value) return p->rot_pre_runs ? 0 : rot_prebuild(p);
         return p->rot_pre_runs ? rot_arena_reset(p, (long long)std::min(p->P.n, 1024) * p->rot_runs) : 0;
+    }
+    // ---- diagnostic ----
+    if (!strcmp(key, "band_timeline")) { p->band_tune.timeline = value != 0; return 0; }
+    // ---- test hooks: paths a default run takes only on rare inputs ----
+    if (!strcmp(key, "fir_generic")) { p->fir_generic = value != 0; return 0; }
+    if (!strcmp(key, "post_generic")) { p->post_generic = value != 0; return 0; }
+    if (!strcmp(key, "k1_lists")) { p->k1_lists = value; return 0; }
+    if (!strcmp(key, "band_first")) { p->band_first = value < 0 ? 0 : value > kBandRounds ? kBandRounds : value; return 0; }
+    if (!strcmp(key, "band_spec")) { p->band_spec_opt = value != 0; return 0; }
+    if (!strcmp(key, "band_selfcheck")) { p->band_tune.selfcheck = value; return 0; }
+    if (!strcmp(key, "rot_pool_rows")) {
+        // (test hook) an empty on-demand rotator checkpoint arena with room for `value` whole rows (a prebuilt one is given
+        // up); only before the first burst
+        if (value < 1 || value > p->P.n) return -1;
+        return rot_arena_reset(p, (long long)value * p->rot_runs);
     }
     if (!strcmp(key, "scratch_outputs")) {
         // (test hook) the decimated / low-passed scratch of every context with room for `value` outputs to begin with;
@@ -3424,34 +3340,6 @@ extern "C" int irdm_set_option(irdm_pipeline_t *p, const char *key, int value)
         }
         return 0;
     }
-    if (!strcmp(key, "fir_slice")) { irdm::g_fir_slice = value < 0 ? 0 : value; return 0; }
-    if (!strcmp(key, "band_coop")) { irdm::g_band_coop = value; return 0; }
-    if (!strcmp(key, "band_tail")) { irdm::g_band_tail = value != 0; return 0; }
-    if (!strcmp(key, "band_spec")) { p->band_spec_opt = value != 0; return 0; }
-    if (!strcmp(key, "band_hist_side")) { irdm::g_band_hist_side = value != 0; return 0; }
-    if (!strcmp(key, "band_sum_restart")) { irdm::g_band_sum_restart = value != 0; return 0; }
-    if (!strcmp(key, "band_tail_threads")) {
-        if (value != 256 && value != 512 && value != 1024) return -1;
-        irdm::g_band_tail_threads = value;
-        return 0;
-    }
-    if (!strcmp(key, "band_cross_wave")) { irdm::g_band_cross_wave = value; return 0; }
-    if (!strcmp(key, "band_sum_bins")) { irdm::g_band_sum_bins = value; return 0; }
-    if (!strcmp(key, "band_selfcheck")) { irdm::g_band_selfcheck = value; return 0; }
-    if (!strcmp(key, "band_timeline")) { irdm::g_band_timeline = value; return 0; }
-    if (!strcmp(key, "band_walk_wave")) { irdm::g_band_walk_wave = value; return 0; }
-    if (!strcmp(key, "band_plan_threads")) { irdm::g_band_plan_threads = value; return 0; }
-    if (!strcmp(key, "band_fuse_commit")) { irdm::g_band_fuse_commit = value; return 0; }
-    if (!strcmp(key, "band_fold_sums0")) { irdm::g_band_fold_sums0 = value != 0; return 0; }
-    if (!strcmp(key, "band_cross_groups")) { irdm::g_band_cross_groups = value; return 0; }
-    if (!strcmp(key, "band_plan_ahead")) { irdm::g_band_plan_ahead = value != 0; return 0; }
-    if (!strcmp(key, "scan_events")) { p->scan_events = value != 0; return 0; }
-    if (!strcmp(key, "kernel_clock")) { p->kernel_clock = value != 0; return 0; }
-    if (!strcmp(key, "scan_chain")) { p->scan_chain = value; return 0; }
-    if (!strcmp(key, "scan_chain_early")) { p->chain_early = value != 0; return 0; }
-    if (!strcmp(key, "fir_reserve_cus")) { irdm::g_fir_reserve_cus = value; return 0; }
-    if (!strcmp(key, "fft_radix2")) { irdm::g_fft_force_radix2 = value; return 0; }
-    if (!strcmp(key, "k1_kernel")) { irdm::g_fft_kernel = value; return 0; }
     return -1;
 }
 
@@ -3490,11 +3378,9 @@ extern "C" int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key)
     if (!strcmp(key, "scratch_grows")) return (int64_t)p->stat_scratch_grows;
     if (!strcmp(key, "tiles_grows")) return (int64_t)p->stat_tiles_grows;
     if (!strcmp(key, "ring_waits")) return (int64_t)p->stat_ring_waits;
-    if (!strcmp(key, "chain_cu_reserved")) return (int64_t)p->chain_cu_reserved;
     if (!strcmp(key, "spec_passes")) return (int64_t)p->stat_spec_passes;
     if (!strcmp(key, "spec_scans")) return (int64_t)p->stat_spec_scans;
     if (!strcmp(key, "sum_restarts")) return (int64_t)p->stat_sum_restarts;
-    if (!strcmp(key, "band_tail_launches")) return (int64_t)irdm::g_band_tail_launches.load();      // (process-wide)
     if (!strcmp(key, "scratch_peak")) return (int64_t)p->stat_scratch_peak;
     if (!strcmp(key, "band_last_flags")) return (int64_t)p->last_band_flags;
     if (!strcmp(key, "scan_dense_frames")) return (int64_t)p->stat_dense_frames;

@@ -49,25 +49,6 @@ __device__ __forceinline__ bool band_void(const BandParams &P, const BandWork &W
     return __hip_atomic_load(W.bar + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)P.serial;
 }
 
-// BandParams::ahead: every workgroup of a walk pass counts itself done when it leaves (BandWork::bar[8], monotonic) -- what
-// a plan pass that was launched ahead of the walk it depends on waits for (tools/ubench/launch_ahead.hip measures why:
-// behind a many-workgroup pass a 1024-thread workgroup starts 6 us late alone and 28 us late beside a chip-filling
-// kernel; resident and waiting on the counter it sees the pass end after 6 us either way)
-struct WalkDone {
-    unsigned *c;
-    __device__ __forceinline__ WalkDone(const BandParams &P, const BandWork &W) : c(P.ahead ? W.bar + 8 : nullptr) {}
-    __device__ __forceinline__ ~WalkDone()
-    {
-        if (c) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-};
-
 // diagnostic timeline (BandParams::tl_sel >= 0): earliest start and latest end over the workgroups of a pass
 struct TlScope {
     unsigned long long *lo, *hi;
@@ -87,30 +68,6 @@ struct TlScope {
     }
     __device__ __forceinline__ ~TlScope() { leave(); }
 };
-
-// band_tail: "the workgroup that leaves a pass last does what depends on the whole pass".  Every workgroup of the pass calls
-// this once, when its own work is done; exactly one call -- the one that brings the counter to the grid's size -- returns
-// true, with everything the other workgroups wrote before their call visible to the whole workgroup, and the counter back at
-// zero for the next pass.  No workgroup waits for another: unlike a grid barrier this needs no residency, and the emulation
-// (workgroups one after the other, in any order) runs it as it is.
-__device__ __forceinline__ bool last_arriver(unsigned *ctr)
-{
-    __shared__ int s_last_arriver;
-    // (every wavefront's own stores have reached the L2 before the workgroup counts as arrived)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == (unsigned)gridDim.x - 1u;
-        if (last) {
-            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        s_last_arriver = last;
-    }
-    __syncthreads();
-    return s_last_arriver != 0;
-}
 
 constexpr int kPlanThreads = 1024;          // one workgroup (256 lanes measured +60 us per plan / commit launch: 0.57 -> 0.81 ms per scan)
 constexpr int kSumDepth = 32;             // update steps per batch of the sums pass (two batches of loads in flight)
@@ -692,45 +649,16 @@ __device__ void band_plan_body(const BandParams &P, const BandWork &W, const uns
 __device__ void band_commit_body(const BandParams &P, const BandWork &W, DetState *__restrict__ st,
                                  float *__restrict__ sum, GoneBurst *__restrict__ gone, int gone_cap,
                                  unsigned char *smem_raw);
-__device__ void band_tail_export(const DetState *__restrict__ st, const uint32_t *__restrict__ gone, int cap,
-                                 uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr, const uint32_t *__restrict__ ctl,
-                                 uint32_t *__restrict__ hp_ctl, int ctl_words, bool voided);
-
-// fuse != 0: a verdict "accepted" is followed by the commit in the same workgroup (the commit pass enqueued behind the
-// rounds then finds its work done) -- one launch and its wait less on the scan's critical path
+// A verdict "accepted" is followed by the commit in the same workgroup -- one launch and its wait less on the scan's critical
+// path (a plan pass without its LDS, selfcheck bit 4, leaves the commit to band_commit_kernel).
 template <int NT>
 __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
                                                        DetState *__restrict__ st, int round, float *__restrict__ sum,
-                                                       GoneBurst *__restrict__ gone, int gone_cap, int fuse,
-                                                       unsigned wait_target, const float *__restrict__ pre,
+                                                       GoneBurst *__restrict__ gone, int gone_cap, const float *__restrict__ pre,
                                                        float *__restrict__ smin_out, const uint64_t *u_busy,
-                                                       const uint64_t *u_forced, int hp_cap, uint32_t *hp_gone,
-                                                       uint32_t *hp_hdr, uint32_t *hp_ctl)
+                                                       const uint64_t *u_forced)
 {
-    // hp_hdr != nullptr (band_hist_side: the launch's last plan pass): this workgroup also exports the control block and the
-    // finished bursts' records to pinned host memory -- what band_history_kernel's first workgroups do otherwise; the
-    // history copy then runs on a side stream, off the chain of scans
     IRDM_DETECTOR_PRIO();
-    if (P.ahead && round >= 1) {
-        // launched ahead of the walk pass whose results it judges (on a second stream): resident, waiting for that pass's
-        // workgroups to have counted themselves done.  Bounded: 200 ms.
-        if (threadIdx.x == 0) {
-            const unsigned long long t0 = wall_clock64();
-            bool ok = true;
-            while ((int)(__hip_atomic_load(W.bar + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_target) < 0) {
-                __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > 20000000ull) {
-                    ok = false;
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            // (timed out: the launch voids itself like a chained launch whose predecessor did not commit -- every later
-            // pass returns at once, nothing of the carried state is written, the host runs the chunk again)
-            if (!ok) __hip_atomic_store(W.bar + 5, (unsigned)P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
     TlScope tl(P, W, 4 * round);
     __shared__ PlanShared sh;
     extern __shared__ __attribute__((aligned(16))) unsigned char plan_lds[];
@@ -752,14 +680,9 @@ __global__ __launch_bounds__(NT) void band_plan_kernel(BandParams P, BandWork W,
             }
         }
     }
-    if (fuse && round >= 1 && !(P.selfcheck & 16)) {
+    if (round >= 1 && !(P.selfcheck & 16)) {
         __syncthreads();
         if (!band_void(P, W) && W.ctl->status == 1) band_commit_body(P, W, st, sum, gone, gone_cap, plan_lds);
-    }
-    if (hp_hdr != nullptr) {
-        __syncthreads();
-        band_tail_export(st, reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap, hp_gone, hp_hdr,
-                         reinterpret_cast<const uint32_t *>(W.ctl), hp_ctl, (int)(sizeof(BandCtl) / 4), band_void(P, W));
     }
 }
 
@@ -874,10 +797,8 @@ __device__ __forceinline__ void band_sum_body(const BandParams &P, const BandWor
     if (!(pre[b] <= 0.9f * P.thr * smin)) atomicOr(W.flags, BAND_F_STALE);
 }
 
-// BPW bins per wavefront (lanes beyond BPW repeat the first ones: same addresses, same values).  64, 32 and 16 measure the
-// same (10 MHz, 1000 and 7600 update steps): the pass is bound by what a step costs one wavefront, not by the cache lines a
-// CU has in flight.
-template <int BPW>
+// 64 bins per wavefront (32 and 16 measured the same, 10 MHz, 1000 and 7600 update steps: the pass is bound by what a step
+// costs one wavefront, not by the cache lines a CU has in flight)
 __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, const float *__restrict__ mag,
                                                       const float *__restrict__ hist, const float *__restrict__ sum,
                                                       const float *__restrict__ pre, float *__restrict__ smin_out,
@@ -886,106 +807,7 @@ __global__ __launch_bounds__(64) void band_sum_kernel(BandParams P, BandWork W, 
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 1);
     if (band_void(P, W) || W.ctl->status != 0) return;
-    band_sum_body(P, W, mag, hist, sum, pre, smin_out, steps, snap, (int)blockIdx.x * BPW + (int)(threadIdx.x % BPW));
-}
-
-// ---- crossing bits of one frame ----
-__global__ __launch_bounds__(256) void band_cross_kernel(BandParams P, BandWork W, const unsigned *__restrict__ counts,
-                                                         const ListEntry *__restrict__ entries)
-{
-    IRDM_DETECTOR_PRIO();
-    __shared__ uint32_t s_bits[16384 / 32];
-    if (band_void(P, W) || W.ctl->status != 0) return;
-    const int f = blockIdx.x, tid = threadIdx.x, N = P.n;
-    const unsigned c = counts[f];
-    if (c == 0 || c > (unsigned)P.list_cap) return;
-    for (int w = tid; w < N / 32; w += 256) s_bits[w] = 0;
-    __syncthreads();
-    const float *__restrict__ srow = W.snap + (size_t)W.slot_pre[f] * N;
-    const ListEntry *__restrict__ e = entries + (size_t)f * P.list_cap;
-    float *__restrict__ rq = W.relq + (size_t)f * N;
-    for (unsigned i = tid; i < c; i += 256) {
-        const int bin = e[i].bin;
-        const float base = srow[bin];
-        const float rel = base > 0 ? e[i].mag / base : 0.0f;      // simd_relative_mag (simd_generic.c:137-145)
-        if (rel > P.thr) {
-            atomicOr(&s_bits[bin >> 5], 1u << (bin & 31));
-            rq[bin] = rel;
-        }
-    }
-    __syncthreads();
-    uint32_t *__restrict__ out = reinterpret_cast<uint32_t *>(W.cross) + (size_t)f * (N / 32);
-    for (int w = tid; w < N / 32; w += 256) out[w] = s_bits[w];
-    if (tid < P.n_bands) {
-        const int w0 = (tid * P.band_w - P.band_w / 2) / 32, nw = 2 * P.band_w / 32;
-        uint32_t any = 0;
-        for (int k = 0; k < nw; k++) {
-            const int w = w0 + k;
-            if (w >= 0 && w < N / 32) any |= s_bits[w];
-        }
-        if (any) atomicOr(reinterpret_cast<unsigned long long *>(&W.occ[(size_t)tid * P.occ_words + (f >> 6)]), 1ull << (f & 63));
-    }
-}
-
-// ---- walk: lane = band, workgroup = 64-frame block ----
-// one wavefront: lane = band, blk = 64-frame block; smem_raw: kBandSlots * 64 * 36 bytes of slot storage
-template <int NW>
-__device__ __forceinline__ void band_walk_body(const BandParams &P, BandIO io, const DetState *__restrict__ st,
-                                               unsigned char *smem_raw, int band, int blk,
-                                               unsigned long long *tl_stat = nullptr)
-{
-    io.act_in = st->act;
-    io.n_act_in = st->n_act;
-    if (band >= P.n_bands) return;
-    int64_t *l_start = reinterpret_cast<int64_t *>(smem_raw);
-    int64_t *l_la = l_start + kBandSlots * 64;
-    int32_t *l_cb = reinterpret_cast<int32_t *>(l_la + kBandSlots * 64);
-    int32_t *l_cf = l_cb + kBandSlots * 64;
-    int32_t *l_seq = l_cf + kBandSlots * 64;
-    float *l_rel = reinterpret_cast<float *>(l_seq + kBandSlots * 64);
-    float *l_base = l_rel + kBandSlots * 64;
-    BandSlots S{ l_start + band, l_la + band, l_cb + band, l_cf + band, l_seq + band, l_rel + band, l_base + band, 64 };
-
-    bool carried = false;
-    int events = 0;
-    if (blk == 0) {
-        BandWalker<NW> w(P, io, S, band);
-        if (w.load_carried() > 0) {
-            carried = true;
-            w.run(0, true);
-            events += w.n_events;
-        }
-    }
-    uint64_t starts = band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, carried);
-    while (starts) {
-        const int j = __builtin_ctzll(starts);
-        starts &= starts - 1;
-        BandWalker<NW> w(P, io, S, band);
-        w.run(64 * blk + j, false);
-        events += w.n_events;
-    }
-    if (tl_stat) {
-        // (diagnostic timeline: the longest lane's and all lanes' event counts of this pass)
-        atomicMax(tl_stat, (unsigned long long)events);
-        atomicAdd(tl_stat + 1, (unsigned long long)events);
-    }
-}
-
-template <int NW>
-__global__ __launch_bounds__(64) void band_walk_kernel(BandParams P, BandWork W, BandIO io, const DetState *__restrict__ st)
-{
-    IRDM_DETECTOR_PRIO();
-    TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 3);
-    WalkDone done(P, W);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    if (band_void(P, W) || W.ctl->status != 0) return;
-    unsigned long long *tl_stat = nullptr;
-    if (P.tl_sel >= 0) {
-        const int r = W.ctl->rounds - 1;
-        // (slots 26 / 27: round 0's longest lane and total, 28 / 29: the later rounds'; in the "end" half of the timeline)
-        tl_stat = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + (r == 0 ? 26 : 28);
-    }
-    band_walk_body<NW>(P, io, st, smem_raw, threadIdx.x, blockIdx.x, tl_stat);
+    band_sum_body(P, W, mag, hist, sum, pre, smin_out, steps, snap, (int)blockIdx.x * 64 + (int)threadIdx.x);
 }
 
 // ---- the walk with a wavefront per band and activity segment (band_wave.hpp) ----
@@ -998,7 +820,6 @@ __global__ __launch_bounds__(256) void band_walk_wave_kernel(BandParams P, BandW
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 3);
-    WalkDone done(P, W);
     if (band_void(P, W) || W.ctl->status != 0) return;
     io.act_in = st->act;
     io.n_act_in = (int32_t)wv_first((uint32_t)st->n_act);
@@ -1057,174 +878,6 @@ __global__ __launch_bounds__(256) void band_walk_wave_kernel(BandParams P, BandW
     }
 }
 
-// ---- band_tail: the walk whose last workgroup judges the round ----
-// The same walk (a wavefront per band and segment), its pairs taken one at a time from the list the crossing pass's last
-// workgroup made; the workgroup that leaves last then runs what used to be the next launch -- the plan pass of round
-// `round` + 1: the verdict on this round, the commit if it is accepted (always fused here), else the next round's plan --
-// and, in the last round the host enqueued (`final`), the export of the control block and the finished bursts' records to
-// pinned host memory (band_history_kernel's first workgroups before).  Per two-round scan: plan0 . cross0 . walk0 . sums1 .
-// cross1 . walk1 and the history copy beside the next chunk, six dependent launches where there were nine -- three times
-// the idle time in front of a single-workgroup launch (26-70 us each at 10 MHz in run, up to 340 us at 12 MHz dense,
-// profiles/r4_scan_timeline.json) and the history pass's 56 us off every chunk's scan.
-// NT threads per workgroup: the plan's own width (its LDS form holds 8192 / NT frames per thread).
-__device__ void band_tail_export(const DetState *__restrict__ st, const uint32_t *__restrict__ gone, int cap,
-                                 uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr, const uint32_t *__restrict__ ctl,
-                                 uint32_t *__restrict__ hp_ctl, int ctl_words, bool voided)
-{
-    // (one workgroup's form of gone_export_body, types.hpp)
-    const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
-    if (voided) {
-        // (the host drains and ignores a void launch; its export slot says so for whoever looks)
-        if (tid == 0) {
-            __hip_atomic_store(hp_ctl + 2, (uint32_t)BAND_F_CHAIN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // flags
-            __hip_atomic_store(hp_ctl + 0, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                      // status
-        }
-        __threadfence_system();
-        return;
-    }
-    for (int i = tid; i < ctl_words; i += nt) __hip_atomic_store(hp_ctl + i, ctl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t n = st->n_gone;
-    const size_t words = (size_t)(n < (uint32_t)cap ? n : (uint32_t)cap) * (sizeof(GoneBurst) / 4);
-    for (size_t i = (size_t)tid; i < words; i += (size_t)nt)
-        __hip_atomic_store(hp_gone + i, gone[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid == 0) {
-        __hip_atomic_store(hp_hdr + 0, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(hp_hdr + 1, st->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(hp_hdr + 2, (uint32_t)st->hist_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(hp_hdr + 3, (uint32_t)st->primed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-}
-
-template <int NW, int NT>
-__global__ __launch_bounds__(NT) void band_walk_tail_kernel(BandParams P, BandWork W, BandIO io, DetState *st,
-                                                            const unsigned *__restrict__ counts, int round, int final,
-                                                            float *sum, GoneBurst *gone, int gone_cap, int hp_cap,
-                                                            uint32_t *hp_gone, uint32_t *hp_hdr, uint32_t *hp_ctl)
-{
-    IRDM_DETECTOR_PRIO();
-    extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
-    __shared__ PlanShared sh;
-    const bool live = !(band_void(P, W) || W.ctl->status != 0);
-    if (live) {
-        TlScope tl(P, W, 4 * round + 3);
-        io.act_in = st->act;
-        io.n_act_in = (int32_t)wv_first((uint32_t)st->n_act);
-        const int lane = threadIdx.x & 63;
-        const int n_pairs = P.n_bands * P.occ_words;
-        const unsigned total = wv_first(W.bar[12]), n_heavy = wv_first(W.bar[13]);
-        unsigned long long *tl_stat = nullptr;
-        if (P.tl_sel >= 0) tl_stat = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + (round == 0 ? 26 : 28);
-        int wave_events = 0;
-        const unsigned long long t_wave = tl_stat ? wall_clock64() : 0;
-        for (;;) {
-            unsigned idx = 0;
-            if (lane == 0) idx = __hip_atomic_fetch_add(W.bar + 11, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            idx = wv_first(idx);
-            if (idx >= total) break;
-            const int p = (int)wv_first(idx < n_heavy ? W.pairs[idx] : W.pairs[n_pairs - 1 - (int)(idx - n_heavy)]);
-            const int band = p / P.occ_words, blk = p % P.occ_words;
-            bool carried = false;
-            int events = 0;
-            if (blk == 0) {
-                WaveWalker<NW> w(P, io, band, lane);
-                if (w.load_carried() > 0) {
-                    carried = true;
-                    w.run(0, true);
-                    events += w.n_events;
-                }
-            }
-            uint64_t starts = wv_first64(band_segment_starts(io.occ + (size_t)band * P.occ_words, blk, P.gap, carried));
-            while (starts) {
-                const int q = __builtin_ctzll(starts);
-                starts &= starts - 1;
-                WaveWalker<NW> w(P, io, band, lane);
-                w.run(64 * blk + q, false);
-                events += w.n_events;
-            }
-            wave_events += events;
-            if (tl_stat && lane == 0) {
-                atomicMax(tl_stat, (unsigned long long)events);
-                atomicAdd(tl_stat + 1, (unsigned long long)events);
-            }
-        }
-        if (tl_stat && lane == 0 && round != 0) {
-            unsigned long long *x = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots + kBandTlSlots + 30;
-            atomicMax(x, (unsigned long long)wave_events);
-            atomicMax(x + 1, wall_clock64() - t_wave);
-        }
-    }
-    if (!last_arriver(W.bar + 10)) return;
-    const bool voided = band_void(P, W);
-    if (!voided && W.ctl->status == 0) {
-        TlScope tl(P, W, 4 * (round + 1));
-        band_plan_body<NT>(P, W, counts, st, round + 1, sh, tail_lds);
-        __syncthreads();
-        if (!band_void(P, W) && W.ctl->status == 1) band_commit_body(P, W, st, sum, gone, gone_cap, tail_lds);
-    }
-    if (final && hp_hdr) {
-        __syncthreads();
-        band_tail_export(st, reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap, hp_gone, hp_hdr,
-                         reinterpret_cast<const uint32_t *>(W.ctl), hp_ctl, (int)(sizeof(BandCtl) / 4), voided);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// The rounds as ONE launch (option band_coop): kCoopGroups workgroups stay resident through plan -> sums -> cross ->
-// walk -> plan ... until a round is accepted or the scan declines, with a grid-wide barrier between the passes.  What
-// this buys over a launch per pass (11 for two rounds): a pass does not queue for wavefront slots behind the per-burst
-// chains' long-running kernels (measured at 12 MHz / 40 bursts per Msample: plan 160-260 us, walk 430-620 us, commit
-// 310-590 us per launch in run against a fraction of that alone), the verdict is taken where the rounds run (no round
-// is enqueued that is not needed, none is missing), and the crossing pass walks its frames instead of asking the
-// dispatcher for 8192 workgroups.
-//
-// Grid barrier: arrive counter + generation word in the workspace, agent-scope release / acquire around them; one lane
-// per workgroup spins (s_sleep).  Every workgroup must be resident for the others to make progress: the grid is far
-// below what the chip holds beside anything else (128 workgroups, 56 KB of LDS each), and the spin is bounded -- a
-// workgroup that waits longer than ~50 ms raises `abort`, every workgroup leaves, the scan reports BAND_F_COOP and the
-// caller falls back to the sequential scan (nothing of the carried state has been written: the commit is a launch of
-// its own behind this one).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int kCoopThreads = 256;
-constexpr int kCoopGroups = 128;
-
-__device__ __forceinline__ bool grid_sync(unsigned *bar, unsigned n_groups)
-{
-    __shared__ int s_ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ok = 1;
-        // release: what this workgroup wrote is visible to the agent before it counts as arrived
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (__hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-            ok = 0;
-        } else {
-            const unsigned gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) {
-                __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                // (relaxed polls: an acquire per poll would invalidate the L2 under the workgroups still working)
-                long long spins = 0;
-                while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (++spins > 400000 || __hip_atomic_load(bar + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = 0;
-                        break;
-                    }
-                }
-            }
-        }
-        // acquire: what the other workgroups wrote before they arrived
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        s_ok = ok;
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-// crossing bits of frame f by ONE wavefront (band_cross_kernel's work; s_bits: N / 32 words of this wavefront's own)
 __device__ __forceinline__ void band_cross_wave(const BandParams &P, const BandWork &W, unsigned c,
                                                 const ListEntry *__restrict__ entries, int f, uint32_t *s_bits, int lane)
 {
@@ -1272,12 +925,10 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 4 * (W.ctl->rounds - 1) + 2);
     __shared__ uint32_t s_bits_all[4][16384 / 32];
-    const bool live = !(band_void(P, W) || W.ctl->status != 0);
-    if (!live && !(P.tail & 1)) return;
+    if (band_void(P, W) || W.ctl->status != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gw = (int)blockIdx.x * 4 + wave, n_waves = (int)gridDim.x * 4;
     uint32_t *s_bits = s_bits_all[wave];
-    if (live)
     for (int f0 = gw; f0 < P.n_frames; f0 += 64 * n_waves) {
         const int fl = f0 + lane * n_waves;
         const unsigned cl = fl < P.n_frames ? counts[fl] : 0u;
@@ -1289,93 +940,8 @@ __global__ __launch_bounds__(256) void band_cross_w_kernel(BandParams P, BandWor
             band_cross_wave(P, W, c, entries, f0 + j * n_waves, s_bits, lane);
         }
     }
-    if (!(P.tail & 1)) return;
-    // band_tail: the workgroup that leaves last lists the (band, 64-frame block) pairs in which a segment starts -- what every
-    // wavefront of the walk pass used to find out for its own share of the pairs, a fixed share: the walk then lasted as long
-    // as its unluckiest wavefront (72 events where the mean was 15: 80 us of a pass whose longest single pair is 31 events).
-    // The walk's wavefronts take the pairs from this list one at a time, the heavy ones (many occupied frames in the block,
-    // block 0 with its carried bursts) first.
-    tl.leave();
-    if (!last_arriver(W.bar + 9)) return;
-    __shared__ unsigned s_nh, s_nl;
-    const int tid = (int)threadIdx.x;
-    if (tid == 0) {
-        s_nh = 0;
-        s_nl = 0;
-    }
-    __syncthreads();
-    const int n_pairs = P.n_bands * P.occ_words;
-    if (live)
-        for (int p = tid; p < n_pairs; p += 256) {
-            const int band = p / P.occ_words, blk = p % P.occ_words;
-            const uint64_t *occ = W.occ + (size_t)band * P.occ_words;
-            if (blk == 0 || band_segment_starts(occ, blk, P.gap, false) != 0) {
-                const bool heavy = blk == 0 || __builtin_popcountll(occ[blk]) >= 12;
-                if (heavy) W.pairs[atomicAdd(&s_nh, 1u)] = (uint32_t)p;
-                else W.pairs[n_pairs - 1 - (int)atomicAdd(&s_nl, 1u)] = (uint32_t)p;
-            }
-        }
-    __syncthreads();
-    if (tid == 0) {
-        W.bar[11] = 0;
-        W.bar[12] = s_nh + s_nl;
-        W.bar[13] = s_nh;
-    }
 }
 
-template <int NW>
-__global__ __launch_bounds__(kCoopThreads) void band_coop_kernel(BandParams P, BandWork W, BandIO io,
-                                                                 const unsigned *__restrict__ counts,
-                                                                 const ListEntry *__restrict__ entries, DetState *st,
-                                                                 const float *__restrict__ mag, const float *hist,
-                                                                 const float *sum, const float *__restrict__ pre,
-                                                                 float *smin, int round_begin, int round_end)
-{
-    IRDM_DETECTOR_PRIO();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = (int)gridDim.x, gw = (int)blockIdx.x * (kCoopThreads / 64) + wave, n_waves = G * (kCoopThreads / 64);
-    unsigned *bar = W.bar;
-    BandCtl *ctl = W.ctl;
-    bool ok = true;
-    for (int round = round_begin;; round++) {
-        // ---- plan (one workgroup): the verdict on the round before, the update steps of this one ----
-        if (blockIdx.x == 0 && (round > round_begin || round_begin == 0))
-            band_plan_body<kCoopThreads>(P, W, counts, st, round, *reinterpret_cast<PlanShared *>(smem_raw), nullptr);
-        if (!(ok = grid_sync(bar, G))) break;
-        if (band_void(P, W)) return;
-        if (__hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || round >= round_end) break;
-        // ---- sums: a lane per bin ----
-        for (int vb = gw; vb < P.n / 64; vb += n_waves)
-            band_sum_body(P, W, mag, hist, sum, pre, smin, W.steps, W.snap, vb * 64 + lane);
-        if (!(ok = grid_sync(bar, G))) break;
-        // ---- cross: a wavefront per frame with list entries ----
-        {
-            uint32_t *s_bits = reinterpret_cast<uint32_t *>(smem_raw) + (size_t)wave * (P.n / 32);
-            for (int f0 = gw; f0 < P.n_frames; f0 += 64 * n_waves) {
-                // (the counts of this wavefront's next 64 frames with one load)
-                const int fl = f0 + lane * n_waves;
-                const unsigned cl = fl < P.n_frames ? counts[fl] : 0u;
-                uint64_t todo = __builtin_amdgcn_ballot_w64(cl != 0 && cl <= (unsigned)P.list_cap);
-                while (todo) {
-                    const int j = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)cl, j);
-                    band_cross_wave(P, W, c, entries, f0 + j * n_waves, s_bits, lane);
-                }
-            }
-        }
-        if (!(ok = grid_sync(bar, G))) break;
-        // ---- walk: a wavefront per 64-frame block, lane = band ----
-        if (wave == 0)
-            for (int blk = (int)blockIdx.x; blk < P.occ_words; blk += G) band_walk_body<NW>(P, io, st, smem_raw, lane, blk);
-        if (!(ok = grid_sync(bar, G))) break;
-    }
-    if (!ok && blockIdx.x == 0 && tid == 0) {
-        ctl->flags |= BAND_F_COOP;
-        ctl->status = 2;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // band_spec: round 0 as a SPECULATION PASS beside the previous chunk's scan.
@@ -1571,17 +1137,6 @@ __device__ void band_commit_body(const BandParams &P, const BandWork &W, DetStat
         }
     }
     for (int b = tid; b < P.n; b += kPlanThreads) sum[b] = W.sum_new[b];
-    if ((P.tail & 2) && W.hist_job) {
-        // what the history pass needs of this chunk, where the next chunk's scan does not touch it (HistJob)
-        const int nu = ctl->n_upd, cnt = nu < kHistory ? nu : kHistory;
-        for (int i = tid; i < cnt; i += kPlanThreads) W.hist_job->frame[i] = W.upd_frame[nu - 1 - i];
-        if (tid == 0) {
-            W.hist_job->n = cnt;
-            W.hist_job->h0 = ctl->h0;
-            W.hist_job->n_upd = nu;
-            W.hist_job->seq = P.seq;
-        }
-    }
     if (tid == 0) {
         const int F = P.n_frames;
         st->index += (uint64_t)F * (uint64_t)P.n;
@@ -1613,32 +1168,11 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
                                                            float *__restrict__ hist, const DetState *__restrict__ st,
                                                            const uint32_t *__restrict__ gone, int gone_cap,
                                                            uint32_t *__restrict__ hp_gone, uint32_t *__restrict__ hp_hdr,
-                                                           uint32_t *__restrict__ hp_ctl, const HistJob *__restrict__ job,
-                                                           uint32_t seq)
+                                                           uint32_t *__restrict__ hp_ctl)
 {
     IRDM_DETECTOR_PRIO();
     TlScope tl(P, W, 25);
     const BandCtl *ctl = W.ctl;
-    if (job != nullptr) {
-        // band_tail: on a side stream, beside the next chunk's round 0 (which has reset the control block by now): the rows
-        // are the ones the commit listed.  A launch behind a scan that did not commit (verdict open, declined, void) finds
-        // another scan's number and does nothing.
-        if (job->seq != seq || (int)blockIdx.x >= job->n) return;
-        const int k = job->n_upd - 1 - (int)blockIdx.x;
-        const float4 *src = reinterpret_cast<const float4 *>(mag + (size_t)job->frame[blockIdx.x] * P.n);
-        float4 *dst = reinterpret_cast<float4 *>(hist + (size_t)((job->h0 + k) % kHistory) * P.n);
-        for (int i0 = threadIdx.x; i0 < P.n / 4; i0 += 8 * 256) {
-            float4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (i0 + 256 * u < P.n / 4) v[u] = src[i0 + 256 * u];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (i0 + 256 * u < P.n / 4) dst[i0 + 256 * u] = v[u];
-        }
-        return;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 3) W.bar[threadIdx.x] = 0;      // (the cooperative kernel's barrier: idle here)
     if (band_void(P, W)) {
         // (the host drains and ignores a void launch; its export slot says so for whoever looks)
         if (hp_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1671,27 +1205,6 @@ __global__ __launch_bounds__(256) void band_history_kernel(BandParams P, BandWor
 }
 
 }  // namespace
-
-int g_band_coop = 0;        // (measured on MI355X, DESIGN.md "The detector scan": 1.21 ms alone / 1.64 ms in run against 0.56 / 1.10 ms for
-                            // a launch per pass -- one workgroup plans at a quarter of the lanes, the step descriptors of the sums pass
-                            // lose their scalar loads, 11 grid barriers; kept as an option and tested)
-
-int g_band_sum_bins = 64;   // bins per wavefront of the sums pass (64 / 32 / 16; no difference measured: the pass is bound by a step's instruction count)
-int g_band_fold_sums0 = 1;         // 1 (default): round 0's sums pass (no update steps) runs inside its plan pass
-int g_band_cross_groups = 256;     // workgroups (of four wavefronts) of the crossing pass: option band_cross_groups
-int g_band_plan_ahead = -1;       // 1: plan passes launched ahead on the side stream; -1: IRDM_PLAN_AHEAD in the environment, else 0
-int g_band_fuse_commit = 1;       // 1: the plan pass that accepts a round commits it in the same launch
-int g_band_plan_threads = 1024;   // threads of the plan pass's workgroup (256 / 512 / 1024)
-int g_band_walk_wave = 1;   // 1: the walk with a wavefront per band and segment (band_wave.hpp); 0: a lane per band (band_core.hpp)
-int g_band_timeline = 0;    // diagnostic, see BandParams::tl_sel
-int g_band_selfcheck = 0;   // test hook, see BandParams::selfcheck
-int g_band_cross_wave = 1;  // 1: the crossing pass as a fixed grid of frame-walking wavefronts; 0: a workgroup per frame
-int g_band_sum_restart = 1;   // BandParams::sum_restart of the launches that follow
-int g_band_hist_side = 0;   // 1: a launch per pass with the history copy on the side stream and the export in the last plan pass
-int g_band_tail = 0;        // 1: six dependent launches per two-round scan instead of nine (band_walk_tail_kernel); needs the wavefront
-                            // walk, the wavefront crossing pass and the LDS plan; 0: a launch per pass
-std::atomic<unsigned long long> g_band_tail_launches{ 0 };     // launches that took the tail form (stat band_tail_launches)
-int g_band_tail_threads = 1024;   // workgroup size of the walk pass that carries the tail (the plan's width): 256 / 512 / 1024
 
 int band_list_cap(int n) { return n < kBandListCap ? n : kBandListCap; }
 
@@ -1746,7 +1259,6 @@ size_t band_work_bytes(int n, size_t max_chunk, bool spec)
     add(4 * (size_t)n); add(4 * kBandMaxTotal); add(8 * kBandMaxTotal); add(256);    // sum_new, tot, ids, flags
     add(256); add(4 * kBandMaxTotal);                                                // bar, rank
     add(8 * 4 * kBandTlSlots);                                                       // tl
-    add(4 * 64 * ((F + 63) / 64)); add(sizeof(HistJob));                             // pairs, hist_job
     return b;
 }
 
@@ -1784,23 +1296,8 @@ int band_work_carve(BandWork *W, void *base, int n, size_t max_chunk, bool spec)
     W->flags = static_cast<uint32_t *>(take(256));
     W->bar = static_cast<unsigned *>(take(256));
     W->rank = static_cast<uint32_t *>(take(4 * kBandMaxTotal));
-    W->walk_host = nullptr;
     W->tl = static_cast<unsigned long long *>(take(8 * 4 * kBandTlSlots));
-    W->pairs = static_cast<uint32_t *>(take(4 * 64 * ((F + 63) / 64)));
-    W->hist_job = static_cast<HistJob *>(take(sizeof(HistJob)));
     return 0;
-}
-
-// Enqueue the whole band scan of one chunk on `stream`.  Nothing of the carried state (st, sum, hist) is written
-// unless BandCtl::status ends as 1 (accepted); the caller reads the control block afterwards.
-// IRDM_PLAN_AHEAD in the environment overrides the default of "band_plan_ahead"; resolved once per process (irdm_create)
-void band_resolve_env()
-{
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char *e = getenv("IRDM_PLAN_AHEAD");
-        if (g_band_plan_ahead < 0) g_band_plan_ahead = e ? (atoi(e) ? 1 : 0) : kBandPlanAheadDefault;
-    });
 }
 
 // (one counter for all contexts of the process, fed from any thread: two launches never share a serial number)
@@ -1816,12 +1313,12 @@ static unsigned next_launch_serial()
 // the crossings are tested against (the scan workspace's sum_new: what the previous chunk's round 1 computed); have_prev: S
 // still holds the previous speculation pass's records (its bursts active at the end become this pass's carried bursts).
 int launch_band_spec(const DetParams &D, BandWork S, DetState *st_spec, const float *sum_src, int n_frames, uint64_t idx0,
-                     const unsigned *counts, const ListEntry *entries, int have_prev, hipStream_t stream)
+                     const unsigned *counts, const ListEntry *entries, int have_prev, hipStream_t stream, const BandTune &tune)
 {
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
     P.serial = (int32_t)next_launch_serial();
-    P.selfcheck = g_band_selfcheck & 8;
+    P.selfcheck = tune.selfcheck & 8;
     BandIO io;
     io.cross = S.cross;
     io.occ = S.occ;
@@ -1837,7 +1334,7 @@ int launch_band_spec(const DetParams &D, BandWork S, DetState *st_spec, const fl
     io.conc = S.conc;
     io.flags = S.flags;
     hipLaunchKernelGGL(band_spec_prep_kernel, dim3(1), dim3(256), 0, stream, P, S, counts, sum_src, st_spec, have_prev);
-    hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, S, counts, entries);
+    hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, S, counts, entries);
     if (P.band_w == 128)
         hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, S, io, st_spec);
     else
@@ -1845,34 +1342,42 @@ int launch_band_spec(const DetParams &D, BandWork S, DetState *st_spec, const fl
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Enqueue the band scan of one chunk on `stream`: rounds [round_begin, round_end) and the verdict on the last of them.  Nothing
+// of the carried state (st, sum, hist) is written unless BandCtl::status ends as 1 (accepted); the caller reads the control
+// block (exported to pinned host memory by the history pass's first workgroups) afterwards.  The host enqueues rounds
+// 0 .. kBandFirst - 1 (two or three suffice on every scene measured; a round that is not needed is four empty launches) and,
+// if the verdict is still open (status 0, no flags), the rest up to kBandRounds with round_begin = kBandFirst: everything a
+// round needs from the one before lives in the workspace.
+//   spec       a speculation pass made this chunk's round 0 on that workspace (launch_band_spec): the scan opens with round 1,
+//              whose plan takes the update vector from spec's bitmaps (round_begin must be 1)
+//   sums_done  recorded behind the first sums pass of this launch (its sum_new is what the NEXT chunk's speculation pass
+//              tests against)
+//   gate_*     time-chunk sharding, irdm_expect_history: the 512-frame history of the previous chunk is still on its way from
+//              the previous rank.  Round 0 speculates "no update" and reads none of it; the first sums pass that does (round 1)
+//              starts behind a one-lane kernel that waits until the HOST has published `gate_seq` (the history has arrived
+//              in the caller's receive buffer) and the copy of it into the ring, both on this stream
+// A launch per pass: plan . [sums . cross . walk . plan]* . history -- the forms with fewer launches (the next plan pass run by
+// the walk pass's last workgroup; every round inside one cooperative launch), plan passes launched ahead on a second stream and
+// the history copy on a side stream were built, exact, and measured slower (docs/rounds/, profiles/r5_tail_ab.json,
+// profiles/r6_option_ab.json); they are not part of the product.
 int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, float *hist, const float *mag,
                      int n_frames, uint64_t idx0, const unsigned *counts, const ListEntry *entries, const float *pre,
                      float *smin, GoneBurst *gone, int gone_cap, int round_begin, int round_end, GoneBurst *hp_gone,
-                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream, hipStream_t side,
-                     hipEvent_t *plan_ev, const uint32_t *gate_flag, uint32_t gate_seq, uint32_t *gate_err, const void *gate_src,
-                     size_t gate_bytes, uint32_t scan_seq, hipEvent_t hist_wait, hipEvent_t hist_done, hipEvent_t hist_hop,
-                     const BandWork *spec, hipEvent_t sums_done)
+                     uint32_t *hp_hdr, void *hp_ctl, int hp_cap, int chained, int tl_sel, hipStream_t stream,
+                     const BandTune &tune, const uint32_t *gate_flag, uint32_t gate_seq, uint32_t *gate_err, const void *gate_src,
+                     size_t gate_bytes, const BandWork *spec, hipEvent_t sums_done)
 {
-    // spec: a speculation pass made this chunk's round 0 on that workspace (launch_band_spec): the scan opens with round 1,
-    // whose plan takes the update vector from spec's bitmaps (round_begin must be 1).  sums_done: recorded behind the first
-    // sums pass of this launch (its sum_new is what the NEXT chunk's speculation pass tests against).
     if (spec && round_begin != 1) return -1;
     const uint64_t *ub = spec ? spec->busy : nullptr, *uf = spec ? spec->forced : nullptr;
     bool sums_noted = sums_done == nullptr;
-    // Rounds [round_begin, round_end) and the verdict on the last of them.  The host enqueues rounds 0 .. kBandFirst - 1
-    // (two or three suffice on every scene measured; a round that is not needed is four empty launches) and, if the
-    // verdict is still open (status 0, no flags), the rest up to kBandRounds with round_begin = kBandFirst: everything a
-    // round needs from the one before lives in the workspace.
-    if (g_band_plan_ahead < 0) band_resolve_env();
     BandParams P;
     if (!band_scan_supported(D, &P, n_frames, idx0) || n_frames < 1) return -1;
     P.serial = (int32_t)next_launch_serial();
     P.chained = chained;
     P.spec_in = spec ? 1 : 0;
-    P.sum_restart = g_band_sum_restart;
-    P.selfcheck = g_band_selfcheck;
-    P.ahead = (g_band_plan_ahead && !g_band_coop && side && plan_ev && W.walk_host) ? 1 : 0;
-    P.tl_sel = g_band_timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;
+    P.sum_restart = tune.sum_restart;
+    P.selfcheck = tune.selfcheck;
+    P.tl_sel = tune.timeline && tl_sel >= 0 && tl_sel < 2 ? tl_sel : -1;
     if (P.tl_sel >= 0 && (round_begin == 0 || spec)) {
         unsigned long long *half = W.tl + (size_t)P.tl_sel * 2 * kBandTlSlots;
         (void)hipMemsetAsync(half, 0xff, 8 * kBandTlSlots, stream);
@@ -1893,205 +1398,43 @@ int launch_band_scan(const DetParams &D, BandWork W, DetState *st, float *sum, f
     io.forced = W.forced;
     io.conc = W.conc;
     io.flags = W.flags;
-    const size_t walk_lds = (size_t)kBandSlots * 64 * (8 + 8 + 4 + 4 + 4 + 4 + 4);
     const size_t commit_lds = (size_t)kBandMaxTotal * (8 + 2);
     // (per launch: the attribute belongs to the device the calling thread is on)
-    (void)hipFuncSetAttribute((const void *)band_walk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
-    (void)hipFuncSetAttribute((const void *)band_walk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
     (void)hipFuncSetAttribute((const void *)band_commit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)commit_lds);
-    (void)hipFuncSetAttribute((const void *)band_plan_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
-    (void)hipFuncSetAttribute((const void *)band_plan_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
-    (void)hipFuncSetAttribute((const void *)band_plan_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
-    const bool tail = g_band_tail && !g_band_coop && !P.ahead && g_band_walk_wave && g_band_cross_wave && !(P.selfcheck & 16) &&
-                      scan_seq != 0 && side && hist_done && hist_hop && round_end > round_begin;
-    if (tail) {
-        // ---- band_tail: plan0 . [sums . cross . walk + the next plan] per round; the history copy on the side stream ----
-        P.tail = 3;
-        P.seq = scan_seq;
-        g_band_tail_launches++;
-        const int nt = g_band_tail_threads == 256 ? 256 : g_band_tail_threads == 512 ? 512 : 1024;
-        const int walk_groups = kWalkWaveGroups * 256 / nt;
-        bool waited = hist_wait == nullptr;
-        // the previous scan's history copy (side stream) must be over before this launch reads or rewrites the ring, or
-        // commits (the commit rewrites the one HistJob); round 0's plan, crossing pass and -- the wait sits in front of it --
-        // walk run beside it
-        auto wait_hist = [&]() -> int {
-            if (!waited && hipStreamWaitEvent(stream, hist_wait, 0) != hipSuccess) return -1;
-            waited = true;
-            return 0;
-        };
-        for (int round = round_begin; round < round_end; round++) {
-            if (round == 0 || (spec && round == 1)) {
-                const float *pre0 = (round == 0 && g_band_fold_sums0) ? pre : nullptr;
-                if (g_band_plan_threads == 256)
-                    hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), kPlanLdsBytes, stream, P, W, counts, st, round, sum, gone, gone_cap, 0, 0u, pre0, smin, ub, uf, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-                else if (g_band_plan_threads == 512)
-                    hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), kPlanLdsBytes, stream, P, W, counts, st, round, sum, gone, gone_cap, 0, 0u, pre0, smin, ub, uf, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-                else
-                    hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), kPlanLdsBytes, stream, P, W, counts, st, round, sum, gone, gone_cap, 0, 0u, pre0, smin, ub, uf, 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-            }
-            if (gate_flag && round == (round_begin > 1 ? round_begin : 1)) {
-                if (wait_hist() != 0) return -1;
-                if (launch_wait_host_flag(gate_flag, gate_seq, gate_err, stream) != 0) return -1;
-                if (hipMemcpyAsync(hist, gate_src, gate_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
-            }
-            if (!(round == 0 && g_band_fold_sums0)) {
-                if (round >= 1 && wait_hist() != 0) return -1;
-                if (g_band_sum_bins == 32)
-                    hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
-                else if (g_band_sum_bins == 16)
-                    hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
-                else
-                    hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
-            if (!sums_noted && round >= 1) {
-                // (the first real sums pass of the scan: its sum_new is what the next chunk's speculation pass tests against)
-                if (hipEventRecord(sums_done, stream) != hipSuccess) return -1;
-                sums_noted = true;
-            }
-            }
-            hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
-            if (wait_hist() != 0) return -1;
-            const int final = round + 1 == round_end ? 1 : 0;
-            uint32_t *hpg = reinterpret_cast<uint32_t *>(hp_gone), *hpc = static_cast<uint32_t *>(hp_ctl);
-#define IRDM_WALK_TAIL(NWv, NTv)                                                                                              \
-            {                                                                                                                 \
-                (void)hipFuncSetAttribute((const void *)band_walk_tail_kernel<NWv, NTv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes); \
-                hipLaunchKernelGGL((band_walk_tail_kernel<NWv, NTv>), dim3(walk_groups), dim3(NTv), kPlanLdsBytes, stream, P, W, io, st, counts, round, \
-                                   final, sum, gone, gone_cap, hp_cap, hpg, hp_hdr, hpc);                                      \
-            }
-            if (P.band_w == 128) {
-                if (nt == 256) IRDM_WALK_TAIL(4, 256) else if (nt == 512) IRDM_WALK_TAIL(4, 512) else IRDM_WALK_TAIL(4, 1024)
-            } else {
-                if (nt == 256) IRDM_WALK_TAIL(8, 256) else if (nt == 512) IRDM_WALK_TAIL(8, 512) else IRDM_WALK_TAIL(8, 1024)
-            }
-#undef IRDM_WALK_TAIL
-        }
-        // the history copy: behind this launch's last pass, on the side stream -- the next scan's round 0 runs beside it
-        if (hipEventRecord(hist_hop, stream) != hipSuccess || hipStreamWaitEvent(side, hist_hop, 0) != hipSuccess) return -1;
-        hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, side, P, W, mag, hist, st,
-                           reinterpret_cast<const uint32_t *>(gone), 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                           W.hist_job, scan_seq);
-        if (hipEventRecord(hist_done, side) != hipSuccess) return -1;
-        return hipGetLastError() == hipSuccess ? 0 : -1;
-    }
-    // band_hist_side: a launch per pass, but the history copy on the side stream (from the HistJob the commit writes) and the
-    // export in the launch's last plan pass -- the copy of 2 x 16-32 MB (56-63 us in run, plus the launch) leaves the chain
-    // of scans.  The previous scan's copy must be over before a pass of this one reads the ring (a sums pass of round >= 1)
-    // or may commit (a plan pass of round >= 1 rewrites the one HistJob).
-    const bool hside = g_band_hist_side && !g_band_coop && !P.ahead && g_band_fuse_commit && !(P.selfcheck & 16) && scan_seq != 0 &&
-                       side && hist_done && hist_hop;
-    bool waited_legacy = hist_wait == nullptr;
-    auto wait_hist_legacy = [&]() -> int {
-        if (!waited_legacy && hipStreamWaitEvent(stream, hist_wait, 0) != hipSuccess) return -1;
-        waited_legacy = true;
-        return 0;
-    };
-    if (hside) {
-        P.tail = 2;
-        P.seq = scan_seq;
-    } else if (wait_hist_legacy() != 0) {
-        // (a launch per pass, or the cooperative kernel: everything on `stream`, behind a history copy an earlier scan may
-        // have left on the side stream)
-        return -1;
-    }
-    if (g_band_coop) {
-        // every round up to the verdict in one launch (the kernel leaves as soon as a round is accepted or declined)
-        (void)round_end;
-        if (P.band_w == 128) {
-            (void)hipFuncSetAttribute((const void *)band_coop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
-            hipLaunchKernelGGL((band_coop_kernel<4>), dim3(kCoopGroups), dim3(kCoopThreads), walk_lds, stream, P, W, io, counts,
-                               entries, st, mag, hist, sum, pre, smin, round_begin, kBandRounds);
-        } else {
-            (void)hipFuncSetAttribute((const void *)band_coop_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds);
-            hipLaunchKernelGGL((band_coop_kernel<8>), dim3(kCoopGroups), dim3(kCoopThreads), walk_lds, stream, P, W, io, counts,
-                               entries, st, mag, hist, sum, pre, smin, round_begin, kBandRounds);
-        }
-    } else
+    (void)hipFuncSetAttribute((const void *)band_plan_kernel<kPlanThreads>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPlanLdsBytes);
     for (int round = round_begin; round <= round_end; round++) {
         // (a continuation starts behind the plan its predecessor's verdict pass already made)
-        if (round > round_begin || round_begin == 0 || spec)
-        {
+        if (round > round_begin || round_begin == 0 || spec) {
             const size_t plan_lds = (P.selfcheck & 16) ? 0 : kPlanLdsBytes;
-            // (ahead: the walk pass this plan judges was enqueued just above; its workgroups bring bar[8] to *walk_host)
-            const bool ahead = P.ahead && round > round_begin && round >= 1;
-            hipStream_t ps = ahead ? side : stream;
-            BandParams Pp = P;
-            Pp.ahead = ahead ? 1 : 0;
-            const unsigned target = ahead ? *W.walk_host : 0u;
-            const float *pre0 = (round == 0 && g_band_fold_sums0) ? pre : nullptr;      // round 0's sums pass inside its plan pass
-            // (band_hist_side: the launch's last plan pass exports; one that may commit goes behind the previous history copy)
-            const bool exp = hside && round == round_end;
-            uint32_t *xg = exp ? reinterpret_cast<uint32_t *>(hp_gone) : nullptr, *xh = exp ? hp_hdr : nullptr,
-                     *xc = exp ? static_cast<uint32_t *>(hp_ctl) : nullptr;
-            if (hside && round >= 1 && !(spec && round == 1) && wait_hist_legacy() != 0) return -1;
-            if (g_band_plan_threads == 256)
-                hipLaunchKernelGGL(band_plan_kernel<256>, dim3(1), dim3(256), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin, ub, uf, hp_cap, xg, xh, xc);
-            else if (g_band_plan_threads == 512)
-                hipLaunchKernelGGL(band_plan_kernel<512>, dim3(1), dim3(512), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin, ub, uf, hp_cap, xg, xh, xc);
-            else
-                hipLaunchKernelGGL(band_plan_kernel<1024>, dim3(1), dim3(1024), plan_lds, ps, Pp, W, counts, st, round, sum, gone, gone_cap, g_band_fuse_commit, target, pre0, smin, ub, uf, hp_cap, xg, xh, xc);
-            if (ahead) {
-                // what follows on the scan's own stream waits for this plan
-                (void)hipEventRecord(plan_ev[round], side);
-                (void)hipStreamWaitEvent(stream, plan_ev[round], 0);
-            }
+            const float *pre0 = round == 0 ? pre : nullptr;      // round 0's sums pass (no update steps) inside its plan pass
+            hipLaunchKernelGGL(band_plan_kernel<kPlanThreads>, dim3(1), dim3(kPlanThreads), plan_lds, stream, P, W, counts, st, round, sum,
+                               gone, gone_cap, pre0, smin, ub, uf);
         }
         if (round == round_end) break;
-        // Gate (time-chunk sharding, irdm_expect_history): the 512-frame history of the previous chunk is still on its way
-        // from the previous rank.  Round 0 speculates "no update" and reads none of it; the first sums pass that does
-        // (round 1) starts behind a one-lane kernel that waits until the HOST has published `gate_seq` (the history has
-        // arrived in the caller's receive buffer) and the copy of it into the ring, both on this stream: nothing the
-        // waiting kernel depends on needs another queue of the GPU.
         if (gate_flag && round == (round_begin > 1 ? round_begin : 1)) {
-            if (wait_hist_legacy() != 0) return -1;
             if (launch_wait_host_flag(gate_flag, gate_seq, gate_err, stream) != 0) return -1;
             if (hipMemcpyAsync(hist, gate_src, gate_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return -1;
         }
-        if (hside && round >= 1 && wait_hist_legacy() != 0) return -1;
-        if (round == 0 && g_band_fold_sums0) {
-            // (done by the plan pass above)
-        } else if (g_band_sum_bins == 32)
-            hipLaunchKernelGGL(band_sum_kernel<32>, dim3(P.n / 32), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
-        else if (g_band_sum_bins == 16)
-            hipLaunchKernelGGL(band_sum_kernel<16>, dim3(P.n / 16), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
-        else
-            hipLaunchKernelGGL(band_sum_kernel<64>, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
+        if (round >= 1)
+            hipLaunchKernelGGL(band_sum_kernel, dim3(P.n / 64), dim3(64), 0, stream, P, W, mag, hist, sum, pre, smin, W.steps, W.snap);
         if (!sums_noted && round >= 1) {
             // (the first real sums pass of the scan: its sum_new is what the next chunk's speculation pass tests against)
             if (hipEventRecord(sums_done, stream) != hipSuccess) return -1;
             sums_noted = true;
         }
-        if (g_band_cross_wave)
-            hipLaunchKernelGGL(band_cross_w_kernel, dim3(g_band_cross_groups > 0 ? g_band_cross_groups : kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
+        hipLaunchKernelGGL(band_cross_w_kernel, dim3(kCrossGroups), dim3(256), 0, stream, P, W, counts, entries);
+        if (P.band_w == 128)
+            hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
         else
-            hipLaunchKernelGGL(band_cross_kernel, dim3(n_frames), dim3(256), 0, stream, P, W, counts, entries);
-        if (P.ahead) *W.walk_host += (unsigned)(g_band_walk_wave ? kWalkWaveGroups : P.occ_words);
-        if (g_band_walk_wave) {
-            if (P.band_w == 128)
-                hipLaunchKernelGGL((band_walk_wave_kernel<4>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
-            else
-                hipLaunchKernelGGL((band_walk_wave_kernel<8>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
-        } else if (P.band_w == 128)
-            hipLaunchKernelGGL((band_walk_kernel<4>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
-        else
-            hipLaunchKernelGGL((band_walk_kernel<8>), dim3(P.occ_words), dim3(64), walk_lds, stream, P, W, io, st);
+            hipLaunchKernelGGL((band_walk_wave_kernel<8>), dim3(kWalkWaveGroups), dim3(256), 0, stream, P, W, io, st);
     }
-    // (with the commit fused into the accepting plan pass there is nothing left for a commit launch to do)
-    if (g_band_coop || !g_band_fuse_commit || (P.selfcheck & 16))
+    // (the commit is part of the accepting plan pass, unless that pass ran without its LDS)
+    if (P.selfcheck & 16)
         hipLaunchKernelGGL(band_commit_kernel, dim3(1), dim3(kPlanThreads), commit_lds, stream, P, W, st, sum, gone, gone_cap);
     static_assert(kHistory >= kExportBlocks, "the export rides on the history pass's first workgroups");
-    if (hside) {
-        // (the export went with the last plan pass; the copy: behind this launch's last pass, on the side stream)
-        if (hipEventRecord(hist_hop, stream) != hipSuccess || hipStreamWaitEvent(side, hist_hop, 0) != hipSuccess) return -1;
-        hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, side, P, W, mag, hist, st,
-                           reinterpret_cast<const uint32_t *>(gone), 0, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                           W.hist_job, scan_seq);
-        if (hipEventRecord(hist_done, side) != hipSuccess) return -1;
-        return hipGetLastError() == hipSuccess ? 0 : -1;
-    }
     hipLaunchKernelGGL(band_history_kernel, dim3(kHistory), dim3(256), 0, stream, P, W, mag, hist, st,
                        reinterpret_cast<const uint32_t *>(gone), hp_cap < gone_cap ? hp_cap : gone_cap,
-                       reinterpret_cast<uint32_t *>(hp_gone), hp_hdr, static_cast<uint32_t *>(hp_ctl), (const HistJob *)nullptr, 0u);
+                       reinterpret_cast<uint32_t *>(hp_gone), hp_hdr, static_cast<uint32_t *>(hp_ctl));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

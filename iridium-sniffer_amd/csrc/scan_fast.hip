@@ -126,7 +126,7 @@ int launch_prefilter(const float *sum, float thr, float *pre, const float *mag, 
                      int n_frames, hipStream_t stream)
 {
     if (n_frames <= 0) return 0;
-    hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + g_small_wg - 1) / g_small_wg), dim3(g_small_wg), 0, stream, sum, thr, pre, n);
+    hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
     const int grid = n_frames < 8192 ? n_frames : 8192;
     hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames, kListCap);
     hipLaunchKernelGGL(list_offsets_kernel, dim3(1), dim3(1024), 0, stream, counts, goff, n_frames);
@@ -145,7 +145,7 @@ __global__ void prefilter_lower_kernel(const float *__restrict__ smin, float thr
 
 int launch_prefilter_threshold(const float *sum, float thr, float *pre, int n, hipStream_t stream)
 {
-    hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + g_small_wg - 1) / g_small_wg), dim3(g_small_wg), 0, stream, sum, thr, pre, n);
+    hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -156,7 +156,7 @@ int launch_prefilter_lists(const float *sum, float thr, float *pre, const float 
     if (smin)
         hipLaunchKernelGGL(prefilter_lower_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, smin, thr, pre, n);
     else
-        hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + g_small_wg - 1) / g_small_wg), dim3(g_small_wg), 0, stream, sum, thr, pre, n);
+        hipLaunchKernelGGL(prefilter_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sum, thr, pre, n);
     const int grid = n_frames < 8192 ? n_frames : 8192;
     hipLaunchKernelGGL(prefilter_kernel, dim3(grid), dim3(256), 0, stream, mag, pre, n, counts, entries, n_frames, cap);
     return hipGetLastError() == hipSuccess ? 0 : -1;

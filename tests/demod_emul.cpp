@@ -1,5 +1,5 @@
 // demod_emul.cpp -- TEST INFRASTRUCTURE: csrc/demod.hip (Gardner timing + PLL a lane per frame, slicer / unique word /
-// DQPSK / LLR a wavefront per frame, the packing kernel) on the CPU emulation of tests/hip_emul/hip/hip_runtime.h.
+// DQPSK / LLR a wavefront per frame, which also writes the compact records) on the CPU emulation of tests/hip_emul/hip/hip_runtime.h.
 // atan2f / sincosf / sqrtf resolve to the host libm here (on the device they are the device library's): what this checks
 // is the kernels' logic and arithmetic order against the reference's own stage-C vectors (tests/golden/ref_stage_c.npz,
 // produced by the reference's qpsk_demod.c), which were computed with the same host libm.
@@ -27,7 +27,17 @@ int demod_emul_run(const float *samples, const int *num_samples, const int *dire
     memset(out, 0, sizeof(DemodOut) * n);
     if (launch_demod(work.data(), n, reinterpret_cast<const float2 *>(samples), use_gardner, sps, ws.data(), out, nullptr) != 0)
         return -1;
-    if (packed && launch_demod_pack(out, n, packed, nullptr) != 0) return -1;
+    if (packed) {
+        // the compact records as the chain's last kernel writes them (demod_par_kernel's export: what a packed_records context
+        // polls), from a second run into a scratch DemodOut
+        std::vector<DemodOut> out2(n);
+        std::vector<BurstWork> work_back(n);
+        memset(out2.data(), 0, sizeof(DemodOut) * n);
+        if (launch_demod(work.data(), n, reinterpret_cast<const float2 *>(samples), use_gardner, sps, ws.data(), out2.data(), nullptr,
+                         packed, work_back.data()) != 0)
+            return -1;
+        if (memcmp(work_back.data(), work.data(), sizeof(BurstWork) * n) != 0) return -2;      // (the work records travel with them)
+    }
     return 0;
 }
 

@@ -1,5 +1,5 @@
 // detect_emul.cpp -- TEST INFRASTRUCTURE: csrc/detect.hip as the GPU build compiles it -- K1 (window, N-point FFT in
-// registers and LDS, fftshift, |.|^2, the candidate lists written in its store stage), the radix-2 LDS form of K1, and
+// registers and LDS, fftshift, |.|^2, the candidate lists written in its store stage; the radix-2 LDS kernel of the small sizes), and
 // the dense sequential detector scan -- on the CPU emulation of tests/hip_emul/hip/hip_runtime.h, with the product's own
 // window and twiddle designs (csrc/host_design.cpp), against the oracle (tests/test_kernels_emul.py).
 #include <hip/hip_runtime.h>
@@ -15,9 +15,10 @@ using namespace irdm;
 
 extern "C" {
 
-// K1 over n_frames frames of `iq` (fmt 2 cf32, 1 ci16, 0 ci8): mag [n_frames][n]; variant 0: radix-16 kernel, 1: the same
-// with candidate lists (pre [n] given; counts [n_frames], entries [n_frames][cap]), 2: radix-2 LDS kernel.  Returns 0, or
-// 1 if this FFT size has no such kernel.  variant + 4: the radix-16 kernel where the 32-points-per-lane kernel is the default.
+// K1 over n_frames frames of `iq` (fmt 2 cf32, 1 ci16, 0 ci8): mag [n_frames][n] by the kernel the size takes (8192 / 16384
+// points: 32 points per lane; 4096: radix 16; up to 2048: the radix-2 LDS kernel); variant 1: with the band scan's candidate
+// lists (pre [n] given; counts [n_frames], entries [n_frames][cap]).  order: fftshift_mag's AVX2 (1) / generic (0) form.
+// Returns 0, or 1 if this FFT size has no such kernel.
 int detect_emul_k1(const void *iq, int fmt, int n, int n_frames, int variant, float *mag, const float *pre,
                    unsigned *counts, ListEntry *entries, int cap)
 {
@@ -26,19 +27,12 @@ int detect_emul_k1(const void *iq, int fmt, int n, int n_frames, int variant, fl
     for (int i = 0; i < n; i++) window[i] /= 0.42f;               // burst_detect.c:249-250, as csrc/pipeline.cpp prepares it
     std::vector<cfloat> tw = design_twiddles(n);
     const float2 *tw2 = reinterpret_cast<const float2 *>(tw.data());
-    g_fft_kernel = variant >= 4 ? 0 : 1;
-    variant &= 3;
-    g_fft_force_radix2 = variant == 2;
-    int rc;
-    if (variant == 1) {
+    const int order = (variant & 8) ? 0 : 1;
+    if ((variant & 3) == 1) {
         memset(counts, 0, sizeof(unsigned) * n_frames);
-        rc = launch_fft_mag_lists(log_n, fmt, iq, window.data(), tw2, mag, n_frames, pre, counts, entries, cap, nullptr);
-    } else {
-        rc = launch_fft_mag(log_n, fmt, iq, window.data(), tw2, mag, n_frames, nullptr);
+        return launch_fft_mag_lists(log_n, fmt, iq, window.data(), tw2, mag, n_frames, pre, counts, entries, cap, nullptr, nullptr, order);
     }
-    g_fft_force_radix2 = 0;
-    g_fft_kernel = 1;
-    return rc;
+    return launch_fft_mag(log_n, fmt, iq, window.data(), tw2, mag, n_frames, nullptr, nullptr, order);
 }
 
 // the dense sequential scan (detect_scan_kernel) over the whole magnitude plane from the first frame of a stream, in

@@ -40,7 +40,7 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
         import ctypes as C
         assert depth >= 1
         ingest = feed.startswith("ingest")
-        look = feed.endswith("lookahead") or feed.endswith("lookahead2")
+        look = feed.endswith("lookahead")
         held = []                # device buffers of chunks begun (not "ingest"): released after their feed_end
 
         def begin(c, off):
@@ -62,7 +62,7 @@ def run_gpu(iq, fs, fmt=irdm.FMT_CF32, chunks=None, scan_mode=0, depth=0, feed="
                 irdm.device_free(ptr)
 
         pending = 0
-        ahead = 2 if feed.endswith("lookahead2") else 1 if look else 0      # chunks begun ahead of the one that is ended
+        ahead = 1 if look else 0      # chunks begun ahead of the one that is ended
         for c in sizes:
             begin(c, off)
             off += c

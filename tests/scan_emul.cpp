@@ -28,29 +28,20 @@ static int g_emul_spec = 0;
 
 extern "C" {
 
-// test hooks of the scan (csrc/kernels.hpp: g_band_*)
+// test hooks of the scan (csrc/kernels.hpp: BandTune -- what a pipeline carries as options band_selfcheck / band_timeline)
+static BandTune g_tune;
 void scan_emul_option(const char *key, int value)
 {
-    if (!strcmp(key, "band_walk_wave")) g_band_walk_wave = value;
-    else if (!strcmp(key, "band_selfcheck")) g_band_selfcheck = value;
-    else if (!strcmp(key, "band_fuse_commit")) g_band_fuse_commit = value;
-    else if (!strcmp(key, "band_plan_threads")) g_band_plan_threads = value;
-    else if (!strcmp(key, "band_plan_ahead")) g_band_plan_ahead = value;
-    else if (!strcmp(key, "band_sum_bins")) g_band_sum_bins = value;
-    else if (!strcmp(key, "band_cross_wave")) g_band_cross_wave = value;
-    else if (!strcmp(key, "band_timeline")) g_band_timeline = value;
-    else if (!strcmp(key, "band_fold_sums0")) g_band_fold_sums0 = value;
+    if (!strcmp(key, "band_selfcheck")) g_tune.selfcheck = value;
+    else if (!strcmp(key, "band_timeline")) g_tune.timeline = value;
+    else if (!strcmp(key, "band_sum_restart")) g_tune.sum_restart = value;
     else if (!strcmp(key, "band_spec")) g_emul_spec = value;
-    else if (!strcmp(key, "band_sum_restart")) g_band_sum_restart = value;
-    else if (!strcmp(key, "band_hist_side")) g_band_hist_side = value;
-    else if (!strcmp(key, "band_tail")) g_band_tail = value;
-    else if (!strcmp(key, "band_tail_threads")) g_band_tail_threads = value;
 }
 
 // mag: [n_frames][n] magnitude frames of a stream from its first sample.  The first 512 frames prime the baseline
 // (burst_detect.c:427-428, :448-452); the rest is scanned in chunks of chunk_frames.  Returns the number of finished
 // bursts written to out (emission order), or -(flags) - 1000 if a chunk was declined.  stats: [0] rounds, [1] chunks,
-// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] launches in the tail form so far, [6] speculation passes, [7] sums passes restarted.
+// [2] bursts still active, [3] stale-list retries, [4] continuation launches, [5] 0, [6] speculation passes, [7] sums passes restarted.
 int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_len, int width, int max_bursts, int max_len,
                   float threshold, int chunk_frames, int first_rounds, GoneBurst *out, int out_cap, float *sum_out, int *stats)
 {
@@ -85,19 +76,12 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     BandWork W;
     band_work_carve(&W, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(ws.data()) + 255) & ~(uintptr_t)255), n, max_chunk);
     memset(W.bar, 0, 256);
-    unsigned walk_host = 0;
-    W.walk_host = &walk_host;
     const int cap = band_list_cap(n);
     std::vector<unsigned> counts(F_cap);
     std::vector<ListEntry> entries((size_t)F_cap * cap);
     const int gone_cap = 8192;
     std::vector<GoneBurst> gone(gone_cap), all;
     memset(stats, 0, sizeof(int) * 8);
-    hipEvent_t plan_ev[kBandRounds + 2] = {};
-    // (band_tail, the default form: a side "stream" for the history copy, the scans numbered, the events the emulation's)
-    hipStream_t side = reinterpret_cast<hipStream_t>(2);
-    hipEvent_t ev_hist = reinterpret_cast<hipEvent_t>(3), ev_hop = reinterpret_cast<hipEvent_t>(4);
-    uint32_t scan_seq = 0;
     std::vector<unsigned char> ws2(band_work_bytes(n, max_chunk, true) + 256);
     BandWork S;
     band_work_carve(&S, reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(ws2.data()) + 255) & ~(uintptr_t)255), n, max_chunk, true);
@@ -108,7 +92,6 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     memset(st_spec_store.data(), 0, sizeof(DetState));
     bool have_prev_spec = false;
     for (int f0 = kHistory; f0 < n_frames; f0 += chunk_frames) {
-        scan_seq++;
         const int F = std::min(chunk_frames, n_frames - f0);
         const float *m0 = mag + (size_t)f0 * n;
         for (int b = 0; b < n; b++) pre[b] = 0.5f * threshold * sum[b];
@@ -132,23 +115,21 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
             const bool use_spec = g_emul_spec && tries == 0 && f0 > kHistory && first >= 2;
             if (use_spec) {
                 if (launch_band_spec(D, S, st_spec_store.data(), W.sum_new, F, st->index, counts.data(), entries.data(),
-                                     (have_prev_spec && g_emul_spec == 1) ? 1 : 0, reinterpret_cast<hipStream_t>(5)) != 0)
+                                     (have_prev_spec && g_emul_spec == 1) ? 1 : 0, reinterpret_cast<hipStream_t>(5), g_tune) != 0)
                     return -3;
                 have_prev_spec = true;
                 stats[6]++;
             }
             if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(), pre.data(),
                                  smin.data(), gone.data(), gone_cap, use_spec ? 1 : 0, first, nullptr, nullptr, nullptr, gone_cap, 0, 0,
-                                 nullptr, side, plan_ev, nullptr, 0, nullptr, nullptr, 0, scan_seq, ev_hist, ev_hist, ev_hop,
-                                 use_spec ? &S : nullptr, nullptr) != 0)
+                                 nullptr, g_tune, nullptr, 0, nullptr, nullptr, 0, use_spec ? &S : nullptr, nullptr) != 0)
                 return -3;
             if (W.ctl->status == 0 && W.ctl->flags == 0) {
                 // verdict still open after the rounds enqueued up front: the rest (csrc/pipeline.cpp: more_rounds)
                 stats[4]++;
                 if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(),
                                      pre.data(), smin.data(), gone.data(), gone_cap, first, kBandRounds, nullptr, nullptr,
-                                     nullptr, gone_cap, 0, 0, nullptr, side, plan_ev, nullptr, 0, nullptr, nullptr, 0, scan_seq,
-                                     ev_hist, ev_hist, ev_hop) != 0)
+                                     nullptr, gone_cap, 0, 0, nullptr, g_tune) != 0)
                     return -3;
             }
             if (W.ctl->status == 1 || W.ctl->flags != BAND_F_STALE || tries >= 2) break;
@@ -181,7 +162,7 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
     for (size_t i = 0; i < all.size(); i++) out[i] = all[i];
     memcpy(sum_out, sum.data(), sizeof(float) * n);
     stats[2] = st->n_act;
-    stats[5] = (int)g_band_tail_launches.load();      // (since the library was loaded)
+    stats[5] = 0;
     return (int)all.size();
 }
 

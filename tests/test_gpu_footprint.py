@@ -131,13 +131,13 @@ def test_context_footprint_10mhz():
     p = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=2)
     u1 = _used()
     p.close()
-    assert u1 - u0 < 5.0e9, u1 - u0        # (8.8 GB with full-length scratch rows; rounds 1-3: 6.1 GB + the 4.5 GB table)
+    assert u1 - u0 < 5.4e9, u1 - u0        # (8.8 GB with full-length scratch rows; rounds 1-3: 6.1 GB + the 4.5 GB table)
     u0 = _used()
     p = irdm.Pipeline(10_000_000, max_chunk_samples=16 * 1024 * 1024, max_bursts_per_chunk=4096, pipeline_depth=2)
     p.set_option("rot_prebuild", 0)
     u2 = _used()
     p.close()
-    assert u2 - u0 < 4.2e9, u2 - u0        # rows on demand: as in round 5
+    assert u2 - u0 < 4.4e9, u2 - u0        # rows on demand: as in round 5
     print("10 MHz context, rows on demand: %.2f GB" % ((u2 - u0) / 1e9))
     print("10 MHz context, 16 Mi-sample chunks, depth 2: %.2f GB" % ((u1 - u0) / 1e9))
 

@@ -183,35 +183,21 @@ def test_detect_only_mode_emits_the_same_bursts():
 
 
 def test_kernel_variants_agree():
-    """The runtime-M decimator and the radix-2 FFT kernels (fallbacks for sizes without a specialised kernel), the
-    one-tile-per-workgroup decimators (row-major and column-major tile), the persistent decimator with one resident
-    grid / the smallest tile budget and the rotator's phase rows stored a row per lane (rot_store 0) give the same records
-    as the default kernels and the oracle."""
+    """The paths a default run at the standard rates never takes: the runtime-tap-count instances of the post filters (test
+    hook post_generic), the any-M decimator in both orders (fir_generic), the reference's generic forms throughout
+    (fir_order 0) -- same records as the oracle in the same order.  The switches are fields of the pipeline: nothing has to be
+    restored afterwards."""
     fs, iq = _scene_2m(seed=19, n_bursts=6, secs=2.0)
     ref = orc.run_stream(iq, fs)
     try:
-        orc.set_fir_order(0)                   # the decimating FIR in the reference's scalar order: the LDS decimators' order
+        orc.set_fir_order(0)                   # the dispatched kernels in the reference's generic forms (--no-simd)
         ref0 = orc.run_stream(iq, fs)
     finally:
         orc.set_fir_order(1)
-    defaults = {"fir_generic": 0, "fft_radix2": 0, "fir_layout": 3, "fir_budget": 4, "post_generic": 0, "fir_order": 1, "rot_store": 1}
-    for opts in ({"fir_generic": 1}, {"fft_radix2": 1}, {"post_generic": 1}, {"fir_order": 0}, {"rot_store": 0}, {"rot_store": 3},
-                 {"fir_order": 0, "fir_generic": 1}, {"fir_order": 0, "fir_layout": 0}, {"fir_order": 0, "fir_layout": 1},
-                 {"fir_order": 0, "fir_layout": 2}, {"fir_order": 0, "fir_budget": 0}, {"fir_order": 0, "fir_budget": 2}):
-        p = irdm.Pipeline(fs, max_chunk_samples=len(iq), max_bursts_per_chunk=1024)
-        p.set_option("keep_frame_samples", 1)
-        try:
-            for k, v in opts.items():
-                p.set_option(k, v)
-            p.feed_host(iq)
-            infos, samples = p.poll_frames()
-            got = dict(bursts=p.poll_bursts(), infos=infos, samples=samples, demods=p.poll_demods(), tagged=p.tagged)
-        finally:
-            for k in opts:
-                p.set_option(k, defaults[k])
-            p.close()
-        parity.compare(got, ref if opts.get("fir_order", 1) else ref0)
-
+    for opts in ({"fir_generic": 1}, {"post_generic": 1}, {"fir_order": 0}, {"fir_order": 0, "fir_generic": 1},
+                 {"fir_order": 0, "post_generic": 1}):
+        parity.compare(parity.run_gpu(iq, fs, options=opts), ref if opts.get("fir_order", 1) else ref0)
+    parity.compare(parity.run_gpu(iq, fs), ref)
 
 def test_known_answer_bits_from_reference_docs():
     """ARCHITECTURE.md:264/:270 -- the documented PRBS15 RAW line: 179 payload symbols, same bits."""

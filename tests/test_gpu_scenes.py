@@ -178,78 +178,41 @@ def _zone_scene():
     return fs, iq
 
 
-def _restore_selfcheck():
-    p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
-    p.set_option("band_selfcheck", 0)
-    p.close()
-
-
 def test_boundary_test_forms_agree_and_both_object():
     """the plan pass's boundary test (scan_band.hip: all boundaries at once from zone lists in LDS) against the plain
-    wavefront search it replaced: option band_selfcheck 1 runs both on every verdict and declines the chunk with
+    wavefront search it replaced: test hook band_selfcheck 1 runs both on every verdict and declines the chunk with
     BAND_F_CHECK (4096) if their answers differ; 3 additionally spoils one band's copy of every record in a boundary
     zone, so both must object (BAND_F_AGREE, 32) and the sequential kernels take the chunk.  Parity either way
     (burst_detect.c:426-632)."""
     fs, iq = _zone_scene()
     ref = orc.run_stream(iq, fs)
-    try:
-        for chunks in (None, _chunks(len(iq), 3)):
-            got = parity.run_gpu(iq, fs, chunks=chunks, depth=1 if chunks else 0, options={"band_selfcheck": 1})
-            parity.compare(got, ref)
-            assert got["stats"]["band_aborts"] == 0 and got["stats"]["band_chunks"] >= 1, got["stats"]
-        spoiled = parity.run_gpu(iq, fs, options={"band_selfcheck": 3})
-        parity.compare(spoiled, ref)
-        st = spoiled["stats"]
-        assert st["band_aborts"] >= 1 and st["scan_fallbacks"] >= 1, st
-        assert st["band_last_flags"] & 32 and not st["band_last_flags"] & 4096, st
-    finally:
-        _restore_selfcheck()
-
-
-@pytest.mark.parametrize("case", ["too_long", "dc_and_edges", "strong_simultaneous", "many_active_10m"])
-def test_lane_per_band_walk_still_agrees(case):
-    """option band_walk_wave 0: the walk pass with a lane per band (band_core.hpp's BandWalker, the form the CPU test
-    drives) instead of a wavefront per band and segment (band_wave.hpp) -- same records as the oracle either way"""
-    if case not in scenes.ALL:
-        pytest.skip("no such scene")
-    fs, iq = scenes.ALL[case]()
-    ref = orc.run_stream(iq, fs)
-    try:
-        got = parity.run_gpu(iq, fs, options={"band_walk_wave": 0})
+    for chunks in (None, _chunks(len(iq), 3)):
+        got = parity.run_gpu(iq, fs, chunks=chunks, depth=1 if chunks else 0, options={"band_selfcheck": 1})
         parity.compare(got, ref)
-        chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, options={"band_walk_wave": 0})
-        parity.compare(chunked, ref)
-    finally:
-        p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
-        p.set_option("band_walk_wave", 1)
-        p.close()
+        assert got["stats"]["band_aborts"] == 0 and got["stats"]["band_chunks"] >= 1, got["stats"]
+    spoiled = parity.run_gpu(iq, fs, options={"band_selfcheck": 3})
+    parity.compare(spoiled, ref)
+    st = spoiled["stats"]
+    assert st["band_aborts"] >= 1 and st["scan_fallbacks"] >= 1, st
+    assert st["band_last_flags"] & 32 and not st["band_last_flags"] & 4096, st
 
 
 @pytest.mark.parametrize("case", ["too_long", "strong_simultaneous", "many_active_10m"])
 def test_wave_walk_without_look_ahead_agrees(case):
-    """option band_selfcheck 8: the wavefront walk event by event (band_wave.hpp without skim()) -- the records must not
+    """test hook band_selfcheck 8: the wavefront walk event by event (band_wave.hpp without skim()) -- the records must not
     depend on the 64-frame look-ahead"""
     fs, iq = scenes.ALL[case]()
     ref = orc.run_stream(iq, fs)
-    try:
-        got = parity.run_gpu(iq, fs, options={"band_selfcheck": 8})
-        parity.compare(got, ref)
-    finally:
-        _restore_selfcheck()
+    parity.compare(parity.run_gpu(iq, fs, options={"band_selfcheck": 8}), ref)
 
 
 @pytest.mark.parametrize("case", ["too_long", "strong_simultaneous"])
-def test_commit_as_a_launch_of_its_own_agrees(case):
-    """option band_fuse_commit 0: the commit pass as its own launch behind the rounds instead of inside the plan pass that
-    accepts the round -- same records"""
+def test_plan_without_lds_and_commit_as_a_launch_of_its_own_agree(case):
+    """test hook band_selfcheck 16: the plan pass through the workspace arrays instead of its LDS (what a chunk of more than
+    8192 frames takes), the commit as its own launch behind the rounds instead of inside the accepting plan pass -- same
+    records"""
     fs, iq = scenes.ALL[case]()
     ref = orc.run_stream(iq, fs)
-    try:
-        got = parity.run_gpu(iq, fs, options={"band_fuse_commit": 0})
-        parity.compare(got, ref)
-        chunked = parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, options={"band_fuse_commit": 0})
-        parity.compare(chunked, ref)
-    finally:
-        p = irdm.Pipeline(2_000_000, max_chunk_samples=65536, max_bursts_per_chunk=64)
-        p.set_option("band_fuse_commit", 1)
-        p.close()
+    parity.compare(parity.run_gpu(iq, fs, options={"band_selfcheck": 16}), ref)
+    parity.compare(parity.run_gpu(iq, fs, chunks=_chunks(len(iq), 4), depth=1, options={"band_selfcheck": 16}), ref)
+

@@ -37,7 +37,7 @@ def emul():
         # the one change: dynamic LDS arrays become pointers into the emulation's LDS buffer
         text, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) unsigned char (\w+)\[\];",
                           r"unsigned char *\1 = hip_emul::dyn_lds();", text)
-        assert n >= 3
+        assert n >= 2
         open(inc, "w").write(text)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-I" + os.path.join(ROOT, "tests", "hip_emul"), "-I" + out_dir, "-I" + CSRC, "-o", so, src])
@@ -90,70 +90,33 @@ def test_scan_kernels_scene_zoo(emul, name):
     stats = check(emul, iq, fs, chunks=(1 << 20, 97))
     assert stats[1] >= 1
     try:
-        # the launch-saving form (band_tail: pair list, the plan pass in the walk pass's last workgroup, the history copy apart)
-        emul.scan_emul_option(b"band_tail", 1)
-        before = run(emul, *_tiny_scene())[3][5]
-        stats = check(emul, iq, fs, chunks=(1 << 20, 97))
-        assert stats[5] - before >= stats[1], "the tail form of the scan did not run: %r" % stats
-        emul.scan_emul_option(b"band_tail", 0)
         # round 0 as a speculation pass on a second workspace (band_spec): with the carried bursts the previous pass left,
         # and with that guess withheld (2) -- a wrong guess costs a round, never a result
         for mode in (1, 2):
             emul.scan_emul_option(b"band_spec", mode)
             stats = check(emul, iq, fs, chunks=(97, 33))
             assert stats[6] >= stats[1] - 1 >= 2, "no speculation passes: %r" % stats
-        emul.scan_emul_option(b"band_tail", 1)
-        check(emul, iq, fs, chunks=(97,))
-        emul.scan_emul_option(b"band_tail", 0)
-        # a launch per pass with the history copy on the side stream and the export in the last plan pass (band_hist_side),
-        # with and without the speculation pass
-        emul.scan_emul_option(b"band_hist_side", 1)
-        check(emul, iq, fs, chunks=(97, 33))
         emul.scan_emul_option(b"band_spec", 0)
-        check(emul, iq, fs, chunks=(1 << 20, 97))
         check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
     finally:
-        emul.scan_emul_option(b"band_tail", 0)
         emul.scan_emul_option(b"band_spec", 0)
-        emul.scan_emul_option(b"band_hist_side", 0)
 
 
 def test_scan_kernels_continuation_and_options(emul):
-    """two rounds enqueued up front where the scene needs more (the continuation launch), the lane-per-band walk, the
-    commit as a launch of its own, the walk without look-ahead, both forms of the boundary test compared on the fly"""
+    """two rounds enqueued up front where the scene needs more (the continuation launch); the test hooks of the scan: the walk
+    without look-ahead (band_selfcheck 8), both forms of the boundary test compared on the fly (1), the plan pass without its
+    LDS and the commit as a launch of its own (16)"""
     fs, iq = scenes.ALL["too_long"]()
     stats = check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
     assert stats[4] >= 1, "no continuation launch was needed: %r" % stats
-    defaults = {b"band_walk_wave": 1, b"band_fuse_commit": 1, b"band_selfcheck": 0, b"band_plan_threads": 1024,
-                b"band_plan_ahead": 0, b"band_fold_sums0": 1, b"band_tail": 0, b"band_tail_threads": 1024}
     try:
-        # the tail form (band_tail: pair list, the plan pass in the walk pass's last workgroup, the history copy apart)
-        # with narrower workgroups, with round 0's sums pass as a launch of its own, with the walk's look-ahead off and the
-        # boundary test's two forms compared
-        emul.scan_emul_option(b"band_tail", 1)
-        for key, value in ((b"band_tail_threads", 256), (b"band_tail_threads", 512), (b"band_fold_sums0", 0),
-                           (b"band_selfcheck", 8), (b"band_selfcheck", 1), (b"band_plan_threads", 256)):
-            emul.scan_emul_option(key, value)
+        check(emul, iq, fs, chunks=(131, 1 << 20))
+        for value in (8, 1, 16):
+            emul.scan_emul_option(b"band_selfcheck", value)
             check(emul, iq, fs, chunks=(131,))
             check(emul, iq, fs, chunks=(1 << 20,), first_rounds=1)
-            emul.scan_emul_option(key, defaults[key])
-        # a launch per pass (band_tail 0), and every option of that form (the lane-per-band walk, the commit as a launch of
-        # its own, plan passes "launched ahead" ... switch the tail form off by themselves)
-        emul.scan_emul_option(b"band_tail", 0)
-        check(emul, iq, fs, chunks=(131, 1 << 20))
-        for key, value in ((b"band_walk_wave", 0), (b"band_fuse_commit", 0), (b"band_selfcheck", 8), (b"band_selfcheck", 1),
-                           (b"band_plan_threads", 256), (b"band_plan_ahead", 1), (b"band_fold_sums0", 0)):
-            emul.scan_emul_option(key, value)
-            check(emul, iq, fs, chunks=(131,))
-            emul.scan_emul_option(key, defaults[key])
-        emul.scan_emul_option(b"band_tail", 1)
-        for key, value in ((b"band_walk_wave", 0), (b"band_plan_ahead", 1), (b"band_selfcheck", 16)):
-            emul.scan_emul_option(key, value)
-            check(emul, iq, fs, chunks=(131,))
-            emul.scan_emul_option(key, defaults[key])
     finally:
-        for key, value in defaults.items():
-            emul.scan_emul_option(key, value)
+        emul.scan_emul_option(b"band_selfcheck", 0)
 
 
 def test_scan_kernels_sums_pass_restart(emul):
@@ -267,10 +230,10 @@ def _k1(L, x, fmt, n, frames, variant, pre=None, cap=4096):
     return rc, mag, counts, entries
 
 
-@pytest.mark.parametrize("fs", [2_000_000, 10_000_000, 12_000_000])
+@pytest.mark.parametrize("fs", [2_000_000, 4_000_000, 10_000_000, 12_000_000])
 def test_k1_kernels_match_the_oracle_fft(detect_emul, fs):
-    """window . N-point FFT . fftshift . |.|^2 (burst_detect.c:679-687) by the radix-16 register kernel, the same kernel
-    writing the band scan's candidate lists, and the radix-2 LDS kernel, for cf32 / ci16 / ci8 input: magnitudes bit for
+    """window . N-point FFT . fftshift . |.|^2 (burst_detect.c:679-687) by the kernel each frame size takes, and by the same
+    kernel writing the band scan's candidate lists, for cf32 / ci16 / ci8 input: magnitudes bit for
     bit those of the oracle's pinned FFT; the lists hold exactly the bins above the prefilter level"""
     n = det_params(fs)["n"]
     frames = 24 if n > 2048 else 64
@@ -287,15 +250,14 @@ def test_k1_kernels_match_the_oracle_fft(detect_emul, fs):
         ref_mag, _, _ = oracle_detect(np.ascontiguousarray(as_cf), fs)
         assert ref_mag.shape[0] >= frames
         ref_mag = ref_mag[:frames]
-        # variants 0 / 1 / 2: the default register kernel (32 points per lane at 8192 / 16384 points), the same with the
-        # candidate lists, the radix-2 LDS kernel; 4 / 5: the radix-16 kernel where it is no longer the default
-        for variant in (0, 2) + ((4,) if n >= 8192 else ()):
-            rc, mag, _, _ = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, variant)
-            assert rc == 0
-            assert np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32)), (fs, fmt, variant)
+        # variant 0: the kernel the size takes (32 points per lane at 8192 / 16384 points, radix 16 at 4096, the radix-2 LDS
+        # kernel at 2048); 1: the same with the candidate lists
+        rc, mag, _, _ = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, 0)
+        assert rc == 0
+        assert np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32)), (fs, fmt)
         if n >= 4096:
             pre = (np.float32(0.5) * np.percentile(ref_mag, 99.0, axis=0)).astype(np.float32)
-            for variant in (1,) + ((5,) if n >= 8192 and fmt == 2 else ()):
+            for variant in (1,):
                 rc, mag, counts, entries = _k1(detect_emul, np.ascontiguousarray(x), fmt, n, frames, variant, pre=pre)
                 assert rc == 0 and np.array_equal(mag.view(np.uint32), ref_mag.view(np.uint32))
                 for f in range(frames):
