@@ -1,6 +1,6 @@
 // bitlayer_emul.cpp -- TEST INFRASTRUCTURE: csrc/bitlayer.hip's frame_decode kernel (frame_decode.c:414-598: access-code
 // check, de-interleave, BCH by syndrome tables, Chase decoding on the LLRs, IRA / IBC field extraction) on the CPU
-// emulation of tests/hip_emul/hip/hip_runtime.h, with the syndrome tables built as csrc/pipeline.cpp builds them
+// emulation of tests/hip_emul/hip/hip_runtime.h, with the syndrome tables built as csrc/create.cpp builds them
 // (frame_decode.c:95-129), against the oracle's frame_decode (itself pinned to the reference's object code).
 #include <hip/hip_runtime.h>
 #include <vector>
@@ -20,7 +20,7 @@ unsigned poly_rem(unsigned poly, unsigned v)
     return v;
 }
 
-// remainder of every 1- and 2-bit error pattern -> (number of errors, pattern); csrc/pipeline.cpp irdm_create
+// remainder of every 1- and 2-bit error pattern -> (number of errors, pattern); csrc/create.cpp irdm_create
 std::vector<int2> syndrome_table(unsigned poly, int nbits, int max_err, int size)
 {
     std::vector<int2> t((size_t)size, make_int2(-1, 0));

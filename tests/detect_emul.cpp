@@ -24,7 +24,7 @@ int detect_emul_k1(const void *iq, int fmt, int n, int n_frames, int variant, fl
 {
     const int log_n = 31 - __builtin_clz((unsigned)n);
     std::vector<float> window = design_blackman(n);
-    for (int i = 0; i < n; i++) window[i] /= 0.42f;               // burst_detect.c:249-250, as csrc/pipeline.cpp prepares it
+    for (int i = 0; i < n; i++) window[i] /= 0.42f;               // burst_detect.c:249-250, as csrc/create.cpp prepares it
     std::vector<cfloat> tw = design_twiddles(n);
     const float2 *tw2 = reinterpret_cast<const float2 *>(tw.data());
     const int order = (variant & 8) ? 0 : 1;

@@ -1,5 +1,5 @@
-"""TEST INFRASTRUCTURE: builds tests/_build/libirdm_emul.so -- the product's sources (every kernel file, csrc/pipeline.cpp,
-csrc/group.cpp, csrc/host_design.cpp, csrc/compat.cpp: the whole C-ABI of include/irdm_hip.h) compiled with g++ against the
+"""TEST INFRASTRUCTURE: builds tests/_build/libirdm_emul.so -- the product's sources (every kernel file,
+the host sources plug / create / chain / scan_host / feed / state / api.cpp, csrc/group.cpp, csrc/host_design.cpp, csrc/compat.cpp: the whole C-ABI of include/irdm_hip.h) compiled with g++ against the
 HIP emulation of tests/hip_emul/hip/hip_runtime.h (and, for group.cpp, the emulated RCCL of tests/hip_emul/rccl/rccl.h), so that the `-m "not gpu"` tests can drive the product end to end without a GPU
 (tests/test_pipeline_emul.py).  Never loaded by the product: iridium-sniffer_amd/irdm.py loads libirdm_hip.so unless a
 test points IRDM_LIB elsewhere.
@@ -24,7 +24,8 @@ EMUL = os.path.join(ROOT, "tests", "hip_emul")
 OUT = os.path.join(ROOT, "tests", "_build", "emul")
 SO = os.path.join(ROOT, "tests", "_build", "libirdm_emul.so")
 SOURCES = ["detect.hip", "scan_fast.hip", "scan_band.hip", "downmix.hip", "fir_reg.hip", "demod.hip", "bitlayer.hip",
-           "pipeline.cpp", "group.cpp", "host_design.cpp", "compat.cpp"]
+           "plug.cpp", "create.cpp", "chain.cpp", "scan_host.cpp", "feed.cpp", "state.cpp", "api.cpp", "group.cpp", "host_design.cpp",
+           "compat.cpp"]
 
 
 def transform(name, text):
@@ -38,7 +39,7 @@ def transform(name, text):
     if name == "host_design.cpp":
         # (hipcc = clang has __builtin_complex in C++; g++ spells it with __real__ / __imag__)
         text = ("#define __builtin_complex(re, im) ({ float _Complex z_; __real__ z_ = (re); __imag__ z_ = (im); z_; })\n" + text)
-    assert "asm(" not in text.replace('asm volatile("" ::: "memory")', "") or name == "pipeline.cpp", name
+    assert "asm(" not in text.replace('asm volatile("" ::: "memory")', "") or name in ("create.cpp", "chain.cpp", "scan_host.cpp", "feed.cpp", "state.cpp", "api.cpp", "plug.cpp"), name
     return text
 
 

@@ -1,7 +1,7 @@
 // scan_emul.cpp -- TEST INFRASTRUCTURE: the band scan exactly as the GPU build compiles it (csrc/scan_band.hip: plan with
 // its LDS path and the boundary test, sums with buffer loads, frame-walking crossing pass, wavefront walk with the
 // look-ahead, commit fused into the accepting plan pass, history) executed on the CPU by the HIP emulation of
-// tests/hip_emul/hip/hip_runtime.h, chunk by chunk through launch_band_scan() as csrc/pipeline.cpp drives it (rounds
+// tests/hip_emul/hip/hip_runtime.h, chunk by chunk through launch_band_scan() as csrc/scan_host.cpp drives it (rounds
 // enqueued up front, continuation if the verdict is open, the stale-list retry), so that the whole speculative scan can
 // be compared with the oracle's sequential detector without a GPU (tests/test_kernels_emul.py).
 //
@@ -22,7 +22,7 @@ int launch_wait_host_flag(const uint32_t *, uint32_t, uint32_t *, hipStream_t) {
 }
 
 // 1: every chunk but the first gets its round 0 from a speculation pass on a second workspace (launch_band_spec), run
-// before the scan as csrc/pipeline.cpp's spec_enqueue does -- on the sums the previous scan computed and the bursts the
+// before the scan as csrc/scan_host.cpp's spec_enqueue does -- on the sums the previous scan computed and the bursts the
 // previous pass left active; 2: the same with the carried bursts withheld (a wrong guess must cost a round, not a result)
 static int g_emul_spec = 0;
 
@@ -125,7 +125,7 @@ int scan_emul_run(const float *mag, int n_frames, int n, int pre_len, int post_l
                                  nullptr, g_tune, nullptr, 0, nullptr, nullptr, 0, use_spec ? &S : nullptr, nullptr) != 0)
                 return -3;
             if (W.ctl->status == 0 && W.ctl->flags == 0) {
-                // verdict still open after the rounds enqueued up front: the rest (csrc/pipeline.cpp: more_rounds)
+                // verdict still open after the rounds enqueued up front: the rest (csrc/scan_host.cpp: more_rounds)
                 stats[4]++;
                 if (launch_band_scan(D, W, st, sum.data(), hist.data(), m0, F, st->index, counts.data(), entries.data(),
                                      pre.data(), smin.data(), gone.data(), gone_cap, first, kBandRounds, nullptr, nullptr,

@@ -2,7 +2,7 @@
 it (plan pass with its LDS path and the all-boundaries test, sums pass with buffer loads, frame-walking crossing pass,
 wavefront walk with the 64-frame look-ahead, commit fused into the accepting plan pass, history) -- compiled with g++
 against the HIP emulation of tests/hip_emul/hip/hip_runtime.h (a workgroup = user-space contexts in lock step, a launch
-= its workgroups one after the other) and driven chunk by chunk through launch_band_scan() the way csrc/pipeline.cpp does
+= its workgroups one after the other) and driven chunk by chunk through launch_band_scan() the way csrc/scan_host.cpp does
 (tests/scan_emul.cpp), against the oracle's sequential detector (burst_detect.c:426-632, :689-698): burst records in
 emission order, ids, and the final baseline sums, bit for bit.  No GPU."""
 import ctypes as C

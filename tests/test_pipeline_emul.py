@@ -1,5 +1,5 @@
 """The product end to end without a GPU: every source of iridium-sniffer_amd/csrc (all kernel files as the gfx950 build
-compiles them, pipeline.cpp, compat.cpp, host_design.cpp: the C-ABI of include/irdm_hip.h) is compiled with g++ against the
+compiles them, the host sources, compat.cpp, host_design.cpp: the C-ABI of include/irdm_hip.h) is compiled with g++ against the
 HIP emulation of tests/hip_emul (tests/emul_build.py says which lines are substituted: the dynamic-LDS declarations, six
 inline-assembly statements, and the generated assembly of fir_mac.inc, restated in C++) and driven through irdm.py exactly
 like the real library; every burst, downmixed frame (samples bit for bit), hard bit and LLR is compared with the oracle by
