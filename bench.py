@@ -160,6 +160,17 @@ def cpu_reference_layout(orc, host, fs, fmt, workers=4):
     return dict(seconds=dt, bursts=counts["bursts"], demods=counts["demods"])
 
 
+def cpu_model():
+    """the host CPU's model string (/proc/cpuinfo), for the cpu_baseline entry"""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def record_msg_bytes(irdm, cap):
     """bytes of one rank's record message: a count word + cap compact records (pack_records)"""
     return 8 + cap * (irdm.Demod.bits.offset + irdm.Demod.bits.size // 8)
@@ -582,9 +593,10 @@ def main():
             nb += pipe.feed_end()
         return nb
 
-    # the records of the stream's FIRST chunk as the timed context produces them (pipeline_depth 3, fed in place with
-    # look-ahead, the other chunks' stages running beside it): what parity_checked compares with the oracle
-    first_chunk = {"bursts": None, "demods": None}
+    # the records of the stream's FIRST TWO chunks as the timed context produces them (pipeline_depth 3, fed in place with
+    # look-ahead, the other chunks' stages running beside them): what parity_checked compares with the oracle run over a
+    # two-chunk prefix of the stream.  Everything the context emits during the warm-up is kept (records leave in stream order).
+    head = {"bursts": [], "demods": [], "open": True}
 
     def step(record):
         ta = time.perf_counter()
@@ -594,8 +606,8 @@ def main():
         pipe.drop_frames()
         demods = poll_demods()          # [n, 176] bytes (packed records; 4544 with the full ones): everything frame_output_print needs
         tc = time.perf_counter()
-        if first_chunk["bursts"] is None and len(bursts):
-            first_chunk["bursts"], first_chunk["demods"] = bursts.copy(), demods.copy()
+        if head["open"] and not record:
+            head["bursts"].append(bursts.copy()); head["demods"].append(demods.copy())
         if record:
             host["feed_call"] += (tb - ta) * 1e3
             host["poll"] += (tc - tb) * 1e3
@@ -623,10 +635,10 @@ def main():
         drain_feed()
         pipe.flush()
         wb = pipe.poll_bursts_raw(); pipe.drop_frames(); wd = poll_demods()
-        if first_chunk["bursts"] is None and len(wb):
-            # (the warm-up chunks' records leave together here when the warm-up is shorter than the pipeline: records
-            # are emitted in chunk order, so the stream's first chunk is the head of them)
-            first_chunk["bursts"], first_chunk["demods"] = wb.copy(), wd.copy()
+        # (the warm-up chunks' records that were still in flight leave together here, in chunk order)
+        head["bursts"].append(wb.copy()); head["demods"].append(wd.copy())
+    head["open"] = False
+    head["chunks"] = args.warmup
     if world > 1:
         for slot in (0, 1):
             gather_wait(slot)
@@ -754,30 +766,61 @@ def main():
                              "achieved_GBps": round(sum(alg_bytes.values()) / (dt / K) / 1e9, 2),
                              "frac": round(sum(alg_bytes.values()) / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)}}
 
-    # ---- PCIe-inclusive rate: the same chunk fed from pinned host memory (never `value`) ----
+    # ---- PCIe-inclusive rates: the same scene fed from pinned HOST memory (never `value`), in the three sample formats the
+    #      reference's files come in -- cf32 (8 B/sample over PCIe), ci16 (4 B) and ci8 (2 B: SURVEY 8f.1, main.c:223-284,
+    #      simd_generic.c:147-153: the conversion is part of K1's and the decimator's load stage) ----
     pcie = None
     if rank == 0 and world == 1 and args.host_steps > 0:
-        nbytes = n * bps
-        hptr, hview = irdm.host_alloc(nbytes)
-        hview[:] = x.view(torch.uint8).reshape(-1).cpu().numpy()
-        for _ in range(2):
-            pipe.feed_host_ptr(hptr, n)
-            pipe.poll_bursts_raw(); pipe.drop_frames(); poll_demods()
-        torch.cuda.synchronize()
-        th = time.perf_counter()
-        for _ in range(args.host_steps):
-            pipe.feed_host_ptr(hptr, n)
-            pipe.poll_bursts_raw(); pipe.drop_frames(); poll_demods()
-        if args.depth:
-            pipe.flush()
-            pipe.poll_bursts_raw(); pipe.drop_frames(); poll_demods()
-        torch.cuda.synchronize()
-        hdt = time.perf_counter() - th
-        pcie = {"value": round(n * args.host_steps / hdt / 1e6, 2), "unit": "Msamples/s",
-                "h2d_GBps": round(nbytes * args.host_steps / hdt / 1e9, 2), "steps": args.host_steps,
-                "note": "irdm_feed_host from pinned host memory, %s (%d B/sample over PCIe); H2D of chunk k+1 " % (args.format, bps) +
-                        "overlaps the detector scan of chunk k"}
-        irdm.host_free(hptr)
+        xf = x if args.format == "cf32" else None
+
+        def quantised(name):
+            if name == args.format:
+                return x
+            if xf is None:
+                return None
+            if name == "ci16":
+                return torch.clamp(torch.round(xf * 131072.0), -32768, 32767).to(torch.int16)
+            return torch.clamp(torch.round(xf * 512.0 * 4), -128, 127).to(torch.int8)
+
+        pcie = {}
+        for name, code, nb_ in (("cf32", irdm.FMT_CF32, 8), ("ci16", irdm.FMT_CI16, 4), ("ci8", irdm.FMT_CI8, 2)):
+            xq = quantised(name)
+            if xq is None:
+                continue
+            if name == args.format:
+                ph, own = pipe, False
+            else:
+                ph = irdm.Pipeline(fs, fmt=code, max_chunk_samples=n, max_bursts_per_chunk=8192, device=local, pipeline_depth=args.depth)
+                if packed:
+                    ph.set_option("packed_records", 1)
+                own = True
+            pollh = ph.poll_demods_packed_raw if packed else ph.poll_demods_raw
+            nbytes = n * nb_
+            hptr, hview = irdm.host_alloc(nbytes)
+            hview[:] = xq.view(torch.uint8).reshape(-1).cpu().numpy()
+            for _ in range(2):
+                ph.feed_host_ptr(hptr, n)
+                ph.poll_bursts_raw(); ph.drop_frames(); pollh()
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            nd = 0
+            for _ in range(args.host_steps):
+                ph.feed_host_ptr(hptr, n)
+                ph.poll_bursts_raw(); ph.drop_frames(); nd += len(pollh())
+            if args.depth:
+                ph.flush()
+                ph.poll_bursts_raw(); ph.drop_frames(); nd += len(pollh())
+            torch.cuda.synchronize()
+            hdt = time.perf_counter() - th
+            pcie[name] = {"value": round(n * args.host_steps / hdt / 1e6, 2), "unit": "Msamples/s",
+                          "h2d_GBps": round(nbytes * args.host_steps / hdt / 1e9, 2), "steps": args.host_steps,
+                          "frames_per_step": round(nd / args.host_steps, 1),
+                          "note": "irdm_feed_host from pinned host memory, %s (%d B/sample over PCIe); H2D of chunk k+1 "
+                                  "overlaps the detector scan of chunk k" % (name, nb_)}
+            irdm.host_free(hptr)
+            if own:
+                ph.close()
+            del xq
 
     # ---- the same stages with one kernel on the chip at a time (pipeline_depth 0), and the chunk's records for the
     #      parity check below ----
@@ -922,19 +965,44 @@ def main():
                    "sample": "one pass over the first %d samples in the reference's thread layout (1 detector + 4 downmix + "
                              "1 demod thread around the oracle's stage functions), %.1f s wall, %d bursts -> %d frames"
                              % (m, lay["seconds"], lay["bursts"], lay["demods"])}
+            cpu["cpu_model"] = cpu_model()
+            cpu["host_cores"] = os.cpu_count()
+            # (b') "all host cores" (SURVEY 8d): downmix workers = cores - 2 beside the detector and the demod thread -- the
+            #      detector thread is the serial part, so this saturates where the reference's layout does unless the host is small
+            nw = max(1, (os.cpu_count() or 6) - 2)
+            if nw != 4:
+                lay2 = cpu_reference_layout(orc, host, fs, int(fmt), workers=nw)
+                cpu["all_cores"] = {"value": round(m / lay2["seconds"] / 1e6, 3), "unit": "Msamples/s", "cores": nw + 2,
+                                    "sample": "the same pass with %d downmix workers (%d busy threads), %.1f s wall" % (nw, nw + 2, lay2["seconds"])}
+            else:
+                cpu["all_cores"] = {"value": cpu["value"], "unit": "Msamples/s", "cores": 6, "sample": "this host has 6 cores: the layout above"}
         except Exception as e:
             cpu = dict(cpu1)
             cpu["sample"] += " [thread-layout run failed: %s]" % str(e)[:80]
-        # (c) parity of the benchmark scene itself: the first chunk's records through the HIP path vs the oracle's --
-        #     from the TIMED context when it has delivered them (else from the pipeline_depth 0 context above)
+        # (c) parity of the benchmark scene itself: the records of the stream's first TWO chunks through the HIP path -- the TIMED
+        #     context's, when the warm-up fed at least three chunks (the bursts still active at the end of chunk 1 leave with
+        #     chunk 2; the oracle, whose stream ends there, never emits them) -- against the oracle run over the two-chunk
+        #     prefix; else the first chunk's, from the timed context or the pipeline_depth 0 context above
         which = None
         timed_llr = True
-        if first_chunk["bursts"] is not None and m == n:
-            fd = first_chunk["demods"][:len(ref.demods)]
+        chunks_checked = [0]
+        hb = np.concatenate([a for a in head["bursts"] if len(a)]) if any(len(a) for a in head["bursts"]) else None
+        hd = np.concatenate([a for a in head["demods"] if len(a)]) if any(len(a) for a in head["demods"]) else None
+        if hb is not None and m == n:
+            if head.get("chunks", 0) >= 3 and args.depth:
+                ref = orc.run_stream(np.concatenate([host, host]), fs, fmt=int(fmt), cap_bursts=16384)
+                chunks_checked = [0, 1]
+            gb_raw = hb[:len(ref.bursts)]
+            ids = set(int(v) for v in gb_raw[:, irdm.Burst.id.offset:irdm.Burst.id.offset + 8].copy().view(np.uint64).reshape(-1))
+            if hd is not None and len(hd):
+                did = hd[:, irdm.Demod.id.offset:irdm.Demod.id.offset + 8].copy().view(np.uint64).reshape(-1)
+                fd = hd[np.array([int(v) in ids for v in did])]
+            else:
+                fd = np.zeros((0, 1), np.uint8)
             if packed:
-                fd = unpack_demods(irdm, fd)           # (no LLRs in the compact records: the level is compared, the
-                timed_llr = False                      # LLRs by the pipeline_depth 0 context's check in the tests)
-            gpu_recs = ([irdm.Burst.from_buffer_copy(bytes(r)) for r in first_chunk["bursts"][:len(ref.bursts)]],
+                fd = unpack_demods(irdm, fd) if len(fd) else fd      # (no LLRs in the compact records: the level is compared,
+                timed_llr = False                                      # the LLRs by the whole-stream test of this configuration)
+            gpu_recs = ([irdm.Burst.from_buffer_copy(bytes(r)) for r in gb_raw],
                         [irdm.Demod.from_buffer_copy(bytes(r)) for r in fd])
             which = "the timed context (pipeline_depth %d, in place %s, look-ahead %s)" % (args.depth, ingest, look)
         elif gpu_recs is not None:
@@ -973,7 +1041,7 @@ def main():
             else:
                 bad("record counts differ")
             parity_checked = {"ok": bool(ok), "bursts": len(gb), "frames": len(gd), "oracle_bursts": len(ref.bursts),
-                              "oracle_frames": len(ref.demods), "max_soft": max_soft, "records_of": which,
+                              "oracle_frames": len(ref.demods), "max_soft": max_soft, "records_of": which, "chunks": chunks_checked,
                               "first_mismatch": first_bad,
                               "what": "ids / indices / centre bins / dB fields / hard bits / confidence exact, level%s within 1e-4"
                                       % (" and LLR" if timed_llr else " (compact records carry no LLRs)")}

@@ -239,11 +239,12 @@ int irdm_feed_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, voi
 /* irdm_feed_device in two halves: _begin = what does not depend on the detector state (K1 of the chunk, its copy into
  * the history ring), _end = detector scan + per-burst work.  A time-sharded rank calls _begin, receives the previous
  * rank's state (irdm_import_state_device), then calls _end.
- * pipeline_depth >= 1: up to two chunks of look-ahead -- irdm_feed_begin(k+1), and irdm_feed_begin(k+2), may be called
- * before irdm_feed_end(k) (the calls alternate after that; a fourth pending begin returns -1), which puts K1 of the
- * chunks ahead on the GPU before the host waits for the detector scan of chunk k-1, and lets the library enqueue the
- * speculation pass and the scan of chunk k+1 with chunk k's.  The buffer handed to _begin may be reused when the matching
- * _end has returned. */
+ * pipeline_depth >= 1: one chunk of look-ahead -- irdm_feed_begin(k+1) may be called before irdm_feed_end(k) (the calls
+ * alternate after that; a third pending begin returns -1), which puts K1 of the next chunk on the GPU before the host
+ * waits for the detector scan of chunk k-1, and lets the library enqueue the speculation pass and the scan of chunk k+1 with
+ * chunk k's.  (A second chunk begun ahead was measured in rounds 5 and 6 -- 70.6 against 74.1-74.4 Gsamples/s -- and removed.)
+ * The buffer handed to _begin may be reused when the matching _end has returned.  A detector state may only be imported
+ * (irdm_import_state*) while no chunk but the one begun last is pending. */
 int irdm_feed_begin(irdm_pipeline_t *p, const void *d_iq, size_t n_samples, void *stream);
 int irdm_feed_end(irdm_pipeline_t *p);
 /* pipeline_depth >= 1: where the producer of the next chunk (an H2D copy, a conversion kernel) may write it so that the
@@ -443,36 +444,56 @@ int irdm_group_poll_ida(irdm_group_t *g, irdm_ida_t *out, int max);
 int irdm_poll_chunk_marks(irdm_pipeline_t *p, irdm_chunk_mark_t *out, int max);
 uint64_t irdm_chunks_complete(const irdm_pipeline_t *p);
 
-/* Options: "decode_frames" / "decode_ida" (0/1, default 0: run the post-demod bit layer, see irdm_poll_decoded /
- * irdm_poll_ida),
- * "detect_only" (0/1, default 0: 1 = stage A alone, burst_detector_feed's role: only burst records are produced --
- * irdm_poll_bursts, irdm_burst_samples; no downmix / demodulation),
- * "keep_frame_samples" (0/1, default 0: irdm_poll_frames returns metadata only),
- * "scan_mode" (0 = band-parallel speculative scan (scan_band.hip) where the FFT size supports it, with the sequential
- *   scans as its exact fallback -- default; 1 = dense sequential scan only; 2 / 3 = round 1's sparse leader scan on one
- *   CU / with "scan_updaters" baseline-update workgroups, dense fallback; 4 = band scan with the dense scan as fallback),
- * "fir_order" (alias "simd_order"; PROCESS-WIDE; default 1 = the arithmetic of the reference's AVX2 kernels, simd_avx2.c --
- *   what simd_init() (simd_generic.c:33-57) selects on x86: fir_ccf_dec :62-108, fir_ccf :28-55, fir_fff :115-138,
- *   fftshift_mag :177-221, mag_squared :304-323; 0 = simd_generic.c, what --no-simd and every non-x86 build run.  The
- *   other six dispatched kernels are the same operations in both files),
- * "kernel_clock" (default 0; see irdm_kernel_clock), "k1_kernel" (default 1: K1 = the 32-points-per-lane streaming kernel
- *   at 8192 / 16384 points; 0 = the radix-16 kernel of rounds 1-3),
- * "scan_updaters" (1..32, default 7: updater workgroups of the multi-CU sparse scan),
- * "k1_lists" (default 1: the FFT kernel writes the band scan's candidate lists; 0 = a prefilter pass does),
- * "k1_first" (default 1: a per-burst chain is enqueued behind the FFT of the newest chunk),
- * "band_first" (default 0 = as many band-scan rounds up front as the previous chunk needed; n = always n; test hook),
- * kernel-variant switches for A/B runs and tests: "fir_layout" (3 register-resident decimator -- default at M = 40 / 48; 2 persistent LDS decimator, 1 / 0 one tile per
- *   workgroup, column-major / polyphase rows), "fir_budget" (tiles per workgroup of the persistent decimator, default 4),
- *   "fir_reserve_cus", "fir_generic", "fft_radix2", "post_generic", "fir_prof", "rot_store" (1, default: the rotator's
- *   phase rows leave through LDS as rows; 0: every lane stores into its own row), "chunk_marks" (see irdm_chunk_mark_t),
- *   "band_sum_restart" (1, default: later rounds' sums passes restart behind the update steps they share with the round
- *   before).
+/* Options (irdm_set_option; every one a field of THIS context -- two contexts of a process may differ in all of them; set them
+ * before the first feed unless noted).  Twenty keys:
+ *
+ *   what a caller chooses
+ *   "keep_frame_samples"  0/1, default 0: irdm_poll_frames returns metadata only
+ *   "packed_records"      0/1, default 0: 1 = only burst records and compact frame records (irdm_poll_demods_packed: what
+ *                         frame_output_print reads, hard bits 8 per byte, no LLRs), written to pinned memory by the chain's
+ *                         last kernel
+ *   "chunk_marks"         0/1, default 0: see irdm_chunk_mark_t (what a group merges its members' records with)
+ *   "decode_frames" / "decode_ida"   0/1, default 0: the post-demod bit layer, see irdm_poll_decoded / irdm_poll_ida
+ *   "detect_only"         0/1, default 0: 1 = stage A alone (burst_detector_feed's role): burst records only
+ *   "fir_order" (alias "simd_order")   default 1 = the arithmetic of the reference's AVX2 kernels, simd_avx2.c -- what
+ *                         simd_init() (simd_generic.c:33-57) selects on x86: fir_ccf_dec :62-108, fir_ccf :28-55, fir_fff
+ *                         :115-138, fftshift_mag :177-221, mag_squared :304-323; 0 = simd_generic.c, what --no-simd and every
+ *                         non-x86 build run.  (The other six dispatched kernels are the same operations in both files.)
+ *   "host_cfo"            0/1, default 0: 1 = the fine-CFO libm step (cexpf) on a host helper thread instead of the device's
+ *                         restatement of glibc's sincosf (forced when irdm_create finds that restatement differs from THIS
+ *                         host's libm)
+ *   "scan_mode"           0 = band-parallel speculative scan where the FFT size supports it, the sequential scans as its
+ *                         exact fallback (default); 1 = dense sequential scan only; 2 / 3 = the sparse leader scan on one CU /
+ *                         with updater workgroups, dense fallback; 4 = band scan with the dense scan as its only fallback
+ *   "rot_prebuild"        0/1, default 1 where pipeline_depth >= 1: every centre bin's rotator-checkpoint row, as far as a burst
+ *                         of ordinary length needs it, built by one background launch behind create (n bins x runs x 16 KB:
+ *                         0.07 / 1.3 / 3.2 GB at 2 / 10 / 12 MHz) instead of by the chains that first meet the bin; only
+ *                         before the first burst
+ *   "kernel_clock"        0/1, default 0: see irdm_kernel_clock
+ *
+ *   diagnostic
+ *   "band_timeline"       0/1: the band scan's passes stamp a device timeline (stats "tl_dur_i" / "tl_gap_i" / "tl_n_i")
+ *
+ *   test hooks (paths a default run at the standard rates takes rarely or never)
+ *   "fir_generic"         1 = the any-M decimator (what 2 / 4 MHz streams take) at every rate
+ *   "post_generic"        1 = the runtime-tap-count instances of the per-burst filters
+ *   "k1_lists"            default 1: the FFT kernel writes the band scan's candidate lists; 0 = a prefilter pass does (what a
+ *                         stale-list retry and an unprimed detector take)
+ *   "band_first"          default 0 = as many band-scan rounds up front as the previous chunk needed; n = always n
+ *   "band_spec"           default 1: round 0 of a chained scan is a speculation pass beside the previous scan; 0 = classical
+ *   "band_selfcheck"      bit mask, see BandParams::selfcheck (csrc/band_core.hpp): both boundary tests compared, records
+ *                         spoilt, the walk without look-ahead, the plan pass without its LDS, the guess spoilt in one frame
+ *   "rot_pool_rows"       n = an empty on-demand checkpoint arena of n whole rows (a prebuilt one is given up)
+ *   "scratch_outputs"     n = the decimated / low-passed scratch of every batch context with room for n outputs to begin with
+ *
  * Stats (irdm_get_stat): "scan_fast_chunks", "scan_fallbacks", "scan_dense_frames", "band_chunks", "band_rounds",
- * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "host_us_0".."host_us_9", "rot_rows",
+ * "band_retries", "band_aborts", "band_extra", "band_last_flags", "k1_lists", "scan_chained", "scan_chain_undone", "spec_passes",
+ * "spec_scans", "sum_restarts", "host_us_0".."host_us_9", "rot_rows", "rot_prebuilt_runs",
  * "rot_rows_cap", "rot_blocks", "rot_blocks_cap", "rot_builds", "rot_runs", "rot_ckpts", "rot_grows" (rotator checkpoints:
- * centre bins with a row / the arena in whole rows / blocks of 2048 checkpoints in use / allocated / build launches / runs
- * built / checkpoints built / times the arena doubled), "band_steps" (update steps the scans' last rounds walked), "scratch_outputs",
- * "scratch_grows", "scratch_peak" (decimated samples a batch context holds / times it doubled / most a batch needed). */
+ * centre bins with a row / runs per bin prebuilt / the arena in whole rows / blocks of 2048 checkpoints in use / allocated /
+ * build launches on chains / runs built / checkpoints built / times the arena doubled), "band_steps" (update steps the scans'
+ * last rounds walked), "scratch_outputs", "scratch_grows", "scratch_peak" (decimated samples a batch context holds / times it
+ * doubled / most a batch needed). */
 int irdm_set_option(irdm_pipeline_t *p, const char *key, int value);
 int64_t irdm_get_stat(const irdm_pipeline_t *p, const char *key);
 
