@@ -40,44 +40,189 @@ __device__ float2 cubic_interp(const float2 *in, int n, float pos)
 
 // Two kernels.
 //
-// demod_seq_kernel -- the true recurrences, ONE LANE PER FRAME (64 frames per wavefront):
-//   * Gardner loop (qpsk_demod.c:85-130): position n+1 depends on the timing error of position n;
-//   * PLL (:145-195): phi_{i+1} depends on phi_i through cabsf / atan2f / cosf / sinf.
-//   Both are chains of a few hundred dependent instructions per symbol (a dependent VALU instruction issues ~20 cycles
-//   after its producer, tools/ubench/valu_chain.hip), <= 448 symbols: ~0.5 ms however they are laid out.  One
-//   wavefront per frame (the earlier layout: lane 0 ran the chains out of 48 KB of LDS) kept 667 wavefronts and 125 KB
-//   of every CU's LDS busy for that long -- the decimator (50 KB per workgroup) and K1 (66 KB) of the other chunks in
-//   flight could not be placed until they retired.  A lane per frame needs 11 wavefronts and no LDS; the samples come
-//   from HBM/L2 (4 neighbours per interpolation, 32 contiguous bytes per lane).
+// demod_seq_kernel -- the true recurrences, ONE LANE PER FRAME, 32 frames per workgroup of TWO wavefronts:
+//   * wavefront 0, the timing loop (qpsk_demod.c:85-130, or decimate_simple :134-141): position n+1 depends on the timing
+//     error of position n -- four samples at pos and four at pos - sps/2, two interpolations, the error: ~130 instructions per
+//     symbol;
+//   * wavefront 1, the PLL (:145-195): phi_{i+1} depends on phi_i through cabsf / two divisions / atan2f / sincosf / cabsf /
+//     two divisions: ~240 instructions per symbol, almost all of them on the chain.
+//   The two recurrences do not feed each other (the reference runs them one after the other over the whole frame), and a
+//   lone wavefront issues an instruction every 6-7 cycles whether or not it depends on the one before (profiles/
+//   r3_valu_issue.txt): with both loops in one wavefront (rounds 3-5: one loop body, skewed by a symbol so that the scheduler
+//   could interleave them) a symbol cost the SUM of their instructions.  Here the timing wavefront hands its symbols over in
+//   blocks of kSeqBlock through LDS, a workgroup barrier per block, and runs one block ahead of the PLL wavefront.
+//   The samples reach the timing loop through an LDS window, not from memory: its loads depend on the position the
+//   previous symbol's error has just set, and beside the decimator and K1 of the other chunks a dependent load took
+//   ~1.2 us -- the timing loop ALONE kept the launch at 0.62 ms in run (0.29 alone; the PLL alone: 0.35 / 0.26;
+//   profiles/r6_demod_split.json).  The positions advance by sps +- 0.5 a symbol, so what the loop will read is known
+//   blocks ahead: every block the wavefront requests the next kSeqChunk samples of each frame (plain 16-byte loads, in
+//   flight while the block's symbols are computed), drops them into a ring of kSeqRing samples per frame at the block's
+//   end, and the interpolations read the ring (64-byte LDS reads).  A frame whose position has drifted out of the ring
+//   (more than +28 / -58 samples off sps per symbol: the loop's own limits allow it, a signal does not do it) reads memory
+//   for that symbol as before -- the ring is a cache, the arithmetic is cubic_interp's either way.
+//   (One wavefront per frame -- the first layout: lane 0 ran the chains out of 48 KB of LDS -- kept 667 wavefronts and
+//   125 KB of every CU's LDS busy for as long as the longest chain.)
 // demod_par_kernel -- everything that is per-symbol independent, one wavefront per frame, short:
 //   slicer, per-symbol magnitudes, confidence flags, unique-word angles, |.| for the LLR scale: one symbol per lane;
 //   only the float sums whose order matters (level :247, LLR scale :489-497) and the end-of-frame rule (:210-225, a
 //   running maximum) are walked in order by lane 0, over values already computed.
-__global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restrict__ work, int n_bursts,
-                                                       const float2 *__restrict__ frames, int use_gardner, float sps,
-                                                       float2 *__restrict__ ws, DemodOut *__restrict__ out)
+constexpr int kSeqFrames = 32;          // frames per workgroup (lanes 0..31 of either wavefront)
+constexpr int kSeqBlock = 4;            // symbols per hand-over block
+constexpr int kSeqChunk = 40;           // samples per frame requested per block (kSeqBlock symbols at 10 samples per symbol)
+constexpr int kSeqRing = 128;           // samples per frame in the LDS window
+constexpr int kSeqLead = 64;            // samples in the window before the first symbol
+constexpr int kSeqPitch = kSeqRing + 3; // + the first three slots once more behind the last (a 4-sample read never wraps); odd
+                                        //   pitch: the 32 rows start on different banks
+static_assert(kSeqChunk % 8 == 0 && kSeqLead % 32 == 0 && kSeqRing % 4 == 0 && kMaxFrameSamples % 4 == 0, "whole 4-sample pieces, half of them per half wavefront");
+
+// qpsk_demod.c:56-81 on four samples already fetched
+__device__ __forceinline__ float2 cubic_interp4(float2 s0, float2 s1, float2 s2, float2 s3, float mu)
 {
+    const float mu2 = mu * mu;
+    const float mu3 = mu2 * mu;
+    const float2 a = cadd(csub(cadd(cscale(-0.5f, s0), cscale(1.5f, s1)), cscale(1.5f, s2)), cscale(0.5f, s3));
+    const float2 b = csub(cadd(csub(s0, cscale(2.5f, s1)), cscale(2.0f, s2)), cscale(0.5f, s3));
+    const float2 c = cadd(cscale(-0.5f, s0), cscale(0.5f, s2));
+    return cadd(cadd(cadd(cscale(mu3, a), cscale(mu2, b)), cscale(mu, c)), s1);
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void demod_seq_kernel(const BurstWork *__restrict__ work, int n_bursts,
+                                                        const float2 *__restrict__ frames, int use_gardner, float sps,
+                                                        float2 *__restrict__ ws, DemodOut *__restrict__ out)
+{
+    // the frames' sample windows (dynamic: with the 33.5 KB in the kernel's static size the compiler takes the workgroups
+    // an LDS can hold for the occupancy and allocates 132 registers; two wavefronts of 128 fit the one 256-register slot
+    // the decimator's resident grid leaves on a SIMD)
+    extern __shared__ __attribute__((aligned(16))) unsigned char seq_smem[];
+    float2 *const s_win = reinterpret_cast<float2 *>(seq_smem);                       // kSeqFrames * kSeqPitch
+    __shared__ float2 s_sym[2][kSeqBlock][kSeqFrames];      // [block parity][symbol of the block][frame]
+    __shared__ int s_cnt[2][kSeqFrames];                    // symbols of the block, per frame
+    __shared__ int s_more[2];                               // a frame of the workgroup goes on behind the block
     // a handful of wavefronts whose dependent chains decide when the chunk's records are complete, sharing SIMDs with
     // the decimator's wavefronts of the next chunk: they go first when they have an instruction ready
     __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= n_bursts) return;
-    if (work[b].drop_reason != 0) return;
-    const int n_samples = work[b].num_samples;
-    const float2 *fr = frames + (size_t)b * kMaxFrameSamples;
-    float2 *dec = ws + (size_t)b * 2 * kMaxSymbols;
-    float2 *po = dec + kMaxSymbols;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;   // (wavefront-uniform: scalar branches)
+    // lane l < 32 runs frame l's chain; lane l + 32 only carries the other half of that frame's sample requests
+    const int b = blockIdx.x * kSeqFrames + (lane & (kSeqFrames - 1));
+    const bool frame_ok = b < n_bursts && work[b].drop_reason == 0;
+    const bool active = frame_ok && lane < kSeqFrames;
+    const int upper = lane >> 5;
+    const int n_samples = frame_ok ? work[b].num_samples : 0;
+    const float2 *fr = frames + (size_t)(frame_ok ? b : 0) * kMaxFrameSamples;
+    float2 *po = ws + (size_t)(frame_ok ? b : 0) * 2 * kMaxSymbols + kMaxSymbols;
+    const int row = (lane & (kSeqFrames - 1)) * kSeqPitch;
 
-    // Steps 1 and 2 in ONE loop: decimate_gardner (qpsk_demod.c:85-130) / decimate_simple (:134-141) produces the
-    // symbols, qpsk_pll (:145-195, alpha = 0.2) consumes them.  The two recurrences -- the timing loop's position and the
-    // PLL's phase -- do not feed each other (the reference runs them one after the other over the whole frame), and a
-    // wavefront issues in order: what the instruction stream holds between a load and its first use is all that hides
-    // the load.  So the loop is skewed by one symbol: an iteration produces symbol i + 1 (four-sample loads at pos and
-    // pos - sps/2 out of L2, the two interpolations, the timing error: ~0.6 k cycles of which the loads are most) and
-    // runs the PLL on symbol i (cabsf, two divisions, atan2f, sincosf, cabsf, two divisions: ~130 dependent
-    // instructions, ~2.2 k cycles), and both are written without branches (the reference's `if`s as selects of values
-    // computed either way) so that the two chains sit in ONE basic block and the scheduler interleaves them: an
-    // iteration costs the PLL chain, not the sum.  Same operations on the same operands in the same order per chain.
+    // ---- wavefront 0: the symbols ----
+    float pos = 0.0f, toff = 0.0f;
+    float2 prev = make_float2(0.0f, 0.0f);
+    int made = 0;
+    const float lim = (float)(n_samples - 3);
+    const int step = (int)sps;
+    int n_simple = step > 0 ? (n_samples + step - 1) / step : 0;
+    if (n_simple > kMaxSymbols) n_simple = kMaxSymbols;
+    int filled = 0;                                 // the window holds the samples [filled - kSeqRing, filled) of every frame
+    // four samples [i, i + 4) of the frame out of memory (zeros behind the frame buffer's end: never interpolated)
+    auto request = [&](int i, float4 &lo, float4 &hi) {
+        lo = hi = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (frame_ok && i + 4 <= kMaxFrameSamples) {
+            const float4 *g = reinterpret_cast<const float4 *>(fr + i);
+            lo = g[0];
+            hi = g[1];
+        }
+    };
+    // ... into their ring slots (i % 4 == 0: the piece does not wrap), slots 0..2 once more behind the ring's end
+    auto deposit = [&](int i, const float4 &lo, const float4 &hi) {
+        const int slot = i & (kSeqRing - 1);
+        float2 *w = s_win + row + slot;
+        w[0] = make_float2(lo.x, lo.y);
+        w[1] = make_float2(lo.z, lo.w);
+        w[2] = make_float2(hi.x, hi.y);
+        w[3] = make_float2(hi.z, hi.w);
+        if (slot == 0) {
+            w[kSeqRing] = make_float2(lo.x, lo.y);
+            w[kSeqRing + 1] = make_float2(lo.z, lo.w);
+            w[kSeqRing + 2] = make_float2(hi.x, hi.y);
+        }
+    };
+    // cubic_interp (qpsk_demod.c:56-81) with the four samples from the window where it holds them
+    auto interp = [&](float p) -> float2 {
+        int idx = (int)p;
+        const float mu = p - (float)idx;
+        if (idx < 1) idx = 1;
+        if (idx >= n_samples - 2) idx = n_samples - 3;
+        const bool in_win = idx - 1 >= filled - kSeqRing && idx + 2 < filled;
+        const float2 *w = s_win + row + ((idx - 1) & (kSeqRing - 1));
+        float2 r = cubic_interp4(w[0], w[1], w[2], w[3], mu);
+        // (the whole interpolation under the branch: a wait for these loads is a wait for the block's requests in front of
+        // them too -- loads return in order -- and with only the loads under the branch the wait stood behind it, in every
+        // symbol's way)
+        if (!in_win) r = cubic_interp4(fr[idx - 1], fr[idx], fr[idx + 1], fr[idx + 2], mu);
+        return r;
+    };
+    auto produce_block = [&](int buf) {
+        int cnt = 0;
+        if (use_gardner) {
+            // the next kSeqChunk samples of every frame: requested now (lanes l and l + 32 half of frame l's each), in the
+            // window from the next block on
+            constexpr int NP = kSeqChunk / 8;
+            float4 lo[NP], hi[NP];
+            const int piece0 = filled + 4 * NP * upper;
+#pragma unroll
+            for (int i = 0; i < NP; i++) request(piece0 + 4 * i, lo[i], hi[i]);
+            // decimate_gardner: symbol `made` at the loop's position, then the timing update (the position of the next one)
+#pragma unroll 1
+            for (int k = 0; k < kSeqBlock; k++) {
+                const bool live = active && pos < lim && made < kMaxSymbols;
+                if (__builtin_amdgcn_ballot_w64(live) == 0) break;
+                if (live) {
+                    const float mid_pos = pos - sps * 0.5f;
+                    // the on-time sample and the mid-point sample (used only where the reference computes it) are independent
+                    const float2 on = interp(pos);
+                    const float2 mid = interp(mid_pos >= 1.0f ? mid_pos : 1.0f);
+                    s_sym[buf][k][lane] = on;
+                    const bool upd = made > 0 && mid_pos >= 1.0f;
+                    const float2 diff = csub(prev, on);
+                    // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
+                    const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
+                    float err = p0 - p1;
+                    err = err > 1.0f ? 1.0f : err;
+                    err = err < -1.0f ? -1.0f : err;
+                    const float t1 = toff + 0.0002f * err;
+                    float adj = 0.02f * err + t1;
+                    adj = adj > 0.5f ? 0.5f : adj;
+                    adj = adj < -0.5f ? -0.5f : adj;
+                    toff = upd ? t1 : toff;
+                    pos = upd ? pos + adj : pos;
+                    prev = on;
+                    pos += sps;
+                    made++;
+                    cnt++;
+                }
+            }
+            // (behind the block's last interpolation in every lane: the wavefront runs in lockstep -- an ordering point for
+            // the compiler and for the CPU emulation, whose lanes do not; no instruction)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < NP; i++) deposit(piece0 + 4 * i, lo[i], hi[i]);
+            filled += kSeqChunk;
+        } else {
+            // decimate_simple: every (int)sps-th sample
+#pragma unroll
+            for (int k = 0; k < kSeqBlock; k++) {
+                if (active && made < n_simple) {
+                    s_sym[buf][k][lane] = fr[(size_t)made * step];
+                    made++;
+                    cnt++;
+                }
+            }
+        }
+        if (lane < kSeqFrames) s_cnt[buf][lane] = cnt;
+        const bool more = use_gardner ? (active && pos < lim && made < kMaxSymbols) : (active && made < n_simple);
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(more);
+        if (lane == 0) s_more[buf] = any != 0;
+    };
+
+    // ---- wavefront 1: qpsk_pll, alpha = 0.2 ----
     int n = 0;
     float2 phi = make_float2(1.0f, 0.0f);
     float total_phase = 0.0f;
@@ -107,63 +252,48 @@ __global__ __launch_bounds__(64) void demod_seq_kernel(const BurstWork *__restri
         total_phase = go ? tp : total_phase;
         phi = go ? p3 : phi;
     };
-    if (use_gardner) {
-        float pos = 0.0f, toff = 0.0f;
-        float2 prev = make_float2(0.0f, 0.0f);
-        int made = 0;
-        // symbol `made` at the loop's position, then the timing update (the position of the next one).  `live` false (the
-        // frame has ended: its last iteration only runs the PLL): the same instructions on clamped positions, nothing
-        // kept -- the store rewrites the last symbol with itself -- so that the loop body stays one basic block.
-        auto produce = [&](bool live, float2 last) -> float2 {
-            const float mid_pos = pos - sps * 0.5f;
-            // the on-time sample and the mid-point sample (used only where the reference computes it) are independent
-            const float2 on = cubic_interp(fr, n_samples, pos);
-            const float2 mid = cubic_interp(fr, n_samples, mid_pos >= 1.0f ? mid_pos : 1.0f);
-            dec[live ? made : made - 1] = live ? on : last;
-            const bool upd = made > 0 && mid_pos >= 1.0f;
-            const float2 diff = csub(prev, on);
-            // crealf(diff * conjf(mid)) = diff.x*mid.x - diff.y*(-mid.y)
-            const float p0 = diff.x * mid.x, p1 = diff.y * (-mid.y);
-            float err = p0 - p1;
-            err = err > 1.0f ? 1.0f : err;
-            err = err < -1.0f ? -1.0f : err;
-            const float t1 = toff + 0.0002f * err;
-            float adj = 0.02f * err + t1;
-            adj = adj > 0.5f ? 0.5f : adj;
-            adj = adj < -0.5f ? -0.5f : adj;
-            toff = upd ? t1 : toff;
-            pos = upd ? pos + adj : pos;
-            prev = on;
-            pos += sps;
-            made++;
-            return on;
-        };
-        const float lim = (float)(n_samples - 3);
-        bool have = pos < lim && made < kMaxSymbols;
-        float2 cur = make_float2(0.0f, 0.0f);
-        if (have) cur = produce(true, cur);
-        while (have) {
-            const bool more = pos < lim && made < kMaxSymbols;
-            const float2 nxt = produce(more, cur);
-            pll(n, cur);
-            n++;
-            cur = nxt;
-            have = more;
+    auto consume_block = [&](int buf) {
+        const int cnt = lane < kSeqFrames ? s_cnt[buf][lane] : 0;
+        // (the next symbol's LDS read is in flight while this one's chain runs)
+        float2 nxt = s_sym[buf][0][lane & (kSeqFrames - 1)];
+#pragma unroll 1
+        for (int k = 0; k < kSeqBlock; k++) {
+            if (__builtin_amdgcn_ballot_w64(k < cnt) == 0) break;
+            const float2 cur = nxt;
+            nxt = s_sym[buf][(k + 1) & (kSeqBlock - 1)][lane & (kSeqFrames - 1)];        // (stale where k + 1 >= cnt: not used)
+            if (k < cnt) pll(n++, cur);
         }
-    } else {
-        const int step = (int)sps;
-        n = (n_samples + step - 1) / step;
-        if (n > kMaxSymbols) n = kMaxSymbols;
-        float2 sym = n > 0 ? fr[0] : make_float2(0.0f, 0.0f);
-        for (int i = 0; i < n; i++) {
-            const float2 nxt = i + 1 < n ? fr[(size_t)(i + 1) * step] : sym;
-            dec[i] = sym;
-            pll(i, sym);
-            sym = nxt;
+    };
+
+    if (role == 0 && use_gardner) {
+        // the first kSeqLead samples of every frame
+        constexpr int NL = kSeqLead / 8;
+#pragma unroll 1
+        for (int h = 0; h < NL; h += 4) {
+            float4 lo[4], hi[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) request(4 * NL * upper + 4 * (h + u), lo[u], hi[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) deposit(4 * NL * upper + 4 * (h + u), lo[u], hi[u]);
         }
+        filled = kSeqLead;
     }
-    out[b].n_symbols = n;               // (demod_par_kernel replaces it by the frame's symbol count)
-    out[b].total_phase = total_phase;
+    // block j is produced in phase j and consumed in phase j + 1
+    bool produced_all = false;
+    for (int j = 0;; j++) {
+        if (role == 0) {
+            if (!produced_all) produce_block(j & 1);
+        } else if (j > 0) {
+            consume_block((j - 1) & 1);
+        }
+        __syncthreads();
+        if (produced_all) break;
+        produced_all = s_more[j & 1] == 0;
+    }
+    if (role == 1 && active) {
+        out[b].n_symbols = n;               // (demod_par_kernel replaces it by the frame's symbol count)
+        out[b].total_phase = total_phase;
+    }
 }
 
 // Export (packed_records): with hp_packed != nullptr the wavefront writes its burst's DemodPacked record -- the six scalars
@@ -358,7 +488,8 @@ int launch_demod(const BurstWork *work, int n_bursts, const float2 *frames, int 
                  float sps, float2 *ws, DemodOut *out, hipStream_t stream, DemodPacked *hp_packed, BurstWork *hp_work)
 {
     if (n_bursts <= 0) return 0;
-    hipLaunchKernelGGL(demod_seq_kernel, dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts,
+    hipLaunchKernelGGL(demod_seq_kernel, dim3((n_bursts + kSeqFrames - 1) / kSeqFrames), dim3(128),
+                       sizeof(float2) * kSeqFrames * kSeqPitch, stream, work, n_bursts,
                        frames, use_gardner, sps, ws, out);
     hipLaunchKernelGGL(demod_par_kernel, dim3(n_bursts), dim3(64), 0, stream, work, n_bursts, ws, out, hp_packed, hp_work);
     return hipGetLastError() == hipSuccess ? 0 : -1;

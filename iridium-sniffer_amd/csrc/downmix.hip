@@ -15,6 +15,8 @@
 
 namespace irdm {
 
+#include "fir_fma.inc"      // (cmul_pk: the four-product complex multiply as three packed instructions)
+
 // 16 consecutive samples (one rotator segment, 16-sample aligned) with the widest loads the format allows, converted
 // exactly as load_iq does
 __device__ __forceinline__ void load_seg16(int fmt, const void *__restrict__ base, size_t idx, float2 (&x)[kRotSeg])
@@ -895,7 +897,7 @@ __device__ __forceinline__ RotStart rot_phase_start(BurstWork *__restrict__ work
                                                     const CfoStep &cfo)
 {
     __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int b = blockIdx.x * 64 + ((int)threadIdx.x & 63);
     const bool live = b < n_bursts;
     int w_drop = 1, w_dec_len = 0, w_start = 0, w_simplex = 0;
     float inc_re = 1.0f, inc_im = 0.0f;
@@ -941,128 +943,103 @@ __device__ __forceinline__ RotStart rot_phase_start(BurstWork *__restrict__ work
 // the phases leave as rows (a row per lane -- rounds 2-4 -- touched 64 cache lines per store instruction: 0.24 ms against 0.11;
 // the same rows with plain stores under a branch instead of buffer stores told the store hazard below from an LDS problem)
 template <int PITCH>
-__global__ __launch_bounds__(64) void rot_phase_rows_kernel(BurstWork *__restrict__ work, int n_bursts,
-                                                            float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
-                                                            CfoStep cfo)
+__global__ __launch_bounds__(128) void rot_phase_rows_kernel(BurstWork *__restrict__ work, int n_bursts,
+                                                             float2 *__restrict__ rrc_ws, const BurstWork *__restrict__ hp_work,
+                                                             CfoStep cfo)
 {
-    const RotStart s0 = rot_phase_start(work, n_bursts, hp_work, cfo);
-    const bool live = s0.live;
-    const int w_drop = s0.drop, w_dec_len = s0.dec_len, w_start = s0.start;
-    const float inc_re = s0.inc_re, inc_im = s0.inc_im;
-    // The chain: phase_{k+1} = phase_k * incr, one lane per burst.  With every lane storing into its own row a store
-    // instruction touched 64 cache lines, and their number, not the multiply chain, set the pace (27 ns per step against
-    // the chain's 14).  Here a tile of kRotTile steps goes through LDS -- lane b writes its phases to row b of the tile
-    // -- and leaves as rows: eight lanes per burst, 16 bytes each, one store instruction = eight bursts x 128 contiguous
-    // bytes.  A first version of this (two workgroup barriers and eight read-then-store passes per tile, in line with the
-    // chain) took 0.44 ms instead of 0.16: the passes' LDS round trips were added to the chain.  Now the loop is skewed by
-    // one tile and has no barrier: an iteration issues the sixteen LDS reads of tile t - 1, runs the chain of tile t into
-    // the OTHER tile buffer, and stores tile t - 1 behind it -- a wavefront's LDS instructions complete in order, the
-    // wavefront is the workgroup, so a wave barrier (an ordering point for the compiler, no instruction) is all the reads
-    // need behind the writes.  Every lane runs to the wavefront's longest frame (the extra products are never stored); a
-    // burst's length gates the stores of ITS row, whichever lanes make them; a pair of phases is stored whole where its
-    // first element is in the frame (the second lands inside the row, behind the frame: kFrameNeed is even).
+    // The chain: phase_{k+1} = phase_k * incr, one lane per burst, 64 bursts per workgroup of TWO wavefronts.  With every
+    // lane storing into its own row a store instruction touched 64 cache lines, and their number, not the multiply chain,
+    // set the pace (27 ns per step against the chain's 14).  So a tile of kRotTile steps goes through LDS -- lane b writes
+    // its phases to row b of the tile -- and leaves as rows: eight lanes per burst, 16 bytes each, one store instruction
+    // = eight bursts x 128 contiguous bytes.  A lone wavefront issues an instruction every ~7 cycles whatever it depends on
+    // (profiles/r3_valu_issue.txt), and with the chain, the LDS reads and the row stores in ONE wavefront (round 5: one
+    // basic block per tile, skewed by a tile) a step cost ten instructions of which four are the chain's.  Here wavefront
+    // 0 runs nothing but the chain (tile t into buffer t & 1) and wavefront 1 nothing but the rows (tile t - 1 out of the
+    // other buffer), a workgroup barrier per tile between them.  Every lane runs to the workgroup's longest frame (the
+    // extra products are never stored); a burst's length gates the stores of ITS row, whichever lanes make them; a pair
+    // of phases is stored whole where its first element is in the frame (the second lands inside the row, behind the
+    // frame: kFrameNeed is even).
     constexpr int kRotTile = 16;                         // steps per tile: 128 bytes of a row
     constexpr int kRotPitch = PITCH;                     // float2 per LDS row (17: rows start on different banks)
     __shared__ float2 s_tile[2][64 * kRotPitch];
     __shared__ int s_len[64];
     static_assert(kFrameNeed % 2 == 0 && kRotTile % 2 == 0, "rows start 16-byte aligned, two phases per store");
-    const int lane = (int)threadIdx.x;
-    int L = 0;
-    if (live && w_drop == 0) {
-        const int frame_len = w_dec_len - w_start;
-        const int need = frame_need(s0.simplex);
-        L = frame_len < need ? frame_len : need;
-        if (L < 0) L = 0;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;   // (wavefront-uniform: scalar branches)
+    v2f inc = { 1.0f, 0.0f };
+    if (role == 0) {
+        const RotStart s0 = rot_phase_start(work, n_bursts, hp_work, cfo);
+        int L = 0;
+        if (s0.live && s0.drop == 0) {
+            const int frame_len = s0.dec_len - s0.start;
+            const int need = frame_need(s0.simplex);
+            L = frame_len < need ? frame_len : need;
+            if (L < 0) L = 0;
+        }
+        s_len[lane] = L;
+        inc = v2f{ s0.inc_re, s0.inc_im };
+    } else {
+        __builtin_amdgcn_s_setprio(3);
     }
-    s_len[lane] = L;
-    int Lmax = L;
+    __syncthreads();
+    int Lmax = s_len[lane];
     for (int d = 32; d >= 1; d >>= 1) {
         const int o = __shfl_xor(Lmax, d);
         Lmax = o > Lmax ? o : Lmax;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // lane -> (burst of pass p, pair of phases): 8 lanes x 2 phases = one 128-byte piece of a row.  The rows leave as
-    // buffer stores over this workgroup's 64 rows (fewer in the last workgroup: rows behind the batch are out of range):
-    // a store whose pair lies behind its burst's frame gets an out-of-range offset and is dropped by the address
-    // check -- no branch, so the stores sit in the chain's basic block.  The tile's offset is part of the VECTOR offset,
-    // the scalar offset is the constant 0: with the tile's offset in an SGPR the compiler scheduled the chain's next
-    // packed multiply -- which overwrites two of the store's four data registers -- directly behind the 128-bit store
-    // (LLVM takes a buffer store with a register in the scalar-offset field to be free of the "store wider than 64 bits,
-    // then a VALU write of its data registers" hazard), and on gfx950 the rows of every other burst arrived with the
-    // NEXT step's products in them (tools/rot_store_debug.py; lanes 8-15, 24-31, ... of the store).  Without a register
-    // there the hazard recognizer separates the two.
+    const int n_tiles = (Lmax + kRotTile - 1) / kRotTile;
+    // wavefront 1: lane -> (burst of pass p, pair of phases): 8 lanes x 2 phases = one 128-byte piece of a row.  The rows
+    // leave as buffer stores over this workgroup's 64 rows (fewer in the last workgroup: rows behind the batch are out of
+    // range): a store whose pair lies behind its burst's frame gets an out-of-range offset and is dropped by the address
+    // check -- no branch.  The tile's offset is part of the VECTOR offset, the scalar offset is the constant 0: with the
+    // tile's offset in an SGPR the compiler scheduled a write of two of the store's four data registers directly behind
+    // the 128-bit store (LLVM takes a buffer store with a register in the scalar-offset field to be free of the "store
+    // wider than 64 bits, then a VALU write of its data registers" hazard), and on gfx950 the rows of every other burst
+    // arrived with the NEXT values in them (docs/rounds/tools/rot_store_debug.py; lanes 8-15, 24-31, ... of the store;
+    // tests/test_isa_store_hazard.py).  Without a register there the hazard recognizer separates the two.
     const int part = lane & 7;
     int len_of[8], off_of[8];
     const int wg0 = (int)blockIdx.x * 64;
     const int rows = n_bursts - wg0 < 64 ? n_bursts - wg0 : 64;
     const __amdgpu_buffer_rsrc_t r_rows = __builtin_amdgcn_make_buffer_rsrc(rrc_ws + (size_t)wg0 * kFrameNeed, 0,
                                                                             rows * kFrameNeed * (int)sizeof(float2), 0x00020000);
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-        const int lb = p * 8 + (lane >> 3);
-        len_of[p] = s_len[lb];
-        off_of[p] = (lb * kFrameNeed + 2 * part) * (int)sizeof(float2);
-    }
-    const float2 inc = make_float2(inc_re, inc_im);
-    float2 ph = make_float2(1.0f, 0.0f);
-    const int n_tiles = (Lmax + kRotTile - 1) / kRotTile;
-    float2 q0[8], q1[8];
-    // tile u out of its buffer: sixteen LDS reads, in flight while whatever follows runs
-    auto fetch = [&](int u) {
-        const float2 *src = s_tile[u & 1];
+    if (role == 1) {
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             const int lb = p * 8 + (lane >> 3);
-            q0[p] = src[lb * kRotPitch + 2 * part];
-            q1[p] = src[lb * kRotPitch + 2 * part + 1];
+            len_of[p] = s_len[lb];
+            off_of[p] = (lb * kFrameNeed + 2 * part) * (int)sizeof(float2);
         }
-    };
-    // the chain of tile u into its buffer
-    auto chain = [&](int u) {
-        float2 *dst = s_tile[u & 1];
+    }
+    v2f ph = { 1.0f, 0.0f };
+    // tile t is computed in phase t and stored in phase t + 1
+    for (int t = 0; t <= n_tiles; t++) {
+        if (role == 0) {
+            if (t < n_tiles) {
+                float2 *dst = s_tile[t & 1];
 #pragma unroll
-        for (int j = 0; j < kRotTile; j++) {
-            dst[lane * kRotPitch + j] = ph;
-            ph = cmul(ph, inc);
-        }
-    };
-    // tile u (fetched) to its rows
-    auto store = [&](int u) {
-        const int k = u * kRotTile + 2 * part;
-#pragma unroll
-        for (int p = 0; p < 8; p++)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                   r_rows, k < len_of[p] ? off_of[p] + u * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
-                                                   0, 0);
-    };
-    auto order = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-    if (n_tiles > 0) {
-        chain(0);
-        order();
-        for (int t = 1; t < n_tiles; t++) {     // one basic block: the reads, the chain and the stores of an iteration
-            fetch(t - 1);
-            // (chain(t) and store(t - 1) written into each other: a store pass in the gap behind every other step)
-            float2 *dst = s_tile[t & 1];
-            const int k = (t - 1) * kRotTile + 2 * part;
-#pragma unroll
-            for (int j = 0; j < kRotTile; j++) {
-                dst[lane * kRotPitch + j] = ph;
-                ph = cmul(ph, inc);
-                if (j & 1) {
-                    const int p = j >> 1;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
-                                                           r_rows, k < len_of[p] ? off_of[p] + (t - 1) * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
-                                                           0, 0);
+                for (int j = 0; j < kRotTile; j++) {
+                    dst[lane * kRotPitch + j] = make_float2(ph.x, ph.y);
+                    ph = cmul_pk(ph, inc);          // (cmul()'s four products and two sums, three packed instructions)
                 }
             }
-            order();
+        } else if (t > 0) {
+            const int u = t - 1;
+            const float2 *src = s_tile[u & 1];
+            const int k = u * kRotTile + 2 * part;
+            float2 q0[8], q1[8];
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int lb = p * 8 + (lane >> 3);
+                q0[p] = src[lb * kRotPitch + 2 * part];
+                q1[p] = src[lb * kRotPitch + 2 * part + 1];
+            }
+#pragma unroll
+            for (int p = 0; p < 8; p++)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rot_u32x4, make_float4(q0[p].x, q0[p].y, q1[p].x, q1[p].y)),
+                                                       r_rows, k < len_of[p] ? off_of[p] + u * kRotTile * (int)sizeof(float2) : 0x7ffffff0,
+                                                       0, 0);
         }
-        fetch(n_tiles - 1);
-        store(n_tiles - 1);
+        __syncthreads();
     }
 }
 
@@ -1246,7 +1223,7 @@ int launch_downmix_post2(BurstWork *work, int n_bursts, const float2 *lpf,
 {
     if (n_bursts <= 0) return 0;
     const size_t lds = sizeof(float2) * (3 * kCorrN) + 64;
-    hipLaunchKernelGGL((rot_phase_rows_kernel<17>), dim3((n_bursts + 63) / 64), dim3(64), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
+    hipLaunchKernelGGL((rot_phase_rows_kernel<17>), dim3((n_bursts + 63) / 64), dim3(128), 0, stream, work, n_bursts, rrc_ws, hp_work, cfo);
     if (rrc_ntaps == 51 && !generic) {
         (void)hipFuncSetAttribute((const void *)downmix_post2_kernel<51>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

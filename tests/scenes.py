@@ -163,3 +163,31 @@ def random_scene(seed, fs=2_000_000, secs=1.6):
         amp = float(np.exp(rng.uniform(np.log(0.0035), np.log(0.5))))
         bursts.append(dict(start=start, freq_hz=f, quads=quads, amp=amp))
     return fs, siggen.make_stream(fs, n, bursts, seed=seed)[0]
+
+
+UW_QUADS = {1: [0, 2, 2, 2, 2, 0, 0, 0, 2, 0, 0, 2], 2: [2, 2, 0, 0, 0, 2, 0, 0, 2, 0, 2, 2]}        # qpsk_demod.c:40-44
+
+
+def stage_c_frames(n, sps, max_frame=4440, seed=77):
+    """Downmixed frames for stage-C tests (qpsk_demod.c:393-535): symbols at quadrant centres (the unique word first), `sps`
+    samples apart, straight lines between them, a constant phase within the slicer's margin, noise -- the timing loop and
+    the PLL lock at any sps.  Lengths from 40 samples to the 4440 of a simplex frame, the first six fixed (maximum, maximum,
+    one short of it, the normal maximum 1910, one more, 43).  Returns (buf [n, 2 * max_frame] float32, lens, directions)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = [int(v) for v in rng.integers(40, max_frame + 1, n)]
+    lens[:6] = [max_frame, max_frame, max_frame - 1, 1910, 1911, 43][:min(6, n)]
+    dirs = np.ascontiguousarray(rng.integers(1, 3, n), np.int32)
+    buf = np.zeros((n, 2 * max_frame), np.float32)
+    r = np.random.default_rng(seed + int(sps * 100))
+    for i in range(n):
+        nsym = int(lens[i] / sps) + 3
+        q = np.concatenate([UW_QUADS[int(dirs[i])], r.integers(0, 4, nsym)])
+        sym = 0.4 * np.exp(1j * (np.pi / 4 + q * np.pi / 2 + r.uniform(-0.2, 0.2)))
+        t = np.arange(lens[i]) / sps
+        k = t.astype(int)
+        x = sym[k] * (1 - (t - k)) + sym[k + 1] * (t - k)
+        x = x + (r.standard_normal(lens[i]) + 1j * r.standard_normal(lens[i])) * 0.4 * float(r.choice([0.01, 0.05, 0.15]))
+        buf[i, 0:2 * lens[i]:2] = x.real
+        buf[i, 1:2 * lens[i]:2] = x.imag
+    return buf, lens, dirs

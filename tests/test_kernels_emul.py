@@ -296,7 +296,10 @@ def demod_emul():
     deps = [src, os.path.join(ROOT, "tests", "hip_emul", "hip", "hip_runtime.h")] + [
         os.path.join(CSRC, h) for h in ("demod.hip", "types.hpp", "kernels.hpp", "common.hpp")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
-        open(inc, "w").write(open(os.path.join(CSRC, "demod.hip")).read())
+        text = open(os.path.join(CSRC, "demod.hip")).read()
+        text = re.sub(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) unsigned char (\w+)\[\];",
+                      r"unsigned char *\1 = hip_emul::dyn_lds();", text)
+        open(inc, "w").write(text)
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-I" + os.path.join(ROOT, "tests", "hip_emul"), "-I" + out_dir, "-I" + CSRC, "-o", so, src])
     L = C.CDLL(so)
@@ -351,6 +354,55 @@ def test_stage_c_kernels_match_the_reference_vectors(demod_emul):
         assert np.array_equal(prec[24:24 + len(want)], want), i
         checked += 1
     assert checked >= 6
+
+
+def test_stage_c_kernels_long_frames_full_workgroups_and_positions_outside_the_window(demod_emul):
+    """demod_seq_kernel's structure (round 6: a timing wavefront and a PLL wavefront per 32 frames, the samples through a
+    ring of 128 per frame in LDS that is filled 40 samples per block of 4 symbols) against the oracle's stage C (pinned to
+    the reference's qpsk_demod.c, tests/test_oracle_vs_ref.py) on what the reference's 18 vectors do not reach: 75 frames
+    (two full workgroups and a ragged third), lengths from 40 samples to the 4440 of a simplex frame (the ring wraps 34
+    times), and samples-per-symbol values for which the timing loop's position runs ahead of / falls behind the window
+    (10.4: +1.6 samples a block, outside after ~18 blocks; 9.25: -3 a block; the oracle sizes its symbol buffers from
+    the rounded value as the reference does, which bounds the choice, and has no 448-symbol cap: frames of at most 4000
+    samples at 9.25) so that the interpolations read memory instead
+    -- same host libm on both sides here, so everything is compared bit for bit, LLRs included; with and without the
+    Gardner loop."""
+    sz = [C.c_int() for _ in range(4)]
+    demod_emul.demod_emul_sizes(*[C.byref(s_) for s_ in sz])
+    out_bytes, packed_bytes, max_frame, max_bits = [s_.value for s_ in sz]
+    n = 75
+    oracle = orc.lib()
+    checked = okd = 0
+    for gardner, sps in ((1, 10.0), (1, 10.4), (1, 9.25), (0, 10.0)):
+        buf, lens, dirs = scenes.stage_c_frames(n, sps, max_frame)
+        nsi = np.ascontiguousarray(np.minimum(lens, 4000) if sps < 10 else lens, np.int32)
+        out = np.zeros(n * out_bytes, np.uint8)
+        rc = demod_emul.demod_emul_run(orc.fptr(buf), nsi.ctypes.data_as(C.POINTER(C.c_int)), dirs.ctypes.data_as(C.POINTER(C.c_int)),
+                                       n, gardner, sps, out.ctypes.data_as(C.c_void_p), None)
+        assert rc == 0
+        for i in range(n):
+            fr = orc.Frame()
+            fr.samples_per_symbol = sps
+            fr.sample_rate = 250000.0
+            fr.direction = int(dirs[i])
+            fr.num_samples = int(nsi[i])
+            np.ctypeslib.as_array(fr.samples)[:] = buf[i]
+            d = orc.Demod()
+            r_o = oracle.orc_qpsk_demod(C.byref(fr), gardner, C.byref(d))
+            rec = out[i * out_bytes:(i + 1) * out_bytes]
+            ok, direction, confidence, n_sym = [int(v) for v in rec[:16].view(np.int32)]
+            assert ok == r_o, (sps, i)
+            checked += 1
+            if not ok:
+                continue
+            okd += 1
+            assert (direction, confidence, n_sym) == (d.direction, d.confidence, d.n_symbols), (sps, i)
+            assert rec[16:20].view(np.uint32)[0] == np.float32(d.level).view(np.uint32), (sps, i)
+            nb = 2 * n_sym
+            assert bytes(rec[24:24 + nb]) == bytes(d.bits[:nb]), (sps, i)
+            llr = rec[24 + max_bits:24 + max_bits + 4 * nb].view(np.uint32)
+            assert np.array_equal(llr, np.array(d.llr[:nb], np.float32).view(np.uint32)), (sps, i)
+    assert checked == 4 * n and okd >= 3 * n, okd
 
 
 # ---- csrc/bitlayer.hip on the same emulation: frame_decode against the oracle (pinned to the reference's object code) ----
