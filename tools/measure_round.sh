@@ -46,15 +46,10 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_
   timeout 200 rocprofv3 --pmc $pass --kernel-include-regex "fir_decimate" -d "$OUT/c5_sq$i" -o pmc --output-format csv -- \
       python $B --steps 2 --warmup 1 --depth 0 $Q $D12 > "$OUT/c5_sq$i.log" 2>&1
 done
-# SQ counters of K1 alone (tools/ubench/k1_bench: the kernel on a random chunk, nothing beside it), two passes
-i=0
-for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" \
-            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
-  i=$((i+1))
-  timeout 120 rocprofv3 --pmc $pass --kernel-include-regex "fft_mag_p32" -d "$OUT/k1sq$i" -o pmc --output-format csv -- \
-      $GRAFT_REPO_ROOT/tools/ubench/k1_bench 13 8192 3 2 200 > "$OUT/k1sq$i.log" 2>&1
-done
+# (K1's own SQ-counter passes ran on docs/rounds/tools/k1_bench.hip until round 5: profiles/r5_k1_pmc_final.json; the kernel has not changed since)
 cd "$GRAFT_REPO_ROOT"
-{ timeout 120 tools/ubench/k1_bench 13 8192 20 2 200; timeout 120 tools/ubench/k1_bench 14 4096 20 2 400; } > "$OUT/k1_bench.txt" 2>&1
+f=$(ls $OUT/*r1_kernel_trace.csv $OUT/*/*r1_kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$f" ] && python tools/trace_gantt.py "$f" 4 > "$OUT/gantt_r1.txt"
+find "$OUT" -name "*kernel_trace.csv" -delete
 timeout 200 python tools/hop_timing.py > "$OUT/hop_timing.txt" 2>/dev/null
 ls "$OUT"
