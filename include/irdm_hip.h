@@ -421,7 +421,11 @@ int irdm_seed_history_device(irdm_pipeline_t *p, const void *d_iq, size_t n_samp
  * and kernel clocks of a member are. */
 typedef struct irdm_group irdm_group_t;
 int irdm_device_count(void);                           /* GPUs this process sees (0: none, or no HIP runtime) */
-/* EXPERIMENTAL for n_gpus > 1 (a warning says so once): run on emulated devices and as ranks sharing one GPU only */
+/* EXPERIMENTAL for n_gpus > 1 (a warning says so once): run on emulated devices and as ranks sharing one GPU only.
+ * While the RCCL communicators are made (in irdm_group_create for n_gpus > 1, and when "group_loopback" is first set on a
+ * group of one) the process's file descriptor 1 is pointed at its stderr and restored afterwards: librccl prints a version
+ * banner on stdout, the stream a host prints its RAW lines to.  A host with other threads writing to stdout in that window
+ * sees their output on stderr; IRDM_GROUP_KEEP_STDOUT=1 in the environment leaves the descriptor alone (banner included). */
 irdm_group_t *irdm_group_create(const irdm_config_t *cfg, int n_gpus, const int *devices);
 void irdm_group_destroy(irdm_group_t *g);
 int irdm_group_size(const irdm_group_t *g);

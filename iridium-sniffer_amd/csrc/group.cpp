@@ -603,8 +603,10 @@ static int group_comms(irdm_group *g)
     // librccl prints a version banner on STDOUT when its first communicator is made -- the stream a host like
     // iridium-sniffer-hip prints its RAW lines to.  While the communicators are made, file descriptor 1 is the process's
     // stderr: whatever the library writes or leaves in stdout's buffer goes there.
+    // (documented at irdm_group_create; IRDM_GROUP_KEEP_STDOUT=1 leaves the descriptor alone)
     fflush(stdout);
-    const int keep = dup(1);
+    const char *ks = getenv("IRDM_GROUP_KEEP_STDOUT");
+    const int keep = (ks && ks[0] == '1') ? -1 : dup(1);
     if (keep >= 0) dup2(2, 1);
     const ncclResult_t e1 = r->CommInitAll(g->c_iq.data(), g->n, devs.data());
     const ncclResult_t e2 = e1 == ncclSuccess ? r->CommInitAll(g->c_state.data(), g->n, devs.data()) : e1;
